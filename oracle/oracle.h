@@ -1,0 +1,117 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the shipped product path.
+ *
+ * C interface of the CPU oracle (restatement of the reference's src/energy + src/features hot path, see the headers of
+ * pba.hpp / pose_alignment.hpp / pyramid.hpp for the file:line citations).  It deliberately has the same shape as the
+ * product's C-ABI (include/dsopp_hip.h) so tests can drive both with identical call sequences and compare outputs.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * PARITY UNPINNED: no reference build / golden vectors exist for this path in this environment. */
+#ifndef DSOPP_ORACLE_H
+#define DSOPP_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int32_t max_iterations;
+  double initial_trust_region_radius;
+  double function_tolerance;
+  double parameter_tolerance;
+  double affine_brightness_regularizer[2];
+  double fixed_state_regularizer;
+  double sigma_huber_loss;
+  int32_t estimate_uncertainty;
+  int32_t force_accept;
+  int32_t first_estimate_jacobians;
+  int32_t optimize_idepths;
+} orc_options;
+
+void orc_default_pba_options(orc_options *o);
+void orc_default_align_options(orc_options *o);
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
+/* ---- sliding-window photometric bundle adjustment ---- */
+typedef struct orc_window orc_window;
+orc_window *orc_window_create(const orc_options *o);
+void orc_window_destroy(orc_window *w);
+/* image / mask buffers are BORROWED (the reference keeps raw pointers to the keyframe's PixelMap, local_frame.hpp:323-325) */
+int orc_window_push_frame(orc_window *w, int frame_id, int64_t timestamp, int width, int height, const double *pixelinfo,
+                          const uint8_t *mask, const double intrinsics[4], const double T_w_agent[7], double exposure_time,
+                          const double affine_brightness[2], int fixed, int is_marginalized);
+/* flags bit0 = is_marginalized, bit1 = is_outlier.  n_total >= current count: existing landmarks get their
+ * marginalisation flags updated (LocalFrame::update, local_frame.hpp:484-505), new ones are appended */
+int orc_window_set_landmarks(orc_window *w, int frame_id, int n_total, const double *uv, const double *idepth,
+                             const double *patch, const uint8_t *flags);
+/* appends ResidualPoints for landmarks [current size, n) of the (ref, tgt) connection with the given statuses */
+int orc_window_set_connection(orc_window *w, int ref_id, int tgt_id, int n, const uint8_t *statuses);
+int orc_window_mark_frame_marginalized(orc_window *w, int frame_id);
+int orc_window_num_frames(orc_window *w);
+
+/* stage-level API (PhotometricBundleAdjustmentProblem methods) */
+int orc_window_begin(orc_window *w); /* construct the problem (+ firstEstimateJacobians when FEJ) */
+int orc_window_calculate_energy(orc_window *w, double *energy, int *n_valid);
+int orc_window_linearize(orc_window *w);
+int orc_window_get_system(orc_window *w, double *H_pp, double *b_pp, double *H_schur, double *b_schur);
+int orc_window_calculate_step(orc_window *w, double lambda, double *step);
+int orc_window_accept_step(orc_window *w, double *state_sq, double *step_sq);
+int orc_window_reject_step(orc_window *w);
+int orc_window_update_point_statuses(orc_window *w);
+/* whole solve (EigenPhotometricBundleAdjustment::solve) */
+int orc_window_solve(orc_window *w, double *energy, int *iterations, int *n_valid);
+
+/* getters */
+int orc_window_get_frame_state(orc_window *w, int frame_id, double T0[7], double ab0[2], double eps[8], double step[8]);
+int orc_window_get_pose(orc_window *w, int frame_id, double T_w_agent[7], double affine_brightness[2]);
+int orc_window_num_landmarks(orc_window *w, int frame_id);
+/* per landmark: idepth, idepth_step, inv_hessian_idepth_idepth, b_idepth_block, relative_baseline (any may be NULL);
+ * flags_out bit0 marginalized, bit1 outlier, bit2 to_marginalize, bit3 ill_conditioned; hpib is n x K */
+int orc_window_get_landmarks(orc_window *w, int frame_id, double *idepth, double *idepth_step, double *inv_hdd, double *b_d,
+                             double *relative_baseline, int32_t *n_inliers, uint8_t *flags_out, double *hpib);
+int orc_window_get_residuals(orc_window *w, int ref_id, int tgt_id, uint8_t *status, uint8_t *candidate, double *energy,
+                             double *huber_weight, double *residuals8, double *J_ref64, double *J_tgt64, double *J_idepth8);
+int orc_window_get_marginalized(orc_window *w, double *H, double *b, double *energy);
+int orc_window_get_covariance(orc_window *w, int ref_id, int tgt_id, double cov[36]);
+
+/* ---- two-frame direct alignment (one pyramid level) ---- */
+typedef struct {
+  double rmse;
+  double energy;
+  int32_t n_valid;
+  int32_t iterations;
+  double T_w_target[7];
+  double affine_brightness[2];
+  double covariance[36];
+  double H[64];
+} orc_align_result;
+/* reference points from a depth map (LocalFrame depth-map ctor): returns count, fills up to cap entries */
+int orc_points_from_depth_map(int width, int height, const double *pixelinfo, const double *idepth_sum, const double *weight,
+                              int cap, double *u, double *v, double *idepth, double *intensity);
+int orc_align_solve(const orc_options *o, int n, const double *u, const double *v, const double *idepth,
+                    const double *intensity, const double ref_intrinsics[4], int ref_width, int ref_height,
+                    const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],
+                    int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
+                    const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2], orc_align_result *out);
+
+/* ---- pyramid ---- */
+/* pixelinfo_out[l] must hold 3*w_l*h_l doubles; plane_out[l] (optional) w_l*h_l */
+int orc_build_pyramid(const uint8_t *image, int width, int height, const double *lut256, const uint8_t *vignetting,
+                      int levels, double **pixelinfo_out, double **plane_out);
+
+/* ---- primitives exposed for identity tests ---- */
+void orc_se3_exp(const double xi[6], double T[7]);
+void orc_se3_mul(const double A[7], const double B[7], double C[7]);
+void orc_se3_inverse(const double A[7], double B[7]);
+void orc_se3_adj(const double A[7], double adj36[36]);
+int orc_reproject_pattern(const double ref_intr[4], int ref_w, int ref_h, const double tgt_intr[4], int tgt_w, int tgt_h,
+                          const double T_t_r[7], int n, const double *u, const double *v, double idepth, int with_jacobians,
+                          double *tu, double *tv, double *d_u_idepth, double *d_v_idepth, double *d_u_T, double *d_v_T);
+int orc_solve_system(int n, const double *H, const double *b, double *x);
+int orc_reduce_system(int n, double *H, double *b, int n_elim, const int32_t *elim, double *H_out, double *b_out);
+int orc_pinv_drop(int n, const double *H, int nullspaces, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

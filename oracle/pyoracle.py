@@ -1,0 +1,326 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes wrapper over oracle/libdsopp_oracle.so (see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product package
+(dsopp_amd) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdsopp_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp", ".h"))]
+    stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libdsopp_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Options(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("initial_trust_region_radius", C.c_double),
+                ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("affine_brightness_regularizer", C.c_double * 2), ("fixed_state_regularizer", C.c_double),
+                ("sigma_huber_loss", C.c_double), ("estimate_uncertainty", C.c_int32), ("force_accept", C.c_int32),
+                ("first_estimate_jacobians", C.c_int32), ("optimize_idepths", C.c_int32)]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("rmse", C.c_double), ("energy", C.c_double), ("n_valid", C.c_int32), ("iterations", C.c_int32),
+                ("T_w_target", C.c_double * 7), ("affine_brightness", C.c_double * 2), ("covariance", C.c_double * 36),
+                ("H", C.c_double * 64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_window_create.restype = C.c_void_p
+        _lib.orc_window_create.argtypes = [C.POINTER(Options)]
+        _lib.orc_window_destroy.argtypes = [C.c_void_p]
+        _lib.orc_window_destroy.restype = None
+    return _lib
+
+
+def _p(a, dtype=np.float64):
+    if a is None:
+        return None
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def default_pba_options(**kw) -> Options:
+    o = Options()
+    lib().orc_default_pba_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "affine_brightness_regularizer":
+            o.affine_brightness_regularizer[0], o.affine_brightness_regularizer[1] = v
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def default_align_options(**kw) -> Options:
+    o = Options()
+    lib().orc_default_align_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "affine_brightness_regularizer":
+            o.affine_brightness_regularizer[0], o.affine_brightness_regularizer[1] = v
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def set_threads(n: int):
+    lib().orc_set_threads(int(n))
+
+
+class OracleWindow:
+    """CPU restatement of EigenPhotometricBundleAdjustment behind the same Python interface as dsopp_amd.HipWindow."""
+
+    def __init__(self, options: Options | None = None):
+        self.options = options or default_pba_options()
+        self._h = C.c_void_p(lib().orc_window_create(C.byref(self.options)))
+        self._keep = []  # borrowed image / mask buffers
+        self.frame_ids = []
+
+    def close(self):
+        if self._h:
+            lib().orc_window_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def K(self) -> int:
+        return 8 * lib().orc_window_num_frames(self._h)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise RuntimeError(f"oracle call failed: {rc}")
+        return rc
+
+    def push_frame(self, frame_id, timestamp, pixelinfo, mask, intrinsics, T_w_agent, exposure, affine, fixed, is_marginalized):
+        pix = _f64(pixelinfo)
+        H, W = pix.shape[:2]
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self._keep.append((pix, m))
+        self._chk(lib().orc_window_push_frame(self._h, int(frame_id), C.c_int64(int(timestamp)), W, H, _p(pix),
+                                              _p(m, np.uint8), _p(_f64(intrinsics)), _p(_f64(T_w_agent)),
+                                              C.c_double(exposure), _p(_f64(affine)), int(bool(fixed)), int(bool(is_marginalized))))
+        self.frame_ids.append(int(frame_id))
+
+    def set_landmarks(self, frame_id, uv, idepth, patch, flags):
+        n = len(idepth)
+        self._chk(lib().orc_window_set_landmarks(self._h, int(frame_id), n, _p(_f64(uv)), _p(_f64(idepth)), _p(_f64(patch)),
+                                                 _p(np.ascontiguousarray(flags, dtype=np.uint8), np.uint8)))
+
+    def set_connection(self, ref_id, tgt_id, statuses):
+        st = np.ascontiguousarray(statuses, dtype=np.uint8)
+        self._chk(lib().orc_window_set_connection(self._h, int(ref_id), int(tgt_id), len(st), _p(st, np.uint8)))
+
+    def mark_frame_marginalized(self, frame_id):
+        self._chk(lib().orc_window_mark_frame_marginalized(self._h, int(frame_id)))
+
+    # --- stage level ---
+    def begin(self):
+        self._chk(lib().orc_window_begin(self._h))
+
+    def calculate_energy(self):
+        e, n = C.c_double(), C.c_int()
+        self._chk(lib().orc_window_calculate_energy(self._h, C.byref(e), C.byref(n)))
+        return e.value, n.value
+
+    def linearize(self):
+        self._chk(lib().orc_window_linearize(self._h))
+
+    def get_system(self):
+        K = self.K
+        Hpp, bpp, Hsc, bsc = np.zeros((K, K)), np.zeros(K), np.zeros((K, K)), np.zeros(K)
+        self._chk(lib().orc_window_get_system(self._h, _p(Hpp), _p(bpp), _p(Hsc), _p(bsc)))
+        return Hpp, bpp, Hsc, bsc
+
+    def calculate_step(self, lam):
+        step = np.zeros(self.K)
+        self._chk(lib().orc_window_calculate_step(self._h, C.c_double(lam), _p(step)))
+        return step
+
+    def accept_step(self):
+        a, b = C.c_double(), C.c_double()
+        self._chk(lib().orc_window_accept_step(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reject_step(self):
+        self._chk(lib().orc_window_reject_step(self._h))
+
+    def update_point_statuses(self):
+        self._chk(lib().orc_window_update_point_statuses(self._h))
+
+    def solve(self):
+        e, it, nv = C.c_double(), C.c_int(), C.c_int()
+        self._chk(lib().orc_window_solve(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    # --- getters ---
+    def get_frame_state(self, frame_id):
+        T0, ab0, eps, step = np.zeros(7), np.zeros(2), np.zeros(8), np.zeros(8)
+        self._chk(lib().orc_window_get_frame_state(self._h, int(frame_id), _p(T0), _p(ab0), _p(eps), _p(step)))
+        return T0, ab0, eps, step
+
+    def get_pose(self, frame_id):
+        T, ab = np.zeros(7), np.zeros(2)
+        self._chk(lib().orc_window_get_pose(self._h, int(frame_id), _p(T), _p(ab)))
+        return T, ab
+
+    def get_landmarks(self, frame_id):
+        n = self._chk(lib().orc_window_num_landmarks(self._h, int(frame_id)))
+        K = self.K
+        out = dict(idepth=np.zeros(n), idepth_step=np.zeros(n), inv_hdd=np.zeros(n), b_d=np.zeros(n),
+                   relative_baseline=np.zeros(n), n_inliers=np.zeros(n, dtype=np.int32), flags=np.zeros(n, dtype=np.uint8),
+                   hpib=np.zeros((n, K)))
+        self._chk(lib().orc_window_get_landmarks(self._h, int(frame_id), _p(out["idepth"]), _p(out["idepth_step"]),
+                                                 _p(out["inv_hdd"]), _p(out["b_d"]), _p(out["relative_baseline"]),
+                                                 _p(out["n_inliers"], np.int32), _p(out["flags"], np.uint8), _p(out["hpib"])))
+        return out
+
+    def get_residuals(self, ref_id, tgt_id, full=False):
+        n = self._chk(lib().orc_window_num_landmarks(self._h, int(ref_id)))
+        out = dict(status=np.zeros(n, dtype=np.uint8), candidate=np.zeros(n, dtype=np.uint8), energy=np.zeros(n),
+                   huber_weight=np.zeros(n))
+        if full:
+            out.update(residuals=np.zeros((n, 8)), J_ref=np.zeros((n, 8, 8)), J_tgt=np.zeros((n, 8, 8)), J_idepth=np.zeros((n, 8)))
+        m = self._chk(lib().orc_window_get_residuals(
+            self._h, int(ref_id), int(tgt_id), _p(out["status"], np.uint8), _p(out["candidate"], np.uint8), _p(out["energy"]),
+            _p(out["huber_weight"]), _p(out.get("residuals")), _p(out.get("J_ref")), _p(out.get("J_tgt")), _p(out.get("J_idepth"))))
+        return {k: v[:m] for k, v in out.items()}
+
+    def get_marginalized(self):
+        K = self.K
+        H, b, e = np.zeros((K, K)), np.zeros(K), C.c_double()
+        self._chk(lib().orc_window_get_marginalized(self._h, _p(H), _p(b), C.byref(e)))
+        return H, b, e.value
+
+    def get_covariance(self, ref_id, tgt_id):
+        cov = np.zeros((6, 6))
+        self._chk(lib().orc_window_get_covariance(self._h, int(ref_id), int(tgt_id), _p(cov)))
+        return cov
+
+
+def build_pyramid(image_u8, lut=None, vignetting=None, levels=4):
+    img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+    H, W = img.shape
+    levels = min(levels, 5)
+    infos, planes = [], []
+    w, h = W, H
+    for _ in range(levels):
+        infos.append(np.zeros((h, w, 3)))
+        planes.append(np.zeros((h, w)))
+        w //= 2
+        h //= 2
+    pi = (C.c_void_p * levels)(*[a.ctypes.data for a in infos])
+    pp = (C.c_void_p * levels)(*[a.ctypes.data for a in planes])
+    lutp = None if lut is None else _p(_f64(lut))
+    vig = None if vignetting is None else np.ascontiguousarray(vignetting, dtype=np.uint8)
+    lib().orc_build_pyramid(_p(img, np.uint8), W, H, lutp, _p(vig, np.uint8), levels, pi, pp)
+    return infos, planes
+
+
+def points_from_depth_map(pixelinfo, idepth_sum, weight):
+    pix = _f64(pixelinfo)
+    H, W = pix.shape[:2]
+    cap = H * W
+    u, v, d, inten = np.zeros(cap), np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    n = lib().orc_points_from_depth_map(W, H, _p(pix), _p(_f64(idepth_sum)), _p(_f64(weight)), cap, _p(u), _p(v), _p(d), _p(inten))
+    return u[:n].copy(), v[:n].copy(), d[:n].copy(), inten[:n].copy()
+
+
+def align_solve(options, u, v, idepth, intensity, ref_intr, ref_size, T_w_ref, ref_exposure, ref_ab, tgt_intr, tgt_pixelinfo,
+                tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab):
+    pix = _f64(tgt_pixelinfo)
+    H, W = pix.shape[:2]
+    m = None if tgt_mask is None else np.ascontiguousarray(tgt_mask, dtype=np.uint8)
+    out = AlignResult()
+    rc = lib().orc_align_solve(C.byref(options), len(u), _p(_f64(u)), _p(_f64(v)), _p(_f64(idepth)), _p(_f64(intensity)),
+                               _p(_f64(ref_intr)), int(ref_size[0]), int(ref_size[1]), _p(_f64(T_w_ref)), C.c_double(ref_exposure),
+                               _p(_f64(ref_ab)), _p(_f64(tgt_intr)), W, H, _p(pix), _p(m, np.uint8), _p(_f64(T_w_tgt_init)),
+                               C.c_double(tgt_exposure), _p(_f64(tgt_ab)), C.byref(out))
+    if rc < 0:
+        raise RuntimeError(f"orc_align_solve failed {rc}")
+    return dict(rmse=out.rmse, energy=out.energy, n_valid=out.n_valid, iterations=out.iterations,
+                T_w_target=np.array(out.T_w_target), affine_brightness=np.array(out.affine_brightness),
+                covariance=np.array(out.covariance).reshape(6, 6), H=np.array(out.H).reshape(8, 8))
+
+
+def se3_exp(xi):
+    T = np.zeros(7)
+    lib().orc_se3_exp(_p(_f64(xi)), _p(T))
+    return T
+
+
+def se3_mul(A, B):
+    Cc = np.zeros(7)
+    lib().orc_se3_mul(_p(_f64(A)), _p(_f64(B)), _p(Cc))
+    return Cc
+
+
+def se3_inverse(A):
+    B = np.zeros(7)
+    lib().orc_se3_inverse(_p(_f64(A)), _p(B))
+    return B
+
+
+def se3_adj(A):
+    M = np.zeros((6, 6))
+    lib().orc_se3_adj(_p(_f64(A)), _p(M))
+    return M
+
+
+def reproject_pattern(ref_intr, ref_size, tgt_intr, tgt_size, T_t_r, u, v, idepth, with_jacobians=True):
+    n = len(u)
+    tu, tv = np.zeros(n), np.zeros(n)
+    dui, dvi, duT, dvT = np.zeros(n), np.zeros(n), np.zeros((n, 6)), np.zeros((n, 6))
+    ok = lib().orc_reproject_pattern(_p(_f64(ref_intr)), int(ref_size[0]), int(ref_size[1]), _p(_f64(tgt_intr)), int(tgt_size[0]),
+                                     int(tgt_size[1]), _p(_f64(T_t_r)), n, _p(_f64(u)), _p(_f64(v)), C.c_double(idepth),
+                                     int(with_jacobians), _p(tu), _p(tv), _p(dui), _p(dvi), _p(duT), _p(dvT))
+    return bool(ok), tu, tv, dui, dvi, duT, dvT
+
+
+def solve_system(H, b):
+    n = len(b)
+    x = np.zeros(n)
+    lib().orc_solve_system(n, _p(_f64(H)), _p(_f64(b)), _p(x))
+    return x
+
+
+def reduce_system(H, b, elim):
+    n = len(b)
+    e = np.ascontiguousarray(elim, dtype=np.int32)
+    nk = n - len(e)
+    Ho, bo = np.zeros((nk, nk)), np.zeros(nk)
+    lib().orc_reduce_system(n, _p(_f64(H)), _p(_f64(b)), len(e), _p(e, np.int32), _p(Ho), _p(bo))
+    return Ho, bo
+
+
+def pinv_drop(H, nullspaces):
+    n = H.shape[0]
+    out = np.zeros((n, n))
+    lib().orc_pinv_drop(n, _p(_f64(H)), int(nullspaces), _p(out))
+    return out
