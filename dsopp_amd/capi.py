@@ -1,0 +1,330 @@
+"""ctypes binding of the product C-ABI (include/dsopp_hip.h -> dsopp_amd/lib/libdsopp_hip.so).
+
+Python is only plumbing here (tests, bench, torch.distributed glue): every compute call goes through the C-ABI into
+hand-written HIP kernels.  There is NO fallback: a missing library raises at import of the symbols, and every compute
+entry point fails with DSOPP_HIP_ERR_HIP when no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdsopp_hip.so")
+
+F64, F32 = 0, 1
+
+
+class Options(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("initial_trust_region_radius", C.c_double),
+                ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("affine_brightness_regularizer", C.c_double * 2), ("fixed_state_regularizer", C.c_double),
+                ("sigma_huber_loss", C.c_double), ("estimate_uncertainty", C.c_int32), ("force_accept", C.c_int32),
+                ("first_estimate_jacobians", C.c_int32), ("optimize_idepths", C.c_int32), ("dtype", C.c_int32)]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("rmse", C.c_double), ("energy", C.c_double), ("n_valid", C.c_int32), ("iterations", C.c_int32),
+                ("T_world_target", C.c_double * 7), ("affine_brightness", C.c_double * 2), ("covariance", C.c_double * 36),
+                ("H", C.c_double * 64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "dsopp_hip_last_error", "dsopp_hip_device_count", "dsopp_hip_version", "dsopp_hip_default_pba_options",
+    "dsopp_hip_default_align_options", "dsopp_hip_pyramid_create", "dsopp_hip_pyramid_destroy", "dsopp_hip_pyramid_build",
+    "dsopp_hip_pyramid_build_device", "dsopp_hip_pyramid_set_level", "dsopp_hip_pyramid_set_mask", "dsopp_hip_pyramid_get_level",
+    "dsopp_hip_pyramid_level_size", "dsopp_hip_window_create", "dsopp_hip_window_destroy", "dsopp_hip_window_push_frame",
+    "dsopp_hip_window_set_landmarks", "dsopp_hip_window_set_connection", "dsopp_hip_window_mark_frame_marginalized",
+    "dsopp_hip_window_num_frames", "dsopp_hip_window_solve", "dsopp_hip_window_begin", "dsopp_hip_window_calculate_energy",
+    "dsopp_hip_window_linearize", "dsopp_hip_window_get_system", "dsopp_hip_window_calculate_step", "dsopp_hip_window_accept_step",
+    "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
+    "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
+    "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
+    "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
+    "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "dsopp_amd has no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.dsopp_hip_last_error.restype = C.c_char_p
+        _lib.dsopp_hip_version.restype = C.c_char_p
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HipError(f"dsopp_hip error {rc}: {lib().dsopp_hip_last_error().decode()}")
+
+
+def _p(a, dtype=np.float64):
+    if a is None:
+        return None
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _chk(lib().dsopp_hip_device_count(C.byref(n)))
+    return n.value
+
+
+def default_pba_options(**kw) -> Options:
+    o = Options()
+    lib().dsopp_hip_default_pba_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "affine_brightness_regularizer":
+            o.affine_brightness_regularizer[0], o.affine_brightness_regularizer[1] = v
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def default_align_options(**kw) -> Options:
+    o = Options()
+    lib().dsopp_hip_default_align_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "affine_brightness_regularizer":
+            o.affine_brightness_regularizer[0], o.affine_brightness_regularizer[1] = v
+        else:
+            setattr(o, k, v)
+    return o
+
+
+class Pyramid:
+    """Device-resident image pyramid of one frame (dsopp_hip_pyramid)."""
+
+    def __init__(self, width, height, levels=1, dtype=F64, device=0, stream=None):
+        self._h = C.c_void_p()
+        self.width, self.height, self.dtype, self.device = int(width), int(height), dtype, device
+        _chk(lib().dsopp_hip_pyramid_create(int(device), C.c_void_p(stream or 0), int(width), int(height), int(levels), int(dtype),
+                                            C.byref(self._h)))
+        self.levels = min(int(levels), 5)
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_pyramid_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, image_u8, lut=None, vignetting=None):
+        img = _u8(image_u8)
+        assert img.shape == (self.height, self.width)
+        _chk(lib().dsopp_hip_pyramid_build(self._h, _p(img, np.uint8), _p(None if lut is None else _f64(lut)), _p(_u8(vignetting), np.uint8)))
+
+    def build_device(self, image_dev_ptr, lut=None, vignetting_dev_ptr=None, vignetting_max=0.0):
+        _chk(lib().dsopp_hip_pyramid_build_device(self._h, C.c_void_p(image_dev_ptr), _p(None if lut is None else _f64(lut)),
+                                                  C.c_void_p(vignetting_dev_ptr or 0), C.c_double(vignetting_max)))
+
+    def set_level(self, level, pixelinfo):
+        _chk(lib().dsopp_hip_pyramid_set_level(self._h, int(level), _p(_f64(pixelinfo))))
+
+    def set_mask(self, level, mask):
+        _chk(lib().dsopp_hip_pyramid_set_mask(self._h, int(level), _p(_u8(mask), np.uint8)))
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _chk(lib().dsopp_hip_pyramid_level_size(self._h, int(level), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def get_level(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w, 3))
+        _chk(lib().dsopp_hip_pyramid_get_level(self._h, int(level), _p(out)))
+        return out
+
+
+class HipWindow:
+    """Sliding-window photometric BA on the GPU; same Python interface as oracle.pyoracle.OracleWindow."""
+
+    def __init__(self, options: Options | None = None, device=0, stream=None):
+        self.options = options or default_pba_options()
+        self.device = device
+        self._stream = stream
+        self._h = C.c_void_p()
+        _chk(lib().dsopp_hip_window_create(C.byref(self.options), int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+        self._pyramids = {}
+        self._cb = None
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_window_destroy(self._h)
+            self._h = C.c_void_p()
+        for p in self._pyramids.values():
+            p.close()
+        self._pyramids = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_frames(self) -> int:
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_num_frames(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def K(self) -> int:
+        return 8 * self.num_frames
+
+    def push_frame(self, frame_id, timestamp, pixelinfo, mask, intrinsics, T_w_agent, exposure, affine, fixed, is_marginalized,
+                   pyramid: Pyramid | None = None, level=0):
+        """pixelinfo: H x W x 3 host array (uploaded into a 1-level pyramid owned by this wrapper) unless `pyramid` given."""
+        if pyramid is None:
+            pix = _f64(pixelinfo)
+            H, W = pix.shape[:2]
+            pyramid = Pyramid(W, H, 1, self.options.dtype, self.device, self._stream)
+            pyramid.set_level(0, pix)
+            if mask is not None:
+                pyramid.set_mask(0, mask)
+            level = 0
+        self._pyramids[int(frame_id)] = pyramid
+        _chk(lib().dsopp_hip_window_push_frame(self._h, int(frame_id), C.c_int64(int(timestamp)), pyramid._h, int(level),
+                                               _p(_f64(intrinsics)), _p(_f64(T_w_agent)), C.c_double(exposure), _p(_f64(affine)),
+                                               int(bool(fixed)), int(bool(is_marginalized))))
+
+    def set_landmarks(self, frame_id, uv, idepth, patch, flags):
+        n = len(idepth)
+        _chk(lib().dsopp_hip_window_set_landmarks(self._h, int(frame_id), n, _p(_f64(uv)), _p(_f64(idepth)), _p(_f64(patch)),
+                                                  _p(_u8(flags), np.uint8)))
+
+    def set_connection(self, ref_id, tgt_id, statuses):
+        st = _u8(statuses)
+        _chk(lib().dsopp_hip_window_set_connection(self._h, int(ref_id), int(tgt_id), len(st), _p(st, np.uint8)))
+
+    def mark_frame_marginalized(self, frame_id):
+        _chk(lib().dsopp_hip_window_mark_frame_marginalized(self._h, int(frame_id)))
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> int.  Keeps the ctypes callback alive."""
+        if fn is None:
+            self._cb = None
+            _chk(lib().dsopp_hip_window_set_allreduce(self._h, None, None))
+            return
+        self._cb = ALLREDUCE_FN(lambda user, ptr, count, stream: int(fn(ptr, count, stream) or 0))
+        _chk(lib().dsopp_hip_window_set_allreduce(self._h, self._cb, None))
+
+    # stage level
+    def begin(self):
+        _chk(lib().dsopp_hip_window_begin(self._h))
+
+    def calculate_energy(self):
+        e, n = C.c_double(), C.c_int32()
+        _chk(lib().dsopp_hip_window_calculate_energy(self._h, C.byref(e), C.byref(n)))
+        return e.value, n.value
+
+    def linearize(self):
+        _chk(lib().dsopp_hip_window_linearize(self._h))
+
+    def get_system(self):
+        K = self.K
+        Hpp, bpp, Hsc, bsc = np.zeros((K, K)), np.zeros(K), np.zeros((K, K)), np.zeros(K)
+        _chk(lib().dsopp_hip_window_get_system(self._h, _p(Hpp), _p(bpp), _p(Hsc), _p(bsc)))
+        return Hpp, bpp, Hsc, bsc
+
+    def calculate_step(self, lam):
+        step = np.zeros(self.K)
+        _chk(lib().dsopp_hip_window_calculate_step(self._h, C.c_double(lam), _p(step)))
+        return step
+
+    def accept_step(self):
+        a, b = C.c_double(), C.c_double()
+        _chk(lib().dsopp_hip_window_accept_step(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reject_step(self):
+        _chk(lib().dsopp_hip_window_reject_step(self._h))
+
+    def update_point_statuses(self):
+        _chk(lib().dsopp_hip_window_update_point_statuses(self._h))
+
+    def solve(self):
+        e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_solve(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    def last_solve_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().dsopp_hip_window_last_solve_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # getters
+    def get_frame_state(self, frame_id):
+        T0, ab0, eps, step = np.zeros(7), np.zeros(2), np.zeros(8), np.zeros(8)
+        _chk(lib().dsopp_hip_window_get_frame_state(self._h, int(frame_id), _p(T0), _p(ab0), _p(eps), _p(step)))
+        return T0, ab0, eps, step
+
+    def get_pose(self, frame_id):
+        T, ab = np.zeros(7), np.zeros(2)
+        _chk(lib().dsopp_hip_window_get_pose(self._h, int(frame_id), _p(T), _p(ab)))
+        return T, ab
+
+    def num_landmarks(self, frame_id):
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_num_landmarks(self._h, int(frame_id), C.byref(n)))
+        return n.value
+
+    def get_landmarks(self, frame_id, with_hpib=True):
+        n = self.num_landmarks(frame_id)
+        K = self.K
+        out = dict(idepth=np.zeros(n), idepth_step=np.zeros(n), inv_hdd=np.zeros(n), b_d=np.zeros(n), relative_baseline=np.zeros(n),
+                   n_inliers=np.zeros(n, dtype=np.int32), flags=np.zeros(n, dtype=np.uint8))
+        hp = np.zeros((n, K)) if with_hpib else None
+        _chk(lib().dsopp_hip_window_get_landmarks(self._h, int(frame_id), _p(out["idepth"]), _p(out["idepth_step"]), _p(out["inv_hdd"]),
+                                                  _p(out["b_d"]), _p(out["relative_baseline"]), _p(out["n_inliers"], np.int32),
+                                                  _p(out["flags"], np.uint8), _p(hp)))
+        if with_hpib:
+            out["hpib"] = hp
+        return out
+
+    def get_residuals(self, ref_id, tgt_id, full=False):
+        n = self.num_landmarks(ref_id)
+        out = dict(status=np.zeros(n, dtype=np.uint8), candidate=np.zeros(n, dtype=np.uint8), energy=np.zeros(n))
+        _chk(lib().dsopp_hip_window_get_residuals(self._h, int(ref_id), int(tgt_id), n, _p(out["status"], np.uint8),
+                                                  _p(out["candidate"], np.uint8), _p(out["energy"])))
+        return out
+
+    def get_marginalized(self):
+        K = self.K
+        H, b, e, sz = np.zeros((K, K)), np.zeros(K), C.c_double(), C.c_int32()
+        _chk(lib().dsopp_hip_window_get_marginalized(self._h, _p(H), _p(b), C.byref(e), C.byref(sz)))
+        return H, b, e.value
+
+    def get_covariance(self, ref_id, tgt_id):
+        cov = np.zeros((6, 6))
+        _chk(lib().dsopp_hip_window_get_covariance(self._h, int(ref_id), int(tgt_id), _p(cov)))
+        return cov

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds the HIP library for gfx950 in-tree: dsopp_amd/lib/libdsopp_hip.so
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function ${DSOPP_HIP_EXTRA_FLAGS:-}"
+pids=()
+for src in pyramid pba align; do
+  if [ -f "$HERE/$src.hip" ]; then
+    $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OUT/$src.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+objs=()
+for src in pyramid pba align; do [ -f "$OUT/$src.o" ] && objs+=("$OUT/$src.o"); done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT/libdsopp_hip.so"
+echo "built $OUT/libdsopp_hip.so"

@@ -1,0 +1,132 @@
+// Common host-side helpers of the HIP library: error reporting, RAII device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dsopp_hip.h"
+
+namespace dsopp_hip {
+
+/** thread-local last error message returned by dsopp_hip_last_error() */
+std::string &lastError();
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+#define HIP_CHECK(expr)                                                                                     \
+  do {                                                                                                      \
+    hipError_t _e = (expr);                                                                                 \
+    if (_e != hipSuccess)                                                                                   \
+      ::dsopp_hip::fail(DSOPP_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+/** run `body`, translate exceptions into the C-ABI's error codes */
+template <typename F>
+int guarded(F &&body) {
+  try {
+    body();
+    return DSOPP_HIP_OK;
+  } catch (const Error &e) {
+    lastError() = e.what();
+    return e.code;
+  } catch (const std::exception &e) {
+    lastError() = e.what();
+    return DSOPP_HIP_ERR_INVALID_ARGUMENT;
+  }
+}
+
+/** growable device buffer (never shrinks); contents preserved on growth */
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t capacity = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  DeviceBuffer(DeviceBuffer &&o) noexcept : ptr(o.ptr), capacity(o.capacity) { o.ptr = nullptr; o.capacity = 0; }
+  DeviceBuffer &operator=(DeviceBuffer &&o) noexcept {
+    if (this != &o) {
+      release();
+      ptr = o.ptr;
+      capacity = o.capacity;
+      o.ptr = nullptr;
+      o.capacity = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    capacity = 0;
+  }
+  /** ensure capacity >= n elements; keeps the first `keep` elements */
+  void reserve(size_t n, size_t keep, hipStream_t stream) {
+    if (n <= capacity) return;
+    size_t cap = capacity ? capacity : 64;
+    while (cap < n) cap *= 2;
+    T *np = nullptr;
+    HIP_CHECK(hipMalloc(&np, cap * sizeof(T)));
+    HIP_CHECK(hipMemsetAsync(np, 0, cap * sizeof(T), stream));
+    if (ptr && keep) HIP_CHECK(hipMemcpyAsync(np, ptr, keep * sizeof(T), hipMemcpyDeviceToDevice, stream));
+    if (ptr) {
+      HIP_CHECK(hipStreamSynchronize(stream));
+      (void)hipFree(ptr);
+    }
+    ptr = np;
+    capacity = cap;
+  }
+  void upload(const T *host, size_t n, size_t offset, hipStream_t stream) {
+    if (n) HIP_CHECK(hipMemcpyAsync(ptr + offset, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+  }
+  void download(T *host, size_t n, size_t offset, hipStream_t stream) const {
+    if (n) HIP_CHECK(hipMemcpyAsync(host, ptr + offset, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+  }
+};
+
+/** owns (or borrows) a stream on a device */
+struct StreamRef {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owned = false;
+  void init(int dev, void *user_stream) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      fail(DSOPP_HIP_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (dev < 0 || dev >= count) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", dev, count);
+    device = dev;
+    HIP_CHECK(hipSetDevice(dev));
+    if (user_stream) {
+      stream = static_cast<hipStream_t>(user_stream);
+      owned = false;
+    } else {
+      HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      owned = true;
+    }
+  }
+  void destroy() {
+    if (owned && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+  void use() const { HIP_CHECK(hipSetDevice(device)); }
+  void sync() const { HIP_CHECK(hipStreamSynchronize(stream)); }
+};
+
+}  // namespace dsopp_hip

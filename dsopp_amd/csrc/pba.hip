@@ -1,0 +1,1251 @@
+// dsopp_hip_window_*: host side of the sliding-window photometric bundle adjustment.
+//
+// Mirrors EigenPhotometricBundleAdjustment (PROB_SRC/eigen_photometric_bundle_adjustment.cpp:47-141) and its base class
+// (PROB_SRC/photometric_bundle_adjustment.cpp:21-435): the window owns per-frame landmark / residual tables in HBM,
+// launches the sweeps, and keeps the small dense pieces the reference also keeps in double on the host
+// (marginal prior, covariance pseudo-inverse).  There is no CPU compute path: every stage is a HIP kernel.
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "host_linalg.hpp"
+#include "pba_kernels.hpp"
+
+namespace dsopp_hip {
+namespace {
+
+struct ResidualTable {
+  DeviceBuffer<uint8_t> status, cand, fej_valid;
+  DeviceBuffer<double> energy;
+  int n = 0;
+};
+
+struct HostFrame {
+  int id = 0;
+  int64_t timestamp = 0;
+  const dsopp_hip_pyramid *pyramid = nullptr;
+  int level = 0;
+  double intr[4] = {0, 0, 0, 0};
+  double exposure = 1;
+  bool fixed = false, is_marginalized = false, to_marginalize = false;
+  int n = 0;
+  int cap = 0;
+  std::vector<uint8_t> flags;  // host mirror of the landmark flags as last uploaded
+  DeviceBuffer<double> uv, idepth, idepth_step, idepth_fej, patch, inv_hdd, b_d, relative_baseline, ublk;
+  DeviceBuffer<int32_t> n_inliers;
+  DeviceBuffer<uint8_t> dflags;
+  std::map<int, std::unique_ptr<ResidualTable>> residuals;  // by target frame id
+  std::map<int, std::array<double, 36>> covariance;
+};
+
+}  // namespace
+}  // namespace dsopp_hip
+
+using namespace dsopp_hip;
+
+struct dsopp_hip_window {
+  StreamRef sr;
+  dsopp_hip_options opt;
+  std::vector<std::unique_ptr<HostFrame>> frames;
+  // host mirror of the dynamic state
+  WindowState hst;
+  // marginal prior (system_marginalized_, energy_marginalized_ — PBA_INC/eigen_photometric_bundle_adjustment.hpp:68-70)
+  std::vector<double> Hm, bm;
+  double energy_marginalized = 0;
+  int marg_size = 0;
+  // device
+  DeviceBuffer<FrameDev> d_frames;
+  DeviceBuffer<WindowState> d_state;
+  DeviceBuffer<PairConst> d_pc;
+  DeviceBuffer<SweepBlock> d_sweep_table;
+  DeviceBuffer<SchurBlock> d_schur_table;
+  DeviceBuffer<int> d_pair_first, d_pair_count;
+  DeviceBuffer<double> d_partials, d_Gpair, d_GT, d_TGT, d_Hpp, d_bpp, d_Hsc, d_bsc, d_Hm, d_bm, d_step, d_scalars;
+  int n_sweep_blocks = 0, n_schur_blocks = 0;
+  bool topology_dirty = true;
+  bool state_dirty = true;   // host mirror newer than device
+  bool marg_dirty = true;
+  bool pair_valid = false;   // pair constants match the device state
+  bool begun = false;
+  bool linearized = false;
+  double last_lambda = 0;
+  std::vector<double> last_step;
+  float last_solve_ms = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  dsopp_hip_allreduce_fn allreduce = nullptr;
+  void *allreduce_user = nullptr;
+
+  int F() const { return static_cast<int>(frames.size()); }
+  int K() const { return kBlk * F(); }
+  bool fej() const { return opt.first_estimate_jacobians != 0; }
+  int slotOf(int id) const {
+    for (size_t i = 0; i < frames.size(); ++i)
+      if (frames[i]->id == id) return static_cast<int>(i);
+    return -1;
+  }
+  HostFrame &frameById(int id) {
+    const int s = slotOf(id);
+    if (s < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", id);
+    return *frames[static_cast<size_t>(s)];
+  }
+};
+
+namespace dsopp_hip {
+namespace {
+
+using W = dsopp_hip_window;
+
+void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
+  if (n <= f.cap) return;
+  int cap = f.cap ? f.cap : 256;
+  while (cap < n) cap *= 2;
+  hipStream_t st = w.sr.stream;
+  const size_t keep = static_cast<size_t>(f.n);
+  f.uv.reserve(2 * static_cast<size_t>(cap), 2 * keep, st);
+  f.idepth.reserve(cap, keep, st);
+  f.idepth_step.reserve(cap, keep, st);
+  f.idepth_fej.reserve(cap, keep, st);
+  f.patch.reserve(static_cast<size_t>(kPat) * cap, kPat * keep, st);
+  f.inv_hdd.reserve(cap, keep, st);
+  f.b_d.reserve(cap, keep, st);
+  f.relative_baseline.reserve(cap, keep, st);
+  f.n_inliers.reserve(cap, keep, st);
+  f.dflags.reserve(cap, keep, st);
+  f.ublk.reserve(static_cast<size_t>(kMaxFrames) * cap * kUblk, 0, st);
+  for (auto &kv : f.residuals) {
+    ResidualTable &rt = *kv.second;
+    const size_t k = static_cast<size_t>(rt.n);
+    rt.status.reserve(cap, k, st);
+    rt.cand.reserve(cap, k, st);
+    rt.fej_valid.reserve(cap, k, st);
+    rt.energy.reserve(cap, k, st);
+  }
+  f.cap = cap;
+  w.topology_dirty = true;
+}
+
+/** rebuild the FrameDev table, the sweep / Schur block tables and upload them */
+void syncTopology(W &w) {
+  if (!w.topology_dirty) return;
+  hipStream_t st = w.sr.stream;
+  const int F = w.F();
+  std::vector<FrameDev> fd(static_cast<size_t>(kMaxFrames));
+  std::memset(fd.data(), 0, fd.size() * sizeof(FrameDev));
+  std::vector<SweepBlock> sweep;
+  std::vector<SchurBlock> schur;
+  std::vector<int> pair_first(kMaxFrames * kMaxFrames, -1), pair_count(kMaxFrames * kMaxFrames, 0);
+  for (int r = 0; r < F; ++r) {
+    HostFrame &f = *w.frames[static_cast<size_t>(r)];
+    FrameDev &d = fd[static_cast<size_t>(r)];
+    const LevelView lv = f.pyramid->view(f.level);
+    d.texels = lv.texels;
+    d.width = lv.width;
+    d.height = lv.height;
+    d.fx = f.intr[0];
+    d.fy = f.intr[1];
+    d.cx = f.intr[2];
+    d.cy = f.intr[3];
+    d.exposure = f.exposure;
+    d.fixed = f.fixed;
+    d.is_marginalized = f.is_marginalized;
+    d.to_marginalize = f.to_marginalize;
+    d.n = f.n;
+    d.cap = f.cap;
+    d.uv = f.uv.ptr;
+    d.idepth = f.idepth.ptr;
+    d.idepth_step = f.idepth_step.ptr;
+    d.idepth_fej = f.idepth_fej.ptr;
+    d.patch = f.patch.ptr;
+    d.inv_hdd = f.inv_hdd.ptr;
+    d.b_d = f.b_d.ptr;
+    d.relative_baseline = f.relative_baseline.ptr;
+    d.n_inliers = f.n_inliers.ptr;
+    d.flags = f.dflags.ptr;
+    d.ublk = f.ublk.ptr;
+    for (int t = 0; t < F; ++t) {
+      if (t == r) continue;
+      auto it = f.residuals.find(w.frames[static_cast<size_t>(t)]->id);
+      if (it == f.residuals.end() || it->second->n == 0) continue;
+      ResidualTable &rt = *it->second;
+      d.status[t] = rt.status.ptr;
+      d.cand[t] = rt.cand.ptr;
+      d.fej_valid[t] = rt.fej_valid.ptr;
+      d.energy[t] = rt.energy.ptr;
+      d.n_res[t] = rt.n;
+      pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
+      int cnt = 0;
+      for (int off = 0; off < rt.n; off += kSweepThreads) {
+        sweep.push_back(SweepBlock{r, t, off, 0});
+        ++cnt;
+      }
+      pair_count[static_cast<size_t>(r * kMaxFrames + t)] = cnt;
+    }
+    for (int off = 0; off < f.n; off += kSchurLandmarks) schur.push_back(SchurBlock{r, off});
+  }
+  w.d_frames.reserve(kMaxFrames, 0, st);
+  w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
+  w.n_sweep_blocks = static_cast<int>(sweep.size());
+  w.n_schur_blocks = static_cast<int>(schur.size());
+  w.d_sweep_table.reserve(std::max<size_t>(1, sweep.size()), 0, st);
+  w.d_sweep_table.upload(sweep.data(), sweep.size(), 0, st);
+  w.d_schur_table.reserve(std::max<size_t>(1, schur.size()), 0, st);
+  w.d_schur_table.upload(schur.data(), schur.size(), 0, st);
+  w.d_pair_first.reserve(kMaxFrames * kMaxFrames, 0, st);
+  w.d_pair_first.upload(pair_first.data(), pair_first.size(), 0, st);
+  w.d_pair_count.reserve(kMaxFrames * kMaxFrames, 0, st);
+  w.d_pair_count.upload(pair_count.data(), pair_count.size(), 0, st);
+  w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
+  w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
+  w.d_Gpair.reserve(kMaxFrames * kMaxFrames * 48, 0, st);
+  w.d_GT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
+  w.d_TGT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
+  const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
+  w.d_Hpp.reserve(KK * KK, 0, st);
+  w.d_bpp.reserve(KK, 0, st);
+  w.d_Hsc.reserve(KK * KK, 0, st);
+  w.d_bsc.reserve(KK, 0, st);
+  w.d_Hm.reserve(KK * KK, 0, st);
+  w.d_bm.reserve(KK, 0, st);
+  w.d_step.reserve(KK, 0, st);
+  w.d_scalars.reserve(16, 0, st);
+  w.sr.sync();  // host staging vectors go out of scope
+  w.topology_dirty = false;
+  w.pair_valid = false;
+}
+
+void uploadState(W &w) {
+  if (!w.state_dirty) return;
+  w.d_state.reserve(1, 0, w.sr.stream);
+  w.d_state.upload(&w.hst, 1, 0, w.sr.stream);
+  w.sr.sync();
+  w.state_dirty = false;
+  w.pair_valid = false;
+}
+
+void downloadState(W &w) {
+  if (w.state_dirty || !w.d_state.ptr) return;
+  w.d_state.download(&w.hst, 1, 0, w.sr.stream);
+  w.sr.sync();
+}
+
+void uploadMarginal(W &w) {
+  if (!w.marg_dirty) return;
+  const int K = w.K();
+  if (w.marg_size != K) fail(DSOPP_HIP_ERR_STATE, "marginal prior has size %d, window %d", w.marg_size, K);
+  w.d_Hm.upload(w.Hm.data(), static_cast<size_t>(K) * K, 0, w.sr.stream);
+  w.d_bm.upload(w.bm.data(), static_cast<size_t>(K), 0, w.sr.stream);
+  w.sr.sync();
+  w.marg_dirty = false;
+}
+
+void prepare(W &w) {
+  w.sr.use();
+  syncTopology(w);
+  uploadState(w);
+  uploadMarginal(w);
+}
+
+void ensurePairConstants(W &w) {
+  if (w.pair_valid) return;
+  const int F = w.F();
+  pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, F, w.fej() ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+  w.pair_valid = true;
+}
+
+template <typename S>
+void launchFej(W &w) {
+  if (!w.n_sweep_blocks) return;
+  fejKernel<S><<<w.n_sweep_blocks, kSweepThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+/** firstEstimateJacobians — PROB_SRC/photometric_bundle_adjustment.cpp:302-305 */
+void firstEstimate(W &w) {
+  ensurePairConstants(w);
+  if (w.opt.dtype == DSOPP_HIP_F64)
+    launchFej<double>(w);
+  else
+    launchFej<float>(w);
+}
+
+template <typename S>
+void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg) {
+  if (!w.n_sweep_blocks) return;
+  SweepParams prm;
+  prm.sigma_huber = w.opt.sigma_huber_loss;
+  prm.for_marginalized = for_marg ? 1 : 0;
+  prm.use_fej_flag = w.fej() ? 1 : 0;
+  dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
+  hipStream_t st = w.sr.stream;
+  const FrameDev *fr = w.d_frames.ptr;
+  const PairConst *pc = w.d_pc.ptr;
+  const SweepBlock *tb = w.d_sweep_table.ptr;
+  double *pa = w.d_partials.ptr;
+  if (!lin) {
+    if (w.fej())
+      sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    else
+      sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+  } else if (w.fej()) {
+    if (huber)
+      sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    else
+      sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+  } else {
+    if (huber)
+      sweepKernel<S, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    else
+      sweepKernel<S, true, false, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void launchSweep(W &w, bool lin, bool huber, bool for_marg) {
+  ensurePairConstants(w);
+  if (w.opt.dtype == DSOPP_HIP_F64)
+    launchSweepTyped<double>(w, lin, huber, for_marg);
+  else
+    launchSweepTyped<float>(w, lin, huber, for_marg);
+}
+
+void launchSchur(W &w, bool for_marg) {
+  const int K = w.K();
+  HIP_CHECK(hipMemsetAsync(w.d_Hsc.ptr, 0, static_cast<size_t>(K) * K * sizeof(double), w.sr.stream));
+  HIP_CHECK(hipMemsetAsync(w.d_bsc.ptr, 0, static_cast<size_t>(K) * sizeof(double), w.sr.stream));
+  if (!w.n_schur_blocks || !w.opt.optimize_idepths) return;
+  const size_t smem = (static_cast<size_t>(kSchurLandmarks) * K + 2 * kSchurLandmarks) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  schurKernel<<<w.n_schur_blocks, kSchurThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_schur_table.ptr, w.d_Hsc.ptr,
+                                                                       w.d_bsc.ptr, w.F(), for_marg ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors) {
+  const int K = w.K();
+  SolveBuffers B;
+  B.partials = w.d_partials.ptr;
+  B.pair_first_block = w.d_pair_first.ptr;
+  B.pair_num_blocks = w.d_pair_count.ptr;
+  B.Gpair = w.d_Gpair.ptr;
+  B.GT = w.d_GT.ptr;
+  B.TGT = w.d_TGT.ptr;
+  B.Hpp = w.d_Hpp.ptr;
+  B.bpp = w.d_bpp.ptr;
+  B.Hsc = w.d_Hsc.ptr;
+  B.bsc = w.d_bsc.ptr;
+  B.Hm = w.d_Hm.ptr;
+  B.bm = w.d_bm.ptr;
+  B.step = w.d_step.ptr;
+  B.energy_out = w.d_scalars.ptr;
+  SolveParams prm;
+  prm.lambda = lambda;
+  prm.affine_reg[0] = add_priors ? w.opt.affine_brightness_regularizer[0] : 0.0;
+  prm.affine_reg[1] = add_priors ? w.opt.affine_brightness_regularizer[1] : 0.0;
+  prm.fixed_reg = add_priors ? w.opt.fixed_state_regularizer : 0.0;
+  prm.F = w.F();
+  prm.n_sweep_blocks = w.n_sweep_blocks;
+  prm.use_marginal = 1;
+  const size_t smem = (static_cast<size_t>(K) * K + 3 * static_cast<size_t>(K)) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assembleSolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    attr_set = true;
+  }
+  assembleSolveKernel<<<1, kSolveThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, B, prm, w.fej() ? 1 : 0,
+                                                               do_solve ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- stages ---------------------------------------------------------------------------------------------------
+
+/** prior / marginal terms of calculateEnergy — problem.hpp:293-312 — evaluated on the host mirror of the state */
+double priorEnergy(const W &w, bool with_step) {
+  const int F = w.F(), K = w.K();
+  std::vector<double> state(static_cast<size_t>(K));
+  for (int f = 0; f < F; ++f)
+    for (int a = 0; a < kBlk; ++a) state[static_cast<size_t>(kBlk * f + a)] = w.hst.eps[f][a] + (with_step ? w.hst.step[f][a] : 0.0);
+  double e = w.energy_marginalized;
+  double quad = 0, lin = 0;
+  for (int i = 0; i < K; ++i) {
+    lin += w.bm[static_cast<size_t>(i)] * state[static_cast<size_t>(i)];
+    double s = 0;
+    for (int j = 0; j < K; ++j) s += w.Hm[static_cast<size_t>(i) * K + j] * state[static_cast<size_t>(j)];
+    quad += state[static_cast<size_t>(i)] * s;
+  }
+  e += lin + quad / 2;
+  for (int f = 0; f < F; ++f) {
+    double t = 0;
+    for (int a = 0; a < 2; ++a) {
+      const double ab = w.hst.ab0[f][a] + state[static_cast<size_t>(kBlk * f + 6 + a)];
+      t += ab * w.opt.affine_brightness_regularizer[a] * ab;
+    }
+    e += t / 2;
+  }
+  return e;
+}
+
+void allreduceIfNeeded(W &w, double *dev, size_t count) {
+  if (!w.allreduce) return;
+  const int rc = w.allreduce(w.allreduce_user, dev, count, w.sr.stream);
+  if (rc != 0) fail(DSOPP_HIP_ERR_HIP, "allreduce callback failed with %d", rc);
+}
+
+void stageBegin(W &w) {
+  if (w.F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
+  prepare(w);
+  if (w.fej()) firstEstimate(w);
+  w.begun = true;
+  w.linearized = false;
+}
+
+std::pair<double, int> stageEnergy(W &w) {
+  if (!w.begun) fail(DSOPP_HIP_ERR_STATE, "call begin first");
+  launchSweep(w, false, true, false);
+  energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr);
+  HIP_CHECK(hipGetLastError());
+  allreduceIfNeeded(w, w.d_scalars.ptr, 2);
+  double out[2];
+  w.d_scalars.download(out, 2, 0, w.sr.stream);
+  w.sr.sync();
+  return {out[0] + priorEnergy(w, true), static_cast<int>(out[1] + 0.5)};
+}
+
+void stageLinearize(W &w, bool huber = true, bool for_marg = false, bool add_priors = true) {
+  if (!w.begun) fail(DSOPP_HIP_ERR_STATE, "call begin first");
+  launchSweep(w, true, huber, for_marg);
+  launchSchur(w, for_marg);
+  launchAssemble(w, 0.0, false, add_priors);
+  w.linearized = true;
+}
+
+void stageStep(W &w, double lambda) {
+  if (!w.linearized) fail(DSOPP_HIP_ERR_STATE, "call linearize first");
+  // the sweep partials and the Schur system are still resident: re-run the (cheap) assembly with the requested lambda
+  launchAssemble(w, lambda, true, true);
+  w.pair_valid = true;  // the solve kernel rebuilt the pair constants for eps + step
+  if (w.opt.optimize_idepths && w.n_schur_blocks) {
+    backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F());
+    HIP_CHECK(hipGetLastError());
+  }
+  const int K = w.K();
+  w.last_step.resize(static_cast<size_t>(K));
+  w.d_step.download(w.last_step.data(), static_cast<size_t>(K), 0, w.sr.stream);
+  w.sr.sync();
+  for (int f = 0; f < w.F(); ++f)
+    for (int a = 0; a < kBlk; ++a) w.hst.step[f][a] = -w.last_step[static_cast<size_t>(kBlk * f + a)];
+  w.last_lambda = lambda;
+}
+
+std::pair<double, double> stageAccept(W &w, bool accept) {
+  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr + 4, 0, 2 * sizeof(double), w.sr.stream));
+  if (w.n_schur_blocks) {
+    acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), accept ? 1 : 0,
+                                                                                w.d_scalars.ptr + 4);
+  }
+  acceptFramesKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F(), accept ? 1 : 0, w.d_scalars.ptr + 4);
+  HIP_CHECK(hipGetLastError());
+  double norms[2];
+  w.d_scalars.download(norms, 2, 4, w.sr.stream);
+  w.sr.sync();
+  // host mirror
+  for (int f = 0; f < w.F(); ++f)
+    for (int a = 0; a < kBlk; ++a) {
+      if (accept) w.hst.eps[f][a] += w.hst.step[f][a];
+      w.hst.step[f][a] = 0;
+    }
+  if (!accept) w.pair_valid = false;  // constants were built for eps + step
+  if (w.allreduce && accept) {
+    // idepth norms are partial sums over this rank's landmark shard; the frame part is replicated -> handled by caller
+  }
+  return {norms[0], norms[1]};
+}
+
+}  // namespace
+}  // namespace dsopp_hip
+
+// ---------------------------------------------------------------------------------------------------------------------
+// point statuses, relinearisation, covariance, marginalisation, solve
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dsopp_hip {
+namespace {
+
+Rigid poseOf(const W &w, int f) {
+  Rigid T0;
+  for (int i = 0; i < 9; ++i) T0.R[i] = w.hst.T0_R[f][i];
+  for (int i = 0; i < 3; ++i) T0.t[i] = w.hst.T0_t[f][i];
+  return rigidMul(T0, rigidExp(w.hst.eps[f]));  // tWorldAgent — local_frame.hpp:525-527
+}
+
+/** relinearizeSystem — PROB_SRC/photometric_bundle_adjustment.cpp:310-316 */
+void relinearize(W &w) {
+  downloadState(w);
+  const int f = w.F() - 1;
+  Rigid T = poseOf(w, f);
+  rigidNormalize(T);
+  for (int i = 0; i < 9; ++i) w.hst.T0_R[f][i] = T.R[i];
+  for (int i = 0; i < 3; ++i) w.hst.T0_t[f][i] = T.t[i];
+  w.hst.ab0[f][0] += w.hst.eps[f][6];
+  w.hst.ab0[f][1] += w.hst.eps[f][7];
+  for (int a = 0; a < kBlk; ++a) w.hst.eps[f][a] = 0;
+  w.state_dirty = true;
+}
+
+/** updatePointStatuses — PROB_SRC/photometric_bundle_adjustment.cpp:321-406.
+ *  Round 1: the 3rd-quartile selection runs on the host over the downloaded energies (once per solve, P*T doubles). */
+void updatePointStatuses(W &w) {
+  prepare(w);
+  downloadState(w);
+  const int F = w.F();
+  hipStream_t st = w.sr.stream;
+  struct Conn {
+    int r, t;
+    std::vector<uint8_t> status, cand;
+    std::vector<double> energy;
+  };
+  std::vector<Conn> conns;
+  std::vector<std::vector<uint8_t>> flags(static_cast<size_t>(F));
+  std::vector<std::vector<double>> idepth(static_cast<size_t>(F)), baseline(static_cast<size_t>(F));
+  for (int r = 0; r < F; ++r) {
+    HostFrame &f = *w.frames[static_cast<size_t>(r)];
+    flags[static_cast<size_t>(r)].resize(static_cast<size_t>(f.n));
+    idepth[static_cast<size_t>(r)].resize(static_cast<size_t>(f.n));
+    baseline[static_cast<size_t>(r)].resize(static_cast<size_t>(f.n));
+    f.dflags.download(flags[static_cast<size_t>(r)].data(), static_cast<size_t>(f.n), 0, st);
+    f.idepth.download(idepth[static_cast<size_t>(r)].data(), static_cast<size_t>(f.n), 0, st);
+    f.relative_baseline.download(baseline[static_cast<size_t>(r)].data(), static_cast<size_t>(f.n), 0, st);
+    for (int t = 0; t < F; ++t) {
+      if (t == r) continue;
+      HostFrame &g = *w.frames[static_cast<size_t>(t)];
+      if (g.is_marginalized) continue;
+      auto it = f.residuals.find(g.id);
+      if (it == f.residuals.end() || it->second->n == 0) continue;
+      Conn c;
+      c.r = r;
+      c.t = t;
+      c.status.resize(static_cast<size_t>(it->second->n));
+      c.cand.resize(static_cast<size_t>(it->second->n));
+      c.energy.resize(static_cast<size_t>(it->second->n));
+      it->second->status.download(c.status.data(), c.status.size(), 0, st);
+      it->second->cand.download(c.cand.data(), c.cand.size(), 0, st);
+      it->second->energy.download(c.energy.data(), c.energy.size(), 0, st);
+      conns.push_back(std::move(c));
+    }
+  }
+  w.sr.sync();
+  std::vector<double> energies;
+  for (const Conn &c : conns)
+    for (size_t i = 0; i < c.status.size(); ++i) {
+      if (flags[static_cast<size_t>(c.r)][i] & kFlagMarginalized) continue;
+      if (c.status[i] == DSOPP_HIP_STATUS_OK) energies.push_back(c.energy[i]);
+    }
+  double threshold = 0;
+  if (!energies.empty()) {
+    const size_t q = static_cast<size_t>(static_cast<double>(energies.size()) * 0.75);
+    std::nth_element(energies.begin(), energies.begin() + static_cast<long>(q), energies.end());
+    threshold = energies[q] + w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
+  }
+  std::vector<std::vector<int32_t>> inliers(static_cast<size_t>(F));
+  std::vector<std::vector<int>> valid(static_cast<size_t>(F));
+  for (int r = 0; r < F; ++r) {
+    inliers[static_cast<size_t>(r)].assign(static_cast<size_t>(w.frames[static_cast<size_t>(r)]->n), 0);
+    valid[static_cast<size_t>(r)].assign(static_cast<size_t>(w.frames[static_cast<size_t>(r)]->n), 0);
+  }
+  for (Conn &c : conns) {
+    const Rigid Tr = poseOf(w, c.r), Tt = poseOf(w, c.t);
+    const double dx = Tr.t[0] - Tt.t[0], dy = Tr.t[1] - Tt.t[1], dz = Tr.t[2] - Tt.t[2];
+    const double distance = std::sqrt(dx * dx + dy * dy + dz * dz);
+    for (size_t i = 0; i < c.status.size(); ++i) {
+      if (flags[static_cast<size_t>(c.r)][i] & kFlagMarginalized) continue;
+      if (c.energy[i] > threshold) {  // residual = {kOutlier}: fresh ResidualPoint, energy 0
+        c.status[i] = DSOPP_HIP_STATUS_OUTLIER;
+        c.cand[i] = DSOPP_HIP_STATUS_OUTLIER;
+        c.energy[i] = 0;
+      }
+      if (c.status[i] == DSOPP_HIP_STATUS_OK) {
+        double &bl = baseline[static_cast<size_t>(c.r)][i];
+        bl = std::max(bl, idepth[static_cast<size_t>(c.r)][i] * distance);
+        valid[static_cast<size_t>(c.r)][i]++;
+        inliers[static_cast<size_t>(c.r)][i]++;
+      }
+    }
+    ResidualTable &rt = *w.frames[static_cast<size_t>(c.r)]->residuals[w.frames[static_cast<size_t>(c.t)]->id];
+    rt.status.upload(c.status.data(), c.status.size(), 0, st);
+    rt.cand.upload(c.cand.data(), c.cand.size(), 0, st);
+    rt.energy.upload(c.energy.data(), c.energy.size(), 0, st);
+  }
+  for (int r = 0; r < F; ++r) {
+    HostFrame &f = *w.frames[static_cast<size_t>(r)];
+    bool any_conn = false;
+    for (const Conn &c : conns) any_conn = any_conn || c.r == r;
+    for (int i = 0; i < f.n; ++i) {
+      uint8_t &fl = flags[static_cast<size_t>(r)][static_cast<size_t>(i)];
+      if (fl & kFlagMarginalized) continue;
+      if (valid[static_cast<size_t>(r)][static_cast<size_t>(i)] < 1) fl |= kFlagOutlier;  // minimum_valid_reprojections_num = 1
+    }
+    (void)any_conn;
+    f.dflags.upload(flags[static_cast<size_t>(r)].data(), static_cast<size_t>(f.n), 0, st);
+    f.relative_baseline.upload(baseline[static_cast<size_t>(r)].data(), static_cast<size_t>(f.n), 0, st);
+    // number_of_inlier_residuals is only reset for non-marginalised landmarks; marginalised ones keep their value
+    std::vector<int32_t> cur(static_cast<size_t>(f.n));
+    f.n_inliers.download(cur.data(), cur.size(), 0, st);
+    w.sr.sync();
+    for (int i = 0; i < f.n; ++i)
+      if (!(flags[static_cast<size_t>(r)][static_cast<size_t>(i)] & kFlagMarginalized)) cur[static_cast<size_t>(i)] = inliers[static_cast<size_t>(r)][static_cast<size_t>(i)];
+    f.n_inliers.upload(cur.data(), cur.size(), 0, st);
+    w.sr.sync();
+    f.flags = flags[static_cast<size_t>(r)];
+  }
+  w.sr.sync();
+}
+
+/** covarianceMatrixPosePose + covarianceMatricesOfRelativePoses — problem.hpp:204-242,
+ *  PBA_INT/covariance_matrices_of_relative_poses.hpp:23-62, se3_motion.hpp:151-158 */
+void estimateUncertainty(W &w) {
+  prepare(w);
+  if (w.fej()) firstEstimate(w);
+  w.begun = true;
+  stageLinearize(w, /*huber=*/false, false, true);
+  const int K = w.K(), F = w.F();
+  std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K);
+  w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
+  w.d_Hsc.download(Hsc.data(), Hsc.size(), 0, w.sr.stream);
+  w.sr.sync();
+  hostla::Mat full(static_cast<size_t>(K) * K);
+  for (size_t i = 0; i < full.size(); ++i) full[i] = Hpp[i] - Hsc[i] + w.Hm[i];
+  const hostla::Mat cov = hostla::pinvDropSmallest(full, K, w.opt.optimize_idepths ? 1 : 0);
+  downloadState(w);
+  for (int r = 0; r < F; ++r)
+    for (int t = 0; t < F; ++t) {
+      if (r == t) continue;
+      double adj[36], s11[36], s22[36], s12[36];
+      rigidAdj(rigidMul(rigidInverse(poseOf(w, t)), poseOf(w, r)), adj);
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          s11[6 * i + j] = cov[static_cast<size_t>(8 * r + i) * K + 8 * r + j];
+          s22[6 * i + j] = cov[static_cast<size_t>(8 * t + i) * K + 8 * t + j];
+          s12[6 * i + j] = cov[static_cast<size_t>(8 * r + i) * K + 8 * t + j];
+        }
+      double a11[36], a12[36];
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double x = 0, y = 0;
+          for (int k = 0; k < 6; ++k) {
+            x += adj[6 * i + k] * s11[6 * k + j];
+            y += adj[6 * i + k] * s12[6 * k + j];
+          }
+          a11[6 * i + j] = x;
+          a12[6 * i + j] = y;
+        }
+      std::array<double, 36> out;
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          double x = 0, y = 0;
+          for (int k = 0; k < 6; ++k) {
+            x += a11[6 * i + k] * adj[6 * j + k];
+            y += s12[6 * k + i] * adj[6 * j + k];
+          }
+          out[static_cast<size_t>(6 * i + j)] = x - y - a12[6 * i + j] + s22[6 * i + j];
+        }
+      w.frames[static_cast<size_t>(r)]->covariance[w.frames[static_cast<size_t>(t)]->id] = out;
+    }
+}
+
+/** updateMarginalizedLinearSystem — problem.hpp:146-203, called from pushFrame before the new frame is appended */
+void foldMarginalized(W &w) {
+  prepare(w);
+  firstEstimate(w);  // pushFrame calls firstEstimateJacobians unconditionally (eigen_photometric_bundle_adjustment.cpp:123)
+  w.begun = true;
+  // evaluateJacobians<..., true, true, true> then changeResidualStatuses (accept), :124-126
+  launchSweep(w, true, true, /*for_marg=*/true);
+  {
+    HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr + 4, 0, 2 * sizeof(double), w.sr.stream));
+    // statuses <- candidates without touching idepths: accept with zero steps
+    if (w.n_schur_blocks)
+      acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), 1, w.d_scalars.ptr + 4);
+    HIP_CHECK(hipGetLastError());
+  }
+  launchSchur(w, true);
+  launchAssemble(w, 0.0, false, /*add_priors=*/false);
+  energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr);
+  HIP_CHECK(hipGetLastError());
+  const int K = w.K(), F = w.F();
+  std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K), bpp(static_cast<size_t>(K)), bsc(static_cast<size_t>(K));
+  double scal[2];
+  w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
+  w.d_Hsc.download(Hsc.data(), Hsc.size(), 0, w.sr.stream);
+  w.d_bpp.download(bpp.data(), bpp.size(), 0, w.sr.stream);
+  w.d_bsc.download(bsc.data(), bsc.size(), 0, w.sr.stream);
+  w.d_scalars.download(scal, 2, 0, w.sr.stream);
+  w.sr.sync();
+  downloadState(w);
+  std::vector<double> state(static_cast<size_t>(K));
+  for (int f = 0; f < F; ++f)
+    for (int a = 0; a < kBlk; ++a) state[static_cast<size_t>(kBlk * f + a)] = w.hst.eps[f][a];
+  std::vector<double> Hp(static_cast<size_t>(K) * K), bp(static_cast<size_t>(K));
+  for (size_t i = 0; i < Hp.size(); ++i) Hp[i] = Hpp[i] - Hsc[i];
+  for (int i = 0; i < K; ++i) bp[static_cast<size_t>(i)] = bpp[static_cast<size_t>(i)] - bsc[static_cast<size_t>(i)];
+  std::vector<double> Hs(static_cast<size_t>(K), 0.0);
+  for (int i = 0; i < K; ++i)
+    for (int j = 0; j < K; ++j) Hs[static_cast<size_t>(i)] += Hp[static_cast<size_t>(i) * K + j] * state[static_cast<size_t>(j)];
+  double sHs = 0, sb = 0;
+  for (int i = 0; i < K; ++i) {
+    sHs += state[static_cast<size_t>(i)] * Hs[static_cast<size_t>(i)];
+    sb += state[static_cast<size_t>(i)] * bp[static_cast<size_t>(i)];
+  }
+  w.energy_marginalized += scal[0] + sHs - sb;  // eq. 8.15 of the DSO paper, problem.hpp:168-170
+  for (int i = 0; i < K; ++i) bp[static_cast<size_t>(i)] -= Hs[static_cast<size_t>(i)];
+  for (size_t i = 0; i < Hp.size(); ++i) w.Hm[i] += Hp[i];
+  for (int i = 0; i < K; ++i) w.bm[static_cast<size_t>(i)] += bp[static_cast<size_t>(i)];
+  // landmark.to_marginalize = false for all landmarks (:175-177)
+  for (auto &fp : w.frames) {
+    HostFrame &f = *fp;
+    bool changed = false;
+    for (auto &fl : f.flags)
+      if (fl & kFlagToMarginalize) {
+        fl &= static_cast<uint8_t>(~kFlagToMarginalize);
+        changed = true;
+      }
+    if (changed) {
+      // device flags may carry ill_conditioned bits set by the Schur kernel: merge
+      std::vector<uint8_t> dev(static_cast<size_t>(f.n));
+      f.dflags.download(dev.data(), dev.size(), 0, w.sr.stream);
+      w.sr.sync();
+      for (int i = 0; i < f.n; ++i) dev[static_cast<size_t>(i)] &= static_cast<uint8_t>(~kFlagToMarginalize);
+      f.dflags.upload(dev.data(), dev.size(), 0, w.sr.stream);
+      w.sr.sync();
+    }
+  }
+  std::vector<int> marginalized_part;
+  for (int f = 0; f < F; ++f)
+    if (w.frames[static_cast<size_t>(f)]->to_marginalize)
+      for (int p = 0; p < kBlk; ++p) marginalized_part.push_back(kBlk * f + p);
+  w.marg_dirty = true;
+  if (marginalized_part.empty()) return;
+  // prior of the frames being marginalised (evaluateLinearSystemPrior with for_marginalized = true, problem.hpp:193-197)
+  std::vector<double> Hprior(static_cast<size_t>(K) * K, 0.0), bprior(static_cast<size_t>(K), 0.0);
+  for (int f = 0; f < F; ++f) {
+    HostFrame &hf = *w.frames[static_cast<size_t>(f)];
+    if (!hf.to_marginalize) continue;
+    if (hf.fixed) {
+      for (int a = 0; a < kBlk; ++a) {
+        Hprior[static_cast<size_t>(kBlk * f + a) * K + kBlk * f + a] += w.opt.fixed_state_regularizer;
+        bprior[static_cast<size_t>(kBlk * f + a)] += w.opt.fixed_state_regularizer * w.hst.eps[f][a];
+      }
+    } else {
+      for (int a = 0; a < 2; ++a) {
+        const double ab = w.hst.ab0[f][a] + w.hst.eps[f][6 + a];
+        Hprior[static_cast<size_t>(kBlk * f + 6 + a) * K + kBlk * f + 6 + a] += w.opt.affine_brightness_regularizer[a];
+        bprior[static_cast<size_t>(kBlk * f + 6 + a)] += w.opt.affine_brightness_regularizer[a] * ab;
+      }
+    }
+  }
+  for (int i = 0; i < K; ++i) {
+    double s = 0;
+    for (int j = 0; j < K; ++j) s += Hprior[static_cast<size_t>(i) * K + j] * state[static_cast<size_t>(j)];
+    bprior[static_cast<size_t>(i)] -= s;
+  }
+  for (size_t i = 0; i < Hprior.size(); ++i) w.Hm[i] += Hprior[i];
+  for (int i = 0; i < K; ++i) w.bm[static_cast<size_t>(i)] += bprior[static_cast<size_t>(i)];
+  hostla::reduceSystem(w.Hm, w.bm, K, marginalized_part);
+  // erase the marginalised frames (:201-202) — state rows shift down
+  WindowState ns = w.hst;
+  std::vector<std::unique_ptr<HostFrame>> kept;
+  int dst = 0;
+  for (int f = 0; f < F; ++f) {
+    if (w.frames[static_cast<size_t>(f)]->to_marginalize) continue;
+    std::memcpy(ns.T0_R[dst], w.hst.T0_R[f], sizeof(ns.T0_R[dst]));
+    std::memcpy(ns.T0_t[dst], w.hst.T0_t[f], sizeof(ns.T0_t[dst]));
+    std::memcpy(ns.ab0[dst], w.hst.ab0[f], sizeof(ns.ab0[dst]));
+    std::memcpy(ns.eps[dst], w.hst.eps[f], sizeof(ns.eps[dst]));
+    std::memcpy(ns.step[dst], w.hst.step[f], sizeof(ns.step[dst]));
+    kept.push_back(std::move(w.frames[static_cast<size_t>(f)]));
+    ++dst;
+  }
+  w.hst = ns;
+  w.frames = std::move(kept);
+  w.marg_size = kBlk * w.F();
+  w.state_dirty = true;
+  w.topology_dirty = true;
+}
+
+/** levenberg_marquardt_algorithm::solve (levenberg_marquardt_algorithm.hpp:77-128) driving the device stages.
+ *  Round 1: control flow on the host (one small D2H per energy evaluation). */
+void lmSolve(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+  const double lambda0 = 1.0 / w.opt.initial_trust_region_radius;
+  const size_t max_it = static_cast<size_t>(w.opt.max_iterations), min_it = 3;
+  const bool force_accept = w.opt.force_accept != 0;
+  double lambda = lambda0;
+  auto e0 = stageEnergy(w);
+  double energy = e0.first;
+  int n_valid = e0.second;
+  bool converged = false, linear_system_valid = false;
+  iterations = 0;
+  bool early_return = false;
+  for (size_t it = 0; it < max_it && !converged && n_valid > 0; ++it) {
+    ++iterations;
+    if (!linear_system_valid) stageLinearize(w);
+    stageStep(w, lambda);
+    auto en = stageEnergy(w);
+    if (en.second == 0) {
+      stageAccept(w, false);
+      break;
+    }
+    converged |= std::abs(energy - en.first) / energy < w.opt.function_tolerance;
+    if (en.first < energy || (force_accept && it < min_it)) {
+      auto nr = stageAccept(w, true);
+      converged |= nr.second < w.opt.parameter_tolerance * (nr.first + w.opt.parameter_tolerance);
+      energy = en.first;
+      n_valid = en.second;
+      lambda /= 1.0;  // decrease_on_accept = 1 (eigen_photometric_bundle_adjustment.cpp:74)
+      linear_system_valid = false;
+    } else {
+      stageAccept(w, false);
+      if (force_accept) {
+        stageEnergy(w);
+        early_return = true;
+        break;
+      }
+      lambda *= 1.0;
+      linear_system_valid = true;
+    }
+  }
+  if (!early_return) stageEnergy(w);
+  energy_out = energy;
+  n_valid_out = n_valid;
+}
+
+}  // namespace
+}  // namespace dsopp_hip
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+void dsopp_hip_default_pba_options(dsopp_hip_options *o) {
+  o->max_iterations = 7;
+  o->initial_trust_region_radius = 1e5;
+  o->function_tolerance = 1e-8;
+  o->parameter_tolerance = 1e-8;
+  o->affine_brightness_regularizer[0] = 1e12;
+  o->affine_brightness_regularizer[1] = 1e8;
+  o->fixed_state_regularizer = 1e16;
+  o->sigma_huber_loss = 20;
+  o->estimate_uncertainty = 1;
+  o->force_accept = 1;
+  o->first_estimate_jacobians = 1;
+  o->optimize_idepths = 1;
+  o->dtype = DSOPP_HIP_F64;
+}
+
+void dsopp_hip_default_align_options(dsopp_hip_options *o) {
+  dsopp_hip_default_pba_options(o);
+  o->max_iterations = 50;
+  o->initial_trust_region_radius = 1e2;
+  o->function_tolerance = 1e-5;
+  o->parameter_tolerance = 1e-5;
+  o->force_accept = 0;
+}
+
+int dsopp_hip_window_create(const dsopp_hip_options *options, int device, void *stream, dsopp_hip_window **out) {
+  return guarded([&] {
+    if (!options || !out) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    auto w = std::make_unique<dsopp_hip_window>();
+    w->opt = *options;
+    if (w->opt.dtype != DSOPP_HIP_F64 && w->opt.dtype != DSOPP_HIP_F32) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad dtype");
+    w->sr.init(device, stream);
+    std::memset(&w->hst, 0, sizeof(w->hst));
+    HIP_CHECK(hipEventCreate(&w->ev0));
+    HIP_CHECK(hipEventCreate(&w->ev1));
+    *out = w.release();
+  });
+}
+
+void dsopp_hip_window_destroy(dsopp_hip_window *w) {
+  if (!w) return;
+  (void)hipSetDevice(w->sr.device);
+  if (w->sr.stream) (void)hipStreamSynchronize(w->sr.stream);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  w->frames.clear();
+  StreamRef sr = w->sr;
+  delete w;
+  sr.destroy();
+}
+
+int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t timestamp, const dsopp_hip_pyramid *pyramid, int level,
+                                const double intrinsics[4], const double T_world_agent[7], double exposure_time,
+                                const double affine_brightness[2], int fixed, int is_marginalized) {
+  return guarded([&] {
+    if (!w || !pyramid || !intrinsics || !T_world_agent || !affine_brightness) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (level < 0 || level >= pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
+    if (pyramid->dtype != w->opt.dtype) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid dtype differs from the window's");
+    if (pyramid->sr.device != w->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid lives on another device");
+    if (!w->frames.empty() && !(w->frames.back()->timestamp < timestamp))
+      fail(DSOPP_HIP_ERR_ORDER, "frames must be pushed in ascending order of time");
+    if (w->slotOf(frame_id) >= 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "frame %d already in the window", frame_id);
+    w->sr.use();
+    if (w->frames.size() > 1) foldMarginalized(*w);
+    if (w->F() >= kMaxFrames) fail(DSOPP_HIP_ERR_CAPACITY, "window holds %d frames already", kMaxFrames);
+    downloadState(*w);
+    auto f = std::make_unique<HostFrame>();
+    f->id = frame_id;
+    f->timestamp = timestamp;
+    f->pyramid = pyramid;
+    f->level = level;
+    for (int i = 0; i < 4; ++i) f->intr[i] = intrinsics[i];
+    f->exposure = exposure_time;
+    f->fixed = fixed != 0;
+    f->is_marginalized = is_marginalized != 0;
+    const int s = w->F();
+    const Rigid T = rigidFromParams(T_world_agent);
+    for (int i = 0; i < 9; ++i) w->hst.T0_R[s][i] = T.R[i];
+    for (int i = 0; i < 3; ++i) w->hst.T0_t[s][i] = T.t[i];
+    w->hst.ab0[s][0] = affine_brightness[0];
+    w->hst.ab0[s][1] = affine_brightness[1];
+    for (int a = 0; a < kBlk; ++a) w->hst.eps[s][a] = w->hst.step[s][a] = 0;
+    w->frames.push_back(std::move(f));
+    // system_marginalized_.resize(new_size) keeping old entries, new rows/cols zero (:134-140)
+    const int Kn = w->K(), Ko = w->marg_size;
+    std::vector<double> Hn(static_cast<size_t>(Kn) * Kn, 0.0), bn(static_cast<size_t>(Kn), 0.0);
+    for (int i = 0; i < std::min(Ko, Kn); ++i) {
+      bn[static_cast<size_t>(i)] = w->bm[static_cast<size_t>(i)];
+      for (int j = 0; j < std::min(Ko, Kn); ++j) Hn[static_cast<size_t>(i) * Kn + j] = w->Hm[static_cast<size_t>(i) * Ko + j];
+    }
+    w->Hm.swap(Hn);
+    w->bm.swap(bn);
+    w->marg_size = Kn;
+    w->marg_dirty = true;
+    w->state_dirty = true;
+    w->topology_dirty = true;
+    w->begun = false;
+  });
+}
+
+int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
+                                   const double *patch, const uint8_t *flags) {
+  return guarded([&] {
+    if (!w || n_total < 0 || (n_total && (!uv || !idepth || !patch || !flags))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    w->sr.use();
+    HostFrame &f = w->frameById(frame_id);
+    if (n_total < f.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "landmarks can only be appended (%d < %d)", n_total, f.n);
+    hipStream_t st = w->sr.stream;
+    ensureLandmarkCapacity(*w, f, n_total);
+    const int old = f.n;
+    // existing landmarks: only flags move (LocalFrame::update, local_frame.hpp:492-497); device flags may carry the
+    // ill_conditioned bit which is preserved
+    std::vector<uint8_t> dev(static_cast<size_t>(old));
+    if (old) {
+      f.dflags.download(dev.data(), dev.size(), 0, st);
+      w->sr.sync();
+    }
+    f.flags.resize(static_cast<size_t>(n_total));
+    for (int i = 0; i < old; ++i) {
+      const bool was_marg = dev[static_cast<size_t>(i)] & kFlagMarginalized;
+      const bool marg = flags[i] & 1, outl = flags[i] & 2;
+      uint8_t v = static_cast<uint8_t>(dev[static_cast<size_t>(i)] & (kFlagOutlier | kFlagIllConditioned));
+      if (marg) v |= kFlagMarginalized;
+      if (!was_marg && marg && !outl) v |= kFlagToMarginalize;
+      f.flags[static_cast<size_t>(i)] = v;
+    }
+    for (int i = old; i < n_total; ++i)
+      f.flags[static_cast<size_t>(i)] = static_cast<uint8_t>(((flags[i] & 1) ? kFlagMarginalized : 0) | ((flags[i] & 2) ? kFlagOutlier : 0));
+    f.dflags.upload(f.flags.data(), static_cast<size_t>(n_total), 0, st);
+    const size_t add = static_cast<size_t>(n_total - old);
+    if (add) {
+      f.uv.upload(uv + 2 * old, 2 * add, 2 * static_cast<size_t>(old), st);
+      f.idepth.upload(idepth + old, add, static_cast<size_t>(old), st);
+      f.patch.upload(patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old), st);
+      HIP_CHECK(hipMemsetAsync(f.idepth_step.ptr + old, 0, add * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(f.idepth_fej.ptr + old, 0, add * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(f.inv_hdd.ptr + old, 0, add * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(f.b_d.ptr + old, 0, add * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(f.relative_baseline.ptr + old, 0, add * sizeof(double), st));
+      HIP_CHECK(hipMemsetAsync(f.n_inliers.ptr + old, 0, add * sizeof(int32_t), st));
+    }
+    w->sr.sync();
+    f.n = n_total;
+    w->topology_dirty = true;
+    w->begun = false;
+  });
+}
+
+int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses) {
+  return guarded([&] {
+    if (!w || n < 0 || (n && !statuses)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    w->sr.use();
+    HostFrame &f = w->frameById(reference_id);
+    if (n > f.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection has %d entries, frame %d only %d landmarks", n, reference_id, f.n);
+    auto &slot = f.residuals[target_id];
+    if (!slot) slot = std::make_unique<ResidualTable>();
+    ResidualTable &rt = *slot;
+    hipStream_t st = w->sr.stream;
+    const size_t cap = static_cast<size_t>(std::max(f.cap, 1));
+    const size_t keep = static_cast<size_t>(rt.n);
+    rt.status.reserve(cap, keep, st);
+    rt.cand.reserve(cap, keep, st);
+    rt.fej_valid.reserve(cap, keep, st);
+    rt.energy.reserve(cap, keep, st);
+    if (n > rt.n) {
+      const size_t add = static_cast<size_t>(n - rt.n);
+      rt.status.upload(statuses + rt.n, add, keep, st);
+      rt.cand.upload(statuses + rt.n, add, keep, st);
+      HIP_CHECK(hipMemsetAsync(rt.fej_valid.ptr + keep, 0, add, st));
+      HIP_CHECK(hipMemsetAsync(rt.energy.ptr + keep, 0, add * sizeof(double), st));
+      w->sr.sync();
+      rt.n = n;
+    }
+    w->topology_dirty = true;
+    w->begun = false;
+  });
+}
+
+int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_id) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    HostFrame &f = w->frameById(frame_id);
+    f.to_marginalize = !f.is_marginalized;
+    f.is_marginalized = true;
+    w->topology_dirty = true;
+  });
+}
+
+int dsopp_hip_window_num_frames(dsopp_hip_window *w, int32_t *n) {
+  return guarded([&] {
+    if (!w || !n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *n = w->F();
+  });
+}
+
+int dsopp_hip_window_begin(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    stageBegin(*w);
+  });
+}
+
+int dsopp_hip_window_calculate_energy(dsopp_hip_window *w, double *energy, int32_t *n_valid) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    auto r = stageEnergy(*w);
+    if (energy) *energy = r.first;
+    if (n_valid) *n_valid = r.second;
+  });
+}
+
+int dsopp_hip_window_linearize(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    stageLinearize(*w);
+    w->sr.sync();
+  });
+}
+
+int dsopp_hip_window_get_system(dsopp_hip_window *w, double *H_pp, double *b_pp, double *H_schur, double *b_schur) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (!w->linearized) fail(DSOPP_HIP_ERR_STATE, "no linearised system available");
+    w->sr.use();
+    const size_t K = static_cast<size_t>(w->K());
+    hipStream_t st = w->sr.stream;
+    if (H_pp) w->d_Hpp.download(H_pp, K * K, 0, st);
+    if (b_pp) w->d_bpp.download(b_pp, K, 0, st);
+    if (H_schur) w->d_Hsc.download(H_schur, K * K, 0, st);
+    if (b_schur) w->d_bsc.download(b_schur, K, 0, st);
+    w->sr.sync();
+  });
+}
+
+int dsopp_hip_window_calculate_step(dsopp_hip_window *w, double lambda, double *step) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    stageStep(*w, lambda);
+    if (step) std::memcpy(step, w->last_step.data(), w->last_step.size() * sizeof(double));
+  });
+}
+
+int dsopp_hip_window_accept_step(dsopp_hip_window *w, double *state_sq, double *step_sq) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    auto r = stageAccept(*w, true);
+    if (state_sq) *state_sq = r.first;
+    if (step_sq) *step_sq = r.second;
+  });
+}
+
+int dsopp_hip_window_reject_step(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    stageAccept(*w, false);
+  });
+}
+
+int dsopp_hip_window_update_point_statuses(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    updatePointStatuses(*w);
+  });
+}
+
+int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (w->F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
+    w->sr.use();
+    prepare(*w);
+    HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
+    stageBegin(*w);
+    double e = 0;
+    int it = 0, nv = 0;
+    lmSolve(*w, e, it, nv);
+    HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
+    HIP_CHECK(hipEventSynchronize(w->ev1));
+    HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
+    relinearize(*w);
+    if (w->opt.estimate_uncertainty) estimateUncertainty(*w);
+    updatePointStatuses(*w);
+    w->begun = false;
+    w->linearized = true;  // the last linearised system stays readable through get_system
+    if (energy) *energy = e;
+    if (iterations) *iterations = it;
+    if (n_valid) *n_valid = nv;
+  });
+}
+
+int dsopp_hip_window_get_frame_state(dsopp_hip_window *w, int32_t frame_id, double T0[7], double ab0[2], double eps[8], double step[8]) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    const int s = w->slotOf(frame_id);
+    if (s < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", frame_id);
+    downloadState(*w);
+    if (T0) {
+      Rigid T;
+      for (int i = 0; i < 9; ++i) T.R[i] = w->hst.T0_R[s][i];
+      for (int i = 0; i < 3; ++i) T.t[i] = w->hst.T0_t[s][i];
+      rigidToParams(T, T0);
+    }
+    if (ab0) {
+      ab0[0] = w->hst.ab0[s][0];
+      ab0[1] = w->hst.ab0[s][1];
+    }
+    if (eps) std::memcpy(eps, w->hst.eps[s], sizeof(double) * kBlk);
+    if (step) std::memcpy(step, w->hst.step[s], sizeof(double) * kBlk);
+  });
+}
+
+int dsopp_hip_window_get_pose(dsopp_hip_window *w, int32_t frame_id, double T_world_agent[7], double affine_brightness[2]) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    const int s = w->slotOf(frame_id);
+    if (s < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", frame_id);
+    downloadState(*w);
+    if (T_world_agent) rigidToParams(poseOf(*w, s), T_world_agent);
+    if (affine_brightness) {
+      affine_brightness[0] = w->hst.ab0[s][0] + w->hst.eps[s][6];
+      affine_brightness[1] = w->hst.ab0[s][1] + w->hst.eps[s][7];
+    }
+  });
+}
+
+int dsopp_hip_window_num_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t *n) {
+  return guarded([&] {
+    if (!w || !n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *n = w->frameById(frame_id).n;
+  });
+}
+
+int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double *idepth, double *idepth_step, double *inv_hessian_idepth,
+                                   double *b_idepth, double *relative_baseline, int32_t *n_inliers, uint8_t *flags_out, double *hpib) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    HostFrame &f = w->frameById(frame_id);
+    hipStream_t st = w->sr.stream;
+    const size_t n = static_cast<size_t>(f.n);
+    if (idepth) f.idepth.download(idepth, n, 0, st);
+    if (idepth_step) f.idepth_step.download(idepth_step, n, 0, st);
+    if (inv_hessian_idepth) f.inv_hdd.download(inv_hessian_idepth, n, 0, st);
+    if (b_idepth) f.b_d.download(b_idepth, n, 0, st);
+    if (relative_baseline) f.relative_baseline.download(relative_baseline, n, 0, st);
+    if (n_inliers) f.n_inliers.download(n_inliers, n, 0, st);
+    if (flags_out) f.dflags.download(flags_out, n, 0, st);
+    w->sr.sync();
+    if (hpib && n) {
+      const int F = w->F(), K = w->K();
+      std::vector<double> blk(static_cast<size_t>(f.cap) * kUblk);
+      for (int t = 0; t < F; ++t) {
+        f.ublk.download(blk.data(), n * kUblk, static_cast<size_t>(t) * f.cap * kUblk, st);
+        w->sr.sync();
+        for (size_t i = 0; i < n; ++i)
+          for (int a = 0; a < kBlk; ++a) hpib[i * K + static_cast<size_t>(kBlk * t + a)] = blk[i * kUblk + static_cast<size_t>(a)];
+      }
+    }
+  });
+}
+
+int dsopp_hip_window_get_residuals(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, uint8_t *status,
+                                   uint8_t *candidate, double *energy) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    HostFrame &f = w->frameById(reference_id);
+    auto it = f.residuals.find(target_id);
+    if (it == f.residuals.end()) fail(DSOPP_HIP_ERR_NOT_FOUND, "no connection %d -> %d", reference_id, target_id);
+    ResidualTable &rt = *it->second;
+    if (n > rt.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection holds %d residuals, %d requested", rt.n, n);
+    hipStream_t st = w->sr.stream;
+    if (status) rt.status.download(status, static_cast<size_t>(n), 0, st);
+    if (candidate) rt.cand.download(candidate, static_cast<size_t>(n), 0, st);
+    if (energy) rt.energy.download(energy, static_cast<size_t>(n), 0, st);
+    w->sr.sync();
+  });
+}
+
+int dsopp_hip_window_get_marginalized(dsopp_hip_window *w, double *H, double *b, double *energy, int32_t *size) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (H) std::memcpy(H, w->Hm.data(), w->Hm.size() * sizeof(double));
+    if (b) std::memcpy(b, w->bm.data(), w->bm.size() * sizeof(double));
+    if (energy) *energy = w->energy_marginalized;
+    if (size) *size = w->marg_size;
+  });
+}
+
+int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, double cov[36]) {
+  return guarded([&] {
+    if (!w || !cov) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    HostFrame &f = w->frameById(reference_id);
+    auto it = f.covariance.find(target_id);
+    if (it == f.covariance.end()) fail(DSOPP_HIP_ERR_NOT_FOUND, "no covariance %d -> %d", reference_id, target_id);
+    std::memcpy(cov, it->second.data(), 36 * sizeof(double));
+  });
+}
+
+int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->allreduce = fn;
+    w->allreduce_user = user;
+  });
+}
+
+int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {
+  return guarded([&] {
+    if (!w || !ms) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *ms = w->last_solve_ms;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// Device-side data model of the sliding window (DESIGN.md §Data layout in HBM).
+#pragma once
+#include <cstdint>
+
+#include "pyramid.hpp"
+#include "se3_math.hpp"
+
+namespace dsopp_hip {
+
+constexpr int kMaxFrames = DSOPP_HIP_MAX_FRAMES;
+constexpr int kBlk = DSOPP_HIP_BLOCK_SIZE;  // 8 = 6 pose + 2 affine
+constexpr int kPat = DSOPP_HIP_PATTERN_SIZE;
+constexpr int kUblk = 10;                   // per (landmark, slot): u[8], hdd, bd
+constexpr int kPartial = 48;                // per sweep block: G (36 upper) + q (8) + energy + n_valid + pad
+constexpr int kSweepThreads = 128;
+
+// landmark flag bits (LocalFrame::Landmark booleans, PBA_INT/local_frame.hpp:276-293)
+constexpr uint8_t kFlagMarginalized = 1, kFlagOutlier = 2, kFlagToMarginalize = 4, kFlagIllConditioned = 8;
+
+/** per-frame topology + landmark SoA + residual tables; uploaded by the host whenever it changes.
+ *  Replaces LocalFrame (PBA_INT/local_frame.hpp:232-584) minus the materialised ResidualPoint Jacobians:
+ *  of ResidualPoint's 259 scalars only status, candidate status, energy and the FEJ validity bit are kept. */
+struct FrameDev {
+  const void *texels;  // Texel<S>* of the level this frame was pushed with
+  int width, height;
+  double fx, fy, cx, cy;
+  double exposure;
+  int fixed, is_marginalized, to_marginalize;
+  int n;    // landmarks
+  int cap;  // landmark capacity (stride of the per-slot planes of ublk)
+  double *uv, *idepth, *idepth_step, *idepth_fej, *patch;
+  double *inv_hdd, *b_d, *relative_baseline;
+  int32_t *n_inliers;
+  uint8_t *flags;
+  double *ublk;  // [kMaxFrames][cap][kUblk]: slot t != r: {-u_pt (= h_p block t), hdd_pt, bd_pt}; slot r: {h_p block r, -, -}
+  uint8_t *status[kMaxFrames], *cand[kMaxFrames], *fej_valid[kMaxFrames];  // by target slot; nullptr = no connection
+  double *energy[kMaxFrames];
+  int n_res[kMaxFrames];
+};
+
+/** dynamic state of the window, lives in HBM and is advanced by the kernels */
+struct WindowState {
+  double T0_R[kMaxFrames][9];
+  double T0_t[kMaxFrames][3];
+  double ab0[kMaxFrames][2];
+  double eps[kMaxFrames][kBlk];
+  double step[kMaxFrames][kBlk];
+};
+
+/** constants of one ordered frame pair (reference r -> target t), rebuilt whenever the state moves */
+struct PairConst {
+  double M[12];    // current reproject_ = K_t [R|t] Kinv_r at eps+step   (camera_reproject.hpp:256)
+  double U[12];    // transform_unproject_ = [R|t] Kinv_r used for the Jacobians: linearisation point when FEJ (:258)
+  double tl[3];    // translation of the transform behind U (:259)
+  double Adj[36];  // rightLogTransformer: Adj(T_tr0) when FEJ else Adj(T_tr) (evaluate_jacobians.hpp:62-64)
+  double fxt, fyt, cxt, cyt;
+  double s;        // current brightness_change_scale (evaluate_jacobians.hpp:56-57)
+  double s0;       // residual.brightness_change_scale cached by firstEstimateJacobians_ (== s when not FEJ)
+  double sigma_r;  // scale behind landmark.corrected_intensities: the LAST connected target's s0 (first_estimate_jacobians.hpp:57-62)
+  double b_t, b_r; // current affine offsets
+  double b_r0;     // reference offset at the linearisation point (== b_r when not FEJ)
+  int valid;       // connection exists
+  int pad;
+};
+
+/** one thread block of a sweep = a chunk of landmarks of one ordered pair */
+struct SweepBlock {
+  int r, t;    // frame slots
+  int offset;  // first landmark
+  int pad;
+};
+
+/** one thread block of the Schur kernel = a chunk of landmarks of one frame */
+struct SchurBlock {
+  int r;
+  int offset;
+};
+
+struct SolveParams {
+  double lambda;
+  double affine_reg[2];
+  double fixed_reg;
+  int F;
+  int n_sweep_blocks;
+  int use_marginal;
+};
+
+}  // namespace dsopp_hip

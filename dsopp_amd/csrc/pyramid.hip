@@ -1,0 +1,316 @@
+// Image pyramid kernels (hot loop G of SURVEY.md §3.3 / §8 a20) and the dsopp_hip_pyramid_* entry points.
+//
+// Replaces PixelDataFrame's constructor chain (src/features/src/pixel_data_frame.cpp:12-31):
+//   level 0  = LUT[u8] * vmax / (vignette + 1)           photometrically_corrected_image.cpp:9-29
+//   level l  = 0.25 * sum of the 2x2 block of level l-1   downscale_image.hpp:16-33 (from the scalar plane)
+//   texel    = (I, 0.5*(I[x+1]-I[x-1]), 0.5*(I[y+1]-I[y-1])), one-sided (x1.0) at the borders
+//                                                          calculate_pixelinfo.cpp:340-374
+// One pure streaming kernel per level: every output texel needs its 4-neighbourhood of the level's scalar plane, which
+// each thread regenerates from the parent plane (u8 + LUT at level 0, 2x2 means above) — reads are coalesced rows that
+// hit L2, writes are one full 16/32-byte texel per lane.  HBM-bound by construction: ~(1 + 4*sizeof(S)) bytes per pixel.
+#include "pyramid.hpp"
+
+namespace dsopp_hip {
+
+std::string &lastError() {
+  static thread_local std::string e;
+  return e;
+}
+
+namespace {
+
+constexpr int kTileX = 64, kTileY = 4;
+
+template <typename S>
+__device__ __forceinline__ S level0Value(const uint8_t *__restrict__ img, const uint8_t *__restrict__ vig, const double *__restrict__ lut,
+                                         double vmax, int W, int x, int y) {
+  const size_t i = static_cast<size_t>(y) * W + x;
+  S v = lut ? static_cast<S>(lut[img[i]]) : static_cast<S>(img[i]);
+  if (vig) v *= static_cast<S>(vmax) / (static_cast<S>(vig[i]) + S(1));
+  return v;
+}
+
+/** level 0: u8 (+LUT, +vignette) -> scalar plane + texels */
+template <typename S>
+__global__ void __launch_bounds__(kTileX *kTileY) pyramidLevel0Kernel(const uint8_t *__restrict__ img, const uint8_t *__restrict__ vig,
+                                                                      const double *__restrict__ lut, double vmax, int W, int H,
+                                                                      S *__restrict__ plane, Texel<S> *__restrict__ tex) {
+  const int x = blockIdx.x * kTileX + threadIdx.x;
+  const int y = blockIdx.y * kTileY + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const S c = level0Value<S>(img, vig, lut, vmax, W, x, y);
+  const int xm = x > 0 ? x - 1 : x, xp = x < W - 1 ? x + 1 : x;
+  const int ym = y > 0 ? y - 1 : y, yp = y < H - 1 ? y + 1 : y;
+  const S l = (xm == x) ? c : level0Value<S>(img, vig, lut, vmax, W, xm, y);
+  const S r = (xp == x) ? c : level0Value<S>(img, vig, lut, vmax, W, xp, y);
+  const S u = (ym == y) ? c : level0Value<S>(img, vig, lut, vmax, W, x, ym);
+  const S d = (yp == y) ? c : level0Value<S>(img, vig, lut, vmax, W, x, yp);
+  const S sx = (x == 0 || x == W - 1) ? S(1) : S(0.5);
+  const S sy = (y == 0 || y == H - 1) ? S(1) : S(0.5);
+  const size_t i = static_cast<size_t>(y) * W + x;
+  plane[i] = c;
+  Texel<S> t;
+  t.I = c;
+  t.mask = tex[i].mask;  // mask lane is owned by set_mask (initialised to 1)
+  t.Ix = sx * (r - l);
+  t.Iy = sy * (d - u);
+  tex[i] = t;
+}
+
+template <typename S>
+__device__ __forceinline__ S boxValue(const S *__restrict__ parent, int Wp, int x, int y) {
+  const size_t i00 = static_cast<size_t>(2 * y) * Wp + 2 * x;
+  // same association order as the reference expression: ((p00 + p11) + p01) + p10
+  return S(0.25) * (parent[i00] + parent[i00 + Wp + 1] + parent[i00 + 1] + parent[i00 + Wp]);
+}
+
+/** level l >= 1: parent scalar plane -> scalar plane + texels */
+template <typename S>
+__global__ void __launch_bounds__(kTileX *kTileY) pyramidLevelKernel(const S *__restrict__ parent, int Wp, int W, int H, S *__restrict__ plane,
+                                                                     Texel<S> *__restrict__ tex) {
+  const int x = blockIdx.x * kTileX + threadIdx.x;
+  const int y = blockIdx.y * kTileY + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const S c = boxValue<S>(parent, Wp, x, y);
+  const S l = (x == 0) ? c : boxValue<S>(parent, Wp, x - 1, y);
+  const S r = (x == W - 1) ? c : boxValue<S>(parent, Wp, x + 1, y);
+  const S u = (y == 0) ? c : boxValue<S>(parent, Wp, x, y - 1);
+  const S d = (y == H - 1) ? c : boxValue<S>(parent, Wp, x, y + 1);
+  const S sx = (x == 0 || x == W - 1) ? S(1) : S(0.5);
+  const S sy = (y == 0 || y == H - 1) ? S(1) : S(0.5);
+  const size_t i = static_cast<size_t>(y) * W + x;
+  plane[i] = c;
+  Texel<S> t;
+  t.I = c;
+  t.mask = tex[i].mask;
+  t.Ix = sx * (r - l);
+  t.Iy = sy * (d - u);
+  tex[i] = t;
+}
+
+template <typename S>
+__global__ void fillMaskKernel(Texel<S> *tex, const uint8_t *mask, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) tex[i].mask = mask ? (mask[i] ? S(1) : S(0)) : S(1);
+}
+
+template <typename S>
+__global__ void setLevelKernel(Texel<S> *tex, S *plane, const double *pixelinfo, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Texel<S> t;
+  t.I = static_cast<S>(pixelinfo[3 * i]);
+  t.mask = tex[i].mask;
+  t.Ix = static_cast<S>(pixelinfo[3 * i + 1]);
+  t.Iy = static_cast<S>(pixelinfo[3 * i + 2]);
+  tex[i] = t;
+  plane[i] = t.I;
+}
+
+template <typename S>
+__global__ void getLevelKernel(const Texel<S> *tex, double *pixelinfo, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pixelinfo[3 * i] = static_cast<double>(tex[i].I);
+  pixelinfo[3 * i + 1] = static_cast<double>(tex[i].Ix);
+  pixelinfo[3 * i + 2] = static_cast<double>(tex[i].Iy);
+}
+
+template <typename S>
+void buildTyped(dsopp_hip_pyramid *p, const uint8_t *img_dev, const uint8_t *vig_dev, const double *lut_dev, double vmax) {
+  hipStream_t st = p->sr.stream;
+  dim3 block(kTileX, kTileY);
+  {
+    dim3 grid((p->w(0) + kTileX - 1) / kTileX, (p->h(0) + kTileY - 1) / kTileY);
+    pyramidLevel0Kernel<S><<<grid, block, 0, st>>>(img_dev, vig_dev, lut_dev, vmax, p->w(0), p->h(0), static_cast<S *>(p->planes[0]),
+                                                   static_cast<Texel<S> *>(p->texels[0]));
+  }
+  for (int l = 1; l < p->levels; ++l) {
+    dim3 grid((p->w(l) + kTileX - 1) / kTileX, (p->h(l) + kTileY - 1) / kTileY);
+    pyramidLevelKernel<S><<<grid, block, 0, st>>>(static_cast<const S *>(p->planes[l - 1]), p->w(l - 1), p->w(l), p->h(l),
+                                                  static_cast<S *>(p->planes[l]), static_cast<Texel<S> *>(p->texels[l]));
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename S>
+void fillMask(dsopp_hip_pyramid *p, int level, const uint8_t *mask_dev) {
+  const size_t n = static_cast<size_t>(p->w(level)) * p->h(level);
+  fillMaskKernel<S><<<static_cast<unsigned>((n + 255) / 256), 256, 0, p->sr.stream>>>(static_cast<Texel<S> *>(p->texels[level]), mask_dev, n);
+  HIP_CHECK(hipGetLastError());
+}
+
+void checkLevel(dsopp_hip_pyramid *p, int level) {
+  if (!p) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pyramid");
+  if (level < 0 || level >= p->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level %d out of range [0,%d)", level, p->levels);
+}
+
+}  // namespace
+}  // namespace dsopp_hip
+
+using namespace dsopp_hip;
+
+extern "C" {
+
+const char *dsopp_hip_last_error(void) { return lastError().c_str(); }
+const char *dsopp_hip_version(void) { return "dsopp-hip 0.1 (gfx950)"; }
+
+int dsopp_hip_device_count(int *count) {
+  return guarded([&] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+  });
+}
+
+int dsopp_hip_pyramid_create(int device, void *stream, int width, int height, int levels, int dtype, dsopp_hip_pyramid **out) {
+  return guarded([&] {
+    if (!out || width <= 0 || height <= 0 || levels <= 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad pyramid dimensions");
+    if (dtype != DSOPP_HIP_F64 && dtype != DSOPP_HIP_F32) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad dtype %d", dtype);
+    levels = levels > DSOPP_HIP_MAX_LEVELS ? DSOPP_HIP_MAX_LEVELS : levels;  // pixel_data_frame.cpp:14
+    auto *p = new dsopp_hip_pyramid();
+    try {
+      p->sr.init(device, stream);
+      p->width = width;
+      p->height = height;
+      p->levels = levels;
+      p->dtype = dtype;
+      for (int l = 0; l < levels; ++l) {
+        const size_t n = static_cast<size_t>(p->w(l)) * p->h(l);
+        if (n == 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level %d is empty", l);
+        HIP_CHECK(hipMalloc(&p->texels[l], n * 4 * p->elemSize()));
+        HIP_CHECK(hipMalloc(&p->planes[l], n * p->elemSize()));
+        if (dtype == DSOPP_HIP_F64)
+          fillMask<double>(p, l, nullptr);
+        else
+          fillMask<float>(p, l, nullptr);
+      }
+      HIP_CHECK(hipMalloc(&p->staging_u8, static_cast<size_t>(width) * height));
+      HIP_CHECK(hipMalloc(&p->staging_vig, static_cast<size_t>(width) * height));
+      HIP_CHECK(hipMalloc(&p->lut_dev, 256 * sizeof(double)));
+      p->sr.sync();
+    } catch (...) {
+      dsopp_hip_pyramid_destroy(p);
+      throw;
+    }
+    *out = p;
+  });
+}
+
+void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->sr.device);
+  if (p->sr.stream) (void)hipStreamSynchronize(p->sr.stream);
+  for (int l = 0; l < DSOPP_HIP_MAX_LEVELS; ++l) {
+    if (p->texels[l]) (void)hipFree(p->texels[l]);
+    if (p->planes[l]) (void)hipFree(p->planes[l]);
+  }
+  if (p->staging_u8) (void)hipFree(p->staging_u8);
+  if (p->staging_vig) (void)hipFree(p->staging_vig);
+  if (p->lut_dev) (void)hipFree(p->lut_dev);
+  p->sr.destroy();
+  delete p;
+}
+
+int dsopp_hip_pyramid_build_device(dsopp_hip_pyramid *p, const void *image_dev, const double *lut256, const void *vignetting_dev,
+                                   double vignetting_max) {
+  return guarded([&] {
+    if (!p || !image_dev) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    p->sr.use();
+    const double *lut_dev = nullptr;
+    if (lut256) {
+      HIP_CHECK(hipMemcpyAsync(p->lut_dev, lut256, 256 * sizeof(double), hipMemcpyHostToDevice, p->sr.stream));
+      lut_dev = p->lut_dev;
+    }
+    if (p->dtype == DSOPP_HIP_F64)
+      buildTyped<double>(p, static_cast<const uint8_t *>(image_dev), static_cast<const uint8_t *>(vignetting_dev), lut_dev, vignetting_max);
+    else
+      buildTyped<float>(p, static_cast<const uint8_t *>(image_dev), static_cast<const uint8_t *>(vignetting_dev), lut_dev, vignetting_max);
+  });
+}
+
+int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, const double *lut256, const uint8_t *vignetting_host) {
+  return guarded([&] {
+    if (!p || !image_host) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    p->sr.use();
+    const size_t n = static_cast<size_t>(p->width) * p->height;
+    HIP_CHECK(hipMemcpyAsync(p->staging_u8, image_host, n, hipMemcpyHostToDevice, p->sr.stream));
+    double vmax = 0;
+    if (vignetting_host) {
+      // cv::minMaxLoc(vignetting, nullptr, &max) — photometrically_corrected_image.cpp:11-13
+      for (size_t i = 0; i < n; ++i) vmax = vignetting_host[i] > vmax ? vignetting_host[i] : vmax;
+      HIP_CHECK(hipMemcpyAsync(p->staging_vig, vignetting_host, n, hipMemcpyHostToDevice, p->sr.stream));
+    }
+    int rc = dsopp_hip_pyramid_build_device(p, p->staging_u8, lut256, vignetting_host ? p->staging_vig : nullptr, vmax);
+    if (rc != DSOPP_HIP_OK) throw Error(rc, lastError());
+    p->sr.sync();  // host buffers may be reused by the caller after return
+  });
+}
+
+int dsopp_hip_pyramid_set_level(dsopp_hip_pyramid *p, int level, const double *pixelinfo_host) {
+  return guarded([&] {
+    checkLevel(p, level);
+    if (!pixelinfo_host) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pixelinfo");
+    p->sr.use();
+    const size_t n = static_cast<size_t>(p->w(level)) * p->h(level);
+    double *tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, n * 3 * sizeof(double)));
+    HIP_CHECK(hipMemcpyAsync(tmp, pixelinfo_host, n * 3 * sizeof(double), hipMemcpyHostToDevice, p->sr.stream));
+    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+    if (p->dtype == DSOPP_HIP_F64)
+      setLevelKernel<double><<<grid, 256, 0, p->sr.stream>>>(static_cast<Texel<double> *>(p->texels[level]), static_cast<double *>(p->planes[level]), tmp, n);
+    else
+      setLevelKernel<float><<<grid, 256, 0, p->sr.stream>>>(static_cast<Texel<float> *>(p->texels[level]), static_cast<float *>(p->planes[level]), tmp, n);
+    HIP_CHECK(hipGetLastError());
+    p->sr.sync();
+    (void)hipFree(tmp);
+  });
+}
+
+int dsopp_hip_pyramid_set_mask(dsopp_hip_pyramid *p, int level, const uint8_t *mask_host) {
+  return guarded([&] {
+    checkLevel(p, level);
+    p->sr.use();
+    const size_t n = static_cast<size_t>(p->w(level)) * p->h(level);
+    const uint8_t *mask_dev = nullptr;
+    if (mask_host) {
+      HIP_CHECK(hipMemcpyAsync(p->staging_u8, mask_host, n, hipMemcpyHostToDevice, p->sr.stream));
+      mask_dev = static_cast<const uint8_t *>(p->staging_u8);
+    }
+    if (p->dtype == DSOPP_HIP_F64)
+      fillMask<double>(p, level, mask_dev);
+    else
+      fillMask<float>(p, level, mask_dev);
+    p->sr.sync();
+  });
+}
+
+int dsopp_hip_pyramid_get_level(dsopp_hip_pyramid *p, int level, double *pixelinfo_host) {
+  return guarded([&] {
+    checkLevel(p, level);
+    if (!pixelinfo_host) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null output");
+    p->sr.use();
+    const size_t n = static_cast<size_t>(p->w(level)) * p->h(level);
+    double *tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, n * 3 * sizeof(double)));
+    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+    if (p->dtype == DSOPP_HIP_F64)
+      getLevelKernel<double><<<grid, 256, 0, p->sr.stream>>>(static_cast<const Texel<double> *>(p->texels[level]), tmp, n);
+    else
+      getLevelKernel<float><<<grid, 256, 0, p->sr.stream>>>(static_cast<const Texel<float> *>(p->texels[level]), tmp, n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(pixelinfo_host, tmp, n * 3 * sizeof(double), hipMemcpyDeviceToHost, p->sr.stream));
+    p->sr.sync();
+    (void)hipFree(tmp);
+  });
+}
+
+int dsopp_hip_pyramid_level_size(dsopp_hip_pyramid *p, int level, int *width, int *height) {
+  return guarded([&] {
+    checkLevel(p, level);
+    if (width) *width = p->w(level);
+    if (height) *height = p->h(level);
+  });
+}
+
+}  // extern "C"

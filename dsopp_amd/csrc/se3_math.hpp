@@ -1,0 +1,151 @@
+// SE3 arithmetic shared by host and device code of the HIP library (double precision).
+// The reference delegates this to Sophus @593db47 through energy::motion::SE3
+// (src/energy/motion/include/energy/motion/se3_motion.hpp:16-253): tangent = (translation, rotation),
+// exp: R = Exp(omega), t = V(omega) upsilon; Adj = [[R, hat(t) R], [0, R]]; storage (qx, qy, qz, qw, t).
+// Poses are kept as rotation matrix + translation here; conversion to/from the quaternion form happens at the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace dsopp_hip {
+
+#define DSOPP_HD __host__ __device__ inline
+
+struct Rigid {
+  double R[9];  // row-major
+  double t[3];
+};
+
+DSOPP_HD Rigid rigidIdentity() {
+  Rigid T;
+  for (int i = 0; i < 9; ++i) T.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  T.t[0] = T.t[1] = T.t[2] = 0;
+  return T;
+}
+
+DSOPP_HD Rigid rigidFromParams(const double *p) {
+  Rigid T;
+  const double x = p[0], y = p[1], z = p[2], w = p[3];
+  T.R[0] = 1 - 2 * (y * y + z * z);
+  T.R[1] = 2 * (x * y - z * w);
+  T.R[2] = 2 * (x * z + y * w);
+  T.R[3] = 2 * (x * y + z * w);
+  T.R[4] = 1 - 2 * (x * x + z * z);
+  T.R[5] = 2 * (y * z - x * w);
+  T.R[6] = 2 * (x * z - y * w);
+  T.R[7] = 2 * (y * z + x * w);
+  T.R[8] = 1 - 2 * (x * x + y * y);
+  T.t[0] = p[4];
+  T.t[1] = p[5];
+  T.t[2] = p[6];
+  return T;
+}
+
+/** rotation matrix -> unit quaternion (x, y, z, w), w >= 0 branch-stable */
+DSOPP_HD void rigidToParams(const Rigid &T, double *p) {
+  const double *R = T.R;
+  const double tr = R[0] + R[4] + R[8];
+  double x, y, z, w;
+  if (tr > 0) {
+    const double s = sqrt(tr + 1.0) * 2;
+    w = 0.25 * s;
+    x = (R[7] - R[5]) / s;
+    y = (R[2] - R[6]) / s;
+    z = (R[3] - R[1]) / s;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+    w = (R[7] - R[5]) / s;
+    x = 0.25 * s;
+    y = (R[1] + R[3]) / s;
+    z = (R[2] + R[6]) / s;
+  } else if (R[4] > R[8]) {
+    const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+    w = (R[2] - R[6]) / s;
+    x = (R[1] + R[3]) / s;
+    y = 0.25 * s;
+    z = (R[5] + R[7]) / s;
+  } else {
+    const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+    w = (R[3] - R[1]) / s;
+    x = (R[2] + R[6]) / s;
+    y = (R[5] + R[7]) / s;
+    z = 0.25 * s;
+  }
+  const double n = sqrt(x * x + y * y + z * z + w * w);
+  p[0] = x / n;
+  p[1] = y / n;
+  p[2] = z / n;
+  p[3] = w / n;
+  p[4] = T.t[0];
+  p[5] = T.t[1];
+  p[6] = T.t[2];
+}
+
+/** exp of the twist (upsilon, omega) */
+DSOPP_HD Rigid rigidExp(const double *xi) {
+  Rigid T;
+  const double wx = xi[3], wy = xi[4], wz = xi[5];
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  const double th = sqrt(th2);
+  double A, B, Cc;  // R = I + A*W + B*W^2 ; V = I + B*W + Cc*W^2
+  if (th < 1e-10) {
+    A = 1.0 - th2 / 6.0;
+    B = 0.5 - th2 / 24.0;
+    Cc = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    A = sin(th) / th;
+    B = (1 - cos(th)) / th2;
+    Cc = (th - sin(th)) / (th2 * th);
+  }
+  // W = hat(w); W^2 = w w^T - th2 I
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  const double W2[9] = {wx * wx - th2, wx * wy, wx * wz, wx * wy, wy * wy - th2, wy * wz, wx * wz, wy * wz, wz * wz - th2};
+  double V[9];
+  for (int i = 0; i < 9; ++i) {
+    const double id = (i % 4 == 0) ? 1.0 : 0.0;
+    T.R[i] = id + A * W[i] + B * W2[i];
+    V[i] = id + B * W[i] + Cc * W2[i];
+  }
+  for (int i = 0; i < 3; ++i) T.t[i] = V[3 * i] * xi[0] + V[3 * i + 1] * xi[1] + V[3 * i + 2] * xi[2];
+  return T;
+}
+
+DSOPP_HD Rigid rigidMul(const Rigid &a, const Rigid &b) {
+  Rigid c;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j] + a.R[3 * i + 2] * b.R[6 + j];
+    c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
+  }
+  return c;
+}
+
+DSOPP_HD Rigid rigidInverse(const Rigid &a) {
+  Rigid c;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * j + i];
+  for (int i = 0; i < 3; ++i) c.t[i] = -(c.R[3 * i] * a.t[0] + c.R[3 * i + 1] * a.t[1] + c.R[3 * i + 2] * a.t[2]);
+  return c;
+}
+
+/** re-orthonormalise a rotation that accumulated products (the reference's quaternion form renormalises on multiply) */
+DSOPP_HD void rigidNormalize(Rigid &T) {
+  double p[7];
+  rigidToParams(T, p);
+  T = rigidFromParams(p);
+}
+
+/** Adjoint, row-major 6x6 */
+DSOPP_HD void rigidAdj(const Rigid &T, double *A) {
+  const double *t = T.t;
+  const double hx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+  for (int i = 0; i < 36; ++i) A[i] = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      A[6 * i + j] = T.R[3 * i + j];
+      A[6 * (i + 3) + (j + 3)] = T.R[3 * i + j];
+      A[6 * i + (j + 3)] = hx[3 * i] * T.R[j] + hx[3 * i + 1] * T.R[3 + j] + hx[3 * i + 2] * T.R[6 + j];
+    }
+}
+
+}  // namespace dsopp_hip

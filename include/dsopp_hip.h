@@ -1,0 +1,229 @@
+/* dsopp_hip.h — C-ABI of the MI355X-native photometric bundle adjustment / direct image alignment hot path.
+ *
+ * This is the drop-in boundary: a thin `extern "C"` layer with plain pointers and sizes that a
+ * `solver: hip` backend of DSOPP binds to.  The reference itself has no FFI; its plugin API is a pair of C++ abstract
+ * class templates selected by a YAML string in a factory (src/tracker/tracker/src/fabric.cpp:58-180).  Each entry point
+ * below cites the reference member function whose work it replaces.  INTEGRATION.md shows the reference-side adapter
+ * classes (`HipPhotometricBundleAdjustment`, `HipPoseAlignment`, mirrored in dsopp_amd/host/) that call these.
+ *
+ * Path shorthands used in citations:
+ *   PBA_INC  = src/energy/problems/include/energy/problems/photometric_bundle_adjustment
+ *   PBA_INT  = src/energy/problems/internal/energy/problems/photometric_bundle_adjustment
+ *   PA_INC   = src/energy/problems/include/energy/problems/pose_alignment
+ *   PROB_SRC = src/energy/problems/src
+ *
+ * Conventions
+ *   - every function returns DSOPP_HIP_OK (0) or a negative error code; dsopp_hip_last_error() gives the message
+ *     (thread-local).  No exceptions cross the boundary.
+ *   - all host buffers are caller-owned and only read/written during the call; handles are opaque and used from one
+ *     thread at a time (the reference calls its solvers from the single tracker thread only).
+ *   - poses are 7 doubles in Sophus::SE3 storage order (qx, qy, qz, qw, tx, ty, tz); tangent vectors are
+ *     (translation, rotation); per-frame state blocks are 8 doubles (6 pose + affine a, b); K = 8 * number of frames.
+ *   - matrices are row-major doubles.
+ *   - there is NO CPU fallback: every entry point that computes fails with DSOPP_HIP_ERR_HIP when no gfx950 device
+ *     is available.
+ */
+#ifndef DSOPP_HIP_H
+#define DSOPP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSOPP_HIP_PATTERN_SIZE 8 /* Pattern::kSize — src/common/pattern/include/common/pattern/pattern.hpp:17 */
+#define DSOPP_HIP_BLOCK_SIZE 8   /* Motion::DoF + 2 */
+#define DSOPP_HIP_MAX_FRAMES 16  /* window capacity (reference configs use 5..15 keyframes) */
+#define DSOPP_HIP_MAX_LEVELS 5   /* PixelDataFrame::kMaxPyramidDepth — src/features/include/features/camera/pixel_data_frame.hpp:26 */
+
+enum {
+  DSOPP_HIP_OK = 0,
+  DSOPP_HIP_ERR_INVALID_ARGUMENT = -1,
+  DSOPP_HIP_ERR_NOT_FOUND = -2,
+  DSOPP_HIP_ERR_ORDER = -3,    /* frames must be pushed in ascending timestamp order (PROB_SRC/photometric_bundle_adjustment.cpp:101-102) */
+  DSOPP_HIP_ERR_HIP = -4,      /* HIP runtime failure / no device */
+  DSOPP_HIP_ERR_CAPACITY = -5, /* window full */
+  DSOPP_HIP_ERR_STATE = -6     /* call sequence violation (e.g. stage call before begin) */
+};
+
+/* track::PointConnectionStatus — src/track/connections/include/track/connections/frame_connection.hpp:19-25 */
+enum { DSOPP_HIP_STATUS_OK = 0, DSOPP_HIP_STATUS_OUTLIER = 1, DSOPP_HIP_STATUS_OCCLUDED = 2, DSOPP_HIP_STATUS_OOB = 3, DSOPP_HIP_STATUS_UNKNOWN = 4 };
+
+/* storage / evaluation scalar of the device images and sweeps.  F64 matches the reference's default build
+ * (Precision = double, src/common/include/common/settings.hpp:10-14); F32 matches its -DUSE_FLOAT=ON build.
+ * Normal equations are accumulated in fp64 in both. */
+enum { DSOPP_HIP_F64 = 0, DSOPP_HIP_F32 = 1 };
+
+const char *dsopp_hip_last_error(void);
+int dsopp_hip_device_count(int *count);
+const char *dsopp_hip_version(void);
+
+/* TrustRegionPhotometricBundleAdjustmentOptions (PBA_INC/trust_region_photometric_bundle_adjustment_options.hpp:14-52)
+ * + the EigenPhotometricBundleAdjustment ctor flags (PROB_SRC/eigen_photometric_bundle_adjustment.cpp:47-57)
+ * + the class template switches FIRST_ESTIMATE_JACOBIANS / OPTIMIZE_IDEPTHS */
+typedef struct dsopp_hip_options {
+  int32_t max_iterations;
+  double initial_trust_region_radius;
+  double function_tolerance;
+  double parameter_tolerance;
+  double affine_brightness_regularizer[2];
+  double fixed_state_regularizer;
+  double sigma_huber_loss;
+  int32_t estimate_uncertainty;
+  int32_t force_accept;
+  int32_t first_estimate_jacobians;
+  int32_t optimize_idepths;
+  int32_t dtype; /* DSOPP_HIP_F64 | DSOPP_HIP_F32 */
+} dsopp_hip_options;
+
+/* production values of createPhotometricBundleAdjustment / createPoseAlignment — src/tracker/tracker/src/fabric.cpp:63-79,127-142 */
+void dsopp_hip_default_pba_options(dsopp_hip_options *o);
+void dsopp_hip_default_align_options(dsopp_hip_options *o);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Image pyramid of one frame, resident in HBM (replaces features::PixelDataFrame / PixelMap<1> levels + CameraMask)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dsopp_hip_pyramid dsopp_hip_pyramid;
+
+/* allocate `levels` (<= DSOPP_HIP_MAX_LEVELS) texel images of width>>l x height>>l on `device`.
+ * `stream` is a hipStream_t (NULL = the library creates its own non-blocking stream). */
+int dsopp_hip_pyramid_create(int device, void *stream, int width, int height, int levels, int dtype, dsopp_hip_pyramid **out);
+void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p);
+/* PixelDataFrame ctor (src/features/src/pixel_data_frame.cpp:12-31): photometric correction LUT[u8] * vmax/(vignette+1)
+ * (src/features/src/photometrically_corrected_image.cpp:9-29), 2x2 box pyramid (downscale_image.hpp:16-33), per-level
+ * (I, dI/dx, dI/dy) (src/features/src/calculate_pixelinfo.cpp:340-374).  lut256 / vignetting may be NULL. */
+int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, const double *lut256, const uint8_t *vignetting_host);
+/* same, the u8 image (and vignette) already in HBM: no PCIe transfer of pixels inside the call and no host sync
+ * (the call only enqueues work on the pyramid's stream).  vignetting_max = max over the vignette image
+ * (cv::minMaxLoc in the reference, a per-camera constant); ignored when vignetting_dev is NULL. */
+int dsopp_hip_pyramid_build_device(dsopp_hip_pyramid *p, const void *image_dev, const double *lut256, const void *vignetting_dev,
+                                   double vignetting_max);
+/* adopt a level built by the reference's host code: pixelinfo = H_l x W_l x (I, dx, dy) doubles = PixelInfo<1>::data_
+ * (src/features/include/features/camera/pixel_map.hpp:79-132) */
+int dsopp_hip_pyramid_set_level(dsopp_hip_pyramid *p, int level, const double *pixelinfo_host);
+/* CameraMask of a level (src/sensors/camera_calibration/include/sensors/camera_calibration/mask/camera_mask.hpp:48-89);
+ * NULL = all valid */
+int dsopp_hip_pyramid_set_mask(dsopp_hip_pyramid *p, int level, const uint8_t *mask_host);
+int dsopp_hip_pyramid_get_level(dsopp_hip_pyramid *p, int level, double *pixelinfo_host);
+int dsopp_hip_pyramid_level_size(dsopp_hip_pyramid *p, int level, int *width, int *height);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sliding-window photometric bundle adjustment
+ * (replaces EigenPhotometricBundleAdjustment<SE3, PinholeCamera, 8, PixelMap, true, true, true, 1>)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dsopp_hip_window dsopp_hip_window;
+
+int dsopp_hip_window_create(const dsopp_hip_options *options, int device, void *stream, dsopp_hip_window **out);
+void dsopp_hip_window_destroy(dsopp_hip_window *w);
+
+/* pushFrame(ActiveKeyframe, level, model, parameterization) — PBA_INC/photometric_bundle_adjustment.hpp:55-56,
+ * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:119-141: when the window already holds > 1 frame, first folds the
+ * landmarks/frames flagged for marginalisation into the marginal prior (updateMarginalizedLinearSystem,
+ * PBA_INT/eigen_photometric_bundle_adjustment_problem.hpp:146-203), then appends the frame.
+ * The pyramid is BORROWED: it must outlive the frame's stay in the window (the reference keeps raw pointers to the
+ * keyframe's PixelMap levels, PBA_INT/local_frame.hpp:323-325).  intrinsics = (fx, fy, cx, cy) of that level. */
+int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t timestamp, const dsopp_hip_pyramid *pyramid,
+                                int level, const double intrinsics[4], const double T_world_agent[7], double exposure_time,
+                                const double affine_brightness[2], int fixed, int is_marginalized);
+/* LocalFrame ctor landmark copy + LocalFrame::update (PBA_INT/local_frame.hpp:309-335,484-505).  n_total >= current count;
+ * existing landmarks only get their flags refreshed (to_marginalize = newly marginalised && !outlier), new ones are
+ * appended.  uv = landmark.projection(), patch = 8 intensities of the host level-0 image (src/track/frames/src/
+ * active_keyframe.cpp:96-110).  flags bit0 = isMarginalized, bit1 = isOutlier. */
+int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
+                                   const double *patch, const uint8_t *flags);
+/* residual lists from FrameConnection statuses (PROB_SRC/photometric_bundle_adjustment.cpp:109-123, local_frame.hpp:507-519):
+ * appends entries [current size, n) of the (reference, target) connection */
+int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses);
+/* updateLocalFrame's frame flags (PROB_SRC/eigen_photometric_bundle_adjustment.cpp:106-113) */
+int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_id);
+int dsopp_hip_window_num_frames(dsopp_hip_window *w, int32_t *n);
+
+/* solve(number_of_threads) -> final energy — PBA_INC/photometric_bundle_adjustment.hpp:154,
+ * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:61-101 (FEJ, LM loop on device, relinearise, covariances, point statuses) */
+int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid);
+
+/* stage-level entry points = PhotometricBundleAdjustmentProblem methods (PBA_INT/eigen_photometric_bundle_adjustment_problem.hpp:290-402)
+ * for host-driven LM and stage-by-stage parity checks */
+int dsopp_hip_window_begin(dsopp_hip_window *w);                                           /* problem ctor + firstEstimateJacobians */
+int dsopp_hip_window_calculate_energy(dsopp_hip_window *w, double *energy, int32_t *n_valid); /* :290-317 */
+int dsopp_hip_window_linearize(dsopp_hip_window *w);                                        /* :322-336 */
+int dsopp_hip_window_get_system(dsopp_hip_window *w, double *H_pp, double *b_pp, double *H_schur, double *b_schur);
+int dsopp_hip_window_calculate_step(dsopp_hip_window *w, double lambda, double *step);     /* :342-361 */
+int dsopp_hip_window_accept_step(dsopp_hip_window *w, double *state_sq, double *step_sq);  /* :366-388 */
+int dsopp_hip_window_reject_step(dsopp_hip_window *w);                                      /* :392-402 */
+int dsopp_hip_window_update_point_statuses(dsopp_hip_window *w);                            /* PROB_SRC/photometric_bundle_adjustment.cpp:321-406 */
+
+/* read-back = PhotometricBundleAdjustment::updateFrame / getPose / getAffineBrightness
+ * (PROB_SRC/photometric_bundle_adjustment.cpp:156-264) */
+int dsopp_hip_window_get_frame_state(dsopp_hip_window *w, int32_t frame_id, double T0[7], double ab0[2], double eps[8], double step[8]);
+int dsopp_hip_window_get_pose(dsopp_hip_window *w, int32_t frame_id, double T_world_agent[7], double affine_brightness[2]);
+int dsopp_hip_window_num_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t *n);
+/* any output may be NULL.  flags_out bit0 marginalized, bit1 outlier, bit2 to_marginalize, bit3 ill_conditioned;
+ * hpib (hessian_poses_idepth_block) is n x K */
+int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double *idepth, double *idepth_step, double *inv_hessian_idepth,
+                                   double *b_idepth, double *relative_baseline, int32_t *n_inliers, uint8_t *flags_out, double *hpib);
+int dsopp_hip_window_get_residuals(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, uint8_t *status,
+                                   uint8_t *candidate, double *energy);
+int dsopp_hip_window_get_marginalized(dsopp_hip_window *w, double *H, double *b, double *energy, int32_t *size);
+int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, double cov[36]);
+
+/* multi-GPU: landmarks are sharded across ranks by the caller (each rank uploads only its shard; frames and images are
+ * replicated).  The library calls `allreduce_sum` on its stream whenever partial sums over landmarks must be combined
+ * (the reduced normal equations once per linearisation, energy + valid count once per energy sweep).  `device_buffer`
+ * is device memory holding `count` doubles to be summed in place across ranks.  With no callback the window is single-GPU. */
+typedef int (*dsopp_hip_allreduce_fn)(void *user, void *device_buffer, size_t count, void *stream);
+int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user);
+
+/* timing / introspection for bench.py (HIP-event time of the last solve's device work, in milliseconds) */
+int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Two-frame direct image alignment of one pyramid level
+ * (replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>, PROB_SRC/eigen_pose_alignment.cpp:26-329)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dsopp_hip_aligner dsopp_hip_aligner;
+
+typedef struct dsopp_hip_align_result {
+  double rmse; /* sqrt(E / n_valid / PatternSize) — eigen_pose_alignment.cpp:328; -1 (kZeroCost) for a known pose */
+  double energy;
+  int32_t n_valid;
+  int32_t iterations;
+  double T_world_target[7];
+  double affine_brightness[2];
+  double covariance[36]; /* tTargetReferenceCovariance — eigen_pose_alignment.cpp:320-323 */
+  double H[64];
+} dsopp_hip_align_result;
+
+int dsopp_hip_aligner_create(const dsopp_hip_options *options, int device, void *stream, dsopp_hip_aligner **out);
+void dsopp_hip_aligner_destroy(dsopp_hip_aligner *a);
+/* reset() — PA_INC/pose_alignment.hpp, eigen_pose_alignment.cpp:261-264 */
+int dsopp_hip_aligner_reset(dsopp_hip_aligner *a);
+/* pushFrame(timestamp, pose, pyramids, masks, depth maps, ...) for the fixed reference frame
+ * (PROB_SRC/photometric_bundle_adjustment.cpp:58-74 + LocalFrame depth-map ctor PBA_INT/local_frame.hpp:350-393): every
+ * pixel with weight > 0 and idepth_sum/weight >= 1e-6 inside the 4-px border becomes a reference point whose intensity
+ * is sampled from the reference pyramid level on the device.  depth maps are H_l x W_l row-major host arrays. */
+int dsopp_hip_aligner_push_reference_depth_map(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                               const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4],
+                                               const double *idepth_sum, const double *weight, double exposure_time,
+                                               const double affine_brightness[2]);
+/* same with an explicit point list (u, v, idepth); intensity sampled on the device */
+int dsopp_hip_aligner_push_reference_points(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                            const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4], int32_t n,
+                                            const double *u, const double *v, const double *idepth, double exposure_time,
+                                            const double affine_brightness[2]);
+/* pushFrame(timestamp, initial pose, pyramids, masks, ...) for the free target frame (photometric_bundle_adjustment.cpp:131-154) */
+int dsopp_hip_aligner_push_target(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent_init[7],
+                                  const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4], double exposure_time,
+                                  const double affine_brightness[2]);
+/* pushKnownPose — eigen_pose_alignment.cpp:268-271 */
+int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7]);
+/* solve -> rmse (or kZeroCost = -1) — eigen_pose_alignment.cpp:275-329 */
+int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result);
+int dsopp_hip_aligner_num_points(dsopp_hip_aligner *a, int32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSOPP_HIP_H */
