@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py — Gauss-Newton iterations/s of the sliding-window photometric bundle adjustment on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+  step      = one Gauss-Newton iteration of the LM loop = linearize + calculateStep + calculateEnergy + accept
+              (levenberg_marquardt_algorithm.hpp:77-128 of the reference)
+  workload  = C1 of BASELINE.json (configs[1]): 7-keyframe window, 2000 active points per GPU, 640x480, full clique,
+              production solver settings (7 LM iterations, lambda = 1e-5, Huber 20, force_accept), synthetic scene.
+              All inputs (images, landmarks, statuses) are resident in HBM before the timed region starts.
+  N > 1     = landmarks sharded across ranks (weak scaling: 2000 points PER GPU, the window grows with N); frames and
+              images replicated; one RCCL all-reduce of the reduced normal equations per linearisation + one of
+              (energy, n_valid) per energy sweep, through torch.distributed (backend nccl = RCCL).
+  value     = world_size * GN iterations / wall time  (2000-point-window GN iterations per second, whole job)
+Extra objects on the same line: roofline (linearisation sweep kernel, measured live with HIP events on the library's
+stream) and cpu_baseline (the oracle = CPU port of the reference algorithm, timed on the host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_linearize(P, F, s):
+    """per point 12 words in; per (point,target) 8 px x 4 texels x 3 ch = 96 words gathered + 1 status in
+    + 3 out; per point K+2 words out."""
+    T, K = F - 1, 8 * F
+    return s * P * (12 + T * 100 + (K + 2))
+
+
+def algorithmic_bytes_energy(P, F, s):
+    return s * P * (12 + (F - 1) * 35)
+
+
+def shard(n, rank, world):
+    """contiguous block partition of n items, balanced to +-1"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=140)
+    ap.add_argument("--warmup", type=int, default=14)
+    ap.add_argument("--frames", type=int, default=7)
+    ap.add_argument("--points", type=int, default=2000, help="active points per GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from dsopp_amd import capi, synthetic as syn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    F, P = args.frames, args.points
+    total_points = P * world
+    # identical synthetic window on every rank (seeded); each rank keeps its landmark shard of every frame
+    win = syn.make_window(num_frames=F, num_points=total_points, width=args.width, height=args.height, seed=0)
+    for f in win.frames:
+        lo, hi = shard(len(f.uv), rank, world)
+        f.uv, f.idepth_gt, f.idepth_init, f.patch = f.uv[lo:hi], f.idepth_gt[lo:hi], f.idepth_init[lo:hi], f.patch[lo:hi]
+    P_local = win.num_points
+
+    stream = torch.cuda.Stream()
+    dtype = capi.F64 if args.dtype == "f64" else capi.F32
+    opts = capi.default_pba_options(dtype=dtype)
+    g = capi.HipWindow(opts, device=local_rank, stream=stream.cuda_stream)
+    syn.load_window(g, win)
+
+    if world > 1:
+        class _DevBuf:
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+        cache = {}
+
+        def allreduce(ptr, count, stream_ptr):
+            key = (ptr, count)
+            t = cache.get(key)
+            if t is None:
+                t = torch.as_tensor(_DevBuf(ptr, count), device=f"cuda:{local_rank}")
+                cache[key] = t
+            with torch.cuda.stream(stream):
+                dist.all_reduce(t)
+            return 0
+
+        g.set_allreduce(allreduce, rank, world)
+
+    g.snapshot()
+
+    def run_iterations(n_target):
+        """executes exactly n_target GN iterations as repeated LM loops from the snapshot; returns iterations done"""
+        done = 0
+        while done < n_target:
+            remaining = n_target - done
+            g.restore()
+            g.set_max_iterations(min(7, remaining))
+            _, it, _ = g.optimize()
+            if it <= 0:
+                raise RuntimeError("LM loop made no progress")
+            done += it
+        g.set_max_iterations(7)
+        return done
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_iterations(max(args.warmup, 7))
+    barrier()
+    t0 = time.perf_counter()
+    steps_done = run_iterations(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- live per-kernel timing (HIP events on the library's stream) -> roofline of the dominant kernel
+    g.set_profiling(True)
+    run_iterations(35)
+    prof = g.get_profile()
+    g.set_profiling(False)
+    s_bytes = 8 if dtype == capi.F64 else 4
+    lin_ms, lin_n = prof["sweep_linearize"]
+    en_ms, en_n = prof["sweep_energy"]
+    lin_avg_s = lin_ms / max(lin_n, 1) * 1e-3
+    b_lin = algorithmic_bytes_linearize(P_local, F, s_bytes)
+    achieved = b_lin / lin_avg_s / 1e9 if lin_avg_s > 0 else 0.0
+    kernels = {k: {"avg_us": (v[0] / v[1] * 1e3 if v[1] else 0.0), "launches": v[1]} for k, v in prof.items() if v[1]}
+    dominant = max(kernels.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0]
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
+
+    if rank == 0:
+        ms_per_step = elapsed / steps_done * 1e3
+        line = {
+            "metric": "Gauss-Newton iters/sec (7-KF window, 2k active pts)",
+            "value": world * steps_done / elapsed,
+            "unit": "GN iterations/s",
+            "n_gpus": world,
+            "steps": steps_done,
+            "warmup": max(args.warmup, 7),
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"C1: {F}-KF window, {P} active points per GPU ({total_points} total), "
+                                   f"{args.width}x{args.height}, full clique, production LM settings",
+                       "frames": F, "points_per_gpu": P, "total_points": total_points,
+                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "sweep_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": lin_avg_s * 1e6,
+                         "energy_sweep": {"algorithmic_bytes_per_launch": algorithmic_bytes_energy(P_local, F, s_bytes),
+                                          "avg_launch_us": en_ms / max(en_n, 1) * 1e3}},
+            "kernels": kernels,
+            "dominant_kernel_by_total_time": dominant,
+        }
+        if cpu_baseline is not None:
+            line["cpu_baseline"] = cpu_baseline
+            line["speedup_vs_cpu_port"] = line["value"] / cpu_baseline["value"]
+        print(json.dumps(line))
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(args, F, P, win, syn):
+    """the oracle (CPU port of the reference algorithm: materialised ResidualPoint AoS, Kahan accumulators, same stage
+    structure) on the same window, with the reference's thread cap clamp(hw,1,8)-1 (dsopp_main.cpp:114-119)."""
+    from oracle import pyoracle as po
+    hw = os.cpu_count() or 1
+    threads = max(1, min(hw, 8) - 1)
+    po.set_threads(threads)
+    o = po.OracleWindow(po.default_pba_options())
+    syn.load_window(o, win)
+    init = [(f.frame_id, syn.mat_to_params(f.T_w_c_init), f.affine_init, f.idepth_init) for f in win.frames]
+
+    def reset():
+        for fid, T, ab, idp in init:
+            o.reset_state(fid, T, ab, idp)
+
+    reset()
+    o.optimize()
+    its, t_used, solves = 0, 0.0, 0
+    while t_used < args.cpu_seconds and solves < 200:
+        reset()
+        t0 = time.perf_counter()
+        _, it, _ = o.optimize()
+        t_used += time.perf_counter() - t0
+        its += it
+        solves += 1
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": its / t_used, "unit": "GN iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{solves} LM solves ({its} GN iterations, {t_used:.1f} s) of the same C1 window ({F} KF, {P} points), "
+                      f"oracle = restatement of the reference CPU path, {threads} threads (reference cap), host {cpu_model} ({hw} hw threads)"}
+
+
+if __name__ == "__main__":
+    main()

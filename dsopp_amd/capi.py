@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsopp_hip.so")
 
 F64, F32 = 0, 1
+NUM_KERNEL_CLASSES = 10
 
 
 class Options(C.Structure):
@@ -45,7 +46,8 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
 ]
@@ -62,6 +64,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.dsopp_hip_last_error.restype = C.c_char_p
         _lib.dsopp_hip_version.restype = C.c_char_p
+        _lib.dsopp_hip_kernel_class_name.restype = C.c_char_p
     return _lib
 
 
@@ -229,14 +232,42 @@ class HipWindow:
     def mark_frame_marginalized(self, frame_id):
         _chk(lib().dsopp_hip_window_mark_frame_marginalized(self._h, int(frame_id)))
 
-    def set_allreduce(self, fn):
+    def set_allreduce(self, fn, rank=0, world_size=1):
         """fn(device_ptr:int, count:int, stream:int) -> int.  Keeps the ctypes callback alive."""
         if fn is None:
             self._cb = None
-            _chk(lib().dsopp_hip_window_set_allreduce(self._h, None, None))
+            _chk(lib().dsopp_hip_window_set_allreduce(self._h, None, None, 0, 1))
             return
         self._cb = ALLREDUCE_FN(lambda user, ptr, count, stream: int(fn(ptr, count, stream) or 0))
-        _chk(lib().dsopp_hip_window_set_allreduce(self._h, self._cb, None))
+        _chk(lib().dsopp_hip_window_set_allreduce(self._h, self._cb, None, int(rank), int(world_size)))
+
+    def optimize(self):
+        """LM loop only (no relinearisation / covariance / point statuses)."""
+        e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    def set_max_iterations(self, n: int):
+        _chk(lib().dsopp_hip_window_set_max_iterations(self._h, int(n)))
+        self.options.max_iterations = int(n)
+
+    def snapshot(self):
+        _chk(lib().dsopp_hip_window_snapshot(self._h))
+
+    def restore(self):
+        _chk(lib().dsopp_hip_window_restore(self._h))
+
+    def set_profiling(self, enable: bool):
+        _chk(lib().dsopp_hip_window_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self):
+        """{kernel class name: (total device ms, launches)} since profiling was enabled."""
+        out = {}
+        for k in range(NUM_KERNEL_CLASSES):
+            ms, n = C.c_double(), C.c_int64()
+            _chk(lib().dsopp_hip_window_get_profile(self._h, k, C.byref(ms), C.byref(n)))
+            out[lib().dsopp_hip_kernel_class_name(k).decode()] = (ms.value, n.value)
+        return out
 
     # stage level
     def begin(self):

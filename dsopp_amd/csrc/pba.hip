@@ -15,9 +15,9 @@ namespace dsopp_hip {
 namespace {
 
 struct ResidualTable {
-  DeviceBuffer<uint8_t> status, cand, fej_valid;
+  DeviceBuffer<uint8_t> status, cand, fej_valid, snap_status;
   DeviceBuffer<double> energy;
-  int n = 0;
+  int n = 0, snap_n = 0;
 };
 
 struct HostFrame {
@@ -33,7 +33,9 @@ struct HostFrame {
   std::vector<uint8_t> flags;  // host mirror of the landmark flags as last uploaded
   DeviceBuffer<double> uv, idepth, idepth_step, idepth_fej, patch, inv_hdd, b_d, relative_baseline, ublk;
   DeviceBuffer<int32_t> n_inliers;
-  DeviceBuffer<uint8_t> dflags;
+  DeviceBuffer<uint8_t> dflags, snap_flags;
+  DeviceBuffer<double> snap_idepth;
+  int snap_n = 0;
   std::map<int, std::unique_ptr<ResidualTable>> residuals;  // by target frame id
   std::map<int, std::array<double, 36>> covariance;
 };
@@ -60,7 +62,18 @@ struct dsopp_hip_window {
   DeviceBuffer<SweepBlock> d_sweep_table;
   DeviceBuffer<SchurBlock> d_schur_table;
   DeviceBuffer<int> d_pair_first, d_pair_count;
-  DeviceBuffer<double> d_partials, d_Gpair, d_GT, d_TGT, d_Hpp, d_bpp, d_Hsc, d_bsc, d_Hm, d_bm, d_step, d_scalars;
+  // d_reduce = [Gpair F*F*48 | Hsc K*K | bsc K]: everything a multi-GPU run must sum across ranks, contiguous
+  DeviceBuffer<double> d_partials, d_reduce, d_GT, d_TGT, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  double *dGpair() const { return d_reduce.ptr; }
+  double *dHsc() const { return d_reduce.ptr + static_cast<size_t>(F()) * F() * 48; }
+  double *dbsc() const { return dHsc() + static_cast<size_t>(K()) * K(); }
+  void d_HscDownload(double *host, size_t n, size_t off, hipStream_t st) const {
+    HIP_CHECK(hipMemcpyAsync(host, dHsc() + off, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  void d_bscDownload(double *host, size_t n, size_t off, hipStream_t st) const {
+    HIP_CHECK(hipMemcpyAsync(host, dbsc() + off, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  size_t reduceCount() const { return static_cast<size_t>(F()) * F() * 48 + static_cast<size_t>(K()) * K() + K(); }
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
   bool state_dirty = true;   // host mirror newer than device
@@ -68,12 +81,28 @@ struct dsopp_hip_window {
   bool pair_valid = false;   // pair constants match the device state
   bool begun = false;
   bool linearized = false;
+  bool reduced_by_collective = false;
   double last_lambda = 0;
   std::vector<double> last_step;
   float last_solve_ms = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   dsopp_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  int rank = 0, world = 1;
+  // per-kernel-class HIP-event timing (bench.py's live roofline measurement)
+  bool profiling = false;
+  struct TimedLaunch {
+    int cls;
+    hipEvent_t a, b;
+  };
+  std::vector<TimedLaunch> timed;
+  std::vector<hipEvent_t> event_pool;
+  double prof_ms[DSOPP_HIP_NUM_KERNEL_CLASSES] = {0};
+  int64_t prof_count[DSOPP_HIP_NUM_KERNEL_CLASSES] = {0};
+  // device-side snapshot of the mutable solver state (bench loops / tracker retries): see dsopp_hip_window_snapshot
+  WindowState snap_state;
+  bool snap_valid = false;
+  int snap_F = 0;
 
   int F() const { return static_cast<int>(frames.size()); }
   int K() const { return kBlk * F(); }
@@ -94,6 +123,45 @@ namespace dsopp_hip {
 namespace {
 
 using W = dsopp_hip_window;
+
+hipEvent_t takeEvent(W &w) {
+  if (!w.event_pool.empty()) {
+    hipEvent_t e = w.event_pool.back();
+    w.event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIP_CHECK(hipEventCreate(&e));
+  return e;
+}
+
+/** brackets the launches issued by `body` with HIP events on the window's stream when profiling is on */
+template <typename Body>
+void timedLaunch(W &w, int cls, Body &&body) {
+  if (!w.profiling) {
+    body();
+    return;
+  }
+  hipEvent_t a = takeEvent(w), b = takeEvent(w);
+  HIP_CHECK(hipEventRecord(a, w.sr.stream));
+  body();
+  HIP_CHECK(hipEventRecord(b, w.sr.stream));
+  w.timed.push_back({cls, a, b});
+}
+
+void collectTimings(W &w) {
+  if (w.timed.empty()) return;
+  w.sr.sync();
+  for (auto &t : w.timed) {
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, t.a, t.b));
+    w.prof_ms[t.cls] += ms;
+    w.prof_count[t.cls] += 1;
+    w.event_pool.push_back(t.a);
+    w.event_pool.push_back(t.b);
+  }
+  w.timed.clear();
+}
 
 void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   if (n <= f.cap) return;
@@ -196,14 +264,12 @@ void syncTopology(W &w) {
   w.d_pair_count.upload(pair_count.data(), pair_count.size(), 0, st);
   w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
-  w.d_Gpair.reserve(kMaxFrames * kMaxFrames * 48, 0, st);
   w.d_GT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
   w.d_TGT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
   w.d_Hpp.reserve(KK * KK, 0, st);
   w.d_bpp.reserve(KK, 0, st);
-  w.d_Hsc.reserve(KK * KK, 0, st);
-  w.d_bsc.reserve(KK, 0, st);
+  w.d_reduce.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * 48 + KK * KK + KK, 0, st);
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
@@ -248,7 +314,9 @@ void prepare(W &w) {
 void ensurePairConstants(W &w) {
   if (w.pair_valid) return;
   const int F = w.F();
-  pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, F, w.fej() ? 1 : 0);
+  timedLaunch(w, DSOPP_HIP_KERNEL_PAIR_SETUP, [&] {
+    pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, F, w.fej() ? 1 : 0);
+  });
   HIP_CHECK(hipGetLastError());
   w.pair_valid = true;
 }
@@ -256,7 +324,8 @@ void ensurePairConstants(W &w) {
 template <typename S>
 void launchFej(W &w) {
   if (!w.n_sweep_blocks) return;
-  fejKernel<S><<<w.n_sweep_blocks, kSweepThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr);
+  timedLaunch(w, DSOPP_HIP_KERNEL_FEJ,
+              [&] { fejKernel<S><<<w.n_sweep_blocks, kSweepThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr); });
   HIP_CHECK(hipGetLastError());
 }
 
@@ -282,22 +351,24 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg) {
   const PairConst *pc = w.d_pc.ptr;
   const SweepBlock *tb = w.d_sweep_table.ptr;
   double *pa = w.d_partials.ptr;
-  if (!lin) {
-    if (w.fej())
-      sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-    else
-      sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-  } else if (w.fej()) {
-    if (huber)
-      sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-    else
-      sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-  } else {
-    if (huber)
-      sweepKernel<S, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-    else
-      sweepKernel<S, true, false, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-  }
+  timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
+    if (!lin) {
+      if (w.fej())
+        sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    } else if (w.fej()) {
+      if (huber)
+        sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    } else {
+      if (huber)
+        sweepKernel<S, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, true, false, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    }
+  });
   HIP_CHECK(hipGetLastError());
 }
 
@@ -311,8 +382,7 @@ void launchSweep(W &w, bool lin, bool huber, bool for_marg) {
 
 void launchSchur(W &w, bool for_marg) {
   const int K = w.K();
-  HIP_CHECK(hipMemsetAsync(w.d_Hsc.ptr, 0, static_cast<size_t>(K) * K * sizeof(double), w.sr.stream));
-  HIP_CHECK(hipMemsetAsync(w.d_bsc.ptr, 0, static_cast<size_t>(K) * sizeof(double), w.sr.stream));
+  HIP_CHECK(hipMemsetAsync(w.dHsc(), 0, (static_cast<size_t>(K) * K + K) * sizeof(double), w.sr.stream));
   if (!w.n_schur_blocks || !w.opt.optimize_idepths) return;
   const size_t smem = (static_cast<size_t>(kSchurLandmarks) * K + 2 * kSchurLandmarks) * sizeof(double);
   static bool attr_set = false;
@@ -320,24 +390,26 @@ void launchSchur(W &w, bool for_marg) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  schurKernel<<<w.n_schur_blocks, kSchurThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_schur_table.ptr, w.d_Hsc.ptr,
-                                                                       w.d_bsc.ptr, w.F(), for_marg ? 1 : 0);
+  timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
+    schurKernel<<<w.n_schur_blocks, kSchurThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_schur_table.ptr, w.dHsc(),
+                                                                         w.dbsc(), w.F(), for_marg ? 1 : 0);
+  });
   HIP_CHECK(hipGetLastError());
 }
 
-void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors) {
+void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool skip_pair_reduce = false) {
   const int K = w.K();
   SolveBuffers B;
   B.partials = w.d_partials.ptr;
   B.pair_first_block = w.d_pair_first.ptr;
   B.pair_num_blocks = w.d_pair_count.ptr;
-  B.Gpair = w.d_Gpair.ptr;
+  B.Gpair = w.dGpair();
   B.GT = w.d_GT.ptr;
   B.TGT = w.d_TGT.ptr;
   B.Hpp = w.d_Hpp.ptr;
   B.bpp = w.d_bpp.ptr;
-  B.Hsc = w.d_Hsc.ptr;
-  B.bsc = w.d_bsc.ptr;
+  B.Hsc = w.dHsc();
+  B.bsc = w.dbsc();
   B.Hm = w.d_Hm.ptr;
   B.bm = w.d_bm.ptr;
   B.step = w.d_step.ptr;
@@ -356,8 +428,10 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assembleSolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     attr_set = true;
   }
-  assembleSolveKernel<<<1, kSolveThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, B, prm, w.fej() ? 1 : 0,
-                                                               do_solve ? 1 : 0);
+  timedLaunch(w, do_solve ? DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE : DSOPP_HIP_KERNEL_ASSEMBLE, [&] {
+    assembleSolveKernel<<<1, kSolveThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, B, prm, w.fej() ? 1 : 0,
+                                                                 do_solve ? 1 : 0, skip_pair_reduce ? 1 : 0);
+  });
   HIP_CHECK(hipGetLastError());
 }
 
@@ -406,7 +480,8 @@ void stageBegin(W &w) {
 std::pair<double, int> stageEnergy(W &w) {
   if (!w.begun) fail(DSOPP_HIP_ERR_STATE, "call begin first");
   launchSweep(w, false, true, false);
-  energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr);
+  timedLaunch(w, DSOPP_HIP_KERNEL_ENERGY_REDUCE,
+              [&] { energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr); });
   HIP_CHECK(hipGetLastError());
   allreduceIfNeeded(w, w.d_scalars.ptr, 2);
   double out[2];
@@ -419,17 +494,27 @@ void stageLinearize(W &w, bool huber = true, bool for_marg = false, bool add_pri
   if (!w.begun) fail(DSOPP_HIP_ERR_STATE, "call begin first");
   launchSweep(w, true, huber, for_marg);
   launchSchur(w, for_marg);
-  launchAssemble(w, 0.0, false, add_priors);
+  if (w.allreduce) {
+    // multi-GPU: landmarks are sharded, so the per-pair Gram sums and the Schur system are partial: sum them across
+    // ranks (one collective over one contiguous buffer) before the replicated assembly
+    pairReduceKernel<<<8, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.d_pair_first.ptr, w.d_pair_count.ptr, w.dGpair(), w.F());
+    HIP_CHECK(hipGetLastError());
+    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+  }
+  w.reduced_by_collective = w.allreduce != nullptr;
+  launchAssemble(w, 0.0, false, add_priors, w.reduced_by_collective);
   w.linearized = true;
 }
 
 void stageStep(W &w, double lambda) {
   if (!w.linearized) fail(DSOPP_HIP_ERR_STATE, "call linearize first");
   // the sweep partials and the Schur system are still resident: re-run the (cheap) assembly with the requested lambda
-  launchAssemble(w, lambda, true, true);
+  launchAssemble(w, lambda, true, true, w.reduced_by_collective);
   w.pair_valid = true;  // the solve kernel rebuilt the pair constants for eps + step
   if (w.opt.optimize_idepths && w.n_schur_blocks) {
-    backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F());
+    timedLaunch(w, DSOPP_HIP_KERNEL_BACKSUB, [&] {
+      backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F());
+    });
     HIP_CHECK(hipGetLastError());
   }
   const int K = w.K();
@@ -442,16 +527,21 @@ void stageStep(W &w, double lambda) {
 }
 
 std::pair<double, double> stageAccept(W &w, bool accept) {
-  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr + 4, 0, 2 * sizeof(double), w.sr.stream));
-  if (w.n_schur_blocks) {
-    acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), accept ? 1 : 0,
-                                                                                w.d_scalars.ptr + 4);
-  }
-  acceptFramesKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F(), accept ? 1 : 0, w.d_scalars.ptr + 4);
+  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr + 4, 0, 4 * sizeof(double), w.sr.stream));
+  timedLaunch(w, DSOPP_HIP_KERNEL_ACCEPT, [&] {
+    if (w.n_schur_blocks) {
+      acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), accept ? 1 : 0,
+                                                                                  w.d_scalars.ptr + 4);
+    }
+    acceptFramesKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F(), accept ? 1 : 0, w.d_scalars.ptr + 6);
+  });
   HIP_CHECK(hipGetLastError());
-  double norms[2];
-  w.d_scalars.download(norms, 2, 4, w.sr.stream);
+  // the idepth part of the norms is a sum over this rank's landmark shard, the frame part is replicated
+  if (accept) allreduceIfNeeded(w, w.d_scalars.ptr + 4, 2);
+  double n4[4];
+  w.d_scalars.download(n4, 4, 4, w.sr.stream);
   w.sr.sync();
+  const double norms[2] = {n4[0] + n4[2], n4[1] + n4[3]};
   // host mirror
   for (int f = 0; f < w.F(); ++f)
     for (int a = 0; a < kBlk; ++a) {
@@ -459,9 +549,6 @@ std::pair<double, double> stageAccept(W &w, bool accept) {
       w.hst.step[f][a] = 0;
     }
   if (!accept) w.pair_valid = false;  // constants were built for eps + step
-  if (w.allreduce && accept) {
-    // idepth norms are partial sums over this rank's landmark shard; the frame part is replicated -> handled by caller
-  }
   return {norms[0], norms[1]};
 }
 
@@ -613,7 +700,7 @@ void estimateUncertainty(W &w) {
   const int K = w.K(), F = w.F();
   std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K);
   w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
-  w.d_Hsc.download(Hsc.data(), Hsc.size(), 0, w.sr.stream);
+  w.d_HscDownload(Hsc.data(), Hsc.size(), 0, w.sr.stream);
   w.sr.sync();
   hostla::Mat full(static_cast<size_t>(K) * K);
   for (size_t i = 0; i < full.size(); ++i) full[i] = Hpp[i] - Hsc[i] + w.Hm[i];
@@ -670,16 +757,22 @@ void foldMarginalized(W &w) {
     HIP_CHECK(hipGetLastError());
   }
   launchSchur(w, true);
-  launchAssemble(w, 0.0, false, /*add_priors=*/false);
+  if (w.allreduce) {
+    pairReduceKernel<<<8, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.d_pair_first.ptr, w.d_pair_count.ptr, w.dGpair(), w.F());
+    HIP_CHECK(hipGetLastError());
+    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+  }
+  launchAssemble(w, 0.0, false, /*add_priors=*/false, w.allreduce != nullptr);
   energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr);
   HIP_CHECK(hipGetLastError());
+  allreduceIfNeeded(w, w.d_scalars.ptr, 2);
   const int K = w.K(), F = w.F();
   std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K), bpp(static_cast<size_t>(K)), bsc(static_cast<size_t>(K));
   double scal[2];
   w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
-  w.d_Hsc.download(Hsc.data(), Hsc.size(), 0, w.sr.stream);
+  w.d_HscDownload(Hsc.data(), Hsc.size(), 0, w.sr.stream);
   w.d_bpp.download(bpp.data(), bpp.size(), 0, w.sr.stream);
-  w.d_bsc.download(bsc.data(), bsc.size(), 0, w.sr.stream);
+  w.d_bscDownload(bsc.data(), bsc.size(), 0, w.sr.stream);
   w.d_scalars.download(scal, 2, 0, w.sr.stream);
   w.sr.sync();
   downloadState(w);
@@ -1057,8 +1150,8 @@ int dsopp_hip_window_get_system(dsopp_hip_window *w, double *H_pp, double *b_pp,
     hipStream_t st = w->sr.stream;
     if (H_pp) w->d_Hpp.download(H_pp, K * K, 0, st);
     if (b_pp) w->d_bpp.download(b_pp, K, 0, st);
-    if (H_schur) w->d_Hsc.download(H_schur, K * K, 0, st);
-    if (b_schur) w->d_bsc.download(b_schur, K, 0, st);
+    if (H_schur) w->d_HscDownload(H_schur, K * K, 0, st);
+    if (b_schur) w->d_bscDownload(b_schur, K, 0, st);
     w->sr.sync();
   });
 }
@@ -1097,23 +1190,41 @@ int dsopp_hip_window_update_point_statuses(dsopp_hip_window *w) {
   });
 }
 
+static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
+  if (w->F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
+  w->sr.use();
+  prepare(*w);
+  HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
+  stageBegin(*w);
+  lmSolve(*w, e, it, nv);
+  HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
+  HIP_CHECK(hipEventSynchronize(w->ev1));
+  HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
+  collectTimings(*w);
+}
+
+int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    double e = 0;
+    int it = 0, nv = 0;
+    runOptimize(w, e, it, nv);
+    if (energy) *energy = e;
+    if (iterations) *iterations = it;
+    if (n_valid) *n_valid = nv;
+  });
+}
+
 int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
-    if (w->F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
-    w->sr.use();
-    prepare(*w);
-    HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
-    stageBegin(*w);
     double e = 0;
     int it = 0, nv = 0;
-    lmSolve(*w, e, it, nv);
-    HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
-    HIP_CHECK(hipEventSynchronize(w->ev1));
-    HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
+    runOptimize(w, e, it, nv);
     relinearize(*w);
     if (w->opt.estimate_uncertainty) estimateUncertainty(*w);
     updatePointStatuses(*w);
+    collectTimings(*w);
     w->begun = false;
     w->linearized = true;  // the last linearised system stays readable through get_system
     if (energy) *energy = e;
@@ -1233,12 +1344,108 @@ int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, i
   });
 }
 
-int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user) {
+int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user, int rank, int world_size) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (fn && (world_size < 1 || rank < 0 || rank >= world_size)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad rank %d / world %d", rank, world_size);
     w->allreduce = fn;
     w->allreduce_user = user;
+    w->rank = fn ? rank : 0;
+    w->world = fn ? world_size : 1;
   });
+}
+
+int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations) {
+  return guarded([&] {
+    if (!w || max_iterations < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+    w->opt.max_iterations = max_iterations;
+  });
+}
+
+int dsopp_hip_window_snapshot(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->sr.use();
+    prepare(*w);
+    downloadState(*w);
+    hipStream_t st = w->sr.stream;
+    for (auto &fp : w->frames) {
+      HostFrame &f = *fp;
+      f.snap_idepth.reserve(static_cast<size_t>(std::max(f.cap, 1)), 0, st);
+      f.snap_flags.reserve(static_cast<size_t>(std::max(f.cap, 1)), 0, st);
+      if (f.n) {
+        HIP_CHECK(hipMemcpyAsync(f.snap_idepth.ptr, f.idepth.ptr, static_cast<size_t>(f.n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(f.snap_flags.ptr, f.dflags.ptr, static_cast<size_t>(f.n), hipMemcpyDeviceToDevice, st));
+      }
+      f.snap_n = f.n;
+      for (auto &kv : f.residuals) {
+        ResidualTable &rt = *kv.second;
+        rt.snap_status.reserve(static_cast<size_t>(std::max(f.cap, 1)), 0, st);
+        if (rt.n) HIP_CHECK(hipMemcpyAsync(rt.snap_status.ptr, rt.status.ptr, static_cast<size_t>(rt.n), hipMemcpyDeviceToDevice, st));
+        rt.snap_n = rt.n;
+      }
+    }
+    w->snap_state = w->hst;
+    w->snap_F = w->F();
+    w->snap_valid = true;
+    w->sr.sync();
+  });
+}
+
+int dsopp_hip_window_restore(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (!w->snap_valid || w->snap_F != w->F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
+    w->sr.use();
+    hipStream_t st = w->sr.stream;
+    for (auto &fp : w->frames) {
+      HostFrame &f = *fp;
+      if (f.snap_n != f.n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", f.id);
+      if (f.n) {
+        HIP_CHECK(hipMemcpyAsync(f.idepth.ptr, f.snap_idepth.ptr, static_cast<size_t>(f.n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(f.dflags.ptr, f.snap_flags.ptr, static_cast<size_t>(f.n), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemsetAsync(f.idepth_step.ptr, 0, static_cast<size_t>(f.n) * sizeof(double), st));
+      }
+      for (auto &kv : f.residuals) {
+        ResidualTable &rt = *kv.second;
+        if (rt.snap_n != rt.n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", f.id);
+        if (rt.n) {
+          HIP_CHECK(hipMemcpyAsync(rt.status.ptr, rt.snap_status.ptr, static_cast<size_t>(rt.n), hipMemcpyDeviceToDevice, st));
+          HIP_CHECK(hipMemcpyAsync(rt.cand.ptr, rt.snap_status.ptr, static_cast<size_t>(rt.n), hipMemcpyDeviceToDevice, st));
+        }
+      }
+    }
+    w->hst = w->snap_state;
+    w->state_dirty = true;
+    w->begun = false;
+  });
+}
+
+int dsopp_hip_window_set_profiling(dsopp_hip_window *w, int enable) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    collectTimings(*w);
+    w->profiling = enable != 0;
+    for (int i = 0; i < DSOPP_HIP_NUM_KERNEL_CLASSES; ++i) {
+      w->prof_ms[i] = 0;
+      w->prof_count[i] = 0;
+    }
+  });
+}
+
+int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *total_ms, int64_t *launches) {
+  return guarded([&] {
+    if (!w || kernel_class < 0 || kernel_class >= DSOPP_HIP_NUM_KERNEL_CLASSES) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad kernel class");
+    collectTimings(*w);
+    if (total_ms) *total_ms = w->prof_ms[kernel_class];
+    if (launches) *launches = w->prof_count[kernel_class];
+  });
+}
+
+const char *dsopp_hip_kernel_class_name(int kernel_class) {
+  static const char *names[DSOPP_HIP_NUM_KERNEL_CLASSES] = {"pair_setup", "fej", "sweep_linearize", "sweep_energy", "schur",
+                                                            "assemble", "assemble_solve", "backsub", "energy_reduce", "accept"};
+  return (kernel_class >= 0 && kernel_class < DSOPP_HIP_NUM_KERNEL_CLASSES) ? names[kernel_class] : "?";
 }
 
 int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {

@@ -512,9 +512,9 @@ struct SolveBuffers {
   const double *partials;       // [n_sweep_blocks][kPartial]
   const int *pair_first_block;  // [kMaxFrames*kMaxFrames] first sweep block of the pair (-1 = none)
   const int *pair_num_blocks;
-  double *Gpair;                // scratch [kMaxFrames*kMaxFrames][48]: G (36) + q (8)
-  double *GT;                   // scratch [kMaxFrames*kMaxFrames][64]: G*T
-  double *TGT;                  // scratch [kMaxFrames*kMaxFrames][64]: T^T*G*T
+  double *Gpair;                // [F*F][48] (compact, pair index r*F+t): G (36 upper) + q (8)
+  double *GT;                   // scratch [F*F][64]: G*T
+  double *TGT;                  // scratch [F*F][64]: T^T*G*T
   double *Hpp, *bpp;            // out: system_pose (with priors), K x K / K
   double *Hsc, *bsc;            // in: schur (upper triangle) ; symmetrised in place
   const double *Hm, *bm;        // marginal prior (K x K, K) or nullptr
@@ -523,16 +523,26 @@ struct SolveBuffers {
 };
 
 /** sums the per-block G/q partials of every pair (deterministic order) */
-__device__ inline void reducePairPartials(const SolveBuffers &B, int F) {
-  for (int idx = threadIdx.x; idx < F * F * 44; idx += blockDim.x) {
-    const int p = idx / 44, e = idx % 44;
+__device__ inline void reducePairPartials(const double *__restrict__ partials, const int *__restrict__ pair_first_block,
+                                          const int *__restrict__ pair_num_blocks, double *__restrict__ Gpair, int F, int tid, int nthreads) {
+  for (int idx = tid; idx < F * F * 48; idx += nthreads) {
+    const int p = idx / 48, e = idx % 48;
     const int r = p / F, t = p % F;
     const int pi = r * kMaxFrames + t;
     double s = 0;
-    const int first = B.pair_first_block[pi], cnt = B.pair_num_blocks[pi];
-    for (int b = 0; b < cnt; ++b) s += B.partials[static_cast<size_t>(first + b) * kPartial + e];
-    B.Gpair[pi * 48 + e] = s;
+    if (e < 44) {
+      const int first = pair_first_block[pi], cnt = pair_num_blocks[pi];
+      for (int b = 0; b < cnt; ++b) s += partials[static_cast<size_t>(first + b) * kPartial + e];
+    }
+    Gpair[p * 48 + e] = s;
   }
+}
+
+/** stand-alone version used when the per-pair sums must be all-reduced across GPUs before the assembly */
+__global__ void pairReduceKernel(const double *__restrict__ partials, const int *__restrict__ pair_first_block,
+                                 const int *__restrict__ pair_num_blocks, double *__restrict__ Gpair, int F) {
+  reducePairPartials(partials, pair_first_block, pair_num_blocks, Gpair, F, blockIdx.x * blockDim.x + threadIdx.x,
+                     gridDim.x * blockDim.x);
 }
 
 /**
@@ -542,7 +552,8 @@ __device__ inline void reducePairPartials(const SolveBuffers &B, int F) {
  * constants for the candidate state so the following energy sweep needs no extra launch.
  */
 __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const FrameDev *__restrict__ frames, WindowState *st, PairConst *pc,
-                                                                     SolveBuffers B, SolveParams prm, int fej, int do_solve) {
+                                                                     SolveBuffers B, SolveParams prm, int fej, int do_solve,
+                                                                     int skip_pair_reduce) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int F = prm.F, K = kBlk * F;
   double *A = reinterpret_cast<double *>(smem_raw);  // K x K
@@ -551,7 +562,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
   double *col = pv + K;                              // K scratch
   const int tid = threadIdx.x;
 
-  reducePairPartials(B, F);
+  if (!skip_pair_reduce) reducePairPartials(B.partials, B.pair_first_block, B.pair_num_blocks, B.Gpair, F, tid, kSolveThreads);
   __syncthreads();
   // per pair: GT = G*T, TGT = T^T*GT with T = blockdiag(Adj, 1, s0)
   for (int idx = tid; idx < F * F * 64; idx += kSolveThreads) {
@@ -559,7 +570,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
     const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
     const PairConst &P = pc[pi];
     if (!P.valid) continue;
-    const double *G = B.Gpair + pi * 48;
+    const double *G = B.Gpair + p * 48;
     double s;
     if (j < 6) {
       s = 0;
@@ -569,7 +580,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
     } else {
       s = G[symIdx(i, 7)] * P.s0;
     }
-    B.GT[pi * 64 + e] = s;
+    B.GT[p * 64 + e] = s;
   }
   __syncthreads();
   for (int idx = tid; idx < F * F * 64; idx += kSolveThreads) {
@@ -577,7 +588,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
     const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
     const PairConst &P = pc[pi];
     if (!P.valid) continue;
-    const double *GT = B.GT + pi * 64;
+    const double *GT = B.GT + p * 64;
     double s;
     if (i < 6) {
       s = 0;
@@ -587,7 +598,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
     } else {
       s = P.s0 * GT[8 * 7 + j];
     }
-    B.TGT[pi * 64 + e] = s;
+    B.TGT[p * 64 + e] = s;
   }
   __syncthreads();
   // H_pp, b_pp
@@ -598,13 +609,13 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
     if (fa == fb) {
       for (int t = 0; t < F; ++t) {
         if (t == fa) continue;
-        if (pc[fa * kMaxFrames + t].valid) s += B.TGT[(fa * kMaxFrames + t) * 64 + 8 * i + j];
-        if (pc[t * kMaxFrames + fa].valid) s += B.Gpair[(t * kMaxFrames + fa) * 48 + symIdx(i, j)];
+        if (pc[fa * kMaxFrames + t].valid) s += B.TGT[(fa * F + t) * 64 + 8 * i + j];
+        if (pc[t * kMaxFrames + fa].valid) s += B.Gpair[(t * F + fa) * 48 + symIdx(i, j)];
       }
     } else {
       // H[r,t] = -T^T G (pair fa->fb) ; H[t,r] of pair (fb->fa) transposed = -(G T)
-      if (pc[fa * kMaxFrames + fb].valid) s -= B.GT[(fa * kMaxFrames + fb) * 64 + 8 * j + i];  // (T^T G)_{ij} = (G T)_{ji}
-      if (pc[fb * kMaxFrames + fa].valid) s -= B.GT[(fb * kMaxFrames + fa) * 64 + 8 * i + j];
+      if (pc[fa * kMaxFrames + fb].valid) s -= B.GT[(fa * F + fb) * 64 + 8 * j + i];  // (T^T G)_{ij} = (G T)_{ji}
+      if (pc[fb * kMaxFrames + fa].valid) s -= B.GT[(fb * F + fa) * 64 + 8 * i + j];
     }
     A[idx] = s;
   }
@@ -616,7 +627,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
       const int prt = fa * kMaxFrames + t, ptr_ = t * kMaxFrames + fa;
       if (pc[prt].valid) {
         // b_r = T^T q
-        const double *q = B.Gpair + prt * 48 + 36;
+        const double *q = B.Gpair + (fa * F + t) * 48 + 36;
         if (i < 6) {
           for (int k = 0; k < 6; ++k) s += pc[prt].Adj[6 * k + i] * q[k];
         } else if (i == 6) {
@@ -625,7 +636,7 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const Frame
           s += pc[prt].s0 * q[7];
         }
       }
-      if (pc[ptr_].valid) s -= B.Gpair[ptr_ * 48 + 36 + i];  // b_t = -q
+      if (pc[ptr_].valid) s -= B.Gpair[(t * F + fa) * 48 + 36 + i];  // b_t = -q
     }
     bv[a] = s;
   }
@@ -796,7 +807,7 @@ __global__ void acceptLandmarksKernel(const FrameDev *__restrict__ frames, const
   }
 }
 
-__global__ void acceptFramesKernel(WindowState *st, int F, int accept, double *norms) {
+__global__ void acceptFramesKernel(WindowState *st, int F, int accept, double *norms /* [2] frame part */) {
   if (threadIdx.x != 0) return;
   double state_sq = 0, step_sq = 0;
   for (int f = 0; f < F; ++f) {
@@ -811,8 +822,8 @@ __global__ void acceptFramesKernel(WindowState *st, int F, int accept, double *n
     if (accept) state_sq += st->ab0[f][0] * st->ab0[f][0] + st->ab0[f][1] * st->ab0[f][1];
   }
   if (accept) {
-    norms[0] += state_sq;
-    norms[1] += step_sq;
+    norms[0] = state_sq;
+    norms[1] = step_sq;
   }
 }
 

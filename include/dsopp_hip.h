@@ -174,10 +174,41 @@ int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, i
  * (the reduced normal equations once per linearisation, energy + valid count once per energy sweep).  `device_buffer`
  * is device memory holding `count` doubles to be summed in place across ranks.  With no callback the window is single-GPU. */
 typedef int (*dsopp_hip_allreduce_fn)(void *user, void *device_buffer, size_t count, void *stream);
-int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user);
+int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user, int rank, int world_size);
 
-/* timing / introspection for bench.py (HIP-event time of the last solve's device work, in milliseconds) */
-int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms);
+/* the Levenberg-Marquardt loop of solve() alone (firstEstimateJacobians + levenberg_marquardt_algorithm::solve,
+ * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:83-86) without the post-processing (relinearise, covariance, statuses).
+ * One loop body = one Gauss-Newton iteration = linearize + calculateStep + calculateEnergy + accept/reject. */
+int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid);
+/* TrustRegion...Options::max_iterations of an existing window */
+int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations);
+
+/* device-side snapshot / restore of the mutable solver state (poses, affine, idepths, flags, connection statuses);
+ * device-to-device copies only.  Lets a caller re-run a solve from the same starting point (benchmark loops, the
+ * tracker's re-tracking tries) without re-uploading the window. */
+int dsopp_hip_window_snapshot(dsopp_hip_window *w);
+int dsopp_hip_window_restore(dsopp_hip_window *w);
+
+/* timing / introspection for bench.py */
+int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms); /* HIP-event time of the last LM loop */
+enum {
+  DSOPP_HIP_KERNEL_PAIR_SETUP = 0,
+  DSOPP_HIP_KERNEL_FEJ,
+  DSOPP_HIP_KERNEL_SWEEP_LINEARIZE,
+  DSOPP_HIP_KERNEL_SWEEP_ENERGY,
+  DSOPP_HIP_KERNEL_SCHUR,
+  DSOPP_HIP_KERNEL_ASSEMBLE,
+  DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE,
+  DSOPP_HIP_KERNEL_BACKSUB,
+  DSOPP_HIP_KERNEL_ENERGY_REDUCE,
+  DSOPP_HIP_KERNEL_ACCEPT,
+  DSOPP_HIP_NUM_KERNEL_CLASSES
+};
+/* when enabled every kernel launch is bracketed by HIP events on the window's stream; get_profile returns the summed
+ * device time and launch count of one kernel class since profiling was (re-)enabled */
+int dsopp_hip_window_set_profiling(dsopp_hip_window *w, int enable);
+int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *total_ms, int64_t *launches);
+const char *dsopp_hip_kernel_class_name(int kernel_class);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Two-frame direct image alignment of one pyramid level

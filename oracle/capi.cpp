@@ -187,6 +187,34 @@ int orc_window_solve(orc_window *w, double *energy, int *iterations, int *n_vali
   return 0;
 }
 
+int orc_window_optimize(orc_window *w, double *energy, int *iterations, int *n_valid) {
+  w->problem.reset();
+  const double e = w->win.optimize();
+  if (energy) *energy = e;
+  if (iterations) *iterations = w->win.last_result.iterations;
+  if (n_valid) *n_valid = w->win.last_result.number_of_valid_residuals;
+  return 0;
+}
+/* overwrite the mutable solver state (poses as linearisation points with zero eps, idepths, statuses = kOk) so a
+ * timing loop can restart from the same point */
+int orc_window_reset_state(orc_window *w, int frame_id, const double T_w_agent[7], const double ab[2], const double *idepth) {
+  LocalFrame *f = w->win.getLocalFrame(frame_id);
+  if (!f) return -2;
+  f->T_w_agent_linearization_point = SE3::fromParams(T_w_agent);
+  f->affine_brightness0[0] = ab[0];
+  f->affine_brightness0[1] = ab[1];
+  for (double &v : f->state_eps) v = 0;
+  for (double &v : f->state_eps_step) v = 0;
+  for (size_t i = 0; i < f->active_landmarks.size(); ++i) {
+    f->active_landmarks[i].idepth = idepth[i];
+    f->active_landmarks[i].idepth_step = 0;
+    f->active_landmarks[i].is_outlier = false;
+  }
+  for (auto &kv : f->residuals)
+    for (auto &r : kv.second) r = ResidualPoint(kOk);
+  return 0;
+}
+
 int orc_window_get_frame_state(orc_window *w, int frame_id, double T0[7], double ab0[2], double eps[8], double step[8]) {
   LocalFrame *f = w->win.getLocalFrame(frame_id);
   if (!f) return -2;

@@ -60,6 +60,9 @@ int orc_window_reject_step(orc_window *w);
 int orc_window_update_point_statuses(orc_window *w);
 /* whole solve (EigenPhotometricBundleAdjustment::solve) */
 int orc_window_solve(orc_window *w, double *energy, int *iterations, int *n_valid);
+/* LM loop only (no relinearisation / covariance / statuses) */
+int orc_window_optimize(orc_window *w, double *energy, int *iterations, int *n_valid);
+int orc_window_reset_state(orc_window *w, int frame_id, const double T_w_agent[7], const double ab[2], const double *idepth);
 
 /* getters */
 int orc_window_get_frame_state(orc_window *w, int frame_id, double T0[7], double ab0[2], double eps[8], double step[8]);

@@ -972,6 +972,24 @@ struct PbaWindow {
     return 0;
   }
 
+  /** the LM part of solve() (eigen_photometric_bundle_adjustment.cpp:67-86), without post-processing: used to time
+   *  Gauss-Newton iterations on the CPU beside the GPU numbers */
+  double optimize() {
+    LmOptions options;
+    options.initial_levenberg_marquardt_regularizer = 1.0 / opt.initial_trust_region_radius;
+    options.function_tolerance = opt.function_tolerance;
+    options.parameter_tolerance = opt.parameter_tolerance;
+    options.max_num_iterations = static_cast<size_t>(opt.max_iterations);
+    options.min_num_iterations = 3;
+    options.force_accept = opt.force_accept;
+    options.levenberg_marquardt_regularizer_decrease_on_accept = 1.;
+    options.levenberg_marquardt_regularizer_increase_on_reject = 1.;
+    PbaProblem problem(frames, opt, system_marginalized, energy_marginalized);
+    if (opt.first_estimate_jacobians) firstEstimateJacobians(frames);
+    last_result = lmSolve(problem, options);
+    return last_result.energy;
+  }
+
   /** solve — eigen_photometric_bundle_adjustment.cpp:61-101 */
   double solve() {
     LmOptions options;

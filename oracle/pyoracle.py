@@ -179,6 +179,14 @@ class OracleWindow:
         self._chk(lib().orc_window_solve(self._h, C.byref(e), C.byref(it), C.byref(nv)))
         return e.value, it.value, nv.value
 
+    def optimize(self):
+        e, it, nv = C.c_double(), C.c_int(), C.c_int()
+        self._chk(lib().orc_window_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    def reset_state(self, frame_id, T_w_agent, affine, idepth):
+        self._chk(lib().orc_window_reset_state(self._h, int(frame_id), _p(_f64(T_w_agent)), _p(_f64(affine)), _p(_f64(idepth))))
+
     # --- getters ---
     def get_frame_state(self, frame_id):
         T0, ab0, eps, step = np.zeros(7), np.zeros(2), np.zeros(8), np.zeros(8)
