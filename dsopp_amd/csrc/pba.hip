@@ -9,7 +9,7 @@
 #include <memory>
 
 #include "host_linalg.hpp"
-#include "pba_kernels.hpp"
+#include "pba_solve_kernels.hpp"
 
 namespace dsopp_hip {
 namespace {
@@ -63,7 +63,9 @@ struct dsopp_hip_window {
   DeviceBuffer<SchurBlock> d_schur_table;
   DeviceBuffer<int> d_pair_first, d_pair_count;
   // d_reduce = [Gpair F*F*48 | Hsc K*K | bsc K]: everything a multi-GPU run must sum across ranks, contiguous
-  DeviceBuffer<double> d_partials, d_reduce, d_GT, d_TGT, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  DeviceBuffer<double> d_partials, d_reduce, d_pairblk, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  DeviceBuffer<LmControl> d_ctrl;
+  bool host_driven_lm = false;  // debug / parity: run the LM control flow on the host through the stage functions
   double *dGpair() const { return d_reduce.ptr; }
   double *dHsc() const { return d_reduce.ptr + static_cast<size_t>(F()) * F() * 48; }
   double *dbsc() const { return dHsc() + static_cast<size_t>(K()) * K(); }
@@ -230,6 +232,7 @@ void syncTopology(W &w) {
     d.n_inliers = f.n_inliers.ptr;
     d.flags = f.dflags.ptr;
     d.ublk = f.ublk.ptr;
+    d.first_conn = -1;
     for (int t = 0; t < F; ++t) {
       if (t == r) continue;
       auto it = f.residuals.find(w.frames[static_cast<size_t>(t)]->id);
@@ -240,6 +243,7 @@ void syncTopology(W &w) {
       d.fej_valid[t] = rt.fej_valid.ptr;
       d.energy[t] = rt.energy.ptr;
       d.n_res[t] = rt.n;
+      if (d.first_conn < 0) d.first_conn = t;
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
       for (int off = 0; off < rt.n; off += kSweepThreads) {
@@ -264,8 +268,8 @@ void syncTopology(W &w) {
   w.d_pair_count.upload(pair_count.data(), pair_count.size(), 0, st);
   w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
-  w.d_GT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
-  w.d_TGT.reserve(kMaxFrames * kMaxFrames * 64, 0, st);
+  w.d_pairblk.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * kPairBlk, 0, st);
+  w.d_ctrl.reserve(2, 0, st);
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
   w.d_Hpp.reserve(KK * KK, 0, st);
   w.d_bpp.reserve(KK, 0, st);
@@ -339,12 +343,13 @@ void firstEstimate(W &w) {
 }
 
 template <typename S>
-void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg) {
+void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl) {
   if (!w.n_sweep_blocks) return;
   SweepParams prm;
   prm.sigma_huber = w.opt.sigma_huber_loss;
   prm.for_marginalized = for_marg ? 1 : 0;
   prm.use_fej_flag = w.fej() ? 1 : 0;
+  prm.ctrl_active = ctrl ? &ctrl->active : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
   const FrameDev *fr = w.d_frames.ptr;
@@ -372,65 +377,119 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg) {
   HIP_CHECK(hipGetLastError());
 }
 
-void launchSweep(W &w, bool lin, bool huber, bool for_marg) {
-  ensurePairConstants(w);
+void launchSweep(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl = nullptr) {
+  if (!ctrl) ensurePairConstants(w);
   if (w.opt.dtype == DSOPP_HIP_F64)
-    launchSweepTyped<double>(w, lin, huber, for_marg);
+    launchSweepTyped<double>(w, lin, huber, for_marg, ctrl);
   else
-    launchSweepTyped<float>(w, lin, huber, for_marg);
+    launchSweepTyped<float>(w, lin, huber, for_marg, ctrl);
 }
 
-void launchSchur(W &w, bool for_marg) {
-  const int K = w.K();
-  HIP_CHECK(hipMemsetAsync(w.dHsc(), 0, (static_cast<size_t>(K) * K + K) * sizeof(double), w.sr.stream));
-  if (!w.n_schur_blocks || !w.opt.optimize_idepths) return;
-  const size_t smem = (static_cast<size_t>(kSchurLandmarks) * K + 2 * kSchurLandmarks) * sizeof(double);
+void allreduceIfNeeded(W &w, double *dev, size_t count) {
+  if (!w.allreduce) return;
+  const int rc = w.allreduce(w.allreduce_user, dev, count, w.sr.stream);
+  if (rc != 0) fail(DSOPP_HIP_ERR_HIP, "allreduce callback failed with %d", rc);
+}
+
+size_t schurSmemBytes(int K) {
+  const int Kp = (K + 15) & ~15;
+  return (static_cast<size_t>(kSchurLandmarks) * schurRowStride(Kp) + 2 * kSchurLandmarks) * sizeof(double);
+}
+
+/** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks) */
+void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl) {
+  const int K = w.K(), F = w.F();
+  hipStream_t st = w.sr.stream;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(schurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(reduceSchurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
+  ReduceSchurArgs a;
+  a.frames = w.d_frames.ptr;
+  a.pc = w.d_pc.ptr;
+  a.schur_table = w.d_schur_table.ptr;
+  a.partials = w.d_partials.ptr;
+  a.pair_first_block = w.d_pair_first.ptr;
+  a.pair_num_blocks = w.d_pair_count.ptr;
+  a.Gpair = w.dGpair();
+  a.pairblk = w.d_pairblk.ptr;
+  a.Hsc = w.dHsc();
+  a.bsc = w.dbsc();
+  a.ctrl = ctrl;
+  a.F = F;
+  a.n_schur_blocks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
+  a.for_marginalized = for_marg ? 1 : 0;
+  a.derive = w.allreduce ? 0 : 1;
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
-    schurKernel<<<w.n_schur_blocks, kSchurThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_schur_table.ptr, w.dHsc(),
-                                                                         w.dbsc(), w.F(), for_marg ? 1 : 0);
+    // the Schur system is accumulated with atomics: clear it first (skipped inside a device-driven loop only when the
+    // kernel itself is skipped — a stale system is then reused, as the reference does when linear_system_valid)
+    clearSchurKernel<<<(K * K + K + 255) / 256, 256, 0, st>>>(w.dHsc(), K * K + K, ctrl);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, schurSmemBytes(K), st>>>(a);
   });
+  HIP_CHECK(hipGetLastError());
+  if (w.allreduce) {
+    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+    pairDeriveKernel<<<F * F, 64, 0, st>>>(w.d_pc.ptr, w.dGpair(), w.d_pairblk.ptr, F, ctrl);
+    HIP_CHECK(hipGetLastError());
+  }
+}
+
+SolveArgs makeSolveArgs(W &w) {
+  SolveArgs a;
+  a.frames = w.d_frames.ptr;
+  a.st = w.d_state.ptr;
+  a.pc = w.d_pc.ptr;
+  a.Gpair = w.dGpair();
+  a.pairblk = w.d_pairblk.ptr;
+  a.Hpp = w.d_Hpp.ptr;
+  a.bpp = w.d_bpp.ptr;
+  a.Hsc = w.dHsc();
+  a.bsc = w.dbsc();
+  a.Hm = w.d_Hm.ptr;
+  a.bm = w.d_bm.ptr;
+  a.step = w.d_step.ptr;
+  a.ctrl = nullptr;
+  a.lambda = 0;
+  a.affine_reg[0] = w.opt.affine_brightness_regularizer[0];
+  a.affine_reg[1] = w.opt.affine_brightness_regularizer[1];
+  a.fixed_reg = w.opt.fixed_state_regularizer;
+  a.energy_marginalized = w.energy_marginalized;
+  a.F = w.F();
+  a.fej = w.fej() ? 1 : 0;
+  a.do_solve = 1;
+  a.store_system = 0;
+  a.add_priors = 1;
+  return a;
+}
+
+size_t solveSmemBytes(int K) {
+  const size_t N = static_cast<size_t>(K) + 1;
+  return (N * (N + 1) + 2 * static_cast<size_t>(K) + 32) * sizeof(double);
+}
+
+/** K3 */
+void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool store_system, LmControl *ctrl) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assembleSolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  SolveArgs a = makeSolveArgs(w);
+  a.lambda = lambda;
+  a.ctrl = ctrl;
+  a.do_solve = do_solve ? 1 : 0;
+  a.add_priors = add_priors ? 1 : 0;
+  a.store_system = store_system ? 1 : 0;
+  timedLaunch(w, do_solve ? DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE : DSOPP_HIP_KERNEL_ASSEMBLE,
+              [&] { assembleSolveKernel<<<1, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
   HIP_CHECK(hipGetLastError());
 }
 
-void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool skip_pair_reduce = false) {
-  const int K = w.K();
-  SolveBuffers B;
-  B.partials = w.d_partials.ptr;
-  B.pair_first_block = w.d_pair_first.ptr;
-  B.pair_num_blocks = w.d_pair_count.ptr;
-  B.Gpair = w.dGpair();
-  B.GT = w.d_GT.ptr;
-  B.TGT = w.d_TGT.ptr;
-  B.Hpp = w.d_Hpp.ptr;
-  B.bpp = w.d_bpp.ptr;
-  B.Hsc = w.dHsc();
-  B.bsc = w.dbsc();
-  B.Hm = w.d_Hm.ptr;
-  B.bm = w.d_bm.ptr;
-  B.step = w.d_step.ptr;
-  B.energy_out = w.d_scalars.ptr;
-  SolveParams prm;
-  prm.lambda = lambda;
-  prm.affine_reg[0] = add_priors ? w.opt.affine_brightness_regularizer[0] : 0.0;
-  prm.affine_reg[1] = add_priors ? w.opt.affine_brightness_regularizer[1] : 0.0;
-  prm.fixed_reg = add_priors ? w.opt.fixed_state_regularizer : 0.0;
-  prm.F = w.F();
-  prm.n_sweep_blocks = w.n_sweep_blocks;
-  prm.use_marginal = 1;
-  const size_t smem = (static_cast<size_t>(K) * K + 3 * static_cast<size_t>(K)) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assembleSolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    attr_set = true;
-  }
-  timedLaunch(w, do_solve ? DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE : DSOPP_HIP_KERNEL_ASSEMBLE, [&] {
-    assembleSolveKernel<<<1, kSolveThreads, smem, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, B, prm, w.fej() ? 1 : 0,
-                                                                 do_solve ? 1 : 0, skip_pair_reduce ? 1 : 0);
+void launchBacksub(W &w, double lambda, const LmControl *ctrl) {
+  if (!w.opt.optimize_idepths || !w.n_schur_blocks) return;
+  timedLaunch(w, DSOPP_HIP_KERNEL_BACKSUB, [&] {
+    backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F(), ctrl);
   });
   HIP_CHECK(hipGetLastError());
 }
@@ -463,12 +522,6 @@ double priorEnergy(const W &w, bool with_step) {
   return e;
 }
 
-void allreduceIfNeeded(W &w, double *dev, size_t count) {
-  if (!w.allreduce) return;
-  const int rc = w.allreduce(w.allreduce_user, dev, count, w.sr.stream);
-  if (rc != 0) fail(DSOPP_HIP_ERR_HIP, "allreduce callback failed with %d", rc);
-}
-
 void stageBegin(W &w) {
   if (w.F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
   prepare(w);
@@ -493,30 +546,17 @@ std::pair<double, int> stageEnergy(W &w) {
 void stageLinearize(W &w, bool huber = true, bool for_marg = false, bool add_priors = true) {
   if (!w.begun) fail(DSOPP_HIP_ERR_STATE, "call begin first");
   launchSweep(w, true, huber, for_marg);
-  launchSchur(w, for_marg);
-  if (w.allreduce) {
-    // multi-GPU: landmarks are sharded, so the per-pair Gram sums and the Schur system are partial: sum them across
-    // ranks (one collective over one contiguous buffer) before the replicated assembly
-    pairReduceKernel<<<8, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.d_pair_first.ptr, w.d_pair_count.ptr, w.dGpair(), w.F());
-    HIP_CHECK(hipGetLastError());
-    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
-  }
-  w.reduced_by_collective = w.allreduce != nullptr;
-  launchAssemble(w, 0.0, false, add_priors, w.reduced_by_collective);
+  launchReduceSchur(w, for_marg, nullptr);
+  launchAssemble(w, 0.0, false, add_priors, /*store_system=*/true, nullptr);
   w.linearized = true;
 }
 
 void stageStep(W &w, double lambda) {
   if (!w.linearized) fail(DSOPP_HIP_ERR_STATE, "call linearize first");
-  // the sweep partials and the Schur system are still resident: re-run the (cheap) assembly with the requested lambda
-  launchAssemble(w, lambda, true, true, w.reduced_by_collective);
+  // the per-pair blocks and the Schur system are still resident: re-run the (cheap) assembly with the requested lambda
+  launchAssemble(w, lambda, true, true, false, nullptr);
   w.pair_valid = true;  // the solve kernel rebuilt the pair constants for eps + step
-  if (w.opt.optimize_idepths && w.n_schur_blocks) {
-    timedLaunch(w, DSOPP_HIP_KERNEL_BACKSUB, [&] {
-      backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F());
-    });
-    HIP_CHECK(hipGetLastError());
-  }
+  launchBacksub(w, lambda, nullptr);
   const int K = w.K();
   w.last_step.resize(static_cast<size_t>(K));
   w.d_step.download(w.last_step.data(), static_cast<size_t>(K), 0, w.sr.stream);
@@ -533,7 +573,7 @@ std::pair<double, double> stageAccept(W &w, bool accept) {
       acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), accept ? 1 : 0,
                                                                                   w.d_scalars.ptr + 4);
     }
-    acceptFramesKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F(), accept ? 1 : 0, w.d_scalars.ptr + 6);
+    acceptFramesKernel<<<1, 128, 0, w.sr.stream>>>(w.d_state.ptr, w.F(), accept ? 1 : 0, w.d_scalars.ptr + 6);
   });
   HIP_CHECK(hipGetLastError());
   // the idepth part of the norms is a sum over this rank's landmark shard, the frame part is replicated
@@ -550,6 +590,88 @@ std::pair<double, double> stageAccept(W &w, bool accept) {
     }
   if (!accept) w.pair_valid = false;  // constants were built for eps + step
   return {norms[0], norms[1]};
+}
+
+/**
+ * levenberg_marquardt_algorithm::solve (levenberg_marquardt_algorithm.hpp:77-128) with the control flow ON THE DEVICE:
+ * the host enqueues max_iterations loop bodies (5 launches each) plus the closing energy evaluation and reads the
+ * control block back once; kernels of loop bodies after termination return immediately.
+ */
+void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+  hipStream_t st = w.sr.stream;
+  const int F = w.F();
+  LmParams prm;
+  prm.function_tolerance = w.opt.function_tolerance;
+  prm.parameter_tolerance = w.opt.parameter_tolerance;
+  prm.decrease_on_accept = 1.0;  // eigen_photometric_bundle_adjustment.cpp:74-75
+  prm.increase_on_reject = 1.0;
+  prm.lambda0 = 1.0 / w.opt.initial_trust_region_radius;
+  prm.max_iterations = w.opt.max_iterations;
+  prm.min_iterations = 3;
+  prm.force_accept = w.opt.force_accept;
+  prm.use_reduced_scalars = w.allreduce ? 1 : 0;
+  LmControl *ctrl = w.d_ctrl.ptr;
+  // result = problem.calculateEnergy()
+  launchSweep(w, false, true, false);
+  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr, 0, 8 * sizeof(double), st));
+  if (w.n_schur_blocks) idepthNormKernel<<<w.n_schur_blocks, kSchurThreads, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_scalars.ptr + 4);
+  if (w.allreduce) {
+    sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr, nullptr);
+    allreduceIfNeeded(w, w.d_scalars.ptr, 5);
+  }
+  {
+    LmInitArgs ia;
+    ia.sa = makeSolveArgs(w);
+    ia.partials = w.d_partials.ptr;
+    ia.scalars = w.d_scalars.ptr;
+    ia.schur_table = w.d_schur_table.ptr;
+    ia.n_sweep_blocks = w.n_sweep_blocks;
+    ia.n_schur_blocks = w.n_schur_blocks;
+    ia.ctrl = ctrl;
+    ia.prm = prm;
+    lmInitKernel<<<1, kSolveThreads, (static_cast<size_t>(w.K()) + 16) * sizeof(double), st>>>(ia);
+  }
+  HIP_CHECK(hipGetLastError());
+  for (int it = 0; it < w.opt.max_iterations; ++it) {
+    LmControl *cin = ctrl + (it & 1), *cout = ctrl + ((it + 1) & 1);
+    launchSweep(w, true, true, false, cin);          // linearize: evaluateJacobians ...
+    launchReduceSchur(w, false, cin);                //            ... pose-pose blocks + Schur complement
+    launchAssemble(w, 0.0, true, true, false, cin);  // calculateStep (lambda from the control block)
+    launchBacksub(w, 0.0, cin);                      //            ... calculateIdepths
+    launchSweep(w, false, true, false, cin);         // calculateEnergy at the candidate state
+    if (w.allreduce) {
+      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr, cin);
+      allreduceIfNeeded(w, w.d_scalars.ptr, 4);
+    }
+    LmDecideArgs da;
+    da.frames = w.d_frames.ptr;
+    da.st = w.d_state.ptr;
+    da.schur_table = w.d_schur_table.ptr;
+    da.partials = w.d_partials.ptr;
+    da.scalars = w.d_scalars.ptr;
+    da.ctrl_in = cin;
+    da.ctrl_out = cout;
+    da.n_sweep_blocks = w.n_sweep_blocks;
+    da.n_schur_blocks = w.n_schur_blocks;
+    da.F = F;
+    da.prm = prm;
+    timedLaunch(w, DSOPP_HIP_KERNEL_ACCEPT,
+                [&] { lmDecideKernel<<<std::max(1, w.n_schur_blocks), kSchurThreads, 0, st>>>(da); });
+    HIP_CHECK(hipGetLastError());
+  }
+  // closing problem.calculateEnergy() at the final state (candidate statuses / energies of the accepted state); the pair
+  // constants are rebuilt unconditionally: they are stale exactly when the last step was rejected
+  const LmControl *cfin = ctrl + (w.opt.max_iterations & 1);
+  w.pair_valid = false;
+  ensurePairConstants(w);
+  launchSweep(w, false, true, false);
+  LmControl h;
+  HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  w.sr.sync();
+  energy_out = h.energy;
+  iterations = h.iteration;
+  n_valid_out = h.n_valid;
+  downloadState(w);
 }
 
 }  // namespace
@@ -756,13 +878,8 @@ void foldMarginalized(W &w) {
       acceptLandmarksKernel<<<w.n_schur_blocks, kSchurThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), 1, w.d_scalars.ptr + 4);
     HIP_CHECK(hipGetLastError());
   }
-  launchSchur(w, true);
-  if (w.allreduce) {
-    pairReduceKernel<<<8, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.d_pair_first.ptr, w.d_pair_count.ptr, w.dGpair(), w.F());
-    HIP_CHECK(hipGetLastError());
-    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
-  }
-  launchAssemble(w, 0.0, false, /*add_priors=*/false, w.allreduce != nullptr);
+  launchReduceSchur(w, true, nullptr);
+  launchAssemble(w, 0.0, false, /*add_priors=*/false, /*store_system=*/true, nullptr);
   energyReduceKernel<<<1, 256, 0, w.sr.stream>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr);
   HIP_CHECK(hipGetLastError());
   allreduceIfNeeded(w, w.d_scalars.ptr, 2);
@@ -1196,7 +1313,10 @@ static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
   prepare(*w);
   HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
   stageBegin(*w);
-  lmSolve(*w, e, it, nv);
+  if (w->host_driven_lm)
+    lmSolve(*w, e, it, nv);
+  else
+    lmSolveDevice(*w, e, it, nv);
   HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
   HIP_CHECK(hipEventSynchronize(w->ev1));
   HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
@@ -1355,6 +1475,13 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
   });
 }
 
+int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->host_driven_lm = host_driven != 0;
+  });
+}
+
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations) {
   return guarded([&] {
     if (!w || max_iterations < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
@@ -1444,7 +1571,7 @@ int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *
 
 const char *dsopp_hip_kernel_class_name(int kernel_class) {
   static const char *names[DSOPP_HIP_NUM_KERNEL_CLASSES] = {"pair_setup", "fej", "sweep_linearize", "sweep_energy", "schur",
-                                                            "assemble", "assemble_solve", "backsub", "energy_reduce", "accept"};
+                                                            "assemble", "assemble_solve", "backsub", "energy_reduce", "accept_decide"};
   return (kernel_class >= 0 && kernel_class < DSOPP_HIP_NUM_KERNEL_CLASSES) ? names[kernel_class] : "?";
 }
 

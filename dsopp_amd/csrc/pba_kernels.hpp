@@ -196,6 +196,7 @@ struct SweepParams {
   double sigma_huber;
   int for_marginalized;  // accumulate only landmarks flagged to_marginalize (FOR_MARGINALIZED of the reference)
   int use_fej_flag;      // FIRST_ESTIMATE_JACOBIANS: success requires reprojection_jacobians_valid
+  const int *ctrl_active;  // nullable: &LmControl::active, followed by linear_system_valid (pba_solve_kernels.hpp)
 };
 
 /**
@@ -209,6 +210,11 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
   __shared__ double red_lds[(kSweepThreads / 64) * kPartial];
+  if (prm.ctrl_active) {
+    // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
+    // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
+    if (!prm.ctrl_active[0] || (LIN && prm.ctrl_active[1])) return;
+  }
   const SweepBlock be = table[blockIdx.x];
   const FrameDev &fr = frames[be.r];
   const FrameDev &ft = frames[be.t];
@@ -388,6 +394,12 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       acc[44] = energy;
       acc[45] = energy > 0 ? 1.0 : 0.0;
     }
+    if (!LIN && be.t == fr.first_conn) {
+      // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
+      const double st = fr.idepth_step[i], id = fr.idepth[i];
+      acc[46] = st * st;
+      acc[47] = id * st;
+    }
     if (LIN) {
       // h_p block of target t is w * J_t^T J_d = -u (hessian_block_evaluation.hpp:207-208); zero for invalid residuals (:190-192)
       double *dst = fr.ublk + (static_cast<size_t>(be.t) * fr.cap + i) * kUblk;
@@ -405,426 +417,5 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Schur complement: per-landmark finalisation + K x K rank-1 accumulation
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kSchurLandmarks = 64;
-constexpr int kSchurThreads = 256;
-
-/**
- * evaluateLinearSystemPoseDepthSchurComplement — hessian_block_evaluation.hpp:169-236.
- * Phase 1 (one thread per landmark): gather the h_p blocks written by the sweep, form the reference-frame block
- * sum_t T^T u, H_dd, b_d, invert, store the landmark caches (b_idepth_block, inv_hessian_idepth_idepth, ill_conditioned).
- * Phase 2 (whole block): H_schur += sum_l inv_l h_l h_l^T (upper triangle), b_schur += sum_l inv_l bd_l h_l.
- */
-__global__ void __launch_bounds__(kSchurThreads) schurKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
-                                                             const SchurBlock *__restrict__ table, double *__restrict__ Hsc,
-                                                             double *__restrict__ bsc, int F, int for_marginalized) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][K]
-  const int K = kBlk * F;
-  double *wgt = hrow + kSchurLandmarks * K;  // inv per landmark (0 = excluded)
-  double *wbd = wgt + kSchurLandmarks;       // inv * bd
-  const SchurBlock be = table[blockIdx.x];
-  const FrameDev &fr = frames[be.r];
-  const int r = be.r;
-  const int l = threadIdx.x;
-  if (l < kSchurLandmarks) {
-    const int i = be.offset + l;
-    double inv = 0, ibd = 0;
-    double *row = hrow + l * K;
-    for (int k = 0; k < K; ++k) row[k] = 0;
-    if (i < fr.n) {
-      uint8_t flg = fr.flags[i];
-      const bool take = for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
-      if (take) {
-        double hr[kBlk];
-#pragma unroll
-        for (int a = 0; a < kBlk; ++a) hr[a] = 0;
-        double hdd = 0, bd = 0;
-        for (int t = 0; t < F; ++t) {
-          if (t == r || fr.status[t] == nullptr) continue;
-          const PairConst &P = pc[r * kMaxFrames + t];
-          const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
-          double ht[kBlk];
-#pragma unroll
-          for (int a = 0; a < kBlk; ++a) {
-            ht[a] = src[a];
-            row[kBlk * t + a] = ht[a];
-          }
-          hdd += src[8];
-          bd += src[9];
-          // reference block += T^T u with u = -ht, T = blockdiag(Adj, 1, s0)
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) s += P.Adj[6 * k + a] * ht[k];
-            hr[a] -= s;
-          }
-          hr[6] -= ht[6];
-          hr[7] -= P.s0 * ht[7];
-        }
-        double *dst = fr.ublk + (static_cast<size_t>(r) * fr.cap + i) * kUblk;
-#pragma unroll
-        for (int a = 0; a < kBlk; ++a) {
-          row[kBlk * r + a] = hr[a];
-          dst[a] = hr[a];
-        }
-        fr.b_d[i] = bd;
-        const double kIdepthNullSpaceThreshold = 1e-15;
-        if (hdd > kIdepthNullSpaceThreshold) {
-          if (for_marginalized && fr.fixed) hdd += 1e8;  // kScaleNullspaceRegularizer
-          inv = 1.0 / hdd;
-          fr.inv_hdd[i] = inv;
-          flg &= static_cast<uint8_t>(~kFlagIllConditioned);
-          ibd = inv * bd;
-        } else {
-          flg |= kFlagIllConditioned;
-        }
-        fr.flags[i] = flg;
-      }
-    }
-    wgt[l] = inv;
-    wbd[l] = ibd;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < K * K; idx += kSchurThreads) {
-    const int a = idx / K, b = idx % K;
-    if (b < a) continue;
-    double s = 0;
-    for (int ll = 0; ll < kSchurLandmarks; ++ll) s += (wgt[ll] * hrow[ll * K + a]) * hrow[ll * K + b];
-    if (s != 0) atomicAdd(&Hsc[a * K + b], s);
-  }
-  for (int a = threadIdx.x; a < K; a += kSchurThreads) {
-    double s = 0;
-    for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * K + a];
-    if (s != 0) atomicAdd(&bsc[a], s);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// assemble + solve (single workgroup)
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kSolveThreads = 256;
-
-struct SolveBuffers {
-  const double *partials;       // [n_sweep_blocks][kPartial]
-  const int *pair_first_block;  // [kMaxFrames*kMaxFrames] first sweep block of the pair (-1 = none)
-  const int *pair_num_blocks;
-  double *Gpair;                // [F*F][48] (compact, pair index r*F+t): G (36 upper) + q (8)
-  double *GT;                   // scratch [F*F][64]: G*T
-  double *TGT;                  // scratch [F*F][64]: T^T*G*T
-  double *Hpp, *bpp;            // out: system_pose (with priors), K x K / K
-  double *Hsc, *bsc;            // in: schur (upper triangle) ; symmetrised in place
-  const double *Hm, *bm;        // marginal prior (K x K, K) or nullptr
-  double *step;                 // out: K
-  double *energy_out;           // out [4]: {sum of landmark energies, n_valid, -, -}
-};
-
-/** sums the per-block G/q partials of every pair (deterministic order) */
-__device__ inline void reducePairPartials(const double *__restrict__ partials, const int *__restrict__ pair_first_block,
-                                          const int *__restrict__ pair_num_blocks, double *__restrict__ Gpair, int F, int tid, int nthreads) {
-  for (int idx = tid; idx < F * F * 48; idx += nthreads) {
-    const int p = idx / 48, e = idx % 48;
-    const int r = p / F, t = p % F;
-    const int pi = r * kMaxFrames + t;
-    double s = 0;
-    if (e < 44) {
-      const int first = pair_first_block[pi], cnt = pair_num_blocks[pi];
-      for (int b = 0; b < cnt; ++b) s += partials[static_cast<size_t>(first + b) * kPartial + e];
-    }
-    Gpair[p * 48 + e] = s;
-  }
-}
-
-/** stand-alone version used when the per-pair sums must be all-reduced across GPUs before the assembly */
-__global__ void pairReduceKernel(const double *__restrict__ partials, const int *__restrict__ pair_first_block,
-                                 const int *__restrict__ pair_num_blocks, double *__restrict__ Gpair, int F) {
-  reducePairPartials(partials, pair_first_block, pair_num_blocks, Gpair, F, blockIdx.x * blockDim.x + threadIdx.x,
-                     gridDim.x * blockDim.x);
-}
-
-/**
- * evaluateLinearSystemPosePose (hessian_block_evaluation.hpp:96-164) from the per-pair G/q, evaluateLinearSystemPrior
- * (problem.hpp:37-77), calculateStep (problem.hpp:342-361) and NormalLinearSystem::solve
- * (normal_linear_system.cpp:10-16,52-59: Jacobi preconditioner + LDL^T) in one workgroup; also rebuilds the pair
- * constants for the candidate state so the following energy sweep needs no extra launch.
- */
-__global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(const FrameDev *__restrict__ frames, WindowState *st, PairConst *pc,
-                                                                     SolveBuffers B, SolveParams prm, int fej, int do_solve,
-                                                                     int skip_pair_reduce) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int F = prm.F, K = kBlk * F;
-  double *A = reinterpret_cast<double *>(smem_raw);  // K x K
-  double *bv = A + K * K;                            // K
-  double *pv = bv + K;                               // K preconditioner
-  double *col = pv + K;                              // K scratch
-  const int tid = threadIdx.x;
-
-  if (!skip_pair_reduce) reducePairPartials(B.partials, B.pair_first_block, B.pair_num_blocks, B.Gpair, F, tid, kSolveThreads);
-  __syncthreads();
-  // per pair: GT = G*T, TGT = T^T*GT with T = blockdiag(Adj, 1, s0)
-  for (int idx = tid; idx < F * F * 64; idx += kSolveThreads) {
-    const int p = idx / 64, e = idx % 64, i = e / 8, j = e % 8;
-    const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
-    const PairConst &P = pc[pi];
-    if (!P.valid) continue;
-    const double *G = B.Gpair + p * 48;
-    double s;
-    if (j < 6) {
-      s = 0;
-      for (int k = 0; k < 6; ++k) s += G[symIdx(i, k)] * P.Adj[6 * k + j];
-    } else if (j == 6) {
-      s = G[symIdx(i, 6)];
-    } else {
-      s = G[symIdx(i, 7)] * P.s0;
-    }
-    B.GT[p * 64 + e] = s;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < F * F * 64; idx += kSolveThreads) {
-    const int p = idx / 64, e = idx % 64, i = e / 8, j = e % 8;
-    const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
-    const PairConst &P = pc[pi];
-    if (!P.valid) continue;
-    const double *GT = B.GT + p * 64;
-    double s;
-    if (i < 6) {
-      s = 0;
-      for (int k = 0; k < 6; ++k) s += P.Adj[6 * k + i] * GT[8 * k + j];
-    } else if (i == 6) {
-      s = GT[8 * 6 + j];
-    } else {
-      s = P.s0 * GT[8 * 7 + j];
-    }
-    B.TGT[p * 64 + e] = s;
-  }
-  __syncthreads();
-  // H_pp, b_pp
-  for (int idx = tid; idx < K * K; idx += kSolveThreads) {
-    const int a = idx / K, b = idx % K;
-    const int fa = a / 8, fb = b / 8, i = a % 8, j = b % 8;
-    double s = 0;
-    if (fa == fb) {
-      for (int t = 0; t < F; ++t) {
-        if (t == fa) continue;
-        if (pc[fa * kMaxFrames + t].valid) s += B.TGT[(fa * F + t) * 64 + 8 * i + j];
-        if (pc[t * kMaxFrames + fa].valid) s += B.Gpair[(t * F + fa) * 48 + symIdx(i, j)];
-      }
-    } else {
-      // H[r,t] = -T^T G (pair fa->fb) ; H[t,r] of pair (fb->fa) transposed = -(G T)
-      if (pc[fa * kMaxFrames + fb].valid) s -= B.GT[(fa * F + fb) * 64 + 8 * j + i];  // (T^T G)_{ij} = (G T)_{ji}
-      if (pc[fb * kMaxFrames + fa].valid) s -= B.GT[(fb * F + fa) * 64 + 8 * i + j];
-    }
-    A[idx] = s;
-  }
-  for (int a = tid; a < K; a += kSolveThreads) {
-    const int fa = a / 8, i = a % 8;
-    double s = 0;
-    for (int t = 0; t < F; ++t) {
-      if (t == fa) continue;
-      const int prt = fa * kMaxFrames + t, ptr_ = t * kMaxFrames + fa;
-      if (pc[prt].valid) {
-        // b_r = T^T q
-        const double *q = B.Gpair + (fa * F + t) * 48 + 36;
-        if (i < 6) {
-          for (int k = 0; k < 6; ++k) s += pc[prt].Adj[6 * k + i] * q[k];
-        } else if (i == 6) {
-          s += q[6];
-        } else {
-          s += pc[prt].s0 * q[7];
-        }
-      }
-      if (pc[ptr_].valid) s -= B.Gpair[(t * F + fa) * 48 + 36 + i];  // b_t = -q
-    }
-    bv[a] = s;
-  }
-  __syncthreads();
-  // priors — problem.hpp:39-62
-  for (int a = tid; a < K; a += kSolveThreads) {
-    const int f = a / 8, i = a % 8;
-    if (frames[f].to_marginalize) continue;  // for_marginalized == false
-    if (frames[f].fixed) {
-      A[a * K + a] += prm.fixed_reg;
-      bv[a] += prm.fixed_reg * st->eps[f][i];
-    } else if (i >= 6) {
-      const double ab = st->ab0[f][i - 6] + st->eps[f][i];
-      A[a * K + a] += prm.affine_reg[i - 6];
-      bv[a] += prm.affine_reg[i - 6] * ab;
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < K * K; idx += kSolveThreads) B.Hpp[idx] = A[idx];
-  for (int a = tid; a < K; a += kSolveThreads) B.bpp[a] = bv[a];
-  // symmetrise the Schur accumulation (upper triangle was accumulated)
-  for (int idx = tid; idx < K * K; idx += kSolveThreads) {
-    const int a = idx / K, b = idx % K;
-    if (b < a) B.Hsc[idx] = B.Hsc[b * K + a];
-  }
-  if (!do_solve) return;
-  __syncthreads();
-  // calculateStep — problem.hpp:347-351
-  const double lam = prm.lambda, sc = -1.0 / (1.0 + lam);
-  for (int idx = tid; idx < K * K; idx += kSolveThreads) {
-    const int a = idx / K, b = idx % K;
-    double v = A[idx];
-    if (a == b) v += A[idx] * lam;
-    if (prm.use_marginal) v += B.Hm[idx];
-    v += sc * B.Hsc[idx];
-    A[idx] = v;
-  }
-  __syncthreads();
-  for (int a = tid; a < K; a += kSolveThreads) {
-    double v = bv[a] + sc * B.bsc[a];
-    if (prm.use_marginal) {
-      v += B.bm[a];
-      double s = 0;
-      for (int k = 0; k < K; ++k) s += B.Hm[a * K + k] * st->eps[k / 8][k % 8];
-      v += s;
-    }
-    bv[a] = v;
-    pv[a] = 1.0 / sqrt(A[a * K + a] + 10.0);  // jacobiPreconditioner — normal_linear_system.cpp:10-16
-  }
-  __syncthreads();
-  for (int idx = tid; idx < K * K; idx += kSolveThreads) {
-    const int a = idx / K, b = idx % K;
-    A[idx] = pv[a] * A[idx] * pv[b];
-  }
-  for (int a = tid; a < K; a += kSolveThreads) bv[a] *= pv[a];
-  __syncthreads();
-  // LDL^T (right-looking, lower triangle), forward substitution fused; zero pivots are skipped as Eigen::LDLT does
-  for (int k = 0; k < K; ++k) {
-    const double d = A[k * K + k];
-    const bool okp = fabs(d) > 1e-300;
-    const double dinv = okp ? 1.0 / d : 0.0;
-    for (int i = k + 1 + tid; i < K; i += kSolveThreads) {
-      const double aik = A[i * K + k];
-      col[i] = aik;             // A(i,k) before scaling
-      A[i * K + k] = aik * dinv;  // L(i,k)
-    }
-    __syncthreads();
-    const int rem = K - k - 1;
-    for (int idx = tid; idx < rem * rem; idx += kSolveThreads) {
-      const int i = k + 1 + idx / rem, j = k + 1 + idx % rem;
-      if (j <= i) A[i * K + j] -= A[i * K + k] * col[j];
-    }
-    // forward: y_i -= L(i,k) * y_k
-    const double yk = bv[k];
-    __syncthreads();
-    for (int i = k + 1 + tid; i < K; i += kSolveThreads) bv[i] -= A[i * K + k] * yk;
-    __syncthreads();
-  }
-  for (int a = tid; a < K; a += kSolveThreads) {
-    const double d = A[a * K + a];
-    bv[a] = fabs(d) > 1e-300 ? bv[a] / d : 0.0;
-  }
-  __syncthreads();
-  // backward: x = L^-T y
-  for (int k = K - 1; k >= 0; --k) {
-    const double xk = bv[k];
-    __syncthreads();
-    for (int i = tid; i < k; i += kSolveThreads) bv[i] -= A[k * K + i] * xk;
-    __syncthreads();
-  }
-  for (int a = tid; a < K; a += kSolveThreads) {
-    const double x = pv[a] * bv[a];
-    B.step[a] = x;
-    st->step[a / 8][a % 8] = -x;  // problem.hpp:353-357
-  }
-  __syncthreads();
-  if (tid < F * F) computePairConst(frames, st, pc, tid / F, tid % F, F, fej != 0);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// back-substitution, accept / reject, energy reduction
-// ---------------------------------------------------------------------------------------------------------------
-/** calculateIdepths — hessian_block_evaluation.hpp:238-263 */
-__global__ void backsubKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, const double *__restrict__ step,
-                              double lambda, int F) {
-  const SchurBlock be = table[blockIdx.x];
-  const FrameDev &fr = frames[be.r];
-  const int i = be.offset + threadIdx.x;
-  if (threadIdx.x >= kSchurLandmarks || i >= fr.n) return;
-  const uint8_t flg = fr.flags[i];
-  if (flg & kFlagMarginalized) return;
-  if (flg & kFlagIllConditioned) return;
-  double d = 0;
-  for (int t = 0; t < F; ++t) {
-    if (t != be.r && fr.status[t] == nullptr) continue;
-    const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
-#pragma unroll
-    for (int a = 0; a < kBlk; ++a) d += src[a] * step[kBlk * t + a];
-  }
-  const double s = (fr.b_d[i] - d) * (1.0 / (1.0 + lambda)) * fr.inv_hdd[i];
-  fr.idepth_step[i] = -s;
-}
-
-/** sums the (energy, n_valid) partials of a residual-only sweep; also usable after a linearisation sweep */
-__global__ void energyReduceKernel(const double *__restrict__ partials, int n_blocks, double *out) {
-  __shared__ double lds[(256 / 64) * 2];
-  double v[2] = {0, 0};
-  for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
-    v[0] += partials[static_cast<size_t>(b) * kPartial + 44];
-    v[1] += partials[static_cast<size_t>(b) * kPartial + 45];
-  }
-  blockSum<2, 256>(v, lds);
-  if (threadIdx.x == 0) {
-    out[0] = v[0];
-    out[1] = v[1];
-  }
-}
-
-/** acceptStep / rejectStep for landmarks and residual statuses — problem.hpp:366-402 + changeResidualStatuses :20-35.
- *  grid: one SchurBlock chunk per block.  norms[0] += sum idepth^2 (before), norms[1] += sum idepth_step^2. */
-__global__ void acceptLandmarksKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, int accept,
-                                      double *norms) {
-  __shared__ double lds[(kSchurThreads / 64) * 2];
-  const SchurBlock be = table[blockIdx.x];
-  const FrameDev &fr = frames[be.r];
-  const int i = be.offset + threadIdx.x;
-  double v[2] = {0, 0};
-  if (threadIdx.x < kSchurLandmarks && i < fr.n) {
-    if (accept) {
-      const double id = fr.idepth[i], st = fr.idepth_step[i];
-      v[0] = id * id;
-      v[1] = st * st;
-      fr.idepth[i] = id + st;
-    }
-    fr.idepth_step[i] = 0;
-    for (int t = 0; t < F; ++t) {
-      if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
-      if (accept)
-        fr.status[t][i] = fr.cand[t][i];
-      else
-        fr.cand[t][i] = fr.status[t][i];
-    }
-  }
-  blockSum<2, kSchurThreads>(v, lds);
-  if (threadIdx.x == 0 && accept) {
-    atomicAdd(&norms[0], v[0]);
-    atomicAdd(&norms[1], v[1]);
-  }
-}
-
-__global__ void acceptFramesKernel(WindowState *st, int F, int accept, double *norms /* [2] frame part */) {
-  if (threadIdx.x != 0) return;
-  double state_sq = 0, step_sq = 0;
-  for (int f = 0; f < F; ++f) {
-    for (int a = 0; a < kBlk; ++a) {
-      if (accept) {
-        state_sq += st->eps[f][a] * st->eps[f][a];
-        step_sq += st->step[f][a] * st->step[f][a];
-        st->eps[f][a] += st->step[f][a];
-      }
-      st->step[f][a] = 0;
-    }
-    if (accept) state_sq += st->ab0[f][0] * st->ab0[f][0] + st->ab0[f][1] * st->ab0[f][1];
-  }
-  if (accept) {
-    norms[0] = state_sq;
-    norms[1] = step_sq;
-  }
-}
 
 }  // namespace dsopp_hip

@@ -1,0 +1,857 @@
+// Reduction, Schur complement, dense solve and Levenberg-Marquardt control kernels (hot loops B, C, D of SURVEY.md §3.2
+// and the LM driver, levenberg_marquardt_algorithm.hpp:77-128, kept on the device so that a whole solve is one stream
+// of launches with no host round trip).
+#pragma once
+#include "pba_kernels.hpp"
+
+namespace dsopp_hip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LM control block (lives in HBM; double-buffered by iteration parity so every workgroup of the decide kernel can read
+// the incoming state while workgroup 0 writes the outgoing one)
+// ---------------------------------------------------------------------------------------------------------------
+struct LmControl {
+  double lambda;
+  double energy;           // result.energy
+  double cand_prior;       // prior + marginal energy of the candidate state eps + step (written by the solve kernel)
+  double idepth_sq;        // running sum of idepth^2 over all landmarks of this rank (state norm part)
+  int n_valid;             // result.number_of_valid_residuals
+  int converged;
+  int active;              // loop still running           (sweep kernels read {active, linear_system_valid} as int[2])
+  int linear_system_valid;
+  int iteration;           // loop bodies executed
+  int need_final_setup;    // last step was rejected: pair constants must be rebuilt before the closing energy sweep
+  int pad0, pad1;
+};
+
+struct LmParams {
+  double function_tolerance, parameter_tolerance;
+  double decrease_on_accept, increase_on_reject;
+  double lambda0;
+  int max_iterations, min_iterations;
+  int force_accept;
+  int use_reduced_scalars;  // multi-GPU: (energy, n_valid, step^2, idepth.step) were summed across ranks into `scalars`
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// K2: per-pair reduction + Schur complement
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSchurLandmarks = 64;
+constexpr int kSchurThreads = 256;
+constexpr int kPairBlk = 144;  // per pair: TGT[64] | GT[64] | T^T q [8] | pad
+
+/** LDS row stride (in doubles) for K-wide rows read as 16-lane x 4-row MFMA operands without bank conflicts:
+ *  smallest s >= Kp with s % 32 == 16 (ds_read_b64 banks = (addr/4) % 64, two rows per 32-lane group) */
+__host__ __device__ inline int schurRowStride(int Kp) {
+  int s = Kp;
+  while (s % 32 != 16) ++s;
+  return s;
+}
+
+/** derived per-pair blocks from G, q:  TGT = T^T G T (H_rr contribution), GT = G T (H_rt = -(GT)^T), Tq = T^T q (b_r),
+ *  T = blockdiag(Adj, 1, s0).  64 lanes. */
+__device__ inline void derivePairBlocks(const double *__restrict__ G /* [48] */, const PairConst &P, double *__restrict__ out /* [kPairBlk] */,
+                                        double *lds /* [64] scratch */, int lane) {
+  const int i = lane >> 3, j = lane & 7;
+  double gt;
+  if (j < 6) {
+    gt = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gt += G[symIdx(i, k)] * P.Adj[6 * k + j];
+  } else if (j == 6) {
+    gt = G[symIdx(i, 6)];
+  } else {
+    gt = G[symIdx(i, 7)] * P.s0;
+  }
+  lds[lane] = gt;
+  out[64 + lane] = gt;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  double tgt;
+  if (i < 6) {
+    tgt = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tgt += P.Adj[6 * k + i] * lds[8 * k + j];
+  } else if (i == 6) {
+    tgt = lds[48 + j];
+  } else {
+    tgt = P.s0 * lds[56 + j];
+  }
+  out[lane] = tgt;
+  if (lane < 8) {
+    const double *q = G + 36;
+    double s;
+    if (lane < 6) {
+      s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += P.Adj[6 * k + lane] * q[k];
+    } else if (lane == 6) {
+      s = q[6];
+    } else {
+      s = P.s0 * q[7];
+    }
+    out[128 + lane] = s;
+  }
+}
+
+struct ReduceSchurArgs {
+  const FrameDev *frames;
+  const PairConst *pc;
+  const SchurBlock *schur_table;
+  const double *partials;
+  const int *pair_first_block, *pair_num_blocks;
+  double *Gpair;    // [F*F][48]
+  double *pairblk;  // [F*F][kPairBlk]
+  double *Hsc, *bsc;
+  const LmControl *ctrl;  // nullable: skip when !active or the linear system is still valid
+  int F;
+  int n_schur_blocks;
+  int for_marginalized;
+  int derive;  // compute pair blocks here (single GPU); multi-GPU derives after the all-reduce
+};
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+/**
+ * grid = n_schur_blocks + F*F workgroups of 256 threads.
+ *  - workgroups [0, n_schur_blocks): evaluateLinearSystemPoseDepthSchurComplement (hessian_block_evaluation.hpp:169-236) for a chunk
+ *    of 64 landmarks of one frame: phase 1 finalises the landmarks (reference-frame block sum_t T^T u, H_dd, b_d, inverse,
+ *    caches), phase 2 accumulates H_schur += A^T W A with the f64 matrix cores (v_mfma_f64_16x16x4_f64): a 16x16 output
+ *    tile takes 4 landmarks per instruction, rows staged in LDS with a conflict-free stride; upper-triangular tiles only.
+ *  - workgroups [n_schur_blocks, +F*F): one frame pair each: deterministic sum of the sweep's per-block partials
+ *    (G, q) and the derived blocks T^T G T, G T, T^T q.
+ */
+__global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) return;
+  const int F = a.F, K = kBlk * F;
+  if (static_cast<int>(blockIdx.x) >= a.n_schur_blocks) {
+    // ---- pair block
+    const int p = blockIdx.x - a.n_schur_blocks;
+    const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
+    const int lane = threadIdx.x;
+    if (lane >= 64) return;
+    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch
+    double s = 0;
+    if (lane < 44) {
+      const int first = a.pair_first_block[pi], cnt = a.pair_num_blocks[pi];
+      for (int b = 0; b < cnt; ++b) s += a.partials[static_cast<size_t>(first + b) * kPartial + lane];
+    }
+    if (lane < 48) {
+      lds[lane] = s;
+      a.Gpair[p * 48 + lane] = s;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (a.derive) {
+      const PairConst &P = a.pc[pi];
+      double *out = a.pairblk + static_cast<size_t>(p) * kPairBlk;
+      if (P.valid) {
+        derivePairBlocks(lds, P, out, lds + 48, lane);
+      } else {
+        out[lane] = 0;
+        out[64 + lane] = 0;
+        if (lane < 8) out[128 + lane] = 0;
+      }
+    }
+    return;
+  }
+  // ---- Schur block
+  const int Kp = (K + 15) & ~15;
+  const int stride = schurRowStride(Kp);
+  double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
+  double *wgt = hrow + kSchurLandmarks * stride;        // inv per landmark (0 = excluded)
+  double *wbd = wgt + kSchurLandmarks;                  // inv * bd
+  const SchurBlock be = a.schur_table[blockIdx.x];
+  const FrameDev &fr = a.frames[be.r];
+  const int r = be.r;
+  // zero the tile rows (pad columns must be 0)
+  for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;
+  __syncthreads();
+  // phase 1: 4 threads per landmark (each handles the targets t = sub, sub+4, ...), combined through LDS atomics-free adds
+  {
+    const int l = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    const int i = be.offset + l;
+    bool take = false;
+    uint8_t flg = 0;
+    if (i < fr.n) {
+      flg = fr.flags[i];
+      take = a.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
+    }
+    double hr[kBlk];
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) hr[c] = 0;
+    double hdd = 0, bd = 0;
+    if (take) {
+      double *row = hrow + l * stride;
+      for (int t = sub; t < F; t += 4) {
+        if (t == r || fr.status[t] == nullptr) continue;
+        const PairConst &P = a.pc[r * kMaxFrames + t];
+        const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
+        double ht[kBlk];
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          ht[c] = src[c];
+          row[kBlk * t + c] = ht[c];
+        }
+        hdd += src[8];
+        bd += src[9];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double s = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) s += P.Adj[6 * k + c] * ht[k];
+          hr[c] -= s;
+        }
+        hr[6] -= ht[6];
+        hr[7] -= P.s0 * ht[7];
+      }
+    }
+    // combine the 4 sub-threads of a landmark (adjacent lanes)
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) {
+      hr[c] += __shfl_xor(hr[c], 1, 64);
+      hr[c] += __shfl_xor(hr[c], 2, 64);
+    }
+    hdd += __shfl_xor(hdd, 1, 64);
+    hdd += __shfl_xor(hdd, 2, 64);
+    bd += __shfl_xor(bd, 1, 64);
+    bd += __shfl_xor(bd, 2, 64);
+    if (sub == 0) {
+      double inv = 0, ibd = 0;
+      if (take) {
+        double *row = hrow + l * stride;
+        double *dst = fr.ublk + (static_cast<size_t>(r) * fr.cap + i) * kUblk;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          row[kBlk * r + c] = hr[c];
+          dst[c] = hr[c];
+        }
+        fr.b_d[i] = bd;
+        const double kIdepthNullSpaceThreshold = 1e-15;
+        if (hdd > kIdepthNullSpaceThreshold) {
+          if (a.for_marginalized && fr.fixed) hdd += 1e8;  // kScaleNullspaceRegularizer
+          inv = 1.0 / hdd;
+          fr.inv_hdd[i] = inv;
+          flg &= static_cast<uint8_t>(~kFlagIllConditioned);
+          ibd = inv * bd;
+        } else {
+          flg |= kFlagIllConditioned;
+        }
+        fr.flags[i] = flg;
+      }
+      wgt[l] = inv;
+      wbd[l] = ibd;
+    }
+  }
+  __syncthreads();
+  // phase 2: H_schur tiles with v_mfma_f64_16x16x4_f64.  A[i][k] = inv_k * h_k[16*ti + i], B[k][j] = h_k[16*tj + j];
+  // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]  (cdna_hip_programming.md §3)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nt = Kp >> 4;
+    const int n_tiles = nt * (nt + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64) {
+      // decode (ti <= tj) from the linear upper-triangular index
+      int ti = 0, rem = tile;
+      while (rem >= nt - ti) {
+        rem -= nt - ti;
+        ++ti;
+      }
+      const int tj = ti + rem;
+      f64x4 acc = {0, 0, 0, 0};
+      const double *pa = hrow + lk * stride + 16 * ti + li;
+      const double *pb = hrow + lk * stride + 16 * tj + li;
+#pragma unroll 4
+      for (int l0 = 0; l0 < kSchurLandmarks; l0 += 4) {
+        const double av = wgt[l0 + lk] * pa[l0 * stride];
+        const double bv = pb[l0 * stride];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+      // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = 16 * ti + lk + 4 * reg, col = 16 * tj + li;
+        const double v = acc[reg];
+        if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.Hsc[row * K + col], v);
+      }
+    }
+    for (int c = threadIdx.x; c < K; c += kSchurThreads) {
+      double s = 0;
+      for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + c];
+      if (s != 0) atomicAdd(&a.bsc[c], s);
+    }
+  }
+}
+
+/** zeroes the Schur accumulation target unless the device-driven loop skips this linearisation */
+__global__ void clearSchurKernel(double *buf, int n, const LmControl *ctrl) {
+  if (ctrl && (!ctrl->active || ctrl->linear_system_valid)) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = 0;
+}
+
+/** multi-GPU: per-pair derived blocks from the all-reduced G/q.  grid = F*F workgroups of 64 threads */
+__global__ void pairDeriveKernel(const PairConst *__restrict__ pc, const double *__restrict__ Gpair, double *__restrict__ pairblk, int F,
+                                 const LmControl *ctrl) {
+  __shared__ double lds[48 + 64];
+  if (ctrl && (!ctrl->active || ctrl->linear_system_valid)) return;
+  const int p = blockIdx.x, r = p / F, t = p % F, pi = r * kMaxFrames + t;
+  const int lane = threadIdx.x;
+  if (lane < 48) lds[lane] = Gpair[p * 48 + lane];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const PairConst &P = pc[pi];
+  double *out = pairblk + static_cast<size_t>(p) * kPairBlk;
+  if (P.valid) {
+    derivePairBlocks(lds, P, out, lds + 48, lane);
+  } else {
+    out[lane] = 0;
+    out[64 + lane] = 0;
+    if (lane < 8) out[128 + lane] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K3: assemble + solve (single workgroup)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSolveThreads = 256;
+
+struct SolveArgs {
+  const FrameDev *frames;
+  WindowState *st;
+  PairConst *pc;
+  const double *Gpair;    // [F*F][48]
+  const double *pairblk;  // [F*F][kPairBlk]
+  double *Hpp, *bpp;      // out (optional store): system_pose with priors
+  double *Hsc, *bsc;      // Schur system, upper triangle accumulated (symmetrised in place when stored)
+  const double *Hm, *bm;  // marginal prior
+  double *step;           // out: K
+  LmControl *ctrl;        // nullable (host-driven stages pass lambda explicitly)
+  double lambda;
+  double affine_reg[2];
+  double fixed_reg;
+  double energy_marginalized;
+  int F;
+  int fej;
+  int do_solve;
+  int store_system;  // write H_pp / b_pp / symmetrised H_schur back (stage API, marginalisation, covariance)
+  int add_priors;
+};
+
+/** prior + marginal energy terms of calculateEnergy (problem.hpp:293-312) for state x = eps (+ step); whole workgroup */
+__device__ inline double priorEnergyBlock(const SolveArgs &a, bool with_step, double *lds /* K + 8 */, int tid) {
+  const int F = a.F, K = kBlk * F;
+  for (int c = tid; c < K; c += kSolveThreads) lds[c] = a.st->eps[c >> 3][c & 7] + (with_step ? a.st->step[c >> 3][c & 7] : 0.0);
+  __syncthreads();
+  double part = 0;
+  for (int c = tid; c < K; c += kSolveThreads) {
+    double s = 0;
+    for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * lds[k];
+    part += a.bm[c] * lds[c] + 0.5 * lds[c] * s;
+    if ((c & 7) >= 6) {
+      const double ab = a.st->ab0[c >> 3][(c & 7) - 6] + lds[c];
+      part += 0.5 * ab * a.affine_reg[(c & 7) - 6] * ab;
+    }
+  }
+  // block reduce
+  part = waveSum(part);
+  __syncthreads();
+  if ((tid & 63) == 0) lds[K + (tid >> 6)] = part;
+  __syncthreads();
+  double total = a.energy_marginalized;
+  for (int w = 0; w < kSolveThreads / 64; ++w) total += lds[K + w];
+  __syncthreads();
+  return total;
+}
+
+/**
+ * evaluateLinearSystemPosePose (hessian_block_evaluation.hpp:96-164) from the per-pair blocks, evaluateLinearSystemPrior
+ * (problem.hpp:37-77), calculateStep (problem.hpp:342-361) and NormalLinearSystem::solve (normal_linear_system.cpp:10-16,
+ * 52-59: Jacobi preconditioner + LDL^T; here a blocked Cholesky with 8x8 frame blocks, the right-hand side carried as an
+ * extra row so the forward substitution rides along) — one workgroup, ~3 barriers per frame block.  Also rebuilds the pair
+ * constants and the prior energy for the candidate state eps + step, so the energy sweep can follow immediately.
+ */
+__global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (a.ctrl && !a.ctrl->active) return;
+  const int F = a.F, K = kBlk * F;
+  const int N = K + 1;   // augmented with the right-hand side row
+  const int ld = N + 1;  // odd leading dimension
+  double *A = reinterpret_cast<double *>(smem_raw);  // N x ld (lower triangle used)
+  double *pv = A + N * ld;                           // K preconditioner
+  double *xs = pv + K;                               // K + 16 scratch
+  const int tid = threadIdx.x;
+  const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
+
+  // ---- H_pp (lower triangle incl. diagonal blocks) and b_pp from the pair blocks
+  for (int e = tid; e < K * K; e += kSolveThreads) {
+    const int row = e / K, col = e - row * K;
+    if (col > row) continue;
+    const int fa = row >> 3, fb = col >> 3, i = row & 7, j = col & 7;
+    double s = 0;
+    if (fa == fb) {
+      for (int t = 0; t < F; ++t) {
+        if (t == fa) continue;
+        s += a.pairblk[static_cast<size_t>(fa * F + t) * kPairBlk + 8 * i + j];  // T^T G T of pair (fa -> t)
+        s += a.Gpair[(t * F + fa) * 48 + symIdx(i, j)];                          // G of pair (t -> fa)
+      }
+    } else {
+      // H[fa, fb] = -(G T)^T of pair (fa -> fb)  -  G T of pair (fb -> fa)
+      s -= a.pairblk[static_cast<size_t>(fa * F + fb) * kPairBlk + 64 + 8 * j + i];
+      s -= a.pairblk[static_cast<size_t>(fb * F + fa) * kPairBlk + 64 + 8 * i + j];
+    }
+    A[row * ld + col] = s;
+  }
+  for (int c = tid; c < K; c += kSolveThreads) {
+    const int fa = c >> 3, i = c & 7;
+    double s = 0;
+    for (int t = 0; t < F; ++t) {
+      if (t == fa) continue;
+      s += a.pairblk[static_cast<size_t>(fa * F + t) * kPairBlk + 128 + i];  // b_r = T^T q
+      s -= a.Gpair[(t * F + fa) * 48 + 36 + i];                             // b_t = -q
+    }
+    A[K * ld + c] = s;
+  }
+  if (tid == 0) A[K * ld + K] = 0;
+  __syncthreads();
+  // ---- priors — problem.hpp:39-62
+  if (a.add_priors) {
+    for (int c = tid; c < K; c += kSolveThreads) {
+      const int f = c >> 3, i = c & 7;
+      if (a.frames[f].to_marginalize) continue;
+      if (a.frames[f].fixed) {
+        A[c * ld + c] += a.fixed_reg;
+        A[K * ld + c] += a.fixed_reg * a.st->eps[f][i];
+      } else if (i >= 6) {
+        const double ab = a.st->ab0[f][i - 6] + a.st->eps[f][i];
+        A[c * ld + c] += a.affine_reg[i - 6];
+        A[K * ld + c] += a.affine_reg[i - 6] * ab;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.store_system) {
+    for (int e = tid; e < K * K; e += kSolveThreads) {
+      const int row = e / K, col = e - row * K;
+      a.Hpp[e] = col <= row ? A[row * ld + col] : A[col * ld + row];
+      if (col < row) a.Hsc[e] = a.Hsc[col * K + row];
+    }
+    for (int c = tid; c < K; c += kSolveThreads) a.bpp[c] = A[K * ld + c];
+  }
+  if (!a.do_solve) return;
+  __syncthreads();
+  // ---- calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam); b likewise + H_m * state
+  const double sc = -1.0 / (1.0 + lam);
+  for (int c = tid; c < K; c += kSolveThreads) xs[c] = a.st->eps[c >> 3][c & 7];
+  __syncthreads();
+  for (int e = tid; e < K * K; e += kSolveThreads) {
+    const int row = e / K, col = e - row * K;
+    if (col > row) continue;
+    double v = A[row * ld + col];
+    if (row == col) v += v * lam;
+    v += a.Hm[e] + sc * a.Hsc[col * K + row];  // Hsc holds the upper triangle
+    A[row * ld + col] = v;
+  }
+  for (int c = tid; c < K; c += kSolveThreads) {
+    double s = 0;
+    for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * xs[k];
+    A[K * ld + c] += sc * a.bsc[c] + a.bm[c] + s;
+  }
+  __syncthreads();
+  // ---- Jacobi preconditioner — normal_linear_system.cpp:10-16
+  for (int c = tid; c < K; c += kSolveThreads) pv[c] = 1.0 / sqrt(A[c * ld + c] + 10.0);
+  __syncthreads();
+  for (int e = tid; e < N * K; e += kSolveThreads) {
+    const int row = e / K, col = e - row * K;
+    if (col > row) continue;
+    A[row * ld + col] *= (row < K ? pv[row] : 1.0) * pv[col];
+  }
+  __syncthreads();
+  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T
+  for (int kb = 0; kb < F; ++kb) {
+    const int k0 = kb * kBlk;
+    // (1) factor the 8x8 diagonal block in place (wave 0, lanes = (i, j))
+    if (tid < 64) {
+      const int i = tid >> 3, j = tid & 7;
+      for (int k = 0; k < kBlk; ++k) {
+        const double d = A[(k0 + k) * ld + k0 + k];
+        const bool okp = d > 1e-300;
+        const double lkk = okp ? sqrt(d) : 0.0, inv = okp ? 1.0 / lkk : 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (j == k && i >= k) A[(k0 + i) * ld + k0 + k] = (i == k) ? lkk : A[(k0 + i) * ld + k0 + k] * inv;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (j > k && i >= j) A[(k0 + i) * ld + k0 + j] -= A[(k0 + i) * ld + k0 + k] * A[(k0 + j) * ld + k0 + k];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    // (2) panel: rows below the block, L_ik = A_ik * L_kk^-T (one thread per row, forward substitution over 8 columns)
+    for (int row = k0 + kBlk + tid; row < N; row += kSolveThreads) {
+      double v[kBlk];
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) v[c] = A[row * ld + k0 + c];
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) {
+        double s = v[c];
+#pragma unroll
+        for (int k = 0; k < kBlk; ++k)
+          if (k < c) s -= v[k] * A[(k0 + c) * ld + k0 + k];
+        const double lcc = A[(k0 + c) * ld + k0 + c];
+        v[c] = lcc > 0 ? s / lcc : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = v[c];
+    }
+    __syncthreads();
+    // (3) trailing update of the lower triangle: A_ij -= sum_c L_ic L_jc
+    const int r0 = k0 + kBlk, rem = N - r0;
+    for (int e = tid; e < rem * rem; e += kSolveThreads) {
+      const int ii = e / rem, jj = e - ii * rem;
+      if (jj > ii) continue;
+      const double *li = A + (r0 + ii) * ld + k0, *lj = A + (r0 + jj) * ld + k0;
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) s += li[c] * lj[c];
+      A[(r0 + ii) * ld + r0 + jj] -= s;
+    }
+    __syncthreads();
+  }
+  // ---- back substitution x = L^-T y, blocked (y = row K of L)
+  for (int c = tid; c < K; c += kSolveThreads) xs[c] = A[K * ld + c];
+  __syncthreads();
+  for (int kb = F - 1; kb >= 0; --kb) {
+    const int k0 = kb * kBlk;
+    if (tid == 0) {
+      for (int c = kBlk - 1; c >= 0; --c) {
+        double s = xs[k0 + c];
+        for (int k = c + 1; k < kBlk; ++k) s -= A[(k0 + k) * ld + k0 + c] * xs[k0 + k];
+        const double lcc = A[(k0 + c) * ld + k0 + c];
+        xs[k0 + c] = lcc > 0 ? s / lcc : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int row = tid; row < k0; row += kSolveThreads) {
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + row] * xs[k0 + c];
+      xs[row] -= s;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < K; c += kSolveThreads) {
+    const double x = pv[c] * xs[c];
+    a.step[c] = x;
+    a.st->step[c >> 3][c & 7] = -x;  // problem.hpp:353-357
+  }
+  __syncthreads();
+  if (tid < F * F) computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, a.fej != 0);
+  if (a.ctrl) {
+    const double pe = priorEnergyBlock(a, true, A, tid);
+    if (tid == 0) a.ctrl->cand_prior = pe;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// back-substitution, energy reduction, LM control
+// ---------------------------------------------------------------------------------------------------------------
+/** calculateIdepths — hessian_block_evaluation.hpp:238-263 */
+__global__ void backsubKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, const double *__restrict__ step,
+                              double lambda, int F, const LmControl *ctrl) {
+  if (ctrl) {
+    if (!ctrl->active) return;
+    lambda = ctrl->lambda;
+  }
+  const SchurBlock be = table[blockIdx.x];
+  const FrameDev &fr = frames[be.r];
+  const int i = be.offset + threadIdx.x;
+  if (threadIdx.x >= kSchurLandmarks || i >= fr.n) return;
+  const uint8_t flg = fr.flags[i];
+  if (flg & kFlagMarginalized) return;
+  if (flg & kFlagIllConditioned) return;
+  double d = 0;
+  for (int t = 0; t < F; ++t) {
+    if (t != be.r && fr.status[t] == nullptr) continue;
+    const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) d += src[c] * step[kBlk * t + c];
+  }
+  const double s = (fr.b_d[i] - d) * (1.0 / (1.0 + lambda)) * fr.inv_hdd[i];
+  fr.idepth_step[i] = -s;
+}
+
+/** sums the (energy, n_valid) partials of a sweep: out[0] = energy, out[1] = n_valid */
+__global__ void energyReduceKernel(const double *__restrict__ partials, int n_blocks, double *out) {
+  __shared__ double lds[(256 / 64) * 2];
+  double v[2] = {0, 0};
+  for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+    v[0] += partials[static_cast<size_t>(b) * kPartial + 44];
+    v[1] += partials[static_cast<size_t>(b) * kPartial + 45];
+  }
+  blockSum<2, 256>(v, lds);
+  if (threadIdx.x == 0) {
+    out[0] = v[0];
+    out[1] = v[1];
+  }
+}
+
+/** acceptStep / rejectStep for landmarks and residual statuses — problem.hpp:366-402 + changeResidualStatuses :20-35.
+ *  norms[0] += sum idepth^2 (before), norms[1] += sum idepth_step^2. */
+__global__ void acceptLandmarksKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, int accept,
+                                      double *norms) {
+  __shared__ double lds[(kSchurThreads / 64) * 2];
+  const SchurBlock be = table[blockIdx.x];
+  const FrameDev &fr = frames[be.r];
+  const int i = be.offset + threadIdx.x;
+  double v[2] = {0, 0};
+  if (threadIdx.x < kSchurLandmarks && i < fr.n) {
+    if (accept) {
+      const double id = fr.idepth[i], st = fr.idepth_step[i];
+      v[0] = id * id;
+      v[1] = st * st;
+      fr.idepth[i] = id + st;
+    }
+    fr.idepth_step[i] = 0;
+    for (int t = 0; t < F; ++t) {
+      if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
+      if (accept)
+        fr.status[t][i] = fr.cand[t][i];
+      else
+        fr.cand[t][i] = fr.status[t][i];
+    }
+  }
+  blockSum<2, kSchurThreads>(v, lds);
+  if (threadIdx.x == 0 && accept) {
+    atomicAdd(&norms[0], v[0]);
+    atomicAdd(&norms[1], v[1]);
+  }
+}
+
+__global__ void acceptFramesKernel(WindowState *st, int F, int accept, double *norms /* [2] frame part */) {
+  __shared__ double lds[4];
+  const int c = threadIdx.x;  // 128 threads
+  double v[2] = {0, 0};
+  if (c < kBlk * F) {
+    const int f = c >> 3, a = c & 7;
+    if (accept) {
+      const double e = st->eps[f][a], s = st->step[f][a];
+      v[0] = e * e;
+      v[1] = s * s;
+      if (a < 2) v[0] += st->ab0[f][a] * st->ab0[f][a];
+      st->eps[f][a] = e + s;
+    }
+    st->step[f][a] = 0;
+  }
+  blockSum<2, 128>(v, lds);
+  if (c == 0 && accept) {
+    norms[0] = v[0];
+    norms[1] = v[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-side Levenberg-Marquardt control — levenberg_marquardt_algorithm.hpp:77-128
+// ---------------------------------------------------------------------------------------------------------------
+struct LmInitArgs {
+  SolveArgs sa;            // frames / st / Hm / bm / regularisers / energy_marginalized
+  const double *partials;  // sweep partials of the initial energy evaluation
+  const double *scalars;   // multi-GPU: all-reduced {energy, n_valid, -, -, idepth_sq}
+  const SchurBlock *schur_table;
+  int n_sweep_blocks, n_schur_blocks;
+  LmControl *ctrl;  // [2]
+  LmParams prm;
+};
+
+/** sum of idepth^2 over this rank's landmarks (state norm of acceptStep, problem.hpp:379); grid = schur blocks */
+__global__ void idepthNormKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, double *out) {
+  __shared__ double lds[kSchurThreads / 64];
+  const SchurBlock be = table[blockIdx.x];
+  const FrameDev &fr = frames[be.r];
+  const int i = be.offset + threadIdx.x;
+  double v[1] = {0};
+  if (threadIdx.x < kSchurLandmarks && i < fr.n) v[0] = fr.idepth[i] * fr.idepth[i];
+  blockSum<1, kSchurThreads>(v, lds);
+  if (threadIdx.x == 0) atomicAdd(out, v[0]);
+}
+
+/** result = calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82); single workgroup */
+__global__ void __launch_bounds__(kSolveThreads) lmInitKernel(LmInitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *lds = reinterpret_cast<double *>(smem_raw);
+  __shared__ double red[(kSolveThreads / 64) * 2];
+  const int tid = threadIdx.x;
+  double v[2] = {0, 0};
+  if (a.prm.use_reduced_scalars) {
+    v[0] = tid == 0 ? a.scalars[0] : 0.0;
+    v[1] = tid == 0 ? a.scalars[1] : 0.0;
+  } else {
+    for (int b = tid; b < a.n_sweep_blocks; b += kSolveThreads) {
+      v[0] += a.partials[static_cast<size_t>(b) * kPartial + 44];
+      v[1] += a.partials[static_cast<size_t>(b) * kPartial + 45];
+    }
+  }
+  blockSum<2, kSolveThreads>(v, red);
+  const double prior = priorEnergyBlock(a.sa, false, lds, tid);
+  if (tid == 0) {
+    LmControl c;
+    c.lambda = a.prm.lambda0;
+    c.energy = v[0] + prior;
+    c.cand_prior = 0;
+    c.idepth_sq = a.scalars[4];
+    c.n_valid = static_cast<int>(v[1] + 0.5);
+    c.converged = 0;
+    c.iteration = 0;
+    c.linear_system_valid = 0;
+    c.need_final_setup = 0;
+    c.active = (a.prm.max_iterations > 0 && c.n_valid > 0) ? 1 : 0;
+    c.pad0 = c.pad1 = 0;
+    a.ctrl[0] = c;
+    a.ctrl[1] = c;
+  }
+}
+
+struct LmDecideArgs {
+  const FrameDev *frames;
+  WindowState *st;
+  const SchurBlock *schur_table;
+  const double *partials;  // energy sweep partials: [44] energy, [45] n_valid, [46] sum step^2, [47] sum idepth*step
+  const double *scalars;   // multi-GPU: the same four sums, all-reduced
+  const LmControl *ctrl_in;
+  LmControl *ctrl_out;
+  int n_sweep_blocks, n_schur_blocks;
+  int F;
+  LmParams prm;
+};
+
+/**
+ * One loop body's tail (levenberg_marquardt_algorithm.hpp:93-123): compare energies, accept or reject, update lambda and
+ * the convergence flags, and apply the decision to the state (acceptStep / rejectStep, problem.hpp:366-402).
+ * grid = one workgroup per landmark chunk (+ at least one): every workgroup derives the same decision from the same
+ * inputs (deterministic reductions), applies it to its own landmarks; workgroup 0 also moves the frame states and
+ * writes the outgoing control block.
+ */
+__global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) {
+  __shared__ double red[(kSchurThreads / 64) * 6];
+  const LmControl cin = *a.ctrl_in;
+  const int tid = threadIdx.x;
+  if (!cin.active) {
+    if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
+    return;
+  }
+  double v[6] = {0, 0, 0, 0, 0, 0};  // energy, n_valid, step_sq(idepth), idepth.step, state_sq(frames), step_sq(frames)
+  if (a.prm.use_reduced_scalars) {
+    if (tid == 0) {
+      v[0] = a.scalars[0];
+      v[1] = a.scalars[1];
+      v[2] = a.scalars[2];
+      v[3] = a.scalars[3];
+    }
+  } else {
+    for (int b = tid; b < a.n_sweep_blocks; b += kSchurThreads) {
+      const double *p = a.partials + static_cast<size_t>(b) * kPartial;
+      v[0] += p[44];
+      v[1] += p[45];
+      v[2] += p[46];
+      v[3] += p[47];
+    }
+  }
+  if (tid < kBlk * a.F) {
+    const int f = tid >> 3, c = tid & 7;
+    const double e = a.st->eps[f][c], s = a.st->step[f][c];
+    v[4] = e * e + (c < 2 ? a.st->ab0[f][c] * a.st->ab0[f][c] : 0.0);
+    v[5] = s * s;
+  }
+  blockSum<6, kSchurThreads>(v, red);
+  __shared__ int s_accept;
+  __shared__ LmControl s_out;
+  if (tid == 0) {
+    LmControl c = cin;
+    const double next_energy = v[0] + cin.cand_prior;
+    const int n_valid = static_cast<int>(v[1] + 0.5);
+    int accept = 0;
+    c.iteration = cin.iteration + 1;
+    if (n_valid == 0) {
+      // problem.rejectStep(); break;
+      c.active = 0;
+      c.need_final_setup = 1;
+    } else {
+      if (fabs(cin.energy - next_energy) / cin.energy < a.prm.function_tolerance) c.converged = 1;
+      if (next_energy < cin.energy || (a.prm.force_accept && cin.iteration < a.prm.min_iterations)) {
+        accept = 1;
+        const double state_sq = v[4] + cin.idepth_sq, step_sq = v[5] + v[2];
+        if (step_sq < a.prm.parameter_tolerance * (state_sq + a.prm.parameter_tolerance)) c.converged = 1;
+        c.energy = next_energy;
+        c.n_valid = n_valid;
+        c.lambda = cin.lambda / a.prm.decrease_on_accept;
+        c.linear_system_valid = 0;
+        c.idepth_sq = cin.idepth_sq + 2.0 * v[3] + v[2];
+        c.need_final_setup = 0;
+      } else {
+        c.need_final_setup = 1;
+        if (a.prm.force_accept) {
+          c.active = 0;  // problem.calculateEnergy(); return result;
+        } else {
+          c.lambda = cin.lambda * a.prm.increase_on_reject;
+          c.linear_system_valid = 1;
+        }
+      }
+      if (c.converged || c.iteration >= a.prm.max_iterations) c.active = 0;
+    }
+    s_accept = accept;
+    s_out = c;
+  }
+  __syncthreads();
+  const int accept = s_accept;
+  // landmarks of this workgroup's chunk
+  if (static_cast<int>(blockIdx.x) < a.n_schur_blocks) {
+    const SchurBlock be = a.schur_table[blockIdx.x];
+    const FrameDev &fr = a.frames[be.r];
+    const int i = be.offset + tid;
+    if (tid < kSchurLandmarks && i < fr.n) {
+      if (accept) fr.idepth[i] += fr.idepth_step[i];
+      fr.idepth_step[i] = 0;
+      for (int t = 0; t < a.F; ++t) {
+        if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
+        if (accept)
+          fr.status[t][i] = fr.cand[t][i];
+        else
+          fr.cand[t][i] = fr.status[t][i];
+      }
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (tid < kBlk * a.F) {
+      const int f = tid >> 3, c = tid & 7;
+      if (accept) a.st->eps[f][c] += a.st->step[f][c];
+      a.st->step[f][c] = 0;
+    }
+    if (tid == 0) *a.ctrl_out = s_out;
+  }
+}
+
+/** sums the four per-block scalars of an energy sweep into out[0..3] (multi-GPU path, before the all-reduce) */
+__global__ void sweepScalarsKernel(const double *__restrict__ partials, int n_blocks, double *out, const LmControl *ctrl) {
+  __shared__ double lds[(256 / 64) * 4];
+  double v[4] = {0, 0, 0, 0};
+  const bool live = !ctrl || ctrl->active;
+  if (live)
+    for (int b = threadIdx.x; b < n_blocks; b += blockDim.x) {
+      const double *p = partials + static_cast<size_t>(b) * kPartial;
+      v[0] += p[44];
+      v[1] += p[45];
+      v[2] += p[46];
+      v[3] += p[47];
+    }
+  blockSum<4, 256>(v, lds);
+  if (threadIdx.x == 0) {
+    out[0] = v[0];
+    out[1] = v[1];
+    out[2] = v[2];
+    out[3] = v[3];
+  }
+}
+
+}  // namespace dsopp_hip

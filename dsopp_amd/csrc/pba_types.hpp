@@ -28,6 +28,8 @@ struct FrameDev {
   int fixed, is_marginalized, to_marginalize;
   int n;    // landmarks
   int cap;  // landmark capacity (stride of the per-slot planes of ublk)
+  int first_conn;  // first connected target slot (-1 = none): the thread of that pair owns per-landmark sums
+  int pad;
   double *uv, *idepth, *idepth_step, *idepth_fej, *patch;
   double *inv_hdd, *b_d, *relative_baseline;
   int32_t *n_inliers;

@@ -90,9 +90,12 @@ def test_stage_parity_small(small_window, fej):
     g.close()
 
 
-def test_full_solve_parity(small_window):
+@pytest.mark.parametrize("host_driven", [False, True])
+def test_full_solve_parity(small_window, host_driven):
+    """solve() with the LM control flow on the device (default) and on the host: both must reproduce the oracle."""
     win = small_window
     o, g = _both(win)
+    g.set_lm_mode(host_driven)
     eo, ito, nvo = o.solve()
     eg, itg, nvg = g.solve()
     assert ito == itg and nvo == nvg
