@@ -57,17 +57,20 @@ struct dsopp_hip_window {
   int marg_size = 0;
   // device
   DeviceBuffer<FrameDev> d_frames;
-  DeviceBuffer<WindowState> d_state;
+  DeviceBuffer<WindowState> d_state, d_state_snap;
   DeviceBuffer<PairConst> d_pc;
   DeviceBuffer<SweepBlock> d_sweep_table;
   DeviceBuffer<SchurBlock> d_schur_table;
   DeviceBuffer<int> d_pair_first, d_pair_count;
-  // d_reduce = [Gpair F*F*48 | Hsc K*K | bsc K]: everything a multi-GPU run must sum across ranks, contiguous
-  DeviceBuffer<double> d_partials, d_reduce, d_pairblk, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  // d_reduce = [Hpp K*K | bpp K | Hsc K*K | bsc K] (no priors): everything a multi-GPU run must sum across ranks, contiguous
+  DeviceBuffer<double> d_partials, d_reduce, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  bool marg_nonzero = false;
+  long long *dbg_stamps = nullptr;
   DeviceBuffer<LmControl> d_ctrl;
   bool host_driven_lm = false;  // debug / parity: run the LM control flow on the host through the stage functions
-  double *dGpair() const { return d_reduce.ptr; }
-  double *dHsc() const { return d_reduce.ptr + static_cast<size_t>(F()) * F() * 48; }
+  double *dHppRaw() const { return d_reduce.ptr; }
+  double *dbppRaw() const { return d_reduce.ptr + static_cast<size_t>(K()) * K(); }
+  double *dHsc() const { return dbppRaw() + K(); }
   double *dbsc() const { return dHsc() + static_cast<size_t>(K()) * K(); }
   void d_HscDownload(double *host, size_t n, size_t off, hipStream_t st) const {
     HIP_CHECK(hipMemcpyAsync(host, dHsc() + off, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -75,7 +78,7 @@ struct dsopp_hip_window {
   void d_bscDownload(double *host, size_t n, size_t off, hipStream_t st) const {
     HIP_CHECK(hipMemcpyAsync(host, dbsc() + off, n * sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  size_t reduceCount() const { return static_cast<size_t>(F()) * F() * 48 + static_cast<size_t>(K()) * K() + K(); }
+  size_t reduceCount() const { return 2 * (static_cast<size_t>(K()) * K() + K()); }
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
   bool state_dirty = true;   // host mirror newer than device
@@ -232,6 +235,8 @@ void syncTopology(W &w) {
     d.n_inliers = f.n_inliers.ptr;
     d.flags = f.dflags.ptr;
     d.ublk = f.ublk.ptr;
+    d.snap_idepth = f.snap_idepth.ptr;
+    d.snap_flags = f.snap_flags.ptr;
     d.first_conn = -1;
     for (int t = 0; t < F; ++t) {
       if (t == r) continue;
@@ -243,6 +248,7 @@ void syncTopology(W &w) {
       d.fej_valid[t] = rt.fej_valid.ptr;
       d.energy[t] = rt.energy.ptr;
       d.n_res[t] = rt.n;
+      d.snap_status[t] = rt.snap_status.ptr;
       if (d.first_conn < 0) d.first_conn = t;
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
@@ -268,12 +274,11 @@ void syncTopology(W &w) {
   w.d_pair_count.upload(pair_count.data(), pair_count.size(), 0, st);
   w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
-  w.d_pairblk.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * kPairBlk, 0, st);
   w.d_ctrl.reserve(2, 0, st);
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
   w.d_Hpp.reserve(KK * KK, 0, st);
   w.d_bpp.reserve(KK, 0, st);
-  w.d_reduce.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * 48 + KK * KK + KK, 0, st);
+  w.d_reduce.reserve(2 * (KK * KK + KK), 0, st);
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
@@ -302,6 +307,9 @@ void uploadMarginal(W &w) {
   if (!w.marg_dirty) return;
   const int K = w.K();
   if (w.marg_size != K) fail(DSOPP_HIP_ERR_STATE, "marginal prior has size %d, window %d", w.marg_size, K);
+  w.marg_nonzero = w.energy_marginalized != 0;
+  for (double v : w.Hm) w.marg_nonzero = w.marg_nonzero || v != 0;
+  for (double v : w.bm) w.marg_nonzero = w.marg_nonzero || v != 0;
   w.d_Hm.upload(w.Hm.data(), static_cast<size_t>(K) * K, 0, w.sr.stream);
   w.d_bm.upload(w.bm.data(), static_cast<size_t>(K), 0, w.sr.stream);
   w.sr.sync();
@@ -343,13 +351,22 @@ void firstEstimate(W &w) {
 }
 
 template <typename S>
-void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl) {
-  if (!w.n_sweep_blocks) return;
+void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl, bool backsub, double lambda) {
+  if (!w.n_sweep_blocks) {
+    if (lin) HIP_CHECK(hipMemsetAsync(w.d_reduce.ptr, 0, w.reduceCount() * sizeof(double), w.sr.stream));
+    return;
+  }
   SweepParams prm;
   prm.sigma_huber = w.opt.sigma_huber_loss;
   prm.for_marginalized = for_marg ? 1 : 0;
   prm.use_fej_flag = w.fej() ? 1 : 0;
   prm.ctrl_active = ctrl ? &ctrl->active : nullptr;
+  prm.clear_buf = lin ? w.d_reduce.ptr : nullptr;
+  prm.clear_count = static_cast<int>(w.reduceCount());
+  prm.step = w.d_step.ptr;
+  prm.lambda_ptr = ctrl ? &ctrl->lambda : nullptr;
+  prm.lambda = lambda;
+  prm.F = w.F();
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
   const FrameDev *fr = w.d_frames.ptr;
@@ -357,7 +374,12 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   const SweepBlock *tb = w.d_sweep_table.ptr;
   double *pa = w.d_partials.ptr;
   timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
-    if (!lin) {
+    if (!lin && backsub) {
+      if (w.fej())
+        sweepKernel<S, false, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, false, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    } else if (!lin) {
       if (w.fej())
         sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
       else
@@ -377,12 +399,13 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   HIP_CHECK(hipGetLastError());
 }
 
-void launchSweep(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl = nullptr) {
+void launchSweep(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl = nullptr, bool backsub = false, double lambda = 0) {
   if (!ctrl) ensurePairConstants(w);
+  backsub = backsub && w.opt.optimize_idepths;
   if (w.opt.dtype == DSOPP_HIP_F64)
-    launchSweepTyped<double>(w, lin, huber, for_marg, ctrl);
+    launchSweepTyped<double>(w, lin, huber, for_marg, ctrl, backsub, lambda);
   else
-    launchSweepTyped<float>(w, lin, huber, for_marg, ctrl);
+    launchSweepTyped<float>(w, lin, huber, for_marg, ctrl, backsub, lambda);
 }
 
 void allreduceIfNeeded(W &w, double *dev, size_t count) {
@@ -412,27 +435,22 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl) {
   a.partials = w.d_partials.ptr;
   a.pair_first_block = w.d_pair_first.ptr;
   a.pair_num_blocks = w.d_pair_count.ptr;
-  a.Gpair = w.dGpair();
-  a.pairblk = w.d_pairblk.ptr;
+  a.Hpp = w.dHppRaw();
+  a.bpp = w.dbppRaw();
   a.Hsc = w.dHsc();
   a.bsc = w.dbsc();
   a.ctrl = ctrl;
   a.F = F;
   a.n_schur_blocks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
   a.for_marginalized = for_marg ? 1 : 0;
-  a.derive = w.allreduce ? 0 : 1;
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
-    // the Schur system is accumulated with atomics: clear it first (skipped inside a device-driven loop only when the
-    // kernel itself is skipped — a stale system is then reused, as the reference does when linear_system_valid)
-    clearSchurKernel<<<(K * K + K + 255) / 256, 256, 0, st>>>(w.dHsc(), K * K + K, ctrl);
-    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, schurSmemBytes(K), st>>>(a);
+    // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
+    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t(4096)), st>>>(a);
   });
   HIP_CHECK(hipGetLastError());
-  if (w.allreduce) {
-    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
-    pairDeriveKernel<<<F * F, 64, 0, st>>>(w.d_pc.ptr, w.dGpair(), w.d_pairblk.ptr, F, ctrl);
-    HIP_CHECK(hipGetLastError());
-  }
+  // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
+  allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+  (void)K;
 }
 
 SolveArgs makeSolveArgs(W &w) {
@@ -440,12 +458,14 @@ SolveArgs makeSolveArgs(W &w) {
   a.frames = w.d_frames.ptr;
   a.st = w.d_state.ptr;
   a.pc = w.d_pc.ptr;
-  a.Gpair = w.dGpair();
-  a.pairblk = w.d_pairblk.ptr;
-  a.Hpp = w.d_Hpp.ptr;
-  a.bpp = w.d_bpp.ptr;
+  a.Hpp_raw = w.dHppRaw();
+  a.bpp_raw = w.dbppRaw();
+  a.Hpp_out = w.d_Hpp.ptr;
+  a.bpp_out = w.d_bpp.ptr;
   a.Hsc = w.dHsc();
   a.bsc = w.dbsc();
+  a.use_marginal = w.marg_nonzero ? 1 : 0;
+  a.dbg_stamps = w.dbg_stamps;
   a.Hm = w.d_Hm.ptr;
   a.bm = w.d_bm.ptr;
   a.step = w.d_step.ptr;
@@ -465,7 +485,7 @@ SolveArgs makeSolveArgs(W &w) {
 
 size_t solveSmemBytes(int K) {
   const size_t N = static_cast<size_t>(K) + 1;
-  return (N * (N + 1) + 2 * static_cast<size_t>(K) + 32) * sizeof(double);
+  return (N * (N + 1) + 2 * static_cast<size_t>(K) + 32 + 36 * static_cast<size_t>(kMaxFrames)) * sizeof(double);
 }
 
 /** K3 */
@@ -637,8 +657,7 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
     launchSweep(w, true, true, false, cin);          // linearize: evaluateJacobians ...
     launchReduceSchur(w, false, cin);                //            ... pose-pose blocks + Schur complement
     launchAssemble(w, 0.0, true, true, false, cin);  // calculateStep (lambda from the control block)
-    launchBacksub(w, 0.0, cin);                      //            ... calculateIdepths
-    launchSweep(w, false, true, false, cin);         // calculateEnergy at the candidate state
+    launchSweep(w, false, true, false, cin, /*backsub=*/true);  // calculateIdepths + calculateEnergy at the candidate state
     if (w.allreduce) {
       sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr, cin);
       allreduceIfNeeded(w, w.d_scalars.ptr, 4);
@@ -667,11 +686,11 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
   launchSweep(w, false, true, false);
   LmControl h;
   HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
-  w.sr.sync();
+  HIP_CHECK(hipMemcpyAsync(&w.hst, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, st));
+  w.sr.sync();  // the only host synchronisation of the solve
   energy_out = h.energy;
   iterations = h.iteration;
   n_valid_out = h.n_valid;
-  downloadState(w);
 }
 
 }  // namespace
@@ -1475,6 +1494,17 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
   });
 }
 
+/* tuning aid (not declared in the public header): wall_clock64 stamps of the solve kernel's phases (100 MHz ticks) */
+int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
+  return guarded([&] {
+    if (!w->dbg_stamps) {
+      HIP_CHECK(hipMalloc(&w->dbg_stamps, 8 * sizeof(long long)));
+      HIP_CHECK(hipMemset(w->dbg_stamps, 0, 8 * sizeof(long long)));
+    }
+    HIP_CHECK(hipMemcpy(out8, w->dbg_stamps, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  });
+}
+
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
@@ -1512,10 +1542,14 @@ int dsopp_hip_window_snapshot(dsopp_hip_window *w) {
         rt.snap_n = rt.n;
       }
     }
+    w->d_state_snap.reserve(1, 0, st);
+    HIP_CHECK(hipMemcpyAsync(w->d_state_snap.ptr, w->d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToDevice, st));
     w->snap_state = w->hst;
     w->snap_F = w->F();
     w->snap_valid = true;
     w->sr.sync();
+    w->topology_dirty = true;  // the frame table must carry the snapshot pointers
+    syncTopology(*w);
   });
 }
 
@@ -1524,26 +1558,22 @@ int dsopp_hip_window_restore(dsopp_hip_window *w) {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (!w->snap_valid || w->snap_F != w->F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
     w->sr.use();
-    hipStream_t st = w->sr.stream;
     for (auto &fp : w->frames) {
-      HostFrame &f = *fp;
-      if (f.snap_n != f.n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", f.id);
-      if (f.n) {
-        HIP_CHECK(hipMemcpyAsync(f.idepth.ptr, f.snap_idepth.ptr, static_cast<size_t>(f.n) * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(f.dflags.ptr, f.snap_flags.ptr, static_cast<size_t>(f.n), hipMemcpyDeviceToDevice, st));
-        HIP_CHECK(hipMemsetAsync(f.idepth_step.ptr, 0, static_cast<size_t>(f.n) * sizeof(double), st));
-      }
-      for (auto &kv : f.residuals) {
-        ResidualTable &rt = *kv.second;
-        if (rt.snap_n != rt.n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", f.id);
-        if (rt.n) {
-          HIP_CHECK(hipMemcpyAsync(rt.status.ptr, rt.snap_status.ptr, static_cast<size_t>(rt.n), hipMemcpyDeviceToDevice, st));
-          HIP_CHECK(hipMemcpyAsync(rt.cand.ptr, rt.snap_status.ptr, static_cast<size_t>(rt.n), hipMemcpyDeviceToDevice, st));
-        }
-      }
+      if (fp->snap_n != fp->n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", fp->id);
+      for (auto &kv : fp->residuals)
+        if (kv.second->snap_n != kv.second->n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", fp->id);
+    }
+    syncTopology(*w);
+    hipStream_t st = w->sr.stream;
+    // two enqueues, no host synchronisation: state block D2D + one kernel over all landmarks
+    HIP_CHECK(hipMemcpyAsync(w->d_state.ptr, w->d_state_snap.ptr, sizeof(WindowState), hipMemcpyDeviceToDevice, st));
+    if (w->n_schur_blocks) {
+      restoreKernel<<<w->n_schur_blocks, kSchurLandmarks, 0, st>>>(w->d_frames.ptr, w->d_schur_table.ptr, w->F());
+      HIP_CHECK(hipGetLastError());
     }
     w->hst = w->snap_state;
-    w->state_dirty = true;
+    w->state_dirty = false;
+    w->pair_valid = false;
     w->begun = false;
   });
 }

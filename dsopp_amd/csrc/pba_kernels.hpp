@@ -50,8 +50,17 @@ __device__ inline double linearisationScale(const FrameDev *frames, const Window
   return (frames[t].exposure / frames[r].exposure) * exp(st->ab0[t][0] - st->ab0[r][0]);
 }
 
-/** evaluate_jacobians.hpp:36-66 (per-pair prologue) + first_estimate_jacobians.hpp:22-31 */
-__device__ inline void computePairConst(const FrameDev *frames, const WindowState *st, PairConst *pc, int r, int t, int F, bool fej) {
+/** exp of the twist eps_f + step_f (sign = +1) or of its negative (sign = -1) */
+__device__ inline Rigid frameIncrement(const WindowState *st, int f, double sign) {
+  double xi[6];
+  for (int i = 0; i < 6; ++i) xi[i] = sign * (st->eps[f][i] + st->step[f][i]);
+  return rigidExp(xi);
+}
+
+/** evaluate_jacobians.hpp:36-66 (per-pair prologue) + first_estimate_jacobians.hpp:22-31.
+ *  Er = exp(eps_r + step_r), Emt = exp(-(eps_t + step_t)) may be supplied by the caller (shared through LDS). */
+__device__ inline void computePairConst(const FrameDev *frames, const WindowState *st, PairConst *pc, int r, int t, int F, bool fej,
+                                        const Rigid *Er = nullptr, const Rigid *Emt = nullptr) {
   PairConst &P = pc[r * kMaxFrames + t];
   const FrameDev &fr = frames[r];
   const FrameDev &ft = frames[t];
@@ -68,12 +77,7 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
     Tt0.t[i] = st->T0_t[t][i];
   }
   const Rigid T_tr0 = rigidMul(rigidInverse(Tt0), Tr0);
-  double xr[6], mxt[6];
-  for (int i = 0; i < 6; ++i) {
-    xr[i] = st->eps[r][i] + st->step[r][i];
-    mxt[i] = -(st->eps[t][i] + st->step[t][i]);
-  }
-  const Rigid T_tr = rigidMul(rigidExp(mxt), rigidMul(T_tr0, rigidExp(xr)));
+  const Rigid T_tr = rigidMul(Emt ? *Emt : frameIncrement(st, t, -1.0), rigidMul(T_tr0, Er ? *Er : frameIncrement(st, r, 1.0)));
   const double a_r = st->ab0[r][0] + st->eps[r][6] + st->step[r][6];
   const double b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
   const double a_t = st->ab0[t][0] + st->eps[t][6] + st->step[t][6];
@@ -197,6 +201,12 @@ struct SweepParams {
   int for_marginalized;  // accumulate only landmarks flagged to_marginalize (FOR_MARGINALIZED of the reference)
   int use_fej_flag;      // FIRST_ESTIMATE_JACOBIANS: success requires reprojection_jacobians_valid
   const int *ctrl_active;  // nullable: &LmControl::active, followed by linear_system_valid (pba_solve_kernels.hpp)
+  double *clear_buf;       // LIN: buffer the following reduction kernel accumulates into with atomics; zeroed here
+  int clear_count;
+  const double *step;      // BACKSUB: pose step of calculateStep (K doubles)
+  const double *lambda_ptr;  // BACKSUB: &LmControl::lambda or nullptr (then `lambda`)
+  double lambda;
+  int F;
 };
 
 /**
@@ -205,7 +215,7 @@ struct SweepParams {
  * (PBA_INT/evaluate_jacobians.hpp:20-202, hessian_block_evaluation.hpp:38-90,198-212).
  *   LIN = false: residual-only sweep (calculateEnergy).   LIN = true: linearisation sweep.
  */
-template <typename S, bool LIN, bool FEJ, bool HUBER>
+template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false>
 __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
@@ -214,6 +224,9 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
     // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
     if (!prm.ctrl_active[0] || (LIN && prm.ctrl_active[1])) return;
+  }
+  if (LIN && prm.clear_buf) {
+    for (int k = blockIdx.x * kSweepThreads + threadIdx.x; k < prm.clear_count; k += gridDim.x * kSweepThreads) prm.clear_buf[k] = 0;
   }
   const SweepBlock be = table[blockIdx.x];
   const FrameDev &fr = frames[be.r];
@@ -234,7 +247,22 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   if (active) {
     const bool accumulate = prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
     const S u = static_cast<S>(fr.uv[2 * i]), v = static_cast<S>(fr.uv[2 * i + 1]);
-    const S idepth = static_cast<S>(fr.idepth[i] + fr.idepth_step[i]);
+    double idepth_step_d = fr.idepth_step[i];
+    if (BACKSUB && !(flg & (kFlagMarginalized | kFlagIllConditioned))) {
+      // calculateIdepths — hessian_block_evaluation.hpp:238-263, recomputed by every target's thread of the landmark
+      // (the h_p rows are L2-resident); the thread of the first connected target stores it
+      double d = 0;
+      for (int tt = 0; tt < prm.F; ++tt) {
+        if (tt != be.r && fr.status[tt] == nullptr) continue;
+        const double *src = fr.ublk + (static_cast<size_t>(tt) * fr.cap + i) * kUblk;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) d += src[c] * prm.step[kBlk * tt + c];
+      }
+      const double lam = prm.lambda_ptr ? *prm.lambda_ptr : prm.lambda;
+      idepth_step_d = -((fr.b_d[i] - d) * (1.0 / (1.0 + lam)) * fr.inv_hdd[i]);
+      if (be.t == fr.first_conn) fr.idepth_step[i] = idepth_step_d;
+    }
+    const S idepth = static_cast<S>(fr.idepth[i] + idepth_step_d);
     const uint8_t status = fr.status[be.t][i];
     const S Wr = S(fr.width), Hr = S(fr.height), Wt = S(ft.width), Ht = S(ft.height);
 
@@ -396,9 +424,9 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
     if (!LIN && be.t == fr.first_conn) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
-      const double st = fr.idepth_step[i], id = fr.idepth[i];
-      acc[46] = st * st;
-      acc[47] = id * st;
+      const double id = fr.idepth[i];
+      acc[46] = idepth_step_d * idepth_step_d;
+      acc[47] = id * idepth_step_d;
     }
     if (LIN) {
       // h_p block of target t is w * J_t^T J_d = -u (hessian_block_evaluation.hpp:207-208); zero for invalid residuals (:190-192)

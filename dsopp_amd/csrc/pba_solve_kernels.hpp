@@ -100,14 +100,12 @@ struct ReduceSchurArgs {
   const SchurBlock *schur_table;
   const double *partials;
   const int *pair_first_block, *pair_num_blocks;
-  double *Gpair;    // [F*F][48]
-  double *pairblk;  // [F*F][kPairBlk]
-  double *Hsc, *bsc;
+  double *Hpp, *bpp;  // pose-pose system without priors, accumulated with atomics (K x K full, K)
+  double *Hsc, *bsc;  // Schur system, upper triangle accumulated with atomics
   const LmControl *ctrl;  // nullable: skip when !active or the linear system is still valid
   int F;
   int n_schur_blocks;
   int for_marginalized;
-  int derive;  // compute pair blocks here (single GPU); multi-GPU derives after the all-reduce
 };
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -118,8 +116,9 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
  *    of 64 landmarks of one frame: phase 1 finalises the landmarks (reference-frame block sum_t T^T u, H_dd, b_d, inverse,
  *    caches), phase 2 accumulates H_schur += A^T W A with the f64 matrix cores (v_mfma_f64_16x16x4_f64): a 16x16 output
  *    tile takes 4 landmarks per instruction, rows staged in LDS with a conflict-free stride; upper-triangular tiles only.
- *  - workgroups [n_schur_blocks, +F*F): one frame pair each: deterministic sum of the sweep's per-block partials
- *    (G, q) and the derived blocks T^T G T, G T, T^T q.
+ *  - workgroups [n_schur_blocks, +F*F): evaluateLinearSystemPosePose (hessian_block_evaluation.hpp:96-164) for one frame pair:
+ *    deterministic sum of the sweep's per-block partials (G, q), the derived blocks T^T G T, G T, T^T q, and their
+ *    scatter into H_pp / b_pp (H_rr += T^T G T, H_tt += G, H_rt = -(G T)^T, H_tr = -G T, b_r += T^T q, b_t -= q).
  */
 __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -131,28 +130,29 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
     const int lane = threadIdx.x;
     if (lane >= 64) return;
-    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch
+    const PairConst &P = a.pc[pi];
+    if (!P.valid) return;
+    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch + [kPairBlk] derived
     double s = 0;
     if (lane < 44) {
       const int first = a.pair_first_block[pi], cnt = a.pair_num_blocks[pi];
       for (int b = 0; b < cnt; ++b) s += a.partials[static_cast<size_t>(first + b) * kPartial + lane];
     }
-    if (lane < 48) {
-      lds[lane] = s;
-      a.Gpair[p * 48 + lane] = s;
-    }
+    if (lane < 48) lds[lane] = s;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    if (a.derive) {
-      const PairConst &P = a.pc[pi];
-      double *out = a.pairblk + static_cast<size_t>(p) * kPairBlk;
-      if (P.valid) {
-        derivePairBlocks(lds, P, out, lds + 48, lane);
-      } else {
-        out[lane] = 0;
-        out[64 + lane] = 0;
-        if (lane < 8) out[128 + lane] = 0;
-      }
+    double *drv = lds + 48 + 64;
+    derivePairBlocks(lds, P, drv, lds + 48, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane >> 3, j = lane & 7;
+    atomicAdd(&a.Hpp[(kBlk * r + i) * K + kBlk * r + j], drv[lane]);
+    atomicAdd(&a.Hpp[(kBlk * t + i) * K + kBlk * t + j], lds[symIdx(i, j)]);
+    atomicAdd(&a.Hpp[(kBlk * r + i) * K + kBlk * t + j], -drv[64 + 8 * j + i]);
+    atomicAdd(&a.Hpp[(kBlk * t + i) * K + kBlk * r + j], -drv[64 + lane]);
+    if (lane < 8) {
+      atomicAdd(&a.bpp[kBlk * r + lane], drv[128 + lane]);
+      atomicAdd(&a.bpp[kBlk * t + lane], -lds[36 + lane]);
     }
     return;
   }
@@ -292,27 +292,6 @@ __global__ void clearSchurKernel(double *buf, int n, const LmControl *ctrl) {
   if (i < n) buf[i] = 0;
 }
 
-/** multi-GPU: per-pair derived blocks from the all-reduced G/q.  grid = F*F workgroups of 64 threads */
-__global__ void pairDeriveKernel(const PairConst *__restrict__ pc, const double *__restrict__ Gpair, double *__restrict__ pairblk, int F,
-                                 const LmControl *ctrl) {
-  __shared__ double lds[48 + 64];
-  if (ctrl && (!ctrl->active || ctrl->linear_system_valid)) return;
-  const int p = blockIdx.x, r = p / F, t = p % F, pi = r * kMaxFrames + t;
-  const int lane = threadIdx.x;
-  if (lane < 48) lds[lane] = Gpair[p * 48 + lane];
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  const PairConst &P = pc[pi];
-  double *out = pairblk + static_cast<size_t>(p) * kPairBlk;
-  if (P.valid) {
-    derivePairBlocks(lds, P, out, lds + 48, lane);
-  } else {
-    out[lane] = 0;
-    out[64 + lane] = 0;
-    if (lane < 8) out[128 + lane] = 0;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // K3: assemble + solve (single workgroup)
 // ---------------------------------------------------------------------------------------------------------------
@@ -322,13 +301,13 @@ struct SolveArgs {
   const FrameDev *frames;
   WindowState *st;
   PairConst *pc;
-  const double *Gpair;    // [F*F][48]
-  const double *pairblk;  // [F*F][kPairBlk]
-  double *Hpp, *bpp;      // out (optional store): system_pose with priors
-  double *Hsc, *bsc;      // Schur system, upper triangle accumulated (symmetrised in place when stored)
-  const double *Hm, *bm;  // marginal prior
-  double *step;           // out: K
-  LmControl *ctrl;        // nullable (host-driven stages pass lambda explicitly)
+  const double *Hpp_raw, *bpp_raw;  // pose-pose sums without priors (K x K full, K)
+  double *Hsc;                      // Schur system, upper triangle accumulated (symmetrised in place when stored)
+  const double *bsc;
+  double *Hpp_out, *bpp_out;        // optional store: system_pose with priors
+  const double *Hm, *bm;            // marginal prior
+  double *step;                     // out: K
+  LmControl *ctrl;                  // nullable (host-driven stages pass lambda explicitly)
   double lambda;
   double affine_reg[2];
   double fixed_reg;
@@ -336,9 +315,12 @@ struct SolveArgs {
   int F;
   int fej;
   int do_solve;
-  int store_system;  // write H_pp / b_pp / symmetrised H_schur back (stage API, marginalisation, covariance)
+  int store_system;  // write H_pp / b_pp (with priors) and the symmetrised H_schur back (stage API, marginalisation, covariance)
   int add_priors;
+  int use_marginal;  // the marginal prior is non-zero
+  long long *dbg_stamps;  // nullable: wall_clock64() stamps of the phases (tuning aid)
 };
+#define DSOPP_STAMP(i) do { if (a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
 /** prior + marginal energy terms of calculateEnergy (problem.hpp:293-312) for state x = eps (+ step); whole workgroup */
 __device__ inline double priorEnergyBlock(const SolveArgs &a, bool with_step, double *lds /* K + 8 */, int tid) {
@@ -347,15 +329,16 @@ __device__ inline double priorEnergyBlock(const SolveArgs &a, bool with_step, do
   __syncthreads();
   double part = 0;
   for (int c = tid; c < K; c += kSolveThreads) {
-    double s = 0;
-    for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * lds[k];
-    part += a.bm[c] * lds[c] + 0.5 * lds[c] * s;
+    if (a.use_marginal) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * lds[k];
+      part += a.bm[c] * lds[c] + 0.5 * lds[c] * s;
+    }
     if ((c & 7) >= 6) {
       const double ab = a.st->ab0[c >> 3][(c & 7) - 6] + lds[c];
       part += 0.5 * ab * a.affine_reg[(c & 7) - 6] * ab;
     }
   }
-  // block reduce
   part = waveSum(part);
   __syncthreads();
   if ((tid & 63) == 0) lds[K + (tid >> 6)] = part;
@@ -366,179 +349,224 @@ __device__ inline double priorEnergyBlock(const SolveArgs &a, bool with_step, do
   return total;
 }
 
+/** packed lower-triangular index of an 8x8 block */
+__host__ __device__ constexpr int lowIdx(int i, int j) { return i * (i + 1) / 2 + j; }
+
 /**
- * evaluateLinearSystemPosePose (hessian_block_evaluation.hpp:96-164) from the per-pair blocks, evaluateLinearSystemPrior
- * (problem.hpp:37-77), calculateStep (problem.hpp:342-361) and NormalLinearSystem::solve (normal_linear_system.cpp:10-16,
- * 52-59: Jacobi preconditioner + LDL^T; here a blocked Cholesky with 8x8 frame blocks, the right-hand side carried as an
- * extra row so the forward substitution rides along) — one workgroup, ~3 barriers per frame block.  Also rebuilds the pair
- * constants and the prior energy for the candidate state eps + step, so the energy sweep can follow immediately.
+ * evaluateLinearSystemPrior (problem.hpp:37-77), calculateStep (problem.hpp:342-361) and NormalLinearSystem::solve
+ * (normal_linear_system.cpp:10-16,52-59: Jacobi preconditioner + LDL^T; here a blocked Cholesky over the 8x8 frame blocks
+ * with the right-hand side carried as an extra row, each thread factoring/inverting the current diagonal block in
+ * registers so a block step costs two barriers) — one workgroup.  Also rebuilds the pair constants and the prior energy
+ * for the candidate state eps + step, so the energy sweep can follow immediately.
  */
 __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (a.ctrl && !a.ctrl->active) return;
   const int F = a.F, K = kBlk * F;
   const int N = K + 1;   // augmented with the right-hand side row
-  const int ld = N + 1;  // odd leading dimension
+  const int ld = N + 1;
   double *A = reinterpret_cast<double *>(smem_raw);  // N x ld (lower triangle used)
   double *pv = A + N * ld;                           // K preconditioner
   double *xs = pv + K;                               // K + 16 scratch
+  double *Linv = xs + K + 16;                        // F x 36 inverses of the diagonal blocks
   const int tid = threadIdx.x;
   const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
+  const double sc = -1.0 / (1.0 + lam);
+  DSOPP_STAMP(0);
 
-  // ---- H_pp (lower triangle incl. diagonal blocks) and b_pp from the pair blocks
-  for (int e = tid; e < K * K; e += kSolveThreads) {
-    const int row = e / K, col = e - row * K;
-    if (col > row) continue;
-    const int fa = row >> 3, fb = col >> 3, i = row & 7, j = col & 7;
-    double s = 0;
-    if (fa == fb) {
-      for (int t = 0; t < F; ++t) {
-        if (t == fa) continue;
-        s += a.pairblk[static_cast<size_t>(fa * F + t) * kPairBlk + 8 * i + j];  // T^T G T of pair (fa -> t)
-        s += a.Gpair[(t * F + fa) * 48 + symIdx(i, j)];                          // G of pair (t -> fa)
-      }
-    } else {
-      // H[fa, fb] = -(G T)^T of pair (fa -> fb)  -  G T of pair (fb -> fa)
-      s -= a.pairblk[static_cast<size_t>(fa * F + fb) * kPairBlk + 64 + 8 * j + i];
-      s -= a.pairblk[static_cast<size_t>(fb * F + fa) * kPairBlk + 64 + 8 * i + j];
-    }
-    A[row * ld + col] = s;
-  }
+  // ---- system_pose = sums + priors (problem.hpp:39-62)
+  for (int c = tid; c < K; c += kSolveThreads) xs[c] = a.st->eps[c >> 3][c & 7];
+  // per-frame prior diagonal (problem.hpp:39-62) in LDS, so the element loop has no dependent frame-table loads
+  double *prior_diag = xs + K;  // first 8 of the 16 spare + Linv area not yet in use: use Linv as scratch
+  prior_diag = Linv;
   for (int c = tid; c < K; c += kSolveThreads) {
-    const int fa = c >> 3, i = c & 7;
-    double s = 0;
-    for (int t = 0; t < F; ++t) {
-      if (t == fa) continue;
-      s += a.pairblk[static_cast<size_t>(fa * F + t) * kPairBlk + 128 + i];  // b_r = T^T q
-      s -= a.Gpair[(t * F + fa) * 48 + 36 + i];                             // b_t = -q
+    const int f = c >> 3, i = c & 7;
+    double pd = 0;
+    if (a.add_priors && !a.frames[f].to_marginalize) pd = a.frames[f].fixed ? a.fixed_reg : (i >= 6 ? a.affine_reg[i - 6] : 0.0);
+    prior_diag[c] = pd;
+  }
+  __syncthreads();
+  {
+    // 16 x 16 thread tile walking the lower triangle: row = tr + 16*m, col = tc + 16*n; loads of a tile are independent
+    const int tr = tid >> 4, tc = tid & 15;
+    for (int r0 = 0; r0 < K; r0 += 16) {
+      const int row = r0 + tr;
+      for (int c0 = 0; c0 <= r0; c0 += 32) {
+        double hp[2], hs[2], hm[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = c0 + 16 * u + tc;
+          const bool in = row < K && col < K && (c0 + 16 * u) <= r0;
+          hp[u] = in ? a.Hpp_raw[row * K + col] : 0.0;
+          hs[u] = in ? (col <= row ? a.Hsc[col * K + row] : a.Hsc[row * K + col]) : 0.0;
+          hm[u] = (in && a.use_marginal) ? a.Hm[row * K + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = c0 + 16 * u + tc;
+          const bool in = row < K && col < K && (c0 + 16 * u) <= r0;
+          if (!in) continue;
+          double v = hp[u];
+          if (row == col) v += prior_diag[row];
+          if (a.store_system) {
+            a.Hpp_out[row * K + col] = v;
+            a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
+            if (col < row) a.Hsc[row * K + col] = hs[u];
+          }
+          if (col <= row) {
+            // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)
+            if (row == col) v += v * lam;
+            A[row * ld + col] = v + sc * hs[u] + hm[u];
+          }
+        }
+      }
     }
-    A[K * ld + c] = s;
+  }
+  __syncthreads();
+  for (int c = tid; c < K; c += kSolveThreads) {
+    const int f = c >> 3, i = c & 7;
+    double v = a.bpp_raw[c];
+    if (a.add_priors && !a.frames[f].to_marginalize) {
+      if (a.frames[f].fixed)
+        v += a.fixed_reg * xs[c];
+      else if (i >= 6)
+        v += a.affine_reg[i - 6] * (a.st->ab0[f][i - 6] + xs[c]);
+    }
+    (void)i;
+    if (a.store_system) a.bpp_out[c] = v;
+    v += sc * a.bsc[c];
+    if (a.use_marginal) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * xs[k];
+      v += a.bm[c] + s;
+    }
+    A[K * ld + c] = v;
+    pv[c] = 1.0 / sqrt(A[c * ld + c] + 10.0);  // jacobiPreconditioner — normal_linear_system.cpp:10-16
   }
   if (tid == 0) A[K * ld + K] = 0;
-  __syncthreads();
-  // ---- priors — problem.hpp:39-62
-  if (a.add_priors) {
-    for (int c = tid; c < K; c += kSolveThreads) {
-      const int f = c >> 3, i = c & 7;
-      if (a.frames[f].to_marginalize) continue;
-      if (a.frames[f].fixed) {
-        A[c * ld + c] += a.fixed_reg;
-        A[K * ld + c] += a.fixed_reg * a.st->eps[f][i];
-      } else if (i >= 6) {
-        const double ab = a.st->ab0[f][i - 6] + a.st->eps[f][i];
-        A[c * ld + c] += a.affine_reg[i - 6];
-        A[K * ld + c] += a.affine_reg[i - 6] * ab;
-      }
-    }
-    __syncthreads();
-  }
-  if (a.store_system) {
-    for (int e = tid; e < K * K; e += kSolveThreads) {
-      const int row = e / K, col = e - row * K;
-      a.Hpp[e] = col <= row ? A[row * ld + col] : A[col * ld + row];
-      if (col < row) a.Hsc[e] = a.Hsc[col * K + row];
-    }
-    for (int c = tid; c < K; c += kSolveThreads) a.bpp[c] = A[K * ld + c];
-  }
   if (!a.do_solve) return;
   __syncthreads();
-  // ---- calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam); b likewise + H_m * state
-  const double sc = -1.0 / (1.0 + lam);
-  for (int c = tid; c < K; c += kSolveThreads) xs[c] = a.st->eps[c >> 3][c & 7];
-  __syncthreads();
-  for (int e = tid; e < K * K; e += kSolveThreads) {
-    const int row = e / K, col = e - row * K;
-    if (col > row) continue;
-    double v = A[row * ld + col];
-    if (row == col) v += v * lam;
-    v += a.Hm[e] + sc * a.Hsc[col * K + row];  // Hsc holds the upper triangle
-    A[row * ld + col] = v;
-  }
-  for (int c = tid; c < K; c += kSolveThreads) {
-    double s = 0;
-    for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * xs[k];
-    A[K * ld + c] += sc * a.bsc[c] + a.bm[c] + s;
-  }
-  __syncthreads();
-  // ---- Jacobi preconditioner — normal_linear_system.cpp:10-16
-  for (int c = tid; c < K; c += kSolveThreads) pv[c] = 1.0 / sqrt(A[c * ld + c] + 10.0);
-  __syncthreads();
-  for (int e = tid; e < N * K; e += kSolveThreads) {
-    const int row = e / K, col = e - row * K;
-    if (col > row) continue;
-    A[row * ld + col] *= (row < K ? pv[row] : 1.0) * pv[col];
+  DSOPP_STAMP(1);
+  {
+    const int tr = tid >> 4, tc = tid & 15;
+    for (int row = tr; row < N; row += 16) {
+      const double pr = row < K ? pv[row] : 1.0;
+      for (int col = tc; col <= row && col < K; col += 16) A[row * ld + col] *= pr * pv[col];
+    }
   }
   __syncthreads();
   // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T
+  DSOPP_STAMP(2);
   for (int kb = 0; kb < F; ++kb) {
     const int k0 = kb * kBlk;
-    // (1) factor the 8x8 diagonal block in place (wave 0, lanes = (i, j))
-    if (tid < 64) {
-      const int i = tid >> 3, j = tid & 7;
-      for (int k = 0; k < kBlk; ++k) {
-        const double d = A[(k0 + k) * ld + k0 + k];
-        const bool okp = d > 1e-300;
-        const double lkk = okp ? sqrt(d) : 0.0, inv = okp ? 1.0 / lkk : 0.0;
-        __builtin_amdgcn_wave_barrier();
-        if (j == k && i >= k) A[(k0 + i) * ld + k0 + k] = (i == k) ? lkk : A[(k0 + i) * ld + k0 + k] * inv;
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        if (j > k && i >= j) A[(k0 + i) * ld + k0 + j] -= A[(k0 + i) * ld + k0 + k] * A[(k0 + j) * ld + k0 + k];
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-      }
+    // (1) every thread factors the 8x8 diagonal block and inverts its Cholesky factor in registers
+    double L[36], Li[36];
+#pragma unroll
+    for (int i = 0; i < kBlk; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[lowIdx(i, j)] = A[(k0 + i) * ld + k0 + j];
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      const double d = L[lowIdx(k, k)];
+      // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64 (pivots of the Jacobi-scaled system are O(1e-13..1));
+      // pivots below 1e-30 are treated as zero, as a rank-revealing factorisation would
+      const bool okp = d > 1e-30;
+      double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = okp ? inv : 0.0;
+      const double lkk = okp ? d * inv : 0.0;
+      L[lowIdx(k, k)] = lkk;
+      Li[lowIdx(k, k)] = inv;
+#pragma unroll
+      for (int i = k + 1; i < kBlk; ++i) L[lowIdx(i, k)] *= inv;
+#pragma unroll
+      for (int j = k + 1; j < kBlk; ++j)
+#pragma unroll
+        for (int i = j; i < kBlk; ++i) L[lowIdx(i, j)] -= L[lowIdx(i, k)] * L[lowIdx(j, k)];
     }
-    __syncthreads();
-    // (2) panel: rows below the block, L_ik = A_ik * L_kk^-T (one thread per row, forward substitution over 8 columns)
-    for (int row = k0 + kBlk + tid; row < N; row += kSolveThreads) {
+    // inverse of the lower-triangular factor: Li_ij = -(sum_{k=j}^{i-1} L_ik Li_kj) / L_ii
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+#pragma unroll
+      for (int i = j + 1; i < kBlk; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int k = j; k < i; ++k) s += L[lowIdx(i, k)] * Li[lowIdx(k, j)];
+        Li[lowIdx(i, j)] = -s * Li[lowIdx(i, i)];
+      }
+    // (2) panel: rows below the block, L_ik = A_ik * L_kk^-T
+    const int row = k0 + kBlk + tid;
+    double out[kBlk];
+    if (row < N) {
       double v[kBlk];
 #pragma unroll
       for (int c = 0; c < kBlk; ++c) v[c] = A[row * ld + k0 + c];
 #pragma unroll
       for (int c = 0; c < kBlk; ++c) {
-        double s = v[c];
+        double s = 0;
 #pragma unroll
-        for (int k = 0; k < kBlk; ++k)
-          if (k < c) s -= v[k] * A[(k0 + c) * ld + k0 + k];
-        const double lcc = A[(k0 + c) * ld + k0 + c];
-        v[c] = lcc > 0 ? s / lcc : 0.0;
+        for (int k = 0; k <= c; ++k) s += v[k] * Li[lowIdx(c, k)];
+        out[c] = s;
       }
+    }
+    __syncthreads();  // all reads of the diagonal block / panel are done
+    if (row < N) {
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = v[c];
+      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = out[c];
+    }
+    if (tid == kSolveThreads - 1) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) Linv[kb * 36 + e] = Li[e];
     }
     __syncthreads();
     // (3) trailing update of the lower triangle: A_ij -= sum_c L_ic L_jc
     const int r0 = k0 + kBlk, rem = N - r0;
-    for (int e = tid; e < rem * rem; e += kSolveThreads) {
-      const int ii = e / rem, jj = e - ii * rem;
-      if (jj > ii) continue;
-      const double *li = A + (r0 + ii) * ld + k0, *lj = A + (r0 + jj) * ld + k0;
-      double s = 0;
+    {
+      const int tr = tid >> 4, tc = tid & 15;
+      for (int ii = tr; ii < rem; ii += 16) {
+        const double *li = A + (r0 + ii) * ld + k0;
+        double lic[kBlk];
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) s += li[c] * lj[c];
-      A[(r0 + ii) * ld + r0 + jj] -= s;
+        for (int c = 0; c < kBlk; ++c) lic[c] = li[c];
+        for (int jj = tc; jj <= ii; jj += 16) {
+          const double *lj = A + (r0 + jj) * ld + k0;
+          double s = 0;
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) s += lic[c] * lj[c];
+          A[(r0 + ii) * ld + r0 + jj] -= s;
+        }
+      }
     }
     __syncthreads();
   }
-  // ---- back substitution x = L^-T y, blocked (y = row K of L)
+  // ---- back substitution x = L^-T y, blocked (y = row K of L); x_k = Linv_kk^T (y_k - sum_{j>k} L_jk^T x_j)
+  DSOPP_STAMP(3);
   for (int c = tid; c < K; c += kSolveThreads) xs[c] = A[K * ld + c];
   __syncthreads();
   for (int kb = F - 1; kb >= 0; --kb) {
     const int k0 = kb * kBlk;
-    if (tid == 0) {
-      for (int c = kBlk - 1; c >= 0; --c) {
-        double s = xs[k0 + c];
-        for (int k = c + 1; k < kBlk; ++k) s -= A[(k0 + k) * ld + k0 + c] * xs[k0 + k];
-        const double lcc = A[(k0 + c) * ld + k0 + c];
-        xs[k0 + c] = lcc > 0 ? s / lcc : 0.0;
-      }
-    }
-    __syncthreads();
-    for (int row = tid; row < k0; row += kSolveThreads) {
+    double xk[kBlk];
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) {
       double s = 0;
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + row] * xs[k0 + c];
-      xs[row] -= s;
+      for (int k = c; k < kBlk; ++k) s += Linv[kb * 36 + lowIdx(k, c)] * xs[k0 + k];
+      xk[c] = s;
+    }
+    __syncthreads();
+    if (tid < kBlk) {
+      double mine = xk[0];
+#pragma unroll
+      for (int c = 1; c < kBlk; ++c) mine = (tid == c) ? xk[c] : mine;
+      xs[k0 + tid] = mine;
+    }
+    for (int row = kBlk + tid; row < kBlk + k0; row += kSolveThreads) {
+      const int rr = row - kBlk;
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + rr] * xk[c];
+      xs[rr] -= s;
     }
     __syncthreads();
   }
@@ -548,11 +576,20 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a
     a.st->step[c >> 3][c & 7] = -x;  // problem.hpp:353-357
   }
   __syncthreads();
-  if (tid < F * F) computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, a.fej != 0);
+  DSOPP_STAMP(4);
+  {
+    Rigid *E = reinterpret_cast<Rigid *>(A);  // [2][F]: exp(+xi_f), exp(-xi_f); A is free now
+    if (tid < 2 * F) E[tid] = frameIncrement(a.st, tid % F, tid < F ? 1.0 : -1.0);
+    __syncthreads();
+    if (tid < F * F) computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, a.fej != 0, &E[tid / F], &E[F + tid % F]);
+  }
+  __syncthreads();
+  DSOPP_STAMP(5);
   if (a.ctrl) {
     const double pe = priorEnergyBlock(a, true, A, tid);
     if (tid == 0) a.ctrl->cand_prior = pe;
   }
+  DSOPP_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -829,6 +866,23 @@ __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) 
       a.st->step[f][c] = 0;
     }
     if (tid == 0) *a.ctrl_out = s_out;
+  }
+}
+
+/** dsopp_hip_window_restore: idepths, flags and connection statuses back to the snapshot; grid = schur blocks */
+__global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F) {
+  const SchurBlock be = table[blockIdx.x];
+  const FrameDev &fr = frames[be.r];
+  const int i = be.offset + threadIdx.x;
+  if (threadIdx.x >= kSchurLandmarks || i >= fr.n) return;
+  fr.idepth[i] = fr.snap_idepth[i];
+  fr.idepth_step[i] = 0;
+  fr.flags[i] = fr.snap_flags[i];
+  for (int t = 0; t < F; ++t) {
+    if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
+    const uint8_t s = fr.snap_status[t][i];
+    fr.status[t][i] = s;
+    fr.cand[t][i] = s;
   }
 }
 

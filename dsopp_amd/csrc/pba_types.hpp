@@ -38,6 +38,10 @@ struct FrameDev {
   uint8_t *status[kMaxFrames], *cand[kMaxFrames], *fej_valid[kMaxFrames];  // by target slot; nullptr = no connection
   double *energy[kMaxFrames];
   int n_res[kMaxFrames];
+  // device-side snapshot (dsopp_hip_window_snapshot / _restore)
+  double *snap_idepth;
+  uint8_t *snap_flags;
+  uint8_t *snap_status[kMaxFrames];
 };
 
 /** dynamic state of the window, lives in HBM and is advanced by the kernels */
