@@ -66,6 +66,8 @@ struct dsopp_hip_window {
   DeviceBuffer<double> d_partials, d_reduce, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
   bool marg_nonzero = false;
   long long *dbg_stamps = nullptr;
+  long long *dbg_sweep = nullptr;
+  bool dbg_sweep_lin = true;
   DeviceBuffer<LmControl> d_ctrl;
   bool host_driven_lm = false;  // debug / parity: run the LM control flow on the host through the stage functions
   double *dHppRaw() const { return d_reduce.ptr; }
@@ -252,7 +254,7 @@ void syncTopology(W &w) {
       if (d.first_conn < 0) d.first_conn = t;
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
-      for (int off = 0; off < rt.n; off += kSweepThreads) {
+      for (int off = 0; off < rt.n; off += kItemsPerBlock) {
         sweep.push_back(SweepBlock{r, t, off, 0});
         ++cnt;
       }
@@ -367,6 +369,7 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.lambda_ptr = ctrl ? &ctrl->lambda : nullptr;
   prm.lambda = lambda;
   prm.F = w.F();
+  prm.dbg = (w.dbg_sweep && lin == w.dbg_sweep_lin) ? w.dbg_sweep : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
   const FrameDev *fr = w.d_frames.ptr;
@@ -1491,6 +1494,21 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
     w->allreduce_user = user;
     w->rank = fn ? rank : 0;
     w->world = fn ? world_size : 1;
+  });
+}
+
+/* tuning aid (not declared in the public header): stamps of the sweep kernel (workgroup grid/2) */
+int dsopp_hip_debug_sweep_stamps(dsopp_hip_window *w, int lin, long long *out16) {
+  return guarded([&] {
+    if (!w->dbg_sweep) {
+      HIP_CHECK(hipMalloc(&w->dbg_sweep, 16 * sizeof(long long)));
+    } else {
+      HIP_CHECK(hipMemcpy(out16, w->dbg_sweep, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    }
+    HIP_CHECK(hipMemset(w->dbg_sweep, 0, 16 * sizeof(long long)));
+    const long long big = 0x7fffffffffffffffLL;
+    HIP_CHECK(hipMemcpy(w->dbg_sweep + 8, &big, sizeof(long long), hipMemcpyHostToDevice));
+    w->dbg_sweep_lin = lin != 0;
   });
 }
 

@@ -207,19 +207,73 @@ struct SweepParams {
   const double *lambda_ptr;  // BACKSUB: &LmControl::lambda or nullptr (then `lambda`)
   double lambda;
   int F;
+  long long *dbg;  // nullable tuning aid: per-phase wall_clock64 stamps of workgroup 0 / max end stamp
 };
+#define SWEEP_STAMP(i) do { if (prm.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) prm.dbg[i] = wall_clock64(); } while (0)
+
+constexpr int kItemsPerBlock = kSweepThreads / kPat;  // 8 lanes (one per pattern pixel) per (landmark, target) item
+
+/** v of the lane selected by a DPP control word (quad_perm / row_half_mirror / ...): pure VALU, no LDS round trip */
+template <int CTRL>
+__device__ __forceinline__ double dppMove(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+/** sum over the 8 lanes of an item (lanes differ in bits 0..2); every lane receives the total.
+ *  quad_perm [1,0,3,2] (0xB1), quad_perm [2,3,0,1] (0x4E), row_half_mirror (0x141: lane i <-> 7 - i) */
+__device__ __forceinline__ double sum8(double v) {
+  v += dppMove<0xB1>(v);
+  v += dppMove<0x4E>(v);
+  v += dppMove<0x141>(v);
+  return v;
+}
+
+constexpr int kRedStride = kSweepThreads + 2;  // even (16-byte aligned rows), 4-bank skew between rows for ds_read_b128
+
+/**
+ * Workgroup sum of acc[FIRST .. FIRST+COUNT) through an LDS transpose: every lane stores its COUNT values as columns
+ * (conflict-free ds_write_b64), then lane e < COUNT adds up row e with ds_read_b128 and writes partials[FIRST + e].
+ * (A shuffle tree of 48 doubles costs 288 dependent ds_bpermute round trips — measured 10 us per workgroup.)
+ */
+template <int FIRST, int COUNT>
+__device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], double *lds /* [COUNT][kRedStride] */,
+                                                 double *__restrict__ out /* [kPartial] */) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < COUNT; ++e) lds[e * kRedStride + t] = acc[FIRST + e];
+  __syncthreads();
+  if (t < COUNT) {
+    const double2 *row = reinterpret_cast<const double2 *>(lds + t * kRedStride);
+    double s0 = 0, s1 = 0;
+#pragma unroll 8
+    for (int j = 0; j < kSweepThreads / 2; ++j) {
+      const double2 p = row[j];
+      s0 += p.x;
+      s1 += p.y;
+    }
+    out[FIRST + t] = s0 + s1;
+  }
+}
 
 /**
  * evaluateJacobians<S, SE3, Pinhole, 8, PixelMap, 1, FEJ, OPT_IDEPTHS, LIN, true, HUBER> fused with
  * evaluateLinearSystemPosePoseBlock and the per-(landmark,target) part of ...SchurComplement
  * (PBA_INT/evaluate_jacobians.hpp:20-202, hessian_block_evaluation.hpp:38-90,198-212).
- *   LIN = false: residual-only sweep (calculateEnergy).   LIN = true: linearisation sweep.
+ *   LIN = false: residual-only sweep (calculateEnergy), optionally with calculateIdepths fused in (BACKSUB).
+ *   LIN = true : linearisation sweep.
+ * Thread mapping: one lane per pattern pixel, 8 adjacent lanes per (landmark, target) item, a workgroup = 16 items of one
+ * ordered frame pair.  The dependent chain of a lane is: landmark words (coalesced, broadcast within the item) ->
+ * 1 reprojection -> 4 texel loads (2 x 64 B segments) -> 1 Jacobian row -> reductions, so a C1-sized sweep is one
+ * memory round trip deep per stage instead of eight.
  */
 template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false>
 __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
-  __shared__ double red_lds[(kSweepThreads / 64) * kPartial];
+  __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? kPartial : 4) * kRedStride];
   if (prm.ctrl_active) {
     // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
     // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
@@ -228,15 +282,20 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   if (LIN && prm.clear_buf) {
     for (int k = blockIdx.x * kSweepThreads + threadIdx.x; k < prm.clear_count; k += gridDim.x * kSweepThreads) prm.clear_buf[k] = 0;
   }
+  SWEEP_STAMP(0);
   const SweepBlock be = table[blockIdx.x];
   const FrameDev &fr = frames[be.r];
   const FrameDev &ft = frames[be.t];
   const PairConst &P = pc[be.r * kMaxFrames + be.t];
-  const int i = be.offset + threadIdx.x;
+  const int k = threadIdx.x & 7;                  // pattern pixel of this lane
+  const int i = be.offset + (threadIdx.x >> 3);   // landmark
+  // pattern offsets (x_i, y_i) — src/common/pattern/include/common/pattern/pattern.hpp:21-32, +2 packed in nibbles
+  const int ox = static_cast<int>((0x21420312u >> (4 * k)) & 0xFu) - 2;
+  const int oy = static_cast<int>((0x01222334u >> (4 * k)) & 0xFu) - 2;
 
   double acc[kPartial];
 #pragma unroll
-  for (int k = 0; k < kPartial; ++k) acc[k] = 0;
+  for (int e = 0; e < kPartial; ++e) acc[e] = 0;
 
   bool active = i < fr.n_res[be.t];
   uint8_t flg = 0;
@@ -244,178 +303,178 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     flg = fr.flags[i];
     active = !((flg & kFlagMarginalized) && !(flg & kFlagToMarginalize));  // evaluate_jacobians.hpp:83-85
   }
+  const bool accumulate = active && (prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0);
+
+  // ---- per-item words (identical addresses within the 8 lanes of an item: one request)
+  S u = S(0), v = S(0);
+  double idepth_d = 0, idepth_step_d = 0;
+  uint8_t status = DSOPP_HIP_STATUS_OOB, cand = DSOPP_HIP_STATUS_OOB;
+  bool fej_ok = true;
+  S patch_k = S(0);
   if (active) {
-    const bool accumulate = prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
-    const S u = static_cast<S>(fr.uv[2 * i]), v = static_cast<S>(fr.uv[2 * i + 1]);
-    double idepth_step_d = fr.idepth_step[i];
-    if (BACKSUB && !(flg & (kFlagMarginalized | kFlagIllConditioned))) {
-      // calculateIdepths — hessian_block_evaluation.hpp:238-263, recomputed by every target's thread of the landmark
-      // (the h_p rows are L2-resident); the thread of the first connected target stores it
-      double d = 0;
-      for (int tt = 0; tt < prm.F; ++tt) {
+    u = static_cast<S>(fr.uv[2 * i]);
+    v = static_cast<S>(fr.uv[2 * i + 1]);
+    idepth_d = fr.idepth[i];
+    idepth_step_d = fr.idepth_step[i];
+    status = fr.status[be.t][i];
+    cand = fr.cand[be.t][i];
+    patch_k = static_cast<S>(fr.patch[kPat * i + k]);
+    if (FEJ && prm.use_fej_flag) fej_ok = fr.fej_valid[be.t][i] != 0;  // evaluate_jacobians.hpp:94
+  }
+  if (BACKSUB) {
+    // calculateIdepths — hessian_block_evaluation.hpp:238-263: lane k of the item takes the frame blocks k, k+8, ... of
+    // h_p^T step; the 8 partial dot products are summed across the item's lanes
+    double d = 0;
+    const bool upd = active && !(flg & (kFlagMarginalized | kFlagIllConditioned));
+    if (upd) {
+      for (int tt = k; tt < prm.F; tt += kPat) {
         if (tt != be.r && fr.status[tt] == nullptr) continue;
         const double *src = fr.ublk + (static_cast<size_t>(tt) * fr.cap + i) * kUblk;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) d += src[c] * prm.step[kBlk * tt + c];
       }
+    }
+    d = sum8(d);
+    if (upd) {
       const double lam = prm.lambda_ptr ? *prm.lambda_ptr : prm.lambda;
       idepth_step_d = -((fr.b_d[i] - d) * (1.0 / (1.0 + lam)) * fr.inv_hdd[i]);
-      if (be.t == fr.first_conn) fr.idepth_step[i] = idepth_step_d;
+      if (k == 0 && be.t == fr.first_conn) fr.idepth_step[i] = idepth_step_d;
     }
-    const S idepth = static_cast<S>(fr.idepth[i] + idepth_step_d);
-    const uint8_t status = fr.status[be.t][i];
-    const S Wr = S(fr.width), Hr = S(fr.height), Wt = S(ft.width), Ht = S(ft.height);
+  }
+  SWEEP_STAMP(1);
+  if (prm.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SWEEP_STAMP(2);
+  const S idepth = static_cast<S>(idepth_d + idepth_step_d);
+  const S Wr = S(fr.width), Hr = S(fr.height), Wt = S(ft.width), Ht = S(ft.height);
 
-    bool success = validIdepth(idepth) && insideROI(u - S(2), v - S(2), Wr, Hr) && insideROI(u + S(2), v + S(2), Wr, Hr);
-    S tu[kPat], tv[kPat];
-    if (!LIN || FEJ) {
-      // reproject without Jacobians — camera_reproject.hpp:270-293
-      const S M0 = S(P.M[0]), M1 = S(P.M[1]), M4 = S(P.M[4]), M5 = S(P.M[5]), M8 = S(P.M[8]), M9 = S(P.M[9]);
-      const S cx = S(P.M[2]) + S(P.M[3]) * idepth, cy = S(P.M[6]) + S(P.M[7]) * idepth, cz = S(P.M[10]) + S(P.M[11]) * idepth;
-#pragma unroll
-      for (int k = 0; k < kPat; ++k) {
-        const S pu = u + S(kPatX[k]), pv = v + S(kPatY[k]);
-        const S x = M0 * pu + M1 * pv + cx, y = M4 * pu + M5 * pv + cy, z = M8 * pu + M9 * pv + cz;
-        tu[k] = x / z;
-        tv[k] = y / z;
-        success = success && (z > S(0));
-      }
-    } else {
-      // non-FEJ linearisation: positions come from the Jacobian path — camera_reproject.hpp:323-333
-      const S U0 = S(P.U[0]), U1 = S(P.U[1]), U4 = S(P.U[4]), U5 = S(P.U[5]), U8 = S(P.U[8]), U9 = S(P.U[9]);
-      const S cX = S(P.U[2]) + S(P.U[3]) * idepth, cY = S(P.U[6]) + S(P.U[7]) * idepth, cZ = S(P.U[10]) + S(P.U[11]) * idepth;
-#pragma unroll
-      for (int k = 0; k < kPat; ++k) {
-        const S pu = u + S(kPatX[k]), pv = v + S(kPatY[k]);
-        const S X = U0 * pu + U1 * pv + cX, Y = U4 * pu + U5 * pv + cY, Z = U8 * pu + U9 * pv + cZ;
-        tu[k] = (S(P.fxt) * X + S(P.cxt) * Z) / Z;
-        tv[k] = (S(P.fyt) * Y + S(P.cyt) * Z) / Z;
-        success = success && (Z > S(0));
-      }
+  // ---- reprojection of this lane's pattern pixel
+  const S pu = u + S(ox), pv = v + S(oy);
+  S tu, tv;
+  bool ok = active && validIdepth(idepth) && insideROI(pu, pv, Wr, Hr);
+  if (!LIN || FEJ) {
+    // reproject without Jacobians — camera_reproject.hpp:270-293
+    const S x = S(P.M[0]) * pu + S(P.M[1]) * pv + (S(P.M[2]) + S(P.M[3]) * idepth);
+    const S y = S(P.M[4]) * pu + S(P.M[5]) * pv + (S(P.M[6]) + S(P.M[7]) * idepth);
+    const S z = S(P.M[8]) * pu + S(P.M[9]) * pv + (S(P.M[10]) + S(P.M[11]) * idepth);
+    tu = x / z;
+    tv = y / z;
+    ok = ok && (z > S(0));
+  } else {
+    // non-FEJ linearisation: positions come from the Jacobian path — camera_reproject.hpp:323-333
+    const S X = S(P.U[0]) * pu + S(P.U[1]) * pv + (S(P.U[2]) + S(P.U[3]) * idepth);
+    const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idepth);
+    const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idepth);
+    tu = (S(P.fxt) * X + S(P.cxt) * Z) / Z;
+    tv = (S(P.fyt) * Y + S(P.cyt) * Z) / Z;
+    ok = ok && (Z > S(0));
+  }
+  ok = ok && insideROI(tu, tv, Wt, Ht);
+
+  // ---- bilinear gather of the stored (I, Ix, Iy) triplet + mask lookup at the rounded position
+  // (pixel_map.hpp:20-40, camera_mask.hpp:64-66); a lane only touches the image when its own pixel is inside the ROI
+  S sI = S(0), sIx = S(0), sIy = S(0);
+  if (ok) {
+    const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(ft.texels);
+    const int W = ft.width;
+    const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
+    const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy);
+    const S dxdy = dx * dy;
+    const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
+    const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+    const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
+    const Texel<S> t00 = p[0], t10 = p[1], t01 = p[W], t11 = p[W + 1];
+    const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
+    ok = (m != S(0));
+    sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
+    if (LIN) {
+      sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
+      sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
     }
-#pragma unroll
-    for (int k = 0; k < kPat; ++k) success = success && insideROI(tu[k], tv[k], Wt, Ht);
-    if (FEJ && prm.use_fej_flag) success = success && (fr.fej_valid[be.t][i] != 0);  // evaluate_jacobians.hpp:94
+  }
+  SWEEP_STAMP(3);
+  // success of the item = all 8 pixels fine (and the FEJ validity bit)
+  const unsigned long long okmask = __ballot(ok);
+  const int shift = (threadIdx.x & 63) & ~7;
+  const bool success = active && fej_ok && (((okmask >> shift) & 0xFFull) == 0xFFull);
 
-    // bilinear gather of the stored (I, Ix, Iy) triplets + mask lookup at the rounded position
-    // (pixel_map.hpp:20-40, camera_mask.hpp:64-66).  Only issued for geometrically valid patterns: the ROI test
-    // guarantees the 2x2 footprints are inside the image.
-    S sI[kPat], sIx[kPat], sIy[kPat];
-    if (success) {
-      const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(ft.texels);
-      const int W = ft.width;
-      bool mask_ok = true;
-#pragma unroll
-      for (int k = 0; k < kPat; ++k) {
-        const int ix = static_cast<int>(tu[k]), iy = static_cast<int>(tv[k]);
-        const S dx = tu[k] - static_cast<S>(ix), dy = tv[k] - static_cast<S>(iy);
-        const S dxdy = dx * dy;
-        const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
-        const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
-        const int rx = static_cast<int>(floor(tu[k] + S(0.5))) - ix, ry = static_cast<int>(floor(tv[k] + S(0.5))) - iy;
-        const S m = ry ? (rx ? p[W + 1].mask : p[W].mask) : (rx ? p[1].mask : p[0].mask);
-        mask_ok = mask_ok && (m != S(0));
-        sI[k] = w11 * p[W + 1].I + w01 * p[W].I + w10 * p[1].I + w00 * p[0].I;
-        if (LIN) {
-          sIx[k] = w11 * p[W + 1].Ix + w01 * p[W].Ix + w10 * p[1].Ix + w00 * p[0].Ix;
-          sIy[k] = w11 * p[W + 1].Iy + w01 * p[W].Iy + w10 * p[1].Iy + w00 * p[0].Iy;
-        }
-      }
-      success = success && mask_ok;
+  if (active && !success) cand = DSOPP_HIP_STATUS_OOB;  // evaluate_jacobians.hpp:111-113
+  const bool evaluate = success && status == DSOPP_HIP_STATUS_OK;
+  if (evaluate) cand = DSOPP_HIP_STATUS_OK;
+
+  // ---- residual, Huber on the norm of the 8-vector — evaluate_jacobians.hpp:124-146
+  const S res = evaluate ? (sI - S(P.b_t)) - S(P.s) * (patch_k - S(P.b_r)) : S(0);
+  const double r2 = sum8(static_cast<double>(res * res));
+  double wgt = 1.0, energy = 0.5 * r2;
+  if (HUBER) {
+    const double sig = prm.sigma_huber;
+    if (r2 > sig * sig) {
+      const double nrm = sqrt(r2);
+      wgt = sig / nrm;
+      energy = sig * nrm - 0.5 * sig * sig;
     }
+  }
+  if (!evaluate) energy = 0;
 
-    uint8_t cand = fr.cand[be.t][i];
-    if (!success) cand = DSOPP_HIP_STATUS_OOB;  // evaluate_jacobians.hpp:111-113
-    double energy = 0;
-    double uvec[kBlk];
-    double hdd = 0, bd = 0;
+  if (LIN) {
+    double gj[kBlk + 2];  // w * g (8), then hdd, bd contributions
 #pragma unroll
-    for (int a = 0; a < kBlk; ++a) uvec[a] = 0;
-
-    if (success && status == DSOPP_HIP_STATUS_OK) {
-      cand = DSOPP_HIP_STATUS_OK;
-      const S s = S(P.s), b_t = S(P.b_t), b_r = S(P.b_r);
-      S res[kPat];
-      S patch[kPat];
-      double r2 = 0;
+    for (int a = 0; a < kBlk + 2; ++a) gj[a] = 0;
+    if (evaluate) {
+      // geometric Jacobians at the linearisation point (FEJ: idepth snapshot) — camera_reproject.hpp:339-365
+      const S idj = FEJ ? static_cast<S>(fr.idepth_fej[i]) : idepth;
+      const S X = S(P.U[0]) * pu + S(P.U[1]) * pv + (S(P.U[2]) + S(P.U[3]) * idj);
+      const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idj);
+      const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idj);
+      const S fxt = S(P.fxt), fyt = S(P.fyt);
+      const S rho = S(1) / Z;
+      const S b0 = X * rho, b1 = Y * rho;
+      const S du_id = fxt * (S(P.tl[0]) * rho - S(P.tl[2]) * (rho * b0));
+      const S dv_id = fyt * (S(P.tl[1]) * rho - S(P.tl[2]) * (rho * b1));
+      const S nid = idj * rho;
+      const S Iu = sIx, Iv = sIy;
+      // g = [ Iv * d_v_T + Iu * d_u_T (6) , c , 1 ] — evaluate_jacobians.hpp:149-157,176-182
+      S g[kBlk];
+      const S b0b1 = b0 * b1;
+      g[0] = Iu * (fxt * nid);
+      g[1] = Iv * (fyt * nid);
+      g[2] = Iv * (fyt * (-nid * b1)) + Iu * (fxt * (-nid * b0));
+      g[3] = Iv * (fyt * (-(b1 * b1 + S(1)))) + Iu * (fxt * (-b0b1));
+      g[4] = Iv * (fyt * b0b1) + Iu * (fxt * (b0 * b0 + S(1)));
+      g[5] = Iv * (fyt * b0) + Iu * (fxt * (-b1));
+      g[6] = S(P.sigma_r) * (patch_k - S(P.b_r0));
+      g[7] = S(1);
+      const double jdd = static_cast<double>(Iu * du_id + Iv * dv_id);  // evaluate_jacobians.hpp:165-174
+      const double rk = static_cast<double>(res);
+      int e = 0;
 #pragma unroll
-      for (int k = 0; k < kPat; ++k) {
-        patch[k] = static_cast<S>(fr.patch[kPat * i + k]);
-        res[k] = (sI[k] - b_t) - s * (patch[k] - b_r);  // evaluate_jacobians.hpp:124-135
-        r2 += static_cast<double>(res[k] * res[k]);
-      }
-      // Huber on the norm of the 8-vector — evaluate_jacobians.hpp:136-146
-      double wgt = 1.0;
-      energy = 0.5 * r2;
-      if (HUBER) {
-        const double sig = prm.sigma_huber;
-        if (r2 > sig * sig) {
-          const double nrm = sqrt(r2);
-          wgt = sig / nrm;
-          energy = sig * nrm - 0.5 * sig * sig;
-        }
-      }
-      if (LIN) {
-        // geometric Jacobians at the linearisation point (FEJ: idepth snapshot) — camera_reproject.hpp:339-365
-        const S idj = FEJ ? static_cast<S>(fr.idepth_fej[i]) : idepth;
-        const S U0 = S(P.U[0]), U1 = S(P.U[1]), U4 = S(P.U[4]), U5 = S(P.U[5]), U8 = S(P.U[8]), U9 = S(P.U[9]);
-        const S cX = S(P.U[2]) + S(P.U[3]) * idj, cY = S(P.U[6]) + S(P.U[7]) * idj, cZ = S(P.U[10]) + S(P.U[11]) * idj;
-        const S fxt = S(P.fxt), fyt = S(P.fyt), t0 = S(P.tl[0]), t1 = S(P.tl[1]), t2 = S(P.tl[2]);
-        const S csc = S(P.sigma_r), b_r0 = S(P.b_r0);
-        double G[36];
-#pragma unroll
-        for (int e = 0; e < 36; ++e) G[e] = 0;
-        double q[kBlk];
-#pragma unroll
-        for (int a = 0; a < kBlk; ++a) q[a] = 0;
-#pragma unroll
-        for (int k = 0; k < kPat; ++k) {
-          const S pu = u + S(kPatX[k]), pv = v + S(kPatY[k]);
-          const S X = U0 * pu + U1 * pv + cX, Y = U4 * pu + U5 * pv + cY, Z = U8 * pu + U9 * pv + cZ;
-          const S rho = S(1) / Z;
-          const S b0 = X * rho, b1 = Y * rho;
-          const S du_id = fxt * (t0 * rho - t2 * (rho * b0));
-          const S dv_id = fyt * (t1 * rho - t2 * (rho * b1));
-          const S nid = idj * rho;
-          const S Iu = sIx[k], Iv = sIy[k];
-          // g = [ Iv * d_v_T + Iu * d_u_T (6) , c , 1 ] — evaluate_jacobians.hpp:149-157,176-182
-          S g[kBlk];
-          const S b0b1 = b0 * b1;
-          g[0] = Iu * (fxt * nid);
-          g[1] = Iv * (fyt * nid);
-          g[2] = Iv * (fyt * (-nid * b1)) + Iu * (fxt * (-nid * b0));
-          g[3] = Iv * (fyt * (-(b1 * b1 + S(1)))) + Iu * (fxt * (-b0b1));
-          g[4] = Iv * (fyt * b0b1) + Iu * (fxt * (b0 * b0 + S(1)));
-          g[5] = Iv * (fyt * b0) + Iu * (fxt * (-b1));
-          g[6] = csc * (patch[k] - b_r0);
-          g[7] = S(1);
-          const S jd = Iu * du_id + Iv * dv_id;  // evaluate_jacobians.hpp:165-174
-          const double rk = static_cast<double>(res[k]), jdd = static_cast<double>(jd);
-          int e = 0;
-#pragma unroll
-          for (int a = 0; a < kBlk; ++a) {
-            const double ga = static_cast<double>(g[a]);
-#pragma unroll
-            for (int b = a; b < kBlk; ++b) G[e++] += ga * static_cast<double>(g[b]);
-            q[a] += ga * rk;
-            uvec[a] += ga * jdd;
-          }
-          hdd += jdd * jdd;
-          bd += jdd * rk;
-        }
-#pragma unroll
-        for (int a = 0; a < kBlk; ++a) uvec[a] *= wgt;
-        hdd *= wgt;
-        bd *= wgt;
+      for (int a = 0; a < kBlk; ++a) {
+        const double wga = wgt * static_cast<double>(g[a]);
         if (accumulate) {
 #pragma unroll
-          for (int e = 0; e < 36; ++e) acc[e] = wgt * G[e];
-#pragma unroll
-          for (int a = 0; a < kBlk; ++a) acc[36 + a] = wgt * q[a];
+          for (int b = a; b < kBlk; ++b) acc[e + (b - a)] = wga * static_cast<double>(g[b]);
+          acc[36 + a] = wga * rk;
         }
+        e += kBlk - a;
+        gj[a] = wga * jdd;
       }
+      gj[8] = wgt * jdd * jdd;
+      gj[9] = wgt * jdd * rk;
     }
-    // NEW_EVALUATION_POINT bookkeeping
+    // per-item Schur quantities: sum over the 8 pixels; h_p block of target t is w * J_t^T J_d = -u
+    // (hessian_block_evaluation.hpp:207-208), zero for invalid residuals (:190-192)
+#pragma unroll
+    for (int a = 0; a < kBlk + 2; ++a) gj[a] = sum8(gj[a]);
+    if (active) {
+      double mine = gj[0];
+#pragma unroll
+      for (int a = 1; a < kBlk; ++a) mine = (k == a) ? gj[a] : mine;
+      double *dst = fr.ublk + (static_cast<size_t>(be.t) * fr.cap + i) * kUblk;
+      dst[k] = -mine;
+      if (k < 2) dst[8 + k] = k == 0 ? gj[8] : gj[9];
+    }
+  }
+  // NEW_EVALUATION_POINT bookkeeping (lane 0 of the item)
+  if (active && k == 0) {
     fr.energy[be.t][i] = energy;
     fr.cand[be.t][i] = cand;
     if (accumulate) {
@@ -424,26 +483,23 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
     if (!LIN && be.t == fr.first_conn) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
-      const double id = fr.idepth[i];
       acc[46] = idepth_step_d * idepth_step_d;
-      acc[47] = id * idepth_step_d;
-    }
-    if (LIN) {
-      // h_p block of target t is w * J_t^T J_d = -u (hessian_block_evaluation.hpp:207-208); zero for invalid residuals (:190-192)
-      double *dst = fr.ublk + (static_cast<size_t>(be.t) * fr.cap + i) * kUblk;
-#pragma unroll
-      for (int a = 0; a < kBlk; ++a) dst[a] = -uvec[a];
-      dst[8] = hdd;
-      dst[9] = bd;
+      acc[47] = idepth_d * idepth_step_d;
     }
   }
-  blockSum<kPartial, kSweepThreads>(acc, red_lds);
-  if (threadIdx.x == 0) {
-    double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
-#pragma unroll
-    for (int k = 0; k < kPartial; ++k) out[k] = acc[k];
+  SWEEP_STAMP(4);
+  double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
+  if (LIN) {
+    blockReduceStore<0, kPartial>(acc, red_lds, out);
+  } else {
+    blockReduceStore<44, 4>(acc, red_lds, out);
+  }
+  SWEEP_STAMP(5);
+  SWEEP_STAMP(6);
+  if (prm.dbg && threadIdx.x == 0) {
+    atomicMin(reinterpret_cast<unsigned long long *>(prm.dbg + 8), static_cast<unsigned long long>(wall_clock64()));
+    atomicMax(reinterpret_cast<unsigned long long *>(prm.dbg + 9), static_cast<unsigned long long>(wall_clock64()));
   }
 }
-
 
 }  // namespace dsopp_hip

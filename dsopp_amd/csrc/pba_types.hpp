@@ -12,7 +12,7 @@ constexpr int kBlk = DSOPP_HIP_BLOCK_SIZE;  // 8 = 6 pose + 2 affine
 constexpr int kPat = DSOPP_HIP_PATTERN_SIZE;
 constexpr int kUblk = 10;                   // per (landmark, slot): u[8], hdd, bd
 constexpr int kPartial = 48;                // per sweep block: G (36 upper) + q (8) + energy + n_valid + pad
-constexpr int kSweepThreads = 128;
+constexpr int kSweepThreads = 128;        // 16 (landmark, target) items x 8 pattern pixels
 
 // landmark flag bits (LocalFrame::Landmark booleans, PBA_INT/local_frame.hpp:276-293)
 constexpr uint8_t kFlagMarginalized = 1, kFlagOutlier = 2, kFlagToMarginalize = 4, kFlagIllConditioned = 8;

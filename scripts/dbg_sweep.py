@@ -1,0 +1,14 @@
+import sys, ctypes as C, numpy as np
+sys.path.insert(0,'.')
+from dsopp_amd import capi, synthetic as syn
+win = syn.make_window(7, 2000, 640, 480, seed=0)
+g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
+out = (C.c_longlong*16)()
+g.snapshot()
+for lin in (1, 0):
+    for rep in range(2):
+        capi.lib().dsopp_hip_debug_sweep_stamps(g._h, lin, out)
+        g.restore(); g.set_max_iterations(1); g.optimize()
+        capi.lib().dsopp_hip_debug_sweep_stamps(g._h, lin, out)
+        st = np.array(list(out), dtype=np.int64)
+        print("lin" if lin else "energy", "phase us:", np.diff(st[:7]) / 100.0, "block total", (st[6]-st[0])/100.0, "kernel span", (st[9]-st[8])/100.0, "mid block start offset", (st[0]-st[8])/100.0)
