@@ -31,6 +31,7 @@ __device__ inline void buildProjectionMatrices(const Rigid &T, const FrameDev &f
   // ArrayReprojector ctor — camera_reproject.hpp:235-260
   const double ifx = 1.0 / fr.fx, ify = 1.0 / fr.fy;
   const double k02 = -fr.cx / fr.fx, k12 = -fr.cy / fr.fy;
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     U[4 * i + 0] = T.R[3 * i + 0] * ifx;
     U[4 * i + 1] = T.R[3 * i + 1] * ify;
@@ -38,6 +39,7 @@ __device__ inline void buildProjectionMatrices(const Rigid &T, const FrameDev &f
     U[4 * i + 3] = T.t[i];
   }
   if (M) {
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       M[0 + j] = ft.fx * U[0 + j] + ft.cx * U[8 + j];
       M[4 + j] = ft.fy * U[4 + j] + ft.cy * U[8 + j];
@@ -77,6 +79,12 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
     Tt0.t[i] = st->T0_t[t][i];
   }
   const Rigid T_tr0 = rigidMul(rigidInverse(Tt0), Tr0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P.T0rel[4 * i + j] = T_tr0.R[3 * i + j];
+    P.T0rel[4 * i + 3] = T_tr0.t[i];
+  }
   const Rigid T_tr = rigidMul(Emt ? *Emt : frameIncrement(st, t, -1.0), rigidMul(T_tr0, Er ? *Er : frameIncrement(st, r, 1.0)));
   const double a_r = st->ab0[r][0] + st->eps[r][6] + st->step[r][6];
   const double b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
@@ -107,6 +115,30 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
     P.b_r0 = b_r;
     P.sigma_r = P.s;
   }
+}
+
+/** FEJ fast path of the solve kernel: only the state-dependent members (M, s, b_t, b_r) move with eps + step */
+__device__ inline void refreshPairCurrent(const FrameDev *frames, const WindowState *st, PairConst *pc, int r, int t, const Rigid &Er,
+                                          const Rigid &Emt) {
+  PairConst &P = pc[r * kMaxFrames + t];
+  if (!P.valid) return;
+  Rigid T0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T0.R[3 * i + j] = P.T0rel[4 * i + j];
+    T0.t[i] = P.T0rel[4 * i + 3];
+  }
+  const Rigid T_tr = rigidMul(Emt, rigidMul(T0, Er));
+  const FrameDev &fr = frames[r];
+  const FrameDev &ft = frames[t];
+  double U[12];
+  buildProjectionMatrices(T_tr, fr, ft, U, P.M);
+  const double a_r = st->ab0[r][0] + st->eps[r][6] + st->step[r][6];
+  const double a_t = st->ab0[t][0] + st->eps[t][6] + st->step[t][6];
+  P.s = (ft.exposure / fr.exposure) * exp(a_t - a_r);
+  P.b_t = st->ab0[t][1] + st->eps[t][7] + st->step[t][7];
+  P.b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
 }
 
 __global__ void pairSetupKernel(const FrameDev *frames, const WindowState *st, PairConst *pc, int F, int fej) {

@@ -359,7 +359,7 @@ __host__ __device__ constexpr int lowIdx(int i, int j) { return i * (i + 1) / 2 
  * registers so a block step costs two barriers) — one workgroup.  Also rebuilds the pair constants and the prior energy
  * for the candidate state eps + step, so the energy sweep can follow immediately.
  */
-__global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a) {
+__global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (a.ctrl && !a.ctrl->active) return;
   const int F = a.F, K = kBlk * F;
@@ -377,47 +377,55 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a
   // ---- system_pose = sums + priors (problem.hpp:39-62)
   for (int c = tid; c < K; c += kSolveThreads) xs[c] = a.st->eps[c >> 3][c & 7];
   // per-frame prior diagonal (problem.hpp:39-62) in LDS, so the element loop has no dependent frame-table loads
-  double *prior_diag = xs + K;  // first 8 of the 16 spare + Linv area not yet in use: use Linv as scratch
-  prior_diag = Linv;
+  double *prior_diag = Linv;  // the Linv area is not in use yet
   for (int c = tid; c < K; c += kSolveThreads) {
     const int f = c >> 3, i = c & 7;
     double pd = 0;
     if (a.add_priors && !a.frames[f].to_marginalize) pd = a.frames[f].fixed ? a.fixed_reg : (i >= 6 ? a.affine_reg[i - 6] : 0.0);
     prior_diag[c] = pd;
   }
-  __syncthreads();
   {
-    // 16 x 16 thread tile walking the lower triangle: row = tr + 16*m, col = tc + 16*n; loads of a tile are independent
+    // 16 x 16 thread tiles over the lower triangle (diagonal tiles included); the loads of up to 8 tiles are issued
+    // back to back so the phase costs ~one memory round trip per 8 tiles instead of one per tile
     const int tr = tid >> 4, tc = tid & 15;
-    for (int r0 = 0; r0 < K; r0 += 16) {
-      const int row = r0 + tr;
-      for (int c0 = 0; c0 <= r0; c0 += 32) {
-        double hp[2], hs[2], hm[2];
+    const int nt = (K + 15) >> 4, n_tiles = nt * (nt + 1) / 2;
+    constexpr int kTileBatch = 12;
+    for (int base = 0; base < n_tiles; base += kTileBatch) {
+      double hp[kTileBatch], hs[kTileBatch], hm[kTileBatch];
+      int rows[kTileBatch], cols[kTileBatch];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int col = c0 + 16 * u + tc;
-          const bool in = row < K && col < K && (c0 + 16 * u) <= r0;
-          hp[u] = in ? a.Hpp_raw[row * K + col] : 0.0;
-          hs[u] = in ? (col <= row ? a.Hsc[col * K + row] : a.Hsc[row * K + col]) : 0.0;
-          hm[u] = (in && a.use_marginal) ? a.Hm[row * K + col] : 0.0;
+      for (int u = 0; u < kTileBatch; ++u) {
+        int tile = base + u, tr0 = 0;
+        while (tile >= tr0 + 1) {  // tile row tr0 holds tr0 + 1 tiles
+          tile -= tr0 + 1;
+          ++tr0;
         }
+        const int row = 16 * tr0 + tr, col = 16 * tile + tc;
+        const bool in = (base + u) < n_tiles && row < K && col < K;
+        rows[u] = in ? row : -1;
+        cols[u] = col;
+        // unconditional loads from clamped addresses (a select around a load makes hipcc branch and drain vmcnt per element)
+        const int rc = min(row, K - 1), cc = min(col, K - 1);
+        hp[u] = a.Hpp_raw[rc * K + cc];
+        hs[u] = a.Hsc[min(rc, cc) * K + max(rc, cc)];
+        hm[u] = a.Hm[rc * K + cc];
+      }
+      __syncthreads();  // prior_diag visible (first batch); harmless afterwards
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int col = c0 + 16 * u + tc;
-          const bool in = row < K && col < K && (c0 + 16 * u) <= r0;
-          if (!in) continue;
-          double v = hp[u];
-          if (row == col) v += prior_diag[row];
-          if (a.store_system) {
-            a.Hpp_out[row * K + col] = v;
-            a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
-            if (col < row) a.Hsc[row * K + col] = hs[u];
-          }
-          if (col <= row) {
-            // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)
-            if (row == col) v += v * lam;
-            A[row * ld + col] = v + sc * hs[u] + hm[u];
-          }
+      for (int u = 0; u < kTileBatch; ++u) {
+        const int row = rows[u], col = cols[u];
+        if (row < 0) continue;
+        double v = hp[u];
+        if (row == col) v += prior_diag[row];
+        if (a.store_system) {
+          a.Hpp_out[row * K + col] = v;
+          a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
+          if (col < row) a.Hsc[row * K + col] = hs[u];
+        }
+        if (col <= row) {
+          // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)
+          if (row == col) v += v * lam;
+          A[row * ld + col] = v + sc * hs[u] + (a.use_marginal ? hm[u] : 0.0);
         }
       }
     }
@@ -540,36 +548,41 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a
     }
     __syncthreads();
   }
-  // ---- back substitution x = L^-T y, blocked (y = row K of L); x_k = Linv_kk^T (y_k - sum_{j>k} L_jk^T x_j)
+  // ---- back substitution x = L^-T y, blocked (y = row K of L); x_k = Linv_kk^T (y_k - sum_{j>k} L_jk^T x_j).
+  // One wave, rows spread over its lanes: no workgroup barriers on this strictly sequential chain.
   DSOPP_STAMP(3);
   for (int c = tid; c < K; c += kSolveThreads) xs[c] = A[K * ld + c];
   __syncthreads();
-  for (int kb = F - 1; kb >= 0; --kb) {
-    const int k0 = kb * kBlk;
-    double xk[kBlk];
+  if (tid < 64) {
+    for (int kb = F - 1; kb >= 0; --kb) {
+      const int k0 = kb * kBlk;
+      double xk[kBlk];
 #pragma unroll
-    for (int c = 0; c < kBlk; ++c) {
-      double s = 0;
+      for (int c = 0; c < kBlk; ++c) {
+        double s = 0;
 #pragma unroll
-      for (int k = c; k < kBlk; ++k) s += Linv[kb * 36 + lowIdx(k, c)] * xs[k0 + k];
-      xk[c] = s;
+        for (int k = c; k < kBlk; ++k) s += Linv[kb * 36 + lowIdx(k, c)] * xs[k0 + k];
+        xk[c] = s;
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (tid < kBlk) {
+        double mine = xk[0];
+#pragma unroll
+        for (int c = 1; c < kBlk; ++c) mine = (tid == c) ? xk[c] : mine;
+        xs[k0 + tid] = mine;
+      }
+      for (int rr = tid; rr < k0; rr += 64) {
+        double s = 0;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + rr] * xk[c];
+        xs[rr] -= s;
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    if (tid < kBlk) {
-      double mine = xk[0];
-#pragma unroll
-      for (int c = 1; c < kBlk; ++c) mine = (tid == c) ? xk[c] : mine;
-      xs[k0 + tid] = mine;
-    }
-    for (int row = kBlk + tid; row < kBlk + k0; row += kSolveThreads) {
-      const int rr = row - kBlk;
-      double s = 0;
-#pragma unroll
-      for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + rr] * xk[c];
-      xs[rr] -= s;
-    }
-    __syncthreads();
   }
+  __syncthreads();
   for (int c = tid; c < K; c += kSolveThreads) {
     const double x = pv[c] * xs[c];
     a.step[c] = x;
@@ -581,7 +594,12 @@ __global__ void __launch_bounds__(kSolveThreads) assembleSolveKernel(SolveArgs a
     Rigid *E = reinterpret_cast<Rigid *>(A);  // [2][F]: exp(+xi_f), exp(-xi_f); A is free now
     if (tid < 2 * F) E[tid] = frameIncrement(a.st, tid % F, tid < F ? 1.0 : -1.0);
     __syncthreads();
-    if (tid < F * F) computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, a.fej != 0, &E[tid / F], &E[F + tid % F]);
+    if (tid < F * F) {
+      if (a.fej)
+        refreshPairCurrent(a.frames, a.st, a.pc, tid / F, tid % F, E[tid / F], E[F + tid % F]);
+      else
+        computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, false, &E[tid / F], &E[F + tid % F]);
+    }
   }
   __syncthreads();
   DSOPP_STAMP(5);

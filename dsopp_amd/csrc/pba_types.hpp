@@ -67,6 +67,7 @@ struct PairConst {
   double b_r0;     // reference offset at the linearisation point (== b_r when not FEJ)
   int valid;       // connection exists
   int pad;
+  double T0rel[12];  // T_tr0 = inv(T_t0) * T_r0 as [R | t] rows (3 x 4): lets the solve kernel refresh M without the frame table
 };
 
 /** one thread block of a sweep = a chunk of landmarks of one ordered pair */

@@ -104,18 +104,22 @@ DSOPP_HD Rigid rigidExp(const double *xi) {
   const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
   const double W2[9] = {wx * wx - th2, wx * wy, wx * wz, wx * wy, wy * wy - th2, wy * wz, wx * wz, wy * wz, wz * wz - th2};
   double V[9];
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
     const double id = (i % 4 == 0) ? 1.0 : 0.0;
     T.R[i] = id + A * W[i] + B * W2[i];
     V[i] = id + B * W[i] + Cc * W2[i];
   }
+#pragma unroll
   for (int i = 0; i < 3; ++i) T.t[i] = V[3 * i] * xi[0] + V[3 * i + 1] * xi[1] + V[3 * i + 2] * xi[2];
   return T;
 }
 
 DSOPP_HD Rigid rigidMul(const Rigid &a, const Rigid &b) {
   Rigid c;
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j] + a.R[3 * i + 2] * b.R[6 + j];
     c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
   }
