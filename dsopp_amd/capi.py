@@ -362,3 +362,55 @@ class HipWindow:
         cov = np.zeros((6, 6))
         _chk(lib().dsopp_hip_window_get_covariance(self._h, int(ref_id), int(tgt_id), _p(cov)))
         return cov
+
+
+class HipAligner:
+    """Two-frame direct image alignment of one pyramid level (dsopp_hip_aligner)."""
+
+    def __init__(self, options: Options | None = None, device=0, stream=None):
+        self.options = options or default_align_options()
+        self._h = C.c_void_p()
+        _chk(lib().dsopp_hip_aligner_create(C.byref(self.options), int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_aligner_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _chk(lib().dsopp_hip_aligner_reset(self._h))
+
+    def push_reference_depth_map(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, idepth_sum, weight, exposure, affine):
+        _chk(lib().dsopp_hip_aligner_push_reference_depth_map(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),
+                                                              _p(_f64(intrinsics)), _p(_f64(idepth_sum)), _p(_f64(weight)), C.c_double(exposure),
+                                                              _p(_f64(affine))))
+
+    def push_reference_points(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, u, v, idepth, exposure, affine):
+        _chk(lib().dsopp_hip_aligner_push_reference_points(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),
+                                                           _p(_f64(intrinsics)), len(u), _p(_f64(u)), _p(_f64(v)), _p(_f64(idepth)),
+                                                           C.c_double(exposure), _p(_f64(affine))))
+
+    def push_target(self, timestamp, T_w_agent_init, pyramid: Pyramid, level, intrinsics, exposure, affine):
+        _chk(lib().dsopp_hip_aligner_push_target(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent_init)), pyramid._h, int(level),
+                                                 _p(_f64(intrinsics)), C.c_double(exposure), _p(_f64(affine))))
+
+    def push_known_pose(self, timestamp, T_w_agent):
+        _chk(lib().dsopp_hip_aligner_push_known_pose(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent))))
+
+    def num_points(self) -> int:
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_aligner_num_points(self._h, C.byref(n)))
+        return n.value
+
+    def solve(self):
+        out = AlignResult()
+        _chk(lib().dsopp_hip_aligner_solve(self._h, C.byref(out)))
+        return dict(rmse=out.rmse, energy=out.energy, n_valid=out.n_valid, iterations=out.iterations,
+                    T_w_target=np.array(out.T_world_target), affine_brightness=np.array(out.affine_brightness),
+                    covariance=np.array(out.covariance).reshape(6, 6), H=np.array(out.H).reshape(8, 8))

@@ -1,0 +1,634 @@
+// dsopp_hip_aligner_*: two-frame direct image alignment of one pyramid level on the GPU
+// (hot loops E, F of SURVEY.md §3.3; replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>,
+// PROB_SRC/eigen_pose_alignment.cpp:26-329).
+//
+// The reference runs this serially: calculateEnergy (reproject + sample every reference point, cache the samples),
+// linearize (8x8 H, b from the cached samples), 8x8 solve, calculateEnergy at the candidate, accept/reject — up to 50 times
+// per level.  With n = 2 000..10 000 points (<= 0.7 MB of traffic) an iteration is pure launch latency on a GPU, so the
+// whole LM iteration is ONE kernel launch here:
+//   * the sweep evaluates energy AND the normal equations at the candidate state in one pass (the reference's linearize
+//     reuses exactly the samples its preceding calculateEnergy cached, so evaluating both at the same state is identical);
+//   * the Levenberg-Marquardt control (compare, accept/reject, lambda update, 8x8 Jacobi-preconditioned solve, next
+//     candidate) runs in the prologue of the next launch, redundantly in every workgroup from the previous launch's
+//     per-workgroup partial sums (deterministic), workgroup 0 publishing the new control block for the launch after;
+//   * the host enqueues launches in small batches and reads the control block back once per batch.
+#include <algorithm>
+#include <map>
+#include <memory>
+
+#include "device_geom.hpp"
+#include "host_linalg.hpp"
+#include "pyramid.hpp"
+#include "se3_math.hpp"
+
+namespace dsopp_hip {
+namespace {
+
+constexpr int kAlignThreads = 256;
+constexpr int kAlignPartial = 48;  // H (36 upper) + b (8) + energy + n_valid + pad
+
+struct AlignFrameDev {
+  const void *texels;
+  int width, height;
+  double fx, fy, cx, cy;
+  double exposure;
+  double ab0[2];
+};
+
+/** LM state of the aligner, double-buffered by launch parity */
+struct AlignControl {
+  double T_tr[12];       // accepted state: [R | t] rows of T_target_reference
+  double ab_eps[2];
+  double cand_T[12];     // candidate evaluated by the launch that reads this block
+  double cand_ab[2];
+  double H[64], b[8];    // system_ of the accepted state (last linearize)
+  double H_used[64];     // system_ used by the most recent calculateStep (== problem.hessian())
+  double step[8];
+  double lambda;
+  double energy;         // result.energy
+  int n_valid;
+  int converged;
+  int active;
+  int iteration;
+  int have_candidate;    // 0: the evaluated state IS the accepted state (first launch)
+  int linear_system_valid;
+  int pad0, pad1;
+};
+
+struct AlignParams {
+  double sigma_huber;
+  double affine_reg[2];
+  double function_tolerance, parameter_tolerance;
+  double decrease_on_accept, increase_on_reject;
+  int max_iterations;
+  int n_points;
+  int n_blocks;
+};
+
+__device__ inline void mat34Compose(const double *A, const double *B, double *C) {
+  // C = A * B for rigid [R|t] 3x4
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[4 * i + j] = A[4 * i] * B[j] + A[4 * i + 1] * B[4 + j] + A[4 * i + 2] * B[8 + j];
+    C[4 * i + 3] = A[4 * i] * B[3] + A[4 * i + 1] * B[7] + A[4 * i + 2] * B[11] + A[4 * i + 3];
+  }
+}
+
+/** 8x8 NormalLinearSystem::solve (Jacobi preconditioner + Cholesky with zero-pivot guard), single thread */
+__device__ inline void solve8(const double *Hin, const double *bin, double *x) {
+  double p[8], A[36], y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = 1.0 / sqrt(Hin[8 * i + i] + 10.0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) A[i * (i + 1) / 2 + j] = p[i] * Hin[8 * i + j] * p[j];
+    y[i] = p[i] * bin[i];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double d = A[k * (k + 1) / 2 + k];
+    const bool ok = d > 1e-300;
+    const double lkk = ok ? sqrt(d) : 0.0, inv = ok ? 1.0 / lkk : 0.0;
+    A[k * (k + 1) / 2 + k] = lkk;
+#pragma unroll
+    for (int i = k + 1; i < 8; ++i) A[i * (i + 1) / 2 + k] *= inv;
+#pragma unroll
+    for (int j = k + 1; j < 8; ++j)
+#pragma unroll
+      for (int i = j; i < 8; ++i) A[i * (i + 1) / 2 + j] -= A[i * (i + 1) / 2 + k] * A[j * (j + 1) / 2 + k];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double s = y[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) s -= A[i * (i + 1) / 2 + j] * y[j];
+    const double l = A[i * (i + 1) / 2 + i];
+    y[i] = l > 0 ? s / l : 0.0;
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    double s = y[i];
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) s -= A[j * (j + 1) / 2 + i] * y[j];
+    const double l = A[i * (i + 1) / 2 + i];
+    y[i] = l > 0 ? s / l : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = p[i] * y[i];
+}
+
+/** sample the reference intensities of the points: PatternPatch::getIntensities with PatternSize 1 (local_frame.hpp:384-388) */
+template <typename S>
+__global__ void sampleReferenceKernel(const Texel<S> *__restrict__ img, int W, const double *__restrict__ u, const double *__restrict__ v,
+                                      double *__restrict__ intensity, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const S x = static_cast<S>(u[i]), y = static_cast<S>(v[i]);
+  const int ix = static_cast<int>(x), iy = static_cast<int>(y);
+  const S dx = x - static_cast<S>(ix), dy = y - static_cast<S>(iy), dxdy = dx * dy;
+  const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
+  intensity[i] = static_cast<double>(dxdy * p[W + 1].I + (dy - dxdy) * p[W].I + (dx - dxdy) * p[1].I + (S(1) - dx - dy + dxdy) * p[0].I);
+}
+
+/**
+ * One LM iteration = one launch: LM control from the previous launch's partial sums (prologue, every workgroup),
+ * then PoseAlignerProblem::calculateEnergy + linearize (eigen_pose_alignment.cpp:55-192) at the new candidate.
+ */
+template <typename S>
+__global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrameDev ref, AlignFrameDev tgt, const double *__restrict__ pu,
+                                                                       const double *__restrict__ pv, const double *__restrict__ pid,
+                                                                       const double *__restrict__ pint, const AlignControl *__restrict__ cin,
+                                                                       AlignControl *__restrict__ cout, const double *__restrict__ prev_partials,
+                                                                       double *__restrict__ partials, AlignParams prm, int launch_index) {
+  __shared__ __attribute__((aligned(16))) double red[kAlignPartial * (kAlignThreads + 2)];
+  __shared__ AlignControl sc;
+  const int tid = threadIdx.x;
+  // ---------------- prologue: LM control ----------------
+  if (launch_index == 0) {
+    if (tid == 0) sc = *cin;  // initial block prepared by the host: candidate == accepted state
+    __syncthreads();
+  } else {
+    if (!cin->active) {
+      if (blockIdx.x == 0 && tid == 0) *cout = *cin;
+      return;
+    }
+    // deterministic sum of the previous launch's partials: thread e < 48 adds column e over all workgroups
+    double tot = 0;
+    if (tid < kAlignPartial)
+      for (int b = 0; b < prm.n_blocks; ++b) tot += prev_partials[static_cast<size_t>(b) * kAlignPartial + tid];
+    if (tid < kAlignPartial) red[tid] = tot;
+    __syncthreads();
+    if (tid == 0) {
+      AlignControl c = *cin;
+      // evaluated state = candidate (or the initial state): energy with the affine prior (eigen_pose_alignment.cpp:101-104)
+      const double tab0 = tgt.ab0[0] + c.cand_ab[0], tab1 = tgt.ab0[1] + c.cand_ab[1];
+      const double e_eval = red[44] + 0.5 * (tab0 * prm.affine_reg[0] * tab0 + tab1 * prm.affine_reg[1] * tab1);
+      const int n_eval = static_cast<int>(red[45] + 0.5);
+      double Hn[64], bn[8];
+      {
+        int e = 0;
+        for (int a = 0; a < 8; ++a)
+          for (int b2 = a; b2 < 8; ++b2) {
+            Hn[8 * a + b2] = Hn[8 * b2 + a] = red[e];
+            ++e;
+          }
+        for (int a = 0; a < 8; ++a) bn[a] = red[36 + a];
+        // affine prior block (eigen_pose_alignment.cpp:183-187)
+        Hn[8 * 6 + 6] += prm.affine_reg[0];
+        Hn[8 * 7 + 7] += prm.affine_reg[1];
+        bn[6] += prm.affine_reg[0] * tab0;
+        bn[7] += prm.affine_reg[1] * tab1;
+      }
+      bool take_system = false;
+      if (!c.have_candidate) {
+        // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
+        c.energy = e_eval;
+        c.n_valid = n_eval;
+        c.active = (prm.max_iterations > 0 && n_eval > 0) ? 1 : 0;
+        take_system = true;
+      } else {
+        c.iteration += 1;
+        if (n_eval == 0) {
+          c.active = 0;  // rejectStep(); break;
+        } else {
+          if (fabs(c.energy - e_eval) / c.energy < prm.function_tolerance) c.converged = 1;
+          if (e_eval < c.energy) {
+            // acceptStep (eigen_pose_alignment.cpp:208-212)
+            const double a0 = tgt.ab0[0] + c.ab_eps[0], a1 = tgt.ab0[1] + c.ab_eps[1];
+            double step_sq = 0;
+            for (int a = 0; a < 8; ++a) step_sq += c.step[a] * c.step[a];
+            if (step_sq < prm.parameter_tolerance * ((a0 * a0 + a1 * a1) + prm.parameter_tolerance)) c.converged = 1;
+            for (int a = 0; a < 12; ++a) c.T_tr[a] = c.cand_T[a];
+            c.ab_eps[0] = c.cand_ab[0];
+            c.ab_eps[1] = c.cand_ab[1];
+            c.energy = e_eval;
+            c.n_valid = n_eval;
+            c.lambda /= prm.decrease_on_accept;
+            take_system = true;
+          } else {
+            c.lambda *= prm.increase_on_reject;  // rejectStep: the accepted state and its system stay
+          }
+          if (c.converged || c.iteration >= prm.max_iterations) c.active = 0;
+        }
+      }
+      if (take_system) {
+        for (int a = 0; a < 64; ++a) c.H[a] = Hn[a];
+        for (int a = 0; a < 8; ++a) c.b[a] = bn[a];
+      }
+      if (c.active) {
+        // calculateStep (eigen_pose_alignment.cpp:194-206): H + lambda * diag(H), leftIncrement, ab_eps -= step[6:8]
+        double Hr[64];
+        for (int a = 0; a < 64; ++a) Hr[a] = c.H[a];
+        for (int a = 0; a < 8; ++a) Hr[8 * a + a] += c.H[8 * a + a] * c.lambda;
+        for (int a = 0; a < 64; ++a) c.H_used[a] = c.H[a];
+        solve8(Hr, c.b, c.step);
+        const Rigid E = rigidExp(c.step);
+        double Em[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Em[4 * i + j] = E.R[3 * i + j];
+          Em[4 * i + 3] = E.t[i];
+        }
+        mat34Compose(Em, c.T_tr, c.cand_T);
+        c.cand_ab[0] = c.ab_eps[0] - c.step[6];
+        c.cand_ab[1] = c.ab_eps[1] - c.step[7];
+        c.have_candidate = 1;
+      }
+      sc = c;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) *cout = sc;
+    if (!sc.active) return;
+    __syncthreads();
+  }
+  if (launch_index == 0 && blockIdx.x == 0 && tid == 0) *cout = sc;
+
+  // ---------------- sweep at the candidate state ----------------
+  double acc[kAlignPartial];
+#pragma unroll
+  for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
+  const double *T = sc.cand_T;
+  // ArrayReprojector ctor — camera_reproject.hpp:235-260
+  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
+  S U[12], M[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double u0 = T[4 * i] * ifx, u1 = T[4 * i + 1] * ify, u2 = T[4 * i] * k02 + T[4 * i + 1] * k12 + T[4 * i + 2], u3 = T[4 * i + 3];
+    U[4 * i] = S(u0);
+    U[4 * i + 1] = S(u1);
+    U[4 * i + 2] = S(u2);
+    U[4 * i + 3] = S(u3);
+  }
+  {
+    const double *Tt = T;
+    double Ud[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Ud[4 * i] = Tt[4 * i] * ifx;
+      Ud[4 * i + 1] = Tt[4 * i + 1] * ify;
+      Ud[4 * i + 2] = Tt[4 * i] * k02 + Tt[4 * i + 1] * k12 + Tt[4 * i + 2];
+      Ud[4 * i + 3] = Tt[4 * i + 3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      M[j] = S(tgt.fx * Ud[j] + tgt.cx * Ud[8 + j]);
+      M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
+      M[8 + j] = S(Ud[8 + j]);
+    }
+  }
+  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
+  const S s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
+  const S b_t = S(tab1), b_r = S(ref.ab0[1]);
+  const S Wr = S(ref.width), Hr_ = S(ref.height), Wt = S(tgt.width), Ht = S(tgt.height);
+  const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(tgt.texels);
+  const int W = tgt.width;
+  for (int i = blockIdx.x * kAlignThreads + tid; i < prm.n_points; i += gridDim.x * kAlignThreads) {
+    const S u = static_cast<S>(pu[i]), v = static_cast<S>(pv[i]), idepth = static_cast<S>(pid[i]);
+    const S iref = static_cast<S>(pint[i]);
+    // reproject (checked) — camera_reproject.hpp:270-293
+    bool ok = validIdepth(idepth) && insideROI(u, v, Wr, Hr_);
+    const S x = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
+    const S y = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
+    const S z = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
+    const S tu = x / z, tv = y / z;
+    ok = ok && (z > S(0)) && insideROI(tu, tv, Wt, Ht);
+    if (!ok) continue;
+    const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
+    const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy), dxdy = dx * dy;
+    const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
+    const Texel<S> t00 = p[0], t10 = p[1], t01 = p[W], t11 = p[W + 1];
+    const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
+    const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
+    if (m == S(0)) continue;  // mask_.valid(target_pattern) — eigen_pose_alignment.cpp:78
+    const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+    const S sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
+    const S sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
+    const S sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
+    const S right = s_scale * (iref - b_r);
+    const double r = static_cast<double>((sI - b_t) - right);
+    const double r2 = r * r, sig = prm.sigma_huber;
+    const bool lin = r2 > sig * sig;
+    const double nrm = fabs(r);
+    const double wgt = lin ? sig / nrm : 1.0;
+    acc[44] += lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2;
+    acc[45] += 1.0;
+    // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
+    const S X = U[0] * u + U[1] * v + (U[2] + U[3] * idepth);
+    const S Y = U[4] * u + U[5] * v + (U[6] + U[7] * idepth);
+    const S Z = U[8] * u + U[9] * v + (U[10] + U[11] * idepth);
+    const S rho = S(1) / Z, b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
+    const S fxt = S(tgt.fx), fyt = S(tgt.fy), b0b1 = b0 * b1;
+    double d[8];
+    d[0] = -static_cast<double>(sIx * (fxt * nid));
+    d[1] = -static_cast<double>(sIy * (fyt * nid));
+    d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
+    d[3] = -static_cast<double>(sIx * (fxt * (-b0b1)) + sIy * (fyt * (-(b1 * b1 + S(1)))));
+    d[4] = -static_cast<double>(sIx * (fxt * (b0 * b0 + S(1))) + sIy * (fyt * b0b1));
+    d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
+    d[6] = -static_cast<double>(right);
+    d[7] = -1.0;
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const double wa = wgt * d[a];
+#pragma unroll
+      for (int b2 = a; b2 < 8; ++b2) acc[e++] += wa * d[b2];
+      acc[36 + a] += wa * r;
+    }
+  }
+  // workgroup reduction through an LDS transpose (see blockReduceStore in pba_kernels.hpp)
+  {
+    constexpr int RS = kAlignThreads + 2;
+#pragma unroll
+    for (int e = 0; e < kAlignPartial; ++e) red[e * RS + tid] = acc[e];
+    __syncthreads();
+    if (tid < kAlignPartial) {
+      const double2 *row = reinterpret_cast<const double2 *>(red + tid * RS);
+      double s0 = 0, s1 = 0;
+#pragma unroll 8
+      for (int j = 0; j < kAlignThreads / 2; ++j) {
+        const double2 q = row[j];
+        s0 += q.x;
+        s1 += q.y;
+      }
+      partials[static_cast<size_t>(blockIdx.x) * kAlignPartial + tid] = s0 + s1;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace dsopp_hip
+
+using namespace dsopp_hip;
+
+struct dsopp_hip_aligner {
+  StreamRef sr;
+  dsopp_hip_options opt;
+  // frames_ of the reference: [0] = fixed reference (with points), back() = free target
+  bool have_ref = false, have_tgt = false;
+  AlignFrameDev ref{}, tgt{};
+  int64_t ref_time = 0, tgt_time = 0;
+  Rigid T_w_ref = rigidIdentity(), T_w_tgt = rigidIdentity();
+  int n_points = 0;
+  DeviceBuffer<double> d_u, d_v, d_id, d_int, d_partials[2];
+  DeviceBuffer<AlignControl> d_ctrl;
+  std::map<int64_t, Rigid> known_poses;
+};
+
+namespace dsopp_hip {
+namespace {
+
+void setFrame(AlignFrameDev &f, const dsopp_hip_pyramid *p, int level, const double intr[4], double exposure, const double ab[2]) {
+  const LevelView lv = p->view(level);
+  f.texels = lv.texels;
+  f.width = lv.width;
+  f.height = lv.height;
+  f.fx = intr[0];
+  f.fy = intr[1];
+  f.cx = intr[2];
+  f.cy = intr[3];
+  f.exposure = exposure;
+  f.ab0[0] = ab[0];
+  f.ab0[1] = ab[1];
+}
+
+void uploadPoints(dsopp_hip_aligner *a, const dsopp_hip_pyramid *pyr, int level, const std::vector<double> &u, const std::vector<double> &v,
+                  const std::vector<double> &id) {
+  const size_t n = u.size();
+  hipStream_t st = a->sr.stream;
+  a->d_u.reserve(std::max<size_t>(n, 1), 0, st);
+  a->d_v.reserve(std::max<size_t>(n, 1), 0, st);
+  a->d_id.reserve(std::max<size_t>(n, 1), 0, st);
+  a->d_int.reserve(std::max<size_t>(n, 1), 0, st);
+  a->d_u.upload(u.data(), n, 0, st);
+  a->d_v.upload(v.data(), n, 0, st);
+  a->d_id.upload(id.data(), n, 0, st);
+  if (n) {
+    const LevelView lv = pyr->view(level);
+    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+    if (pyr->dtype == DSOPP_HIP_F64)
+      sampleReferenceKernel<double><<<grid, 256, 0, st>>>(static_cast<const Texel<double> *>(lv.texels), lv.width, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, static_cast<int>(n));
+    else
+      sampleReferenceKernel<float><<<grid, 256, 0, st>>>(static_cast<const Texel<float> *>(lv.texels), lv.width, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, static_cast<int>(n));
+    HIP_CHECK(hipGetLastError());
+  }
+  a->sr.sync();
+  a->n_points = static_cast<int>(n);
+}
+
+void checkPyramid(dsopp_hip_aligner *a, const dsopp_hip_pyramid *p, int level) {
+  if (!p) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pyramid");
+  if (level < 0 || level >= p->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
+  if (p->dtype != a->opt.dtype) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid dtype differs from the aligner's");
+  if (p->sr.device != a->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid lives on another device");
+}
+
+}  // namespace
+}  // namespace dsopp_hip
+
+extern "C" {
+
+int dsopp_hip_aligner_create(const dsopp_hip_options *options, int device, void *stream, dsopp_hip_aligner **out) {
+  return guarded([&] {
+    if (!options || !out) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    auto a = std::make_unique<dsopp_hip_aligner>();
+    a->opt = *options;
+    if (a->opt.dtype != DSOPP_HIP_F64 && a->opt.dtype != DSOPP_HIP_F32) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad dtype");
+    a->sr.init(device, stream);
+    a->d_ctrl.reserve(2, 0, a->sr.stream);
+    a->sr.sync();
+    *out = a.release();
+  });
+}
+
+void dsopp_hip_aligner_destroy(dsopp_hip_aligner *a) {
+  if (!a) return;
+  (void)hipSetDevice(a->sr.device);
+  if (a->sr.stream) (void)hipStreamSynchronize(a->sr.stream);
+  StreamRef sr = a->sr;
+  delete a;
+  sr.destroy();
+}
+
+int dsopp_hip_aligner_reset(dsopp_hip_aligner *a) {
+  return guarded([&] {
+    if (!a) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null aligner");
+    a->have_ref = a->have_tgt = false;
+    a->n_points = 0;
+  });
+}
+
+int dsopp_hip_aligner_push_reference_points(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                            const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4], int32_t n,
+                                            const double *u, const double *v, const double *idepth, double exposure_time,
+                                            const double affine_brightness[2]) {
+  return guarded([&] {
+    if (!a || !T_world_agent || !intrinsics || !affine_brightness || n < 0 || (n && (!u || !v || !idepth)))
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    checkPyramid(a, pyramid, level);
+    if (a->have_ref || a->have_tgt) fail(DSOPP_HIP_ERR_ORDER, "the reference frame must be pushed first after reset()");
+    a->sr.use();
+    setFrame(a->ref, pyramid, level, intrinsics, exposure_time, affine_brightness);
+    a->T_w_ref = rigidFromParams(T_world_agent);
+    a->ref_time = timestamp;
+    std::vector<double> uu(u, u + n), vv(v, v + n), dd(idepth, idepth + n);
+    uploadPoints(a, pyramid, level, uu, vv, dd);
+    a->have_ref = true;
+  });
+}
+
+int dsopp_hip_aligner_push_reference_depth_map(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                               const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4],
+                                               const double *idepth_sum, const double *weight, double exposure_time,
+                                               const double affine_brightness[2]) {
+  return guarded([&] {
+    if (!a || !T_world_agent || !intrinsics || !affine_brightness || !idepth_sum || !weight) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    checkPyramid(a, pyramid, level);
+    if (a->have_ref || a->have_tgt) fail(DSOPP_HIP_ERR_ORDER, "the reference frame must be pushed first after reset()");
+    a->sr.use();
+    // LocalFrame depth-map ctor (PBA_INT/local_frame.hpp:367-392): row-major scan, 4-px border, weight > 0, idepth >= 1e-6.
+    // The scan keeps the reference's point order (hence its summation order); intensities are sampled on the device.
+    const int W = pyramid->w(level), H = pyramid->h(level);
+    std::vector<double> uu, vv, dd;
+    for (int y = 4; y < H - 4; ++y)
+      for (int x = 4; x < W - 4; ++x) {
+        const size_t i = static_cast<size_t>(y) * W + x;
+        if (weight[i] > 0) {
+          const double id = idepth_sum[i] / weight[i];
+          if (id < 1e-6) continue;
+          uu.push_back(x);
+          vv.push_back(y);
+          dd.push_back(id);
+        }
+      }
+    setFrame(a->ref, pyramid, level, intrinsics, exposure_time, affine_brightness);
+    a->T_w_ref = rigidFromParams(T_world_agent);
+    a->ref_time = timestamp;
+    uploadPoints(a, pyramid, level, uu, vv, dd);
+    a->have_ref = true;
+  });
+}
+
+int dsopp_hip_aligner_push_target(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent_init[7],
+                                  const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4], double exposure_time,
+                                  const double affine_brightness[2]) {
+  return guarded([&] {
+    if (!a || !T_world_agent_init || !intrinsics || !affine_brightness) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    checkPyramid(a, pyramid, level);
+    if (a->have_ref && a->ref_time > timestamp) fail(DSOPP_HIP_ERR_ORDER, "frames must be processed in ascending order of time");
+    setFrame(a->tgt, pyramid, level, intrinsics, exposure_time, affine_brightness);
+    a->T_w_tgt = rigidFromParams(T_world_agent_init);
+    a->tgt_time = timestamp;
+    a->have_tgt = true;
+  });
+}
+
+int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7]) {
+  return guarded([&] {
+    if (!a || !T_world_agent) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    a->known_poses[timestamp] = rigidFromParams(T_world_agent);
+  });
+}
+
+int dsopp_hip_aligner_num_points(dsopp_hip_aligner *a, int32_t *n) {
+  return guarded([&] {
+    if (!a || !n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *n = a->n_points;
+  });
+}
+
+int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result) {
+  return guarded([&] {
+    if (!a || !result) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (!a->have_tgt) fail(DSOPP_HIP_ERR_STATE, "no target frame pushed");
+    std::memset(result, 0, sizeof(*result));
+    // known pose short-cut — eigen_pose_alignment.cpp:281-288
+    auto kp = a->known_poses.find(a->tgt_time);
+    if (kp != a->known_poses.end()) {
+      a->T_w_tgt = kp->second;
+      result->rmse = -1;  // kZeroCost
+      rigidToParams(a->T_w_tgt, result->T_world_target);
+      result->affine_brightness[0] = a->tgt.ab0[0];
+      result->affine_brightness[1] = a->tgt.ab0[1];
+      return;
+    }
+    if (!a->have_ref) fail(DSOPP_HIP_ERR_STATE, "no reference frame pushed");
+    a->sr.use();
+    hipStream_t st = a->sr.stream;
+    const int n = a->n_points;
+    const int n_blocks = std::max(1, std::min(256, (n + kAlignThreads - 1) / kAlignThreads));
+    a->d_partials[0].reserve(static_cast<size_t>(n_blocks) * kAlignPartial, 0, st);
+    a->d_partials[1].reserve(static_cast<size_t>(n_blocks) * kAlignPartial, 0, st);
+    AlignParams prm;
+    prm.sigma_huber = a->opt.sigma_huber_loss;
+    prm.affine_reg[0] = a->opt.affine_brightness_regularizer[0];
+    prm.affine_reg[1] = a->opt.affine_brightness_regularizer[1];
+    prm.function_tolerance = a->opt.function_tolerance;
+    prm.parameter_tolerance = a->opt.parameter_tolerance;
+    prm.decrease_on_accept = 2.0;  // eigen_pose_alignment.cpp:304-305
+    prm.increase_on_reject = 2.0;
+    prm.max_iterations = a->opt.max_iterations;
+    prm.n_points = n;
+    prm.n_blocks = n_blocks;
+    AlignControl c;
+    std::memset(&c, 0, sizeof(c));
+    const Rigid T_tr = rigidMul(rigidInverse(a->T_w_tgt), a->T_w_ref);  // eigen_pose_alignment.cpp:307-308
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) c.T_tr[4 * i + j] = c.cand_T[4 * i + j] = T_tr.R[3 * i + j];
+      c.T_tr[4 * i + 3] = c.cand_T[4 * i + 3] = T_tr.t[i];
+    }
+    c.lambda = 1.0 / a->opt.initial_trust_region_radius;
+    c.active = 1;
+    a->d_ctrl.upload(&c, 1, 0, st);
+    a->sr.sync();
+    const int total_launches = a->opt.max_iterations + 2;  // initial evaluation + one per iteration + final control pass
+    int launch = 0;
+    AlignControl h;
+    const int kBatch = 8;
+    while (true) {
+      const int end = std::min(total_launches, launch + kBatch);
+      for (; launch < end; ++launch) {
+        const AlignControl *cin = a->d_ctrl.ptr + ((launch + 1) & 1);
+        AlignControl *cout = a->d_ctrl.ptr + (launch & 1);
+        if (launch == 0) cin = a->d_ctrl.ptr;  // host-prepared block
+        const double *prev = a->d_partials[(launch + 1) & 1].ptr;
+        double *cur = a->d_partials[launch & 1].ptr;
+        if (a->opt.dtype == DSOPP_HIP_F64)
+          alignIterationKernel<double><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr, a->d_int.ptr, cin, cout, prev, cur, prm, launch);
+        else
+          alignIterationKernel<float><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr, a->d_int.ptr, cin, cout, prev, cur, prm, launch);
+      }
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(&h, a->d_ctrl.ptr + ((launch - 1) & 1), sizeof(AlignControl), hipMemcpyDeviceToHost, st));
+      a->sr.sync();
+      if (!h.active || launch >= total_launches) break;
+    }
+    // result — eigen_pose_alignment.cpp:320-328
+    Rigid Tfin;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = h.T_tr[4 * i + j];
+      Tfin.t[i] = h.T_tr[4 * i + 3];
+    }
+    rigidNormalize(Tfin);
+    a->T_w_tgt = rigidMul(a->T_w_ref, rigidInverse(Tfin));
+    a->tgt.ab0[0] += h.ab_eps[0];
+    a->tgt.ab0[1] += h.ab_eps[1];
+    result->energy = h.energy;
+    result->n_valid = h.n_valid;
+    result->iterations = h.iteration;
+    result->rmse = std::sqrt(h.energy / static_cast<double>(h.n_valid) / 1.0);
+    rigidToParams(a->T_w_tgt, result->T_world_target);
+    result->affine_brightness[0] = a->tgt.ab0[0];
+    result->affine_brightness[1] = a->tgt.ab0[1];
+    hostla::Mat Hm(h.H_used, h.H_used + 64);
+    const hostla::Mat pinv = hostla::pinvRankRevealing(Hm, 8);
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) result->covariance[6 * i + j] = pinv[static_cast<size_t>(8 * i + j)];
+    std::memcpy(result->H, h.H_used, sizeof(h.H_used));
+  });
+}
+
+}  // extern "C"

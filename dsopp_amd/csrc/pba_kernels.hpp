@@ -12,6 +12,7 @@
 // Work is laid out so that a wavefront shares one frame pair: pair constants are wave-uniform (scalar registers),
 // landmark SoA reads are coalesced, the image is a gather of 2 x 64 B segments per pattern pixel.
 #pragma once
+#include "device_geom.hpp"
 #include "pba_types.hpp"
 
 namespace dsopp_hip {
@@ -178,20 +179,6 @@ __device__ __forceinline__ void blockSum(double (&vals)[N], double *lds /* [THRE
       }
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// geometry helpers (templated on the evaluation scalar S)
-// ---------------------------------------------------------------------------------------------------------------
-template <typename S>
-__device__ __forceinline__ bool insideROI(S u, S v, S width, S height) {
-  // CameraModelBase::insideCameraROI — camera_model_base.hpp:52-60 (border 4)
-  return (u >= S(4)) && (v >= S(4)) && (u <= width - S(5)) && (v <= height - S(5));
-}
-template <typename S>
-__device__ __forceinline__ bool validIdepth(S idepth) {
-  // CameraModelBase::validIdepth — camera_model_base.hpp:67-74
-  return idepth > S(-1e-4) && idepth < S(1.0 / 0.001 + 1e1);
 }
 
 /** firstEstimateJacobians_ (first_estimate_jacobians.hpp:14-71): validity of the reprojection at the linearisation point
