@@ -40,13 +40,6 @@ def algorithmic_bytes_energy(P, F, s):
     return s * P * (12 + (F - 1) * 35)
 
 
-def shard(n, rank, world):
-    """contiguous block partition of n items, balanced to +-1"""
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +55,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from dsopp_amd import capi, synthetic as syn
+    from dsopp_amd import capi, distributed, synthetic as syn
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,9 +75,7 @@ def main():
     total_points = P * world
     # identical synthetic window on every rank (seeded); each rank keeps its landmark shard of every frame
     win = syn.make_window(num_frames=F, num_points=total_points, width=args.width, height=args.height, seed=0)
-    for f in win.frames:
-        lo, hi = shard(len(f.uv), rank, world)
-        f.uv, f.idepth_gt, f.idepth_init, f.patch = f.uv[lo:hi], f.idepth_gt[lo:hi], f.idepth_init[lo:hi], f.patch[lo:hi]
+    distributed.shard_window(win, rank, world)
     P_local = win.num_points
 
     stream = torch.cuda.Stream()
@@ -94,23 +85,7 @@ def main():
     syn.load_window(g, win)
 
     if world > 1:
-        class _DevBuf:
-            def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3}
-
-        cache = {}
-
-        def allreduce(ptr, count, stream_ptr):
-            key = (ptr, count)
-            t = cache.get(key)
-            if t is None:
-                t = torch.as_tensor(_DevBuf(ptr, count), device=f"cuda:{local_rank}")
-                cache[key] = t
-            with torch.cuda.stream(stream):
-                dist.all_reduce(t)
-            return 0
-
-        g.set_allreduce(allreduce, rank, world)
+        g.set_allreduce(distributed.make_device_allreduce(dist, torch, stream, local_rank), rank, world)
 
     g.snapshot()
 

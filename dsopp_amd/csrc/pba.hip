@@ -774,6 +774,32 @@ void updatePointStatuses(W &w) {
       if (flags[static_cast<size_t>(c.r)][i] & kFlagMarginalized) continue;
       if (c.status[i] == DSOPP_HIP_STATUS_OK) energies.push_back(c.energy[i]);
     }
+  if (w.allreduce && w.world > 1) {
+    // the 3rd-quartile threshold is a statistic of ALL kOk residual energies of the window, landmarks are sharded:
+    // gather the per-rank energy lists with two sum-collectives (counts, then zero-padded slices)
+    std::vector<double> counts(static_cast<size_t>(w.world), 0.0);
+    counts[static_cast<size_t>(w.rank)] = static_cast<double>(energies.size());
+    w.d_gather.reserve(static_cast<size_t>(w.world), 0, st);
+    w.d_gather.upload(counts.data(), counts.size(), 0, st);
+    allreduceIfNeeded(w, w.d_gather.ptr, counts.size());
+    w.d_gather.download(counts.data(), counts.size(), 0, st);
+    w.sr.sync();
+    size_t total = 0, offset = 0;
+    for (int r = 0; r < w.world; ++r) {
+      if (r < w.rank) offset += static_cast<size_t>(counts[static_cast<size_t>(r)] + 0.5);
+      total += static_cast<size_t>(counts[static_cast<size_t>(r)] + 0.5);
+    }
+    std::vector<double> all(total, 0.0);
+    std::copy(energies.begin(), energies.end(), all.begin() + static_cast<long>(offset));
+    if (total) {
+      w.d_gather.reserve(total, 0, st);
+      w.d_gather.upload(all.data(), total, 0, st);
+      allreduceIfNeeded(w, w.d_gather.ptr, total);
+      w.d_gather.download(all.data(), total, 0, st);
+      w.sr.sync();
+    }
+    energies.swap(all);
+  }
   double threshold = 0;
   if (!energies.empty()) {
     const size_t q = static_cast<size_t>(static_cast<double>(energies.size()) * 0.75);
