@@ -1,0 +1,314 @@
+// Host-side C++ mirror of the reference's solver interfaces over the C-ABI (include/dsopp_hip.h).
+//
+// The reference selects its solvers through two abstract class templates:
+//   energy::problem::PhotometricBundleAdjustment<Precision, SE3, PinholeCamera, 8, PixelMap, true, true, true, 1>
+//       virtuals  pushFrame(const ActiveKeyframe&, size_t level, const Model&, FrameParameterization)      PBA_INC/photometric_bundle_adjustment.hpp:55-56
+//                 updateLocalFrame(const ActiveKeyframe&)                                                   :127
+//                 solve(size_t number_of_threads) -> Precision                                              :154
+//       services  updateFrame(ActiveKeyframe&), getPose(time), getAffineBrightness(time)                   PROB_SRC/photometric_bundle_adjustment.cpp:156-264
+//   energy::problem::PoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1>                                      PA_INC/pose_alignment.hpp:24-63
+//       virtuals  solve -> rmse | kZeroCost, reset(), pushKnownPose(time, Motion), setRotationPrior(Matrix3)
+// Those headers drag in Eigen / Sophus / glog / Ceres / OpenCV, none of which exist in this build environment, so this
+// file states the SAME interface (names, argument meaning, error behaviour) over small value types that carry exactly
+// what the solvers read from `track::ActiveKeyframe` / `sensors::calibration::CameraCalibration`.  INTEGRATION.md shows
+// the ~60-line adapter that derives from the reference's real base classes and forwards to these.
+//
+// Ownership mirrors the reference: the solver copies what it needs at pushFrame, image pyramids are borrowed (they must
+// outlive the frame's stay in the solver, as the keyframe's PixelMap does there), single-threaded use per object.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dsopp_hip.h"
+
+namespace dsopp_hip_host {
+
+using time_point = int64_t;                 // dsopp::time (time_point of the keyframe), as integer ticks
+using Motion = std::array<double, 7>;       // energy::motion::SE3<Precision>: Sophus storage (qx, qy, qz, qw, tx, ty, tz)
+using Vector2 = std::array<double, 2>;
+using Matrix6 = std::array<double, 36>;
+
+enum class FrameParameterization { kFree = 0, kFixed = 1 };  // PBA_INC/frame_parameterization.hpp:9-12
+
+/** energy::model::PinholeCamera<Precision> at a pyramid level (focal lengths, principal point), pinhole_camera.hpp:21-200 */
+struct PinholeModel {
+  double fx, fy, cx, cy;
+};
+
+struct SolverError : std::runtime_error {
+  int code;
+  SolverError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+inline void check(int rc) {
+  // the reference aborts through glog CHECK on contract violations; a library cannot, so violations throw
+  if (rc != DSOPP_HIP_OK) throw SolverError(rc, dsopp_hip_last_error());
+}
+
+/** device-resident pyramid of one frame = features::PixelDataFrame / ActiveKeyframe::pyramids() + masks */
+class DevicePyramid {
+ public:
+  DevicePyramid(int width, int height, int levels, int device = 0, void *stream = nullptr, int dtype = DSOPP_HIP_F64) {
+    check(dsopp_hip_pyramid_create(device, stream, width, height, levels, dtype, &p_));
+  }
+  ~DevicePyramid() { dsopp_hip_pyramid_destroy(p_); }
+  DevicePyramid(const DevicePyramid &) = delete;
+  DevicePyramid &operator=(const DevicePyramid &) = delete;
+  /** PixelDataFrame(image, photometric_calibration, vignetting, levels) */
+  void build(const uint8_t *image, const double *photometric_calibration256 = nullptr, const uint8_t *vignetting = nullptr) {
+    check(dsopp_hip_pyramid_build(p_, image, photometric_calibration256, vignetting));
+  }
+  /** adopt a PixelMap<1> level built on the host by the reference */
+  void setLevel(int level, const double *pixelinfo) { check(dsopp_hip_pyramid_set_level(p_, level, pixelinfo)); }
+  void setMask(int level, const uint8_t *mask) { check(dsopp_hip_pyramid_set_mask(p_, level, mask)); }
+  dsopp_hip_pyramid *handle() const { return p_; }
+
+ private:
+  dsopp_hip_pyramid *p_ = nullptr;
+};
+
+/** what the solvers read from track::landmarks::ActiveTrackingLandmark */
+struct LandmarkView {
+  Vector2 projection;
+  double idepth;
+  std::array<double, DSOPP_HIP_PATTERN_SIZE> patch;
+  bool is_marginalized;
+  bool is_outlier;
+};
+
+/** what the solvers read from / write to track::ActiveKeyframe<Motion> (frames/include/track/frames/active_keyframe.hpp:36-274) */
+struct KeyframeView {
+  int32_t keyframe_id;
+  time_point timestamp;
+  Motion t_world_agent;
+  double exposure_time;
+  Vector2 affine_brightness;
+  bool is_marginalized;
+  const DevicePyramid *pyramids;
+  std::vector<LandmarkView> active_landmarks;
+  /** connections: other keyframe id -> statuses of THIS frame's landmarks reprojected into the other frame
+   *  (FrameConnection::referenceReprojectionStatuses / targetReprojectionStatuses, whichever side this frame is) */
+  std::map<int32_t, std::vector<uint8_t>> reprojection_statuses;
+  // --- written back by updateFrame ---
+  std::vector<double> idepth_variance;
+  std::vector<int32_t> inlier_residuals;
+  std::vector<double> relative_baseline;
+  std::map<int32_t, Matrix6> covariances;
+};
+
+/** TrustRegionPhotometricBundleAdjustmentOptions<Precision> — trust_region_photometric_bundle_adjustment_options.hpp:14-52 */
+struct TrustRegionOptions {
+  size_t max_iterations;
+  double initial_trust_region_radius, function_tolerance, parameter_tolerance;
+  Vector2 affine_brightness_regularizer;
+  double fixed_state_regularizer;
+  double sigma_huber_loss = 5;
+};
+
+/** mirror of EigenPhotometricBundleAdjustment<SE3, PinholeCamera, 8, PixelMap, true, true, true, 1> backed by HIP kernels */
+class HipPhotometricBundleAdjustment {
+ public:
+  /** EigenPhotometricBundleAdjustment(options, estimate_uncertainty, force_accept) — eigen_photometric_bundle_adjustment.cpp:47-57 */
+  HipPhotometricBundleAdjustment(const TrustRegionOptions &o, bool estimate_uncertainty = true, bool force_accept = true, int device = 0,
+                                 void *stream = nullptr)
+      : estimate_uncertainty_(estimate_uncertainty) {
+    dsopp_hip_options c;
+    dsopp_hip_default_pba_options(&c);
+    c.max_iterations = static_cast<int32_t>(o.max_iterations);
+    c.initial_trust_region_radius = o.initial_trust_region_radius;
+    c.function_tolerance = o.function_tolerance;
+    c.parameter_tolerance = o.parameter_tolerance;
+    c.affine_brightness_regularizer[0] = o.affine_brightness_regularizer[0];
+    c.affine_brightness_regularizer[1] = o.affine_brightness_regularizer[1];
+    c.fixed_state_regularizer = o.fixed_state_regularizer;
+    c.sigma_huber_loss = o.sigma_huber_loss;
+    c.estimate_uncertainty = estimate_uncertainty ? 1 : 0;
+    c.force_accept = force_accept ? 1 : 0;
+    check(dsopp_hip_window_create(&c, device, stream, &w_));
+  }
+  ~HipPhotometricBundleAdjustment() { dsopp_hip_window_destroy(w_); }
+  HipPhotometricBundleAdjustment(const HipPhotometricBundleAdjustment &) = delete;
+  HipPhotometricBundleAdjustment &operator=(const HipPhotometricBundleAdjustment &) = delete;
+
+  /** pushFrame(frame, level, model, frame_parameterization): local copy of the keyframe + residual lists between the new
+   *  frame and all previous ones (photometric_bundle_adjustment.cpp:98-124); folds pending marginalisations first
+   *  (eigen_photometric_bundle_adjustment.cpp:119-141) */
+  void pushFrame(const KeyframeView &frame, size_t level, const PinholeModel &model,
+                 FrameParameterization frame_parameterization = FrameParameterization::kFree) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_window_push_frame(w_, frame.keyframe_id, frame.timestamp, frame.pyramids->handle(), static_cast<int>(level), intr,
+                                      frame.t_world_agent.data(), frame.exposure_time, frame.affine_brightness.data(),
+                                      frame_parameterization == FrameParameterization::kFixed ? 1 : 0, frame.is_marginalized ? 1 : 0));
+    times_[frame.timestamp] = frame.keyframe_id;
+    uploadLandmarks(frame);
+    uploadConnections(frame);
+  }
+  /** updateLocalFrame(frame): freshly matured landmarks, marginalisation flags, new connections
+   *  (eigen_photometric_bundle_adjustment.cpp:103-113, local_frame.hpp:484-521) */
+  void updateLocalFrame(const KeyframeView &frame) {
+    uploadLandmarks(frame);
+    uploadConnections(frame);
+    if (frame.is_marginalized) check(dsopp_hip_window_mark_frame_marginalized(w_, frame.keyframe_id));
+  }
+  /** solve(number_of_threads) -> final energy; number_of_threads is accepted and ignored, as in the Eigen backend */
+  double solve(const size_t number_of_threads = 1) {
+    (void)number_of_threads;
+    double e = 0;
+    int32_t it = 0, nv = 0;
+    check(dsopp_hip_window_solve(w_, &e, &it, &nv));
+    return e;
+  }
+  /** updateFrame(frame): poses, affine brightness, idepths, variances, inlier counts, baselines, statuses, covariances
+   *  (photometric_bundle_adjustment.cpp:182-264) */
+  void updateFrame(KeyframeView &frame) {
+    check(dsopp_hip_window_get_pose(w_, frame.keyframe_id, frame.t_world_agent.data(), frame.affine_brightness.data()));
+    int32_t n = 0;
+    check(dsopp_hip_window_num_landmarks(w_, frame.keyframe_id, &n));
+    std::vector<double> idepth(n), inv_h(n), baseline(n);
+    std::vector<int32_t> inliers(n);
+    std::vector<uint8_t> flags(n);
+    check(dsopp_hip_window_get_landmarks(w_, frame.keyframe_id, idepth.data(), nullptr, inv_h.data(), nullptr, baseline.data(), inliers.data(),
+                                         flags.data(), nullptr));
+    frame.idepth_variance.assign(n, 1e-5);
+    frame.inlier_residuals.assign(n, 0);
+    frame.relative_baseline.resize(n, 0.0);
+    const double kIdepthEps = 1e-8;
+    for (int32_t i = 0; i < n && i < static_cast<int32_t>(frame.active_landmarks.size()); ++i) {
+      LandmarkView &lm = frame.active_landmarks[static_cast<size_t>(i)];
+      if (flags[i] & 2) lm.is_outlier = true;
+      if (flags[i] & 1) continue;  // marginalised landmarks keep their values
+      if (std::abs(idepth[i]) < kIdepthEps)
+        lm.idepth = 0;
+      else if (idepth[i] < 0)
+        lm.is_outlier = true;
+      else
+        lm.idepth = idepth[i];
+      if (estimate_uncertainty_) frame.idepth_variance[i] = inv_h[i];
+      frame.inlier_residuals[i] = inliers[i];
+      if (baseline[i] > frame.relative_baseline[i]) frame.relative_baseline[i] = baseline[i];
+    }
+    for (auto &kv : frame.reprojection_statuses) {
+      std::vector<uint8_t> st(kv.second.size());
+      if (st.empty()) continue;
+      if (dsopp_hip_window_get_residuals(w_, frame.keyframe_id, kv.first, static_cast<int32_t>(st.size()), st.data(), nullptr, nullptr) == DSOPP_HIP_OK)
+        kv.second = st;
+      Matrix6 cov;
+      if (estimate_uncertainty_ && dsopp_hip_window_get_covariance(w_, frame.keyframe_id, kv.first, cov.data()) == DSOPP_HIP_OK)
+        frame.covariances[kv.first] = cov;
+    }
+  }
+  Motion getPose(time_point timestamp) const {
+    Motion T;
+    check(dsopp_hip_window_get_pose(w_, idOf(timestamp), T.data(), nullptr));
+    return T;
+  }
+  Vector2 getAffineBrightness(time_point timestamp) const {
+    Vector2 ab{0, 0};
+    auto it = times_.find(timestamp);
+    if (it == times_.end()) return ab;  // the reference returns zero for an unknown frame
+    check(dsopp_hip_window_get_pose(w_, it->second, nullptr, ab.data()));
+    return ab;
+  }
+  dsopp_hip_window *handle() const { return w_; }
+
+ private:
+  int32_t idOf(time_point t) const {
+    auto it = times_.find(t);
+    if (it == times_.end()) throw SolverError(DSOPP_HIP_ERR_NOT_FOUND, "no local copy of this frame in the solver");
+    return it->second;
+  }
+  void uploadLandmarks(const KeyframeView &frame) {
+    const size_t n = frame.active_landmarks.size();
+    std::vector<double> uv(2 * n), idepth(n), patch(DSOPP_HIP_PATTERN_SIZE * n);
+    std::vector<uint8_t> flags(n);
+    for (size_t i = 0; i < n; ++i) {
+      const LandmarkView &lm = frame.active_landmarks[i];
+      uv[2 * i] = lm.projection[0];
+      uv[2 * i + 1] = lm.projection[1];
+      idepth[i] = lm.idepth;
+      for (int k = 0; k < DSOPP_HIP_PATTERN_SIZE; ++k) patch[DSOPP_HIP_PATTERN_SIZE * i + static_cast<size_t>(k)] = lm.patch[static_cast<size_t>(k)];
+      flags[i] = static_cast<uint8_t>((lm.is_marginalized ? 1 : 0) | (lm.is_outlier ? 2 : 0));
+    }
+    check(dsopp_hip_window_set_landmarks(w_, frame.keyframe_id, static_cast<int32_t>(n), uv.data(), idepth.data(), patch.data(), flags.data()));
+  }
+  void uploadConnections(const KeyframeView &frame) {
+    int32_t nf = 0;
+    check(dsopp_hip_window_num_frames(w_, &nf));
+    for (const auto &kv : frame.reprojection_statuses) {
+      if (kv.second.empty()) continue;
+      const int rc = dsopp_hip_window_set_connection(w_, frame.keyframe_id, kv.first, static_cast<int32_t>(kv.second.size()), kv.second.data());
+      if (rc != DSOPP_HIP_OK && rc != DSOPP_HIP_ERR_NOT_FOUND) check(rc);
+    }
+  }
+  dsopp_hip_window *w_ = nullptr;
+  bool estimate_uncertainty_;
+  std::map<time_point, int32_t> times_;
+};
+
+/** mirror of EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true> backed by HIP kernels */
+class HipPoseAlignment {
+ public:
+  static constexpr double kZeroCost = -1;  // PA_INC/pose_alignment.hpp
+  explicit HipPoseAlignment(const TrustRegionOptions &o, int device = 0, void *stream = nullptr) {
+    dsopp_hip_options c;
+    dsopp_hip_default_align_options(&c);
+    c.max_iterations = static_cast<int32_t>(o.max_iterations);
+    c.initial_trust_region_radius = o.initial_trust_region_radius;
+    c.function_tolerance = o.function_tolerance;
+    c.parameter_tolerance = o.parameter_tolerance;
+    c.affine_brightness_regularizer[0] = o.affine_brightness_regularizer[0];
+    c.affine_brightness_regularizer[1] = o.affine_brightness_regularizer[1];
+    c.sigma_huber_loss = o.sigma_huber_loss;
+    check(dsopp_hip_aligner_create(&c, device, stream, &a_));
+  }
+  ~HipPoseAlignment() { dsopp_hip_aligner_destroy(a_); }
+  HipPoseAlignment(const HipPoseAlignment &) = delete;
+  HipPoseAlignment &operator=(const HipPoseAlignment &) = delete;
+
+  void reset() { check(dsopp_hip_aligner_reset(a_)); }
+  /** pushFrame(timestamp, t_world_agent, pyramids, masks, depths_maps, exposure, affine, level, model, kFixed)
+   *  — photometric_bundle_adjustment.cpp:58-74; depth maps are H_l x W_l {idepth sum, weight} (energy/problems/depth_map.hpp) */
+  void pushFrame(time_point timestamp, const Motion &t_world_agent, const DevicePyramid &pyramids, const double *depth_idepth_sum,
+                 const double *depth_weight, double exposure_time, const Vector2 &affine_brightness, size_t level, const PinholeModel &model) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_aligner_push_reference_depth_map(a_, timestamp, t_world_agent.data(), pyramids.handle(), static_cast<int>(level), intr,
+                                                     depth_idepth_sum, depth_weight, exposure_time, affine_brightness.data()));
+  }
+  /** pushFrame(timestamp, t_world_agent_init, pyramids, masks, exposure, affine, level, model, kFree) — :131-154 */
+  void pushFrame(time_point timestamp, const Motion &t_world_agent_init, const DevicePyramid &pyramids, double exposure_time,
+                 const Vector2 &affine_brightness, size_t level, const PinholeModel &model) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_aligner_push_target(a_, timestamp, t_world_agent_init.data(), pyramids.handle(), static_cast<int>(level), intr,
+                                        exposure_time, affine_brightness.data()));
+    target_time_ = timestamp;
+  }
+  void pushKnownPose(time_point timestamp, const Motion &t_w_agent) { check(dsopp_hip_aligner_push_known_pose(a_, timestamp, t_w_agent.data())); }
+  /** solve(number_of_threads) -> rmse, or kZeroCost when the pose was known */
+  double solve(const size_t number_of_threads = 1) {
+    (void)number_of_threads;
+    check(dsopp_hip_aligner_solve(a_, &last_));
+    return last_.rmse;
+  }
+  Motion getPose(time_point) const {
+    Motion T;
+    for (int i = 0; i < 7; ++i) T[static_cast<size_t>(i)] = last_.T_world_target[i];
+    return T;
+  }
+  Vector2 getAffineBrightness(time_point) const { return {last_.affine_brightness[0], last_.affine_brightness[1]}; }
+  Matrix6 tTargetReferenceCovariance() const {
+    Matrix6 c;
+    for (int i = 0; i < 36; ++i) c[static_cast<size_t>(i)] = last_.covariance[i];
+    return c;
+  }
+
+ private:
+  dsopp_hip_aligner *a_ = nullptr;
+  dsopp_hip_align_result last_{};
+  time_point target_time_ = 0;
+};
+
+}  // namespace dsopp_hip_host

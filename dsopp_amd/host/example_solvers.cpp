@@ -1,0 +1,112 @@
+// Self-contained C++ driver of the host mirror classes (dsopp_hip_solvers.hpp): a 3-keyframe window over an analytic
+// scene (fronto-parallel textured plane at z = 4, camera translating along x), solved with
+// HipPhotometricBundleAdjustment, then one HipPoseAlignment of the third frame against the first.
+// Exit code 0 = energies decreased and the perturbed poses moved toward the ground truth.
+//   g++ -std=c++17 example_solvers.cpp -L../lib -ldsopp_hip -Wl,-rpath,$PWD/../lib -o example_solvers
+#include <cmath>
+#include <cstdio>
+#include <random>
+
+#include "dsopp_hip_solvers.hpp"
+
+using namespace dsopp_hip_host;
+
+namespace {
+constexpr int W = 320, H = 240;
+constexpr double fx = 224, fy = 224, cx = 160, cy = 120, Z = 4.0;
+
+double texture(double X, double Y) {  // radiance of the plane point (X, Y, Z)
+  return 127.5 + 55 * std::sin(9.0 * X) * std::cos(7.0 * Y) + 35 * std::sin(23.0 * X + 1.0) * std::sin(19.0 * Y) + 20 * std::cos(41.0 * (X + Y));
+}
+
+std::vector<uint8_t> render(double tx) {  // camera at (tx, 0, 0), identity rotation
+  std::vector<uint8_t> img(static_cast<size_t>(W) * H);
+  for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+      const double X = (u - cx) / fx * Z + tx, Y = (v - cy) / fy * Z;
+      const double val = std::min(255.0, std::max(0.0, texture(X, Y)));
+      img[static_cast<size_t>(v) * W + u] = static_cast<uint8_t>(std::lround(val));
+    }
+  return img;
+}
+}  // namespace
+
+int main() {
+  int n_dev = 0;
+  dsopp_hip_device_count(&n_dev);
+  if (n_dev < 1) {
+    std::printf("no GPU: the HIP backend has no CPU fallback\n");
+    return 2;
+  }
+  const double tx_gt[3] = {0.0, 0.10, 0.20};
+  const double tx_init[3] = {0.0, 0.115, 0.18};
+  std::vector<std::unique_ptr<DevicePyramid>> pyramids;
+  std::vector<std::vector<uint8_t>> images;
+  for (int i = 0; i < 3; ++i) {
+    images.push_back(render(tx_gt[i]));
+    pyramids.push_back(std::make_unique<DevicePyramid>(W, H, 3));
+    pyramids.back()->build(images.back().data());
+  }
+  // production options of createPhotometricBundleAdjustment (src/tracker/tracker/src/fabric.cpp:63-79)
+  TrustRegionOptions opt{7, 1e5, 1e-8, 1e-8, {1e12, 1e8}, 1e16, 20};
+  HipPhotometricBundleAdjustment pba(opt, true, true);
+  std::mt19937 rng(1);
+  std::uniform_int_distribution<int> ux(20, W - 21), uy(20, H - 21);
+  std::vector<KeyframeView> frames(3);
+  const PinholeModel model{fx, fy, cx, cy};
+  for (int i = 0; i < 3; ++i) {
+    KeyframeView &f = frames[static_cast<size_t>(i)];
+    f.keyframe_id = i;
+    f.timestamp = 1000 * (i + 1);
+    f.t_world_agent = {0, 0, 0, 1, tx_init[i], 0, 0};
+    f.exposure_time = 1;
+    f.affine_brightness = {0, 0};
+    f.is_marginalized = false;
+    f.pyramids = pyramids[static_cast<size_t>(i)].get();
+    for (int k = 0; k < 120; ++k) {
+      LandmarkView lm;
+      const int u = ux(rng), v = uy(rng);
+      lm.projection = {static_cast<double>(u), static_cast<double>(v)};
+      lm.idepth = 1.0 / Z * (1 + 0.002 * ((k % 7) - 3));
+      static const int px[8] = {0, -1, 1, -2, 0, 2, -1, 0}, py[8] = {2, 1, 1, 0, 0, 0, -1, -2};
+      for (int p = 0; p < 8; ++p) lm.patch[static_cast<size_t>(p)] = images[static_cast<size_t>(i)][static_cast<size_t>(v + py[p]) * W + u + px[p]];
+      lm.is_marginalized = lm.is_outlier = false;
+      f.active_landmarks.push_back(lm);
+    }
+    for (int j = 0; j < i; ++j) {
+      f.reprojection_statuses[j] = std::vector<uint8_t>(f.active_landmarks.size(), DSOPP_HIP_STATUS_OK);
+      frames[static_cast<size_t>(j)].reprojection_statuses[i] = std::vector<uint8_t>(frames[static_cast<size_t>(j)].active_landmarks.size(), DSOPP_HIP_STATUS_OK);
+    }
+    pba.pushFrame(f, 0, model, i == 0 ? FrameParameterization::kFixed : FrameParameterization::kFree);
+    for (int j = 0; j < i; ++j) pba.updateLocalFrame(frames[static_cast<size_t>(j)]);  // new connections of the older frames
+  }
+  const double energy = pba.solve(1);
+  bool ok = std::isfinite(energy);
+  for (int i = 1; i < 3; ++i) {
+    pba.updateFrame(frames[static_cast<size_t>(i)]);
+    const double err0 = std::abs(tx_init[i] - tx_gt[i]), err1 = std::abs(frames[static_cast<size_t>(i)].t_world_agent[4] - tx_gt[i]);
+    std::printf("frame %d: |tx error| %.5f -> %.5f\n", i, err0, err1);
+    ok = ok && err1 < 0.6 * err0 + 2e-3;
+  }
+  std::printf("final PBA energy %.3f\n", energy);
+
+  // coarse alignment of frame 2 against frame 0 at level 1 with a sparse reference depth map
+  TrustRegionOptions aopt{50, 1e2, 1e-5, 1e-5, {1e12, 1e8}, 1e16, 20};
+  HipPoseAlignment align(aopt);
+  const int w1 = W / 2, h1 = H / 2;
+  std::vector<double> idsum(static_cast<size_t>(w1) * h1, 0.0), weight(static_cast<size_t>(w1) * h1, 0.0);
+  for (int k = 0; k < 900; ++k) {
+    const int u = ux(rng) / 2, v = uy(rng) / 2;
+    idsum[static_cast<size_t>(v) * w1 + u] = 1.0 / Z;
+    weight[static_cast<size_t>(v) * w1 + u] = 1.0;
+  }
+  const PinholeModel model1{fx / 2, fy / 2, cx / 2, cy / 2};
+  align.reset();
+  align.pushFrame(1000, Motion{0, 0, 0, 1, 0, 0, 0}, *pyramids[0], idsum.data(), weight.data(), 1.0, Vector2{0, 0}, 1, model1);
+  align.pushFrame(3000, Motion{0, 0, 0, 1, 0.17, 0, 0}, *pyramids[2], 1.0, Vector2{0, 0}, 1, model1);
+  const double rmse = align.solve(1);
+  const Motion Ta = align.getPose(3000);
+  std::printf("alignment: rmse %.3f, tx 0.17000 -> %.5f (ground truth 0.20000)\n", rmse, Ta[4]);
+  ok = ok && rmse > 0 && std::abs(Ta[4] - 0.2) < 0.015;
+  return ok ? 0 : 1;
+}
