@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -250,6 +250,15 @@ class HipWindow:
     def set_max_iterations(self, n: int):
         _chk(lib().dsopp_hip_window_set_max_iterations(self._h, int(n)))
         self.options.max_iterations = int(n)
+
+    KERNEL_CLASSES = {"pair_setup": 0, "fej": 1, "sweep_linearize": 2, "sweep_energy": 3, "schur": 4, "assemble": 5, "assemble_solve": 6,
+                      "backsub": 7, "energy_reduce": 8, "accept_decide": 9}
+
+    def time_kernel(self, name: str, repeats: int = 50) -> float:
+        """average microseconds of `repeats` back-to-back launches of one kernel class (one HIP event pair)"""
+        us = C.c_double()
+        _chk(lib().dsopp_hip_window_time_kernel(self._h, self.KERNEL_CLASSES[name], int(repeats), C.byref(us)))
+        return us.value
 
     def set_lm_mode(self, host_driven: bool):
         _chk(lib().dsopp_hip_window_set_lm_mode(self._h, int(bool(host_driven))))

@@ -1549,6 +1549,40 @@ int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
   });
 }
 
+int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repeats, double *avg_us) {
+  return guarded([&] {
+    if (!w || !avg_us || repeats < 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+    w->sr.use();
+    if (!w->begun) stageBegin(*w);
+    const bool saved = w->profiling;
+    w->profiling = false;
+    ensurePairConstants(*w);
+    auto once = [&] {
+      switch (kernel_class) {
+        case DSOPP_HIP_KERNEL_SWEEP_LINEARIZE: launchSweep(*w, true, true, false); break;
+        case DSOPP_HIP_KERNEL_SWEEP_ENERGY: launchSweep(*w, false, true, false); break;
+        case DSOPP_HIP_KERNEL_SCHUR: launchReduceSchur(*w, false, nullptr); break;
+        case DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE: launchAssemble(*w, 1e-5, true, true, false, nullptr); break;
+        default: fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "kernel class %d cannot be timed in isolation", kernel_class);
+      }
+    };
+    if (kernel_class == DSOPP_HIP_KERNEL_SCHUR || kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) launchSweep(*w, true, true, false);
+    if (kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) launchReduceSchur(*w, false, nullptr);
+    once();  // warm
+    HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
+    for (int i = 0; i < repeats; ++i) once();
+    HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
+    HIP_CHECK(hipEventSynchronize(w->ev1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    *avg_us = static_cast<double>(ms) * 1e3 / repeats;
+    w->profiling = saved;
+    // the repeated solve launches moved the candidate step: drop it so the window state is unchanged
+    if (kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) stageAccept(*w, false);
+    w->linearized = false;
+  });
+}
+
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");

@@ -213,6 +213,10 @@ enum {
 int dsopp_hip_window_set_profiling(dsopp_hip_window *w, int enable);
 int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *total_ms, int64_t *launches);
 const char *dsopp_hip_kernel_class_name(int kernel_class);
+/* average duration (microseconds) of `repeats` back-to-back launches of one kernel class at the window's current state,
+ * bracketed by ONE pair of HIP events on the window's stream (amortises the ~5 us an event pair costs around a single
+ * short kernel).  Supported: SWEEP_LINEARIZE, SWEEP_ENERGY, SCHUR, ASSEMBLE_SOLVE.  The window state is left unchanged. */
+int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repeats, double *avg_us);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Two-frame direct image alignment of one pyramid level
