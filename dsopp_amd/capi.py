@@ -260,8 +260,9 @@ class HipWindow:
         _chk(lib().dsopp_hip_window_time_kernel(self._h, self.KERNEL_CLASSES[name], int(repeats), C.byref(us)))
         return us.value
 
-    def set_lm_mode(self, host_driven: bool):
-        _chk(lib().dsopp_hip_window_set_lm_mode(self._h, int(bool(host_driven))))
+    def set_lm_mode(self, mode: int):
+        """0 fused device loop (default), 1 host-driven stages, 2 unfused device loop"""
+        _chk(lib().dsopp_hip_window_set_lm_mode(self._h, int(mode)))
 
     def snapshot(self):
         _chk(lib().dsopp_hip_window_snapshot(self._h))

@@ -69,7 +69,7 @@ struct dsopp_hip_window {
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
   DeviceBuffer<LmControl> d_ctrl;
-  bool host_driven_lm = false;  // debug / parity: run the LM control flow on the host through the stage functions
+  int lm_mode = 0;  // 0: fused device loop (3 launches / iteration), 1: host-driven stages, 2: unfused device loop (5 launches)
   double *dHppRaw() const { return d_reduce.ptr; }
   double *dbppRaw() const { return d_reduce.ptr + static_cast<size_t>(K()) * K(); }
   double *dHsc() const { return dbppRaw() + K(); }
@@ -186,7 +186,7 @@ void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   f.relative_baseline.reserve(cap, keep, st);
   f.n_inliers.reserve(cap, keep, st);
   f.dflags.reserve(cap, keep, st);
-  f.ublk.reserve(static_cast<size_t>(kMaxFrames) * cap * kUblk, 0, st);
+  f.ublk.reserve(2 * static_cast<size_t>(kMaxFrames) * cap * kUblk, 0, st);  // double-buffered (fused LM loop)
   for (auto &kv : f.residuals) {
     ResidualTable &rt = *kv.second;
     const size_t k = static_cast<size_t>(rt.n);
@@ -329,7 +329,7 @@ void ensurePairConstants(W &w) {
   if (w.pair_valid) return;
   const int F = w.F();
   timedLaunch(w, DSOPP_HIP_KERNEL_PAIR_SETUP, [&] {
-    pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, F, w.fej() ? 1 : 0);
+    pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, F, w.fej() ? 1 : 0, nullptr);
   });
   HIP_CHECK(hipGetLastError());
   w.pair_valid = true;
@@ -352,8 +352,16 @@ void firstEstimate(W &w) {
     launchFej<float>(w);
 }
 
+/** extras of the fused device loop (all zero / null for the plain launches) */
+struct SweepExtras {
+  int ublk_read = 0, ublk_write = 0;
+  const int *pending_ptr = nullptr;
+  const int *run_flag = nullptr;
+  bool fused_lin_backsub = false;
+};
+
 template <typename S>
-void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl, bool backsub, double lambda) {
+void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl, bool backsub, double lambda, const SweepExtras &ex) {
   if (!w.n_sweep_blocks) {
     if (lin) HIP_CHECK(hipMemsetAsync(w.d_reduce.ptr, 0, w.reduceCount() * sizeof(double), w.sr.stream));
     return;
@@ -369,6 +377,10 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.lambda_ptr = ctrl ? &ctrl->lambda : nullptr;
   prm.lambda = lambda;
   prm.F = w.F();
+  prm.ublk_read = ex.ublk_read;
+  prm.ublk_write = ex.ublk_write;
+  prm.pending_ptr = ex.pending_ptr;
+  prm.run_flag = ex.run_flag;
   prm.dbg = (w.dbg_sweep && lin == w.dbg_sweep_lin) ? w.dbg_sweep : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
@@ -377,7 +389,13 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   const SweepBlock *tb = w.d_sweep_table.ptr;
   double *pa = w.d_partials.ptr;
   timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
-    if (!lin && backsub) {
+    if (lin && ex.fused_lin_backsub) {
+      // fused LM loop: linearisation at the candidate state = its energy evaluation + calculateIdepths in one pass
+      if (w.fej())
+        sweepKernel<S, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    } else if (!lin && backsub) {
       if (w.fej())
         sweepKernel<S, false, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
       else
@@ -402,13 +420,14 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   HIP_CHECK(hipGetLastError());
 }
 
-void launchSweep(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl = nullptr, bool backsub = false, double lambda = 0) {
-  if (!ctrl) ensurePairConstants(w);
+void launchSweep(W &w, bool lin, bool huber, bool for_marg, const LmControl *ctrl = nullptr, bool backsub = false, double lambda = 0,
+                 const SweepExtras &ex = SweepExtras()) {
+  if (!ctrl && !ex.run_flag) ensurePairConstants(w);
   backsub = backsub && w.opt.optimize_idepths;
   if (w.opt.dtype == DSOPP_HIP_F64)
-    launchSweepTyped<double>(w, lin, huber, for_marg, ctrl, backsub, lambda);
+    launchSweepTyped<double>(w, lin, huber, for_marg, ctrl, backsub, lambda, ex);
   else
-    launchSweepTyped<float>(w, lin, huber, for_marg, ctrl, backsub, lambda);
+    launchSweepTyped<float>(w, lin, huber, for_marg, ctrl, backsub, lambda, ex);
 }
 
 void allreduceIfNeeded(W &w, double *dev, size_t count) {
@@ -422,8 +441,15 @@ size_t schurSmemBytes(int K) {
   return (static_cast<size_t>(kSchurLandmarks) * schurRowStride(Kp) + 2 * kSchurLandmarks) * sizeof(double);
 }
 
-/** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks) */
-void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl) {
+struct FusedReduce {
+  int ublk_parity;
+  LmControl *ctrl_out;
+  LmParams prm;
+};
+
+/** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
+ *  in the fused loop it starts with the LM decision for the pending candidate */
+void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
   static bool attr_set = false;
@@ -446,9 +472,16 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl) {
   a.F = F;
   a.n_schur_blocks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
   a.for_marginalized = for_marg ? 1 : 0;
+  a.ublk_parity = fused ? fused->ublk_parity : 0;
+  a.ctrl_out = fused ? fused->ctrl_out : nullptr;
+  a.st = w.d_state.ptr;
+  a.scalars = w.d_scalars.ptr;
+  a.n_sweep_blocks = w.n_sweep_blocks;
+  a.total_blocks = a.n_schur_blocks + F * F;
+  if (fused) a.prm = fused->prm;
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
-    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t(4096)), st>>>(a);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t(16384)), st>>>(a);
   });
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
@@ -687,6 +720,87 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
   w.pair_valid = false;
   ensurePairConstants(w);
   launchSweep(w, false, true, false);
+  LmControl h;
+  HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&w.hst, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, st));
+  w.sr.sync();  // the only host synchronisation of the solve
+  energy_out = h.energy;
+  iterations = h.iteration;
+  n_valid_out = h.n_valid;
+}
+
+
+/**
+ * Same algorithm, three launches per Gauss-Newton iteration.  A linearisation sweep at the candidate state x + step
+ * already contains the candidate's energy (NEW_EVALUATION_POINT) and, if the step is accepted, IS the next linearisation:
+ *   round r:  K1  linearise at eps + step_r (step_0 = 0)  [+ calculateIdepths for step_r]
+ *             K2' decide step_r from K1's energy, apply accept/reject, then pose-pose + Schur reduction
+ *             K3  solve -> step_{r+1}
+ * max_iterations + 1 rounds, one host synchronisation.  A rejected step without force_accept costs one extra round (the
+ * sweep re-linearises at the reverted state, which reproduces the system the reference keeps via linear_system_valid).
+ * The Schur rows are double-buffered because K1 reads the previous round's rows while writing this round's.
+ */
+void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+  hipStream_t st = w.sr.stream;
+  LmParams prm;
+  prm.function_tolerance = w.opt.function_tolerance;
+  prm.parameter_tolerance = w.opt.parameter_tolerance;
+  prm.decrease_on_accept = 1.0;  // eigen_photometric_bundle_adjustment.cpp:74-75
+  prm.increase_on_reject = 1.0;
+  prm.lambda0 = 1.0 / w.opt.initial_trust_region_radius;
+  prm.max_iterations = w.opt.max_iterations;
+  prm.min_iterations = 3;
+  prm.force_accept = w.opt.force_accept;
+  prm.use_reduced_scalars = w.allreduce ? 1 : 0;
+  LmControl *ctrl = w.d_ctrl.ptr;
+  ensurePairConstants(w);
+  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr, 0, 8 * sizeof(double), st));
+  if (w.n_schur_blocks) idepthNormKernel<<<w.n_schur_blocks, kSchurThreads, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_scalars.ptr + 4);
+  if (w.allreduce) allreduceIfNeeded(w, w.d_scalars.ptr + 4, 1);
+  {
+    LmInitArgs ia;
+    ia.sa = makeSolveArgs(w);
+    ia.partials = w.d_partials.ptr;
+    ia.scalars = w.d_scalars.ptr;
+    ia.schur_table = w.d_schur_table.ptr;
+    ia.n_sweep_blocks = w.n_sweep_blocks;
+    ia.n_schur_blocks = w.n_schur_blocks;
+    ia.ctrl = ctrl;
+    ia.prm = prm;
+    lmBeginKernel<<<1, kSolveThreads, (static_cast<size_t>(w.K()) + 16) * sizeof(double), st>>>(ia);
+  }
+  HIP_CHECK(hipGetLastError());
+  const int rounds = w.opt.max_iterations + 1;
+  for (int r = 0; r < rounds; ++r) {
+    LmControl *cin = ctrl + (r & 1), *cout = ctrl + ((r + 1) & 1);
+    SweepExtras ex;
+    ex.ublk_read = (r + 1) & 1;
+    ex.ublk_write = r & 1;
+    ex.pending_ptr = &cin->pending;
+    ex.fused_lin_backsub = true;
+    launchSweep(w, true, true, false, cin, true, 0.0, ex);
+    if (w.allreduce) {
+      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr, cin);
+      allreduceIfNeeded(w, w.d_scalars.ptr, 4);
+    }
+    FusedReduce fr;
+    fr.ublk_parity = r & 1;
+    fr.ctrl_out = cout;
+    fr.prm = prm;
+    launchReduceSchur(w, false, cin, &fr);
+    if (r + 1 < rounds) launchAssemble(w, 0.0, true, true, false, cout);
+  }
+  // closing problem.calculateEnergy() at the final state: the last sweep already evaluated it unless the last step was
+  // rejected — then the pair constants are rebuilt and a residual sweep re-evaluates energies / candidate statuses
+  LmControl *cfin = ctrl + (rounds & 1);
+  pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, st>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), w.fej() ? 1 : 0, &cfin->need_final_setup);
+  {
+    SweepExtras ex;
+    ex.run_flag = &cfin->need_final_setup;
+    launchSweep(w, false, true, false, nullptr, false, 0.0, ex);
+  }
+  HIP_CHECK(hipGetLastError());
+  w.pair_valid = false;
   LmControl h;
   HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(&w.hst, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, st));
@@ -1361,10 +1475,12 @@ static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
   prepare(*w);
   HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
   stageBegin(*w);
-  if (w->host_driven_lm)
+  if (w->lm_mode == 1)
     lmSolve(*w, e, it, nv);
-  else
+  else if (w->lm_mode == 2)
     lmSolveDevice(*w, e, it, nv);
+  else
+    lmSolveFused(*w, e, it, nv);
   HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
   HIP_CHECK(hipEventSynchronize(w->ev1));
   HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
@@ -1586,7 +1702,7 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
-    w->host_driven_lm = host_driven != 0;
+    w->lm_mode = host_driven;
   });
 }
 

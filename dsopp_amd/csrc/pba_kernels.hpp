@@ -142,7 +142,8 @@ __device__ inline void refreshPairCurrent(const FrameDev *frames, const WindowSt
   P.b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
 }
 
-__global__ void pairSetupKernel(const FrameDev *frames, const WindowState *st, PairConst *pc, int F, int fej) {
+__global__ void pairSetupKernel(const FrameDev *frames, const WindowState *st, PairConst *pc, int F, int fej, const int *run_flag) {
+  if (run_flag && !*run_flag) return;
   const int idx = threadIdx.x;
   if (idx >= F * F) return;
   computePairConst(frames, st, pc, idx / F, idx % F, F, fej != 0);
@@ -226,6 +227,9 @@ struct SweepParams {
   const double *lambda_ptr;  // BACKSUB: &LmControl::lambda or nullptr (then `lambda`)
   double lambda;
   int F;
+  int ublk_read, ublk_write;  // parity of the double-buffered Schur rows read by BACKSUB / written by LIN (0, 0 outside the fused loop)
+  const int *pending_ptr;     // fused loop: &LmControl::pending — BACKSUB only when a candidate step is pending
+  const int *run_flag;        // nullable: launch is a no-op unless *run_flag != 0 (closing evaluation after a rejected step)
   long long *dbg;  // nullable tuning aid: per-phase wall_clock64 stamps of workgroup 0 / max end stamp
 };
 #define SWEEP_STAMP(i) do { if (prm.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) prm.dbg[i] = wall_clock64(); } while (0)
@@ -293,6 +297,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
   __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? kPartial : 4) * kRedStride];
+  if (prm.run_flag && !*prm.run_flag) return;
   if (prm.ctrl_active) {
     // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
     // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
@@ -344,11 +349,11 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     // calculateIdepths — hessian_block_evaluation.hpp:238-263: lane k of the item takes the frame blocks k, k+8, ... of
     // h_p^T step; the 8 partial dot products are summed across the item's lanes
     double d = 0;
-    const bool upd = active && !(flg & (kFlagMarginalized | kFlagIllConditioned));
+    const bool upd = active && !(flg & (kFlagMarginalized | kFlagIllConditioned)) && (!prm.pending_ptr || *prm.pending_ptr);
     if (upd) {
       for (int tt = k; tt < prm.F; tt += kPat) {
         if (tt != be.r && fr.status[tt] == nullptr) continue;
-        const double *src = fr.ublk + (static_cast<size_t>(tt) * fr.cap + i) * kUblk;
+        const double *src = fr.ublk + ((static_cast<size_t>(prm.ublk_read) * kMaxFrames + tt) * fr.cap + i) * kUblk;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) d += src[c] * prm.step[kBlk * tt + c];
       }
@@ -487,7 +492,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       double mine = gj[0];
 #pragma unroll
       for (int a = 1; a < kBlk; ++a) mine = (k == a) ? gj[a] : mine;
-      double *dst = fr.ublk + (static_cast<size_t>(be.t) * fr.cap + i) * kUblk;
+      double *dst = fr.ublk + ((static_cast<size_t>(prm.ublk_write) * kMaxFrames + be.t) * fr.cap + i) * kUblk;
       dst[k] = -mine;
       if (k < 2) dst[8 + k] = k == 0 ? gj[8] : gj[9];
     }
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       acc[44] = energy;
       acc[45] = energy > 0 ? 1.0 : 0.0;
     }
-    if (!LIN && be.t == fr.first_conn) {
+    if ((!LIN || BACKSUB) && be.t == fr.first_conn) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
       acc[46] = idepth_step_d * idepth_step_d;
       acc[47] = idepth_d * idepth_step_d;

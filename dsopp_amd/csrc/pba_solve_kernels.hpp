@@ -21,7 +21,8 @@ struct LmControl {
   int linear_system_valid;
   int iteration;           // loop bodies executed
   int need_final_setup;    // last step was rejected: pair constants must be rebuilt before the closing energy sweep
-  int pad0, pad1;
+  int pending;             // fused loop: a candidate step is waiting for its energy (0 in the first round / after a re-linearisation)
+  int relin;               // fused loop: the last candidate was rejected, the next sweep re-linearises at the reverted state
 };
 
 struct LmParams {
@@ -106,9 +107,152 @@ struct ReduceSchurArgs {
   int F;
   int n_schur_blocks;
   int for_marginalized;
+  int ublk_parity;  // which half of the double-buffered Schur rows the preceding sweep wrote
+  // fused loop (nullable ctrl_out = plain reduction): the decision of the pending candidate is taken HERE, from the
+  // energy the linearisation sweep at the candidate state produced (levenberg_marquardt_algorithm.hpp:93-123)
+  LmControl *ctrl_out;
+  WindowState *st;
+  const double *scalars;  // multi-GPU: all-reduced {energy, n_valid, step^2, idepth.step}
+  int n_sweep_blocks;
+  int total_blocks;
+  LmParams prm;
 };
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+/**
+ * Fused-loop prologue of the reduction kernel, executed identically by every workgroup: take the LM decision for the
+ * pending candidate from the energy the linearisation sweep just produced at the candidate state, apply it to this
+ * workgroup's landmark chunk (acceptStep / rejectStep, problem.hpp:366-402), workgroup 0 also moves the frame states and
+ * publishes the outgoing control block.  Returns true when a linear system has to be built from the sweep's output.
+ */
+__device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /* >= 6 * 258 doubles */) {
+  __shared__ LmControl s_out;
+  __shared__ int s_accept, s_proceed;
+  const int tid = threadIdx.x;
+  const LmControl cin = *a.ctrl;
+  if (!cin.active) {
+    if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
+    return false;
+  }
+  // deterministic sums: energy, n_valid, |idepth step|^2, idepth . step (sweep partials) and the frame norms
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  if (a.prm.use_reduced_scalars) {
+    if (tid == 0) {
+      v[0] = a.scalars[0];
+      v[1] = a.scalars[1];
+      v[2] = a.scalars[2];
+      v[3] = a.scalars[3];
+    }
+  } else {
+    for (int b = tid; b < a.n_sweep_blocks; b += kSchurThreads) {
+      const double *p = a.partials + static_cast<size_t>(b) * kPartial;
+      v[0] += p[44];
+      v[1] += p[45];
+      v[2] += p[46];
+      v[3] += p[47];
+    }
+  }
+  if (tid < kBlk * a.F) {
+    const int f = tid >> 3, c = tid & 7;
+    const double e = a.st->eps[f][c], s = a.st->step[f][c];
+    v[4] = e * e + (c < 2 ? a.st->ab0[f][c] * a.st->ab0[f][c] : 0.0);
+    v[5] = s * s;
+  }
+  constexpr int RS = kSchurThreads + 2;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) lds[e * RS + tid] = v[e];
+  __syncthreads();
+  if (tid < 6) {
+    double s = 0;
+    for (int j = 0; j < kSchurThreads; ++j) s += lds[tid * RS + j];
+    lds[6 * RS + tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double *t = lds + 6 * RS;
+    LmControl c = cin;
+    int accept = 0, proceed = 0;
+    const double eval_energy = t[0] + cin.cand_prior;
+    const int n_valid = static_cast<int>(t[1] + 0.5);
+    if (!cin.pending) {
+      if (cin.relin) {
+        // re-linearisation at the reverted state after a rejected step: nothing to decide
+        c.relin = 0;
+        proceed = 1;
+      } else {
+        // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
+        c.energy = eval_energy;
+        c.n_valid = n_valid;
+        c.active = (a.prm.max_iterations > 0 && n_valid > 0) ? 1 : 0;
+        proceed = c.active;
+      }
+    } else {
+      c.iteration = cin.iteration + 1;
+      c.pending = 0;
+      if (n_valid == 0) {
+        c.active = 0;  // problem.rejectStep(); break;
+        c.need_final_setup = 1;
+      } else {
+        if (fabs(cin.energy - eval_energy) / cin.energy < a.prm.function_tolerance) c.converged = 1;
+        if (eval_energy < cin.energy || (a.prm.force_accept && cin.iteration < a.prm.min_iterations)) {
+          accept = 1;
+          const double state_sq = t[4] + cin.idepth_sq, step_sq = t[5] + t[2];
+          if (step_sq < a.prm.parameter_tolerance * (state_sq + a.prm.parameter_tolerance)) c.converged = 1;
+          c.energy = eval_energy;
+          c.n_valid = n_valid;
+          c.lambda = cin.lambda / a.prm.decrease_on_accept;
+          c.idepth_sq = cin.idepth_sq + 2.0 * t[3] + t[2];
+          c.need_final_setup = 0;
+          proceed = 1;
+        } else {
+          c.need_final_setup = 1;
+          if (a.prm.force_accept) {
+            c.active = 0;  // problem.calculateEnergy(); return result;
+          } else {
+            c.lambda = cin.lambda * a.prm.increase_on_reject;
+            c.relin = 1;  // the sweep's output belongs to the rejected state: re-linearise at the reverted one
+          }
+        }
+        if (c.converged || c.iteration >= a.prm.max_iterations) c.active = 0;
+      }
+      if (!c.active) proceed = 0;
+    }
+    s_accept = accept;
+    s_proceed = proceed;
+    s_out = c;
+  }
+  __syncthreads();
+  const int accept = s_accept;
+  if (cin.pending) {
+    if (static_cast<int>(blockIdx.x) < a.n_schur_blocks) {
+      const SchurBlock be = a.schur_table[blockIdx.x];
+      const FrameDev &fr = a.frames[be.r];
+      const int i = be.offset + tid;
+      if (tid < kSchurLandmarks && i < fr.n) {
+        if (accept) fr.idepth[i] += fr.idepth_step[i];
+        fr.idepth_step[i] = 0;
+        for (int t = 0; t < a.F; ++t) {
+          if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
+          if (accept)
+            fr.status[t][i] = fr.cand[t][i];
+          else
+            fr.cand[t][i] = fr.status[t][i];
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid < kBlk * a.F) {
+      const int f = tid >> 3, c = tid & 7;
+      if (accept) a.st->eps[f][c] += a.st->step[f][c];
+      a.st->step[f][c] = 0;
+    }
+  } else if (!cin.relin) {
+    // first round: candidate statuses of the initial evaluation are NOT promoted (the reference only promotes on accept)
+  }
+  if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = s_out;
+  __syncthreads();
+  return s_proceed != 0;
+}
 
 /**
  * grid = n_schur_blocks + F*F workgroups of 256 threads.
@@ -122,7 +266,11 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
  */
 __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) return;
+  if (a.ctrl_out) {
+    if (!fusedDecideApply(a, reinterpret_cast<double *>(smem_raw))) return;
+  } else if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) {
+    return;
+  }
   const int F = a.F, K = kBlk * F;
   if (static_cast<int>(blockIdx.x) >= a.n_schur_blocks) {
     // ---- pair block
@@ -187,7 +335,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       for (int t = sub; t < F; t += 4) {
         if (t == r || fr.status[t] == nullptr) continue;
         const PairConst &P = a.pc[r * kMaxFrames + t];
-        const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
+        const double *src = fr.ublk + ((static_cast<size_t>(a.ublk_parity) * kMaxFrames + t) * fr.cap + i) * kUblk;
         double ht[kBlk];
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) {
@@ -221,7 +369,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       double inv = 0, ibd = 0;
       if (take) {
         double *row = hrow + l * stride;
-        double *dst = fr.ublk + (static_cast<size_t>(r) * fr.cap + i) * kUblk;
+        double *dst = fr.ublk + ((static_cast<size_t>(a.ublk_parity) * kMaxFrames + r) * fr.cap + i) * kUblk;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) {
           row[kBlk * r + c] = hr[c];
@@ -361,7 +509,7 @@ __host__ __device__ constexpr int lowIdx(int i, int j) { return i * (i + 1) / 2 
  */
 __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (a.ctrl && !a.ctrl->active) return;
+  if (a.ctrl && (!a.ctrl->active || a.ctrl->relin)) return;
   const int F = a.F, K = kBlk * F;
   const int N = K + 1;   // augmented with the right-hand side row
   const int ld = N + 1;
@@ -605,7 +753,10 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
   DSOPP_STAMP(5);
   if (a.ctrl) {
     const double pe = priorEnergyBlock(a, true, A, tid);
-    if (tid == 0) a.ctrl->cand_prior = pe;
+    if (tid == 0) {
+      a.ctrl->cand_prior = pe;
+      a.ctrl->pending = 1;
+    }
   }
   DSOPP_STAMP(6);
 }
@@ -762,7 +913,8 @@ __global__ void __launch_bounds__(kSolveThreads) lmInitKernel(LmInitArgs a) {
     c.linear_system_valid = 0;
     c.need_final_setup = 0;
     c.active = (a.prm.max_iterations > 0 && c.n_valid > 0) ? 1 : 0;
-    c.pad0 = c.pad1 = 0;
+    c.pending = 0;
+    c.relin = 0;
     a.ctrl[0] = c;
     a.ctrl[1] = c;
   }
@@ -901,6 +1053,29 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
     const uint8_t s = fr.snap_status[t][i];
     fr.status[t][i] = s;
     fr.cand[t][i] = s;
+  }
+}
+
+/** fused loop: control block before the first sweep (prior energy of the initial state goes to cand_prior); one workgroup */
+__global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
+  if (threadIdx.x == 0) {
+    LmControl c;
+    c.lambda = a.prm.lambda0;
+    c.energy = 0;
+    c.cand_prior = prior;
+    c.idepth_sq = a.scalars[4];
+    c.n_valid = 0;
+    c.converged = 0;
+    c.active = 1;
+    c.linear_system_valid = 0;
+    c.iteration = 0;
+    c.need_final_setup = 0;
+    c.pending = 0;
+    c.relin = 0;
+    a.ctrl[0] = c;
+    a.ctrl[1] = c;
   }
 }
 

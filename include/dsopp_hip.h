@@ -180,10 +180,11 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
  * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:83-86) without the post-processing (relinearise, covariance, statuses).
  * One loop body = one Gauss-Newton iteration = linearize + calculateStep + calculateEnergy + accept/reject. */
 int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid);
-/* 0 (default): the LM control flow of solve/optimize runs on the device (one stream of launches, one read-back);
- * 1: it runs on the host through the stage entry points (one small read-back per energy evaluation) — same arithmetic,
- * kept for debugging and as a parity cross-check of the device control logic */
-int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven);
+/* 0 (default): fused device-side LM loop — 3 launches per Gauss-Newton iteration, one read-back per solve;
+ * 1: control flow on the host through the stage entry points (one small read-back per energy evaluation);
+ * 2: unfused device-side loop (5 launches per iteration).  Same arithmetic in all three; 1 and 2 are kept for debugging and
+ * as parity cross-checks of the fused control logic */
+int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int mode);
 /* TrustRegion...Options::max_iterations of an existing window */
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations);
 

@@ -90,7 +90,7 @@ def test_stage_parity_small(small_window, fej):
     g.close()
 
 
-@pytest.mark.parametrize("host_driven", [False, True])
+@pytest.mark.parametrize("host_driven", [0, 1, 2])
 def test_full_solve_parity(small_window, host_driven):
     """solve() with the LM control flow on the device (default) and on the host: both must reproduce the oracle."""
     win = small_window
