@@ -479,6 +479,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
   if (fused) a.prm = fused->prm;
+  a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
     reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t(16384)), st>>>(a);
@@ -1658,10 +1659,10 @@ int dsopp_hip_debug_sweep_stamps(dsopp_hip_window *w, int lin, long long *out16)
 int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
   return guarded([&] {
     if (!w->dbg_stamps) {
-      HIP_CHECK(hipMalloc(&w->dbg_stamps, 8 * sizeof(long long)));
-      HIP_CHECK(hipMemset(w->dbg_stamps, 0, 8 * sizeof(long long)));
+      HIP_CHECK(hipMalloc(&w->dbg_stamps, 16 * sizeof(long long)));
+      HIP_CHECK(hipMemset(w->dbg_stamps, 0, 16 * sizeof(long long)));
     }
-    HIP_CHECK(hipMemcpy(out8, w->dbg_stamps, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out8, w->dbg_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   });
 }
 

@@ -116,7 +116,9 @@ struct ReduceSchurArgs {
   int n_sweep_blocks;
   int total_blocks;
   LmParams prm;
+  long long *dbg;  // nullable tuning aid
 };
+#define RS_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[i] = wall_clock64(); } while (0)
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -266,6 +268,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /*
  */
 __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  RS_STAMP(0);
   if (a.ctrl_out) {
     if (!fusedDecideApply(a, reinterpret_cast<double *>(smem_raw))) return;
   } else if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) {
@@ -313,9 +316,11 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   const SchurBlock be = a.schur_table[blockIdx.x];
   const FrameDev &fr = a.frames[be.r];
   const int r = be.r;
+  RS_STAMP(1);
   // zero the tile rows (pad columns must be 0)
   for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;
   __syncthreads();
+  RS_STAMP(2);
   // phase 1: 4 threads per landmark (each handles the targets t = sub, sub+4, ...), combined through LDS atomics-free adds
   {
     const int l = threadIdx.x >> 2, sub = threadIdx.x & 3;
@@ -393,6 +398,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     }
   }
   __syncthreads();
+  RS_STAMP(3);
   // phase 2: H_schur tiles with v_mfma_f64_16x16x4_f64.  A[i][k] = inv_k * h_k[16*ti + i], B[k][j] = h_k[16*tj + j];
   // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]  (cdna_hip_programming.md §3)
   {
@@ -425,11 +431,13 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
         if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.Hsc[row * K + col], v);
       }
     }
+    RS_STAMP(4);
     for (int c = threadIdx.x; c < K; c += kSchurThreads) {
       double s = 0;
       for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + c];
       if (s != 0) atomicAdd(&a.bsc[c], s);
     }
+    RS_STAMP(5);
   }
 }
 
@@ -611,12 +619,16 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
     }
   }
   __syncthreads();
-  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T
+  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T.
+  // Look-ahead schedule, one barrier per 8x8 frame block: wave 0 ("panel wave") brings block column kb+1 up to date with
+  // panel kb, factors its diagonal block in registers and solves the panel below it, WHILE waves 1..3 apply panel kb to
+  // the rest of the trailing matrix (columns >= kb+2).  The sequential factor chain is thus off the other waves' path.
   DSOPP_STAMP(2);
-  for (int kb = 0; kb < F; ++kb) {
+  const int wave = tid >> 6, lane = tid & 63;
+  auto factorAndPanel = [&](int kb) {
+    // wave 0 only: Cholesky of the diagonal block kb (redundantly per lane, in registers), then the panel rows below it
     const int k0 = kb * kBlk;
-    // (1) every thread factors the 8x8 diagonal block and inverts its Cholesky factor in registers
-    double L[36], Li[36];
+    double L[36], invd[kBlk];
 #pragma unroll
     for (int i = 0; i < kBlk; ++i)
 #pragma unroll
@@ -631,9 +643,8 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = okp ? inv : 0.0;
-      const double lkk = okp ? d * inv : 0.0;
-      L[lowIdx(k, k)] = lkk;
-      Li[lowIdx(k, k)] = inv;
+      L[lowIdx(k, k)] = okp ? d * inv : 0.0;
+      invd[k] = inv;
 #pragma unroll
       for (int i = k + 1; i < kBlk; ++i) L[lowIdx(i, k)] *= inv;
 #pragma unroll
@@ -641,61 +652,92 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
 #pragma unroll
         for (int i = j; i < kBlk; ++i) L[lowIdx(i, j)] -= L[lowIdx(i, k)] * L[lowIdx(j, k)];
     }
-    // inverse of the lower-triangular factor: Li_ij = -(sum_{k=j}^{i-1} L_ik Li_kj) / L_ii
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j)
-#pragma unroll
-      for (int i = j + 1; i < kBlk; ++i) {
-        double s = 0;
-#pragma unroll
-        for (int k = j; k < i; ++k) s += L[lowIdx(i, k)] * Li[lowIdx(k, j)];
-        Li[lowIdx(i, j)] = -s * Li[lowIdx(i, i)];
-      }
-    // (2) panel: rows below the block, L_ik = A_ik * L_kk^-T
-    const int row = k0 + kBlk + tid;
-    double out[kBlk];
-    if (row < N) {
+    // panel: L_row = A_row * L_kk^-T by forward substitution (rows k0+8 .. N-1, one or two per lane)
+    for (int row = k0 + kBlk + lane; row < N; row += 64) {
       double v[kBlk];
 #pragma unroll
       for (int c = 0; c < kBlk; ++c) v[c] = A[row * ld + k0 + c];
 #pragma unroll
       for (int c = 0; c < kBlk; ++c) {
-        double s = 0;
+        double sacc = v[c];
 #pragma unroll
-        for (int k = 0; k <= c; ++k) s += v[k] * Li[lowIdx(c, k)];
-        out[c] = s;
+        for (int k = 0; k < c; ++k) sacc -= v[k] * L[lowIdx(c, k)];
+        v[c] = sacc * invd[c];
+      }
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = v[c];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < kBlk; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) A[(k0 + i) * ld + k0 + j] = L[lowIdx(i, j)];
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) Linv[kb * 36 + lowIdx(c, c)] = invd[c];  // diagonal of the inverse; completed below
+    }
+  };
+  if (wave == 0) factorAndPanel(0);
+  __syncthreads();
+  for (int kb = 0; kb < F; ++kb) {
+    const int k0 = kb * kBlk, k1 = k0 + kBlk, k2 = k1 + kBlk;
+    if (kb + 1 < F) {
+      // all waves: block column kb+1 (rows k1 .. N-1, columns k1 .. k1+7) -= panel kb contribution (one element per thread)
+      const int n_el = (N - k1) * kBlk;
+      for (int e = tid; e < n_el; e += kSolveThreads) {
+        const int row = k1 + (e >> 3), col = k1 + (e & 7);
+        if (col > row) continue;
+        const double *li = A + row * ld + k0, *lj = A + col * ld + k0;
+        double sacc = 0;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) sacc += li[c] * lj[c];
+        A[row * ld + col] -= sacc;
       }
     }
-    __syncthreads();  // all reads of the diagonal block / panel are done
-    if (row < N) {
-#pragma unroll
-      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = out[c];
-    }
-    if (tid == kSolveThreads - 1) {
-#pragma unroll
-      for (int e = 0; e < 36; ++e) Linv[kb * 36 + e] = Li[e];
-    }
     __syncthreads();
-    // (3) trailing update of the lower triangle: A_ij -= sum_c L_ic L_jc
-    const int r0 = k0 + kBlk, rem = N - r0;
-    {
-      const int tr = tid >> 4, tc = tid & 15;
-      for (int ii = tr; ii < rem; ii += 16) {
-        const double *li = A + (r0 + ii) * ld + k0;
+    if (wave == 0) {
+      if (kb + 1 < F) factorAndPanel(kb + 1);
+    } else {
+      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
+      const int t = tid - 64, tr = t >> 4, tc = t & 15;
+      for (int row = k2 + tr; row < N; row += 12) {
+        const double *li = A + row * ld + k0;
         double lic[kBlk];
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) lic[c] = li[c];
-        for (int jj = tc; jj <= ii; jj += 16) {
-          const double *lj = A + (r0 + jj) * ld + k0;
-          double s = 0;
+        for (int col = k2 + tc; col <= row; col += 16) {
+          const double *lj = A + col * ld + k0;
+          double sacc = 0;
 #pragma unroll
-          for (int c = 0; c < kBlk; ++c) s += lic[c] * lj[c];
-          A[(r0 + ii) * ld + r0 + jj] -= s;
+          for (int c = 0; c < kBlk; ++c) sacc += lic[c] * lj[c];
+          A[row * ld + col] -= sacc;
         }
       }
     }
     __syncthreads();
   }
+  // inverses of the F diagonal factors, all at once (thread f inverts block f): Li_ij = -(sum_{k=j}^{i-1} L_ik Li_kj) / L_ii
+  if (tid < F) {
+    const int k0 = tid * kBlk;
+    double L[36], Li[36];
+#pragma unroll
+    for (int i = 0; i < kBlk; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) L[lowIdx(i, j)] = A[(k0 + i) * ld + k0 + j];
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) Li[lowIdx(c, c)] = Linv[tid * 36 + lowIdx(c, c)];
+#pragma unroll
+    for (int j = 0; j < kBlk; ++j)
+#pragma unroll
+      for (int i = j + 1; i < kBlk; ++i) {
+        double sacc = 0;
+#pragma unroll
+        for (int k = j; k < i; ++k) sacc += L[lowIdx(i, k)] * Li[lowIdx(k, j)];
+        Li[lowIdx(i, j)] = -sacc * Li[lowIdx(i, i)];
+      }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) Linv[tid * 36 + e] = Li[e];
+  }
+  __syncthreads();
   // ---- back substitution x = L^-T y, blocked (y = row K of L); x_k = Linv_kk^T (y_k - sum_{j>k} L_jk^T x_j).
   // One wave, rows spread over its lanes: no workgroup barriers on this strictly sequential chain.
   DSOPP_STAMP(3);

@@ -3,11 +3,12 @@ sys.path.insert(0,'.')
 from dsopp_amd import capi, synthetic as syn
 win = syn.make_window(7, 2000, 640, 480, seed=0)
 g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
-out = (C.c_longlong*8)()
+out = (C.c_longlong*16)()
 capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
 g.snapshot()
 for _ in range(3):
     g.restore(); g.optimize()
 capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
 st = np.array(list(out), dtype=np.int64)
-print("phase us:", np.diff(st[:7]) / 100.0, "total", (st[6]-st[0])/100.0)
+print("solve phase us:", np.diff(st[:7]) / 100.0, "total", (st[6]-st[0])/100.0)
+print("reduceSchur (wg 1) phase us:", np.diff(st[8:14]) / 100.0, "total", (st[13]-st[8])/100.0)
