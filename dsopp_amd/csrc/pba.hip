@@ -260,7 +260,29 @@ void syncTopology(W &w) {
       }
       pair_count[static_cast<size_t>(r * kMaxFrames + t)] = cnt;
     }
-    for (int off = 0; off < f.n; off += kSchurLandmarks) schur.push_back(SchurBlock{r, off});
+    for (int off = 0; off < f.n; off += kSchurLandmarks) {
+      SchurBlock sb;
+      std::memset(&sb, 0, sizeof(sb));
+      sb.r = r;
+      sb.offset = off;
+      sb.n = d.n;
+      sb.cap = d.cap;
+      sb.fixed = d.fixed;
+      sb.idepth = d.idepth;
+      sb.idepth_step = d.idepth_step;
+      sb.inv_hdd = d.inv_hdd;
+      sb.b_d = d.b_d;
+      sb.ublk = d.ublk;
+      sb.flags = d.flags;
+      for (int t = 0; t < F; ++t) {
+        if (d.status[t] == nullptr) continue;
+        sb.conn_mask |= 1u << t;
+        sb.status[t] = d.status[t];
+        sb.cand[t] = d.cand[t];
+        sb.n_res[t] = d.n_res[t];
+      }
+      schur.push_back(sb);
+    }
   }
   w.d_frames.reserve(kMaxFrames, 0, st);
   w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
@@ -438,7 +460,7 @@ void allreduceIfNeeded(W &w, double *dev, size_t count) {
 
 size_t schurSmemBytes(int K) {
   const int Kp = (K + 15) & ~15;
-  return (static_cast<size_t>(kSchurLandmarks) * schurRowStride(Kp) + 2 * kSchurLandmarks) * sizeof(double);
+  return (static_cast<size_t>(kSchurLandmarks) * schurRowStride(Kp) + 2 * kSchurLandmarks + 40 * static_cast<size_t>(kMaxFrames)) * sizeof(double);
 }
 
 struct FusedReduce {
@@ -482,7 +504,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
-    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t(16384)), st>>>(a);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8)), st>>>(a);
   });
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer

@@ -236,6 +236,11 @@ struct SweepParams {
 
 constexpr int kItemsPerBlock = kSweepThreads / kPat;  // 8 lanes (one per pattern pixel) per (landmark, target) item
 
+/** Workgroup barrier that only orders LDS traffic: unlike __syncthreads() it does not drain outstanding global stores
+ *  (vmcnt), which costs 1-2 us when a phase ends with scattered stores nobody in the workgroup reads back. */
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
 /** v of the lane selected by a DPP control word (quad_perm / row_half_mirror / ...): pure VALU, no LDS round trip */
 template <int CTRL>
 __device__ __forceinline__ double dppMove(double v) {
@@ -267,7 +272,7 @@ __device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], 
   const int t = threadIdx.x;
 #pragma unroll
   for (int e = 0; e < COUNT; ++e) lds[e * kRedStride + t] = acc[FIRST + e];
-  __syncthreads();
+  ldsBarrier();
   if (t < COUNT) {
     const double2 *row = reinterpret_cast<const double2 *>(lds + t * kRedStride);
     double s0 = 0, s1 = 0;

@@ -38,15 +38,13 @@ struct LmParams {
 // K2: per-pair reduction + Schur complement
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSchurLandmarks = 64;
-constexpr int kSchurThreads = 256;
+constexpr int kSchurThreads = 512;  // 8 lanes per landmark in the finalisation phase, 8 waves for the MFMA tiles
 constexpr int kPairBlk = 144;  // per pair: TGT[64] | GT[64] | T^T q [8] | pad
 
 /** LDS row stride (in doubles) for K-wide rows read as 16-lane x 4-row MFMA operands without bank conflicts:
  *  smallest s >= Kp with s % 32 == 16 (ds_read_b64 banks = (addr/4) % 64, two rows per 32-lane group) */
 __host__ __device__ inline int schurRowStride(int Kp) {
-  int s = Kp;
-  while (s % 32 != 16) ++s;
-  return s;
+  return ((Kp + 15) / 32) * 32 + 16;  // smallest s >= Kp with s % 32 == 16 (closed form: a search loop here gets strength-reduced into the kernel)
 }
 
 /** derived per-pair blocks from G, q:  TGT = T^T G T (H_rr contribution), GT = G T (H_rt = -(GT)^T), Tq = T^T q (b_r),
@@ -128,14 +126,89 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
  * workgroup's landmark chunk (acceptStep / rejectStep, problem.hpp:366-402), workgroup 0 also moves the frame states and
  * publishes the outgoing control block.  Returns true when a linear system has to be built from the sweep's output.
  */
-__device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /* >= 6 * 258 doubles */) {
+struct ApplyRegs {
+  uint8_t *p_status[2], *p_cand[2];
+  uint8_t v_status[2], v_cand[2];
+  double *p_idepth, *p_istep;
+  double v_idepth, v_istep;
+  double st_eps, st_step;
+  const LmControl *out;  // LDS copy of the outgoing control block (workgroup 0 publishes it)
+  int accept, pending, publish;
+};
+
+/** the stores of acceptStep / rejectStep decided by fusedDecideApply.  Issued at the END of the kernel: gfx9 counts
+ *  stores in vmcnt, so any load wait that follows a store also waits for the store's round trip to HBM. */
+__device__ inline void applyDecision(const ReduceSchurArgs &a, const ApplyRegs &ar) {
+  const int tid = threadIdx.x;
+  if (ar.pending) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (ar.p_status[h] == nullptr) continue;
+      if (ar.accept)
+        *ar.p_status[h] = ar.v_cand[h];
+      else
+        *ar.p_cand[h] = ar.v_status[h];
+    }
+    if (ar.p_idepth != nullptr) {
+      if (ar.accept) *ar.p_idepth = ar.v_idepth + ar.v_istep;
+      *ar.p_istep = 0;
+    }
+    if (blockIdx.x == 0 && tid < kBlk * a.F) {
+      const int f = tid >> 3, c = tid & 7;
+      if (ar.accept) a.st->eps[f][c] = ar.st_eps + ar.st_step;
+      a.st->step[f][c] = 0;
+    }
+  }
+  if (ar.publish && blockIdx.x == 0 && tid == 0) *a.ctrl_out = *ar.out;
+}
+
+__device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, long long *dbg_out, ApplyRegs &ar) {
   __shared__ LmControl s_out;
   __shared__ int s_accept, s_proceed;
+  __shared__ long long s_dbg[2];
   const int tid = threadIdx.x;
   const LmControl cin = *a.ctrl;
-  if (!cin.active) {
-    if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
-    return false;
+  ar.out = &s_out;
+  ar.pending = 0;
+  ar.accept = 0;
+  ar.publish = 0;
+  // Everything the apply phase needs is fetched up front, so that the dependent chain table -> pointer -> value
+  // overlaps the reduction instead of following the decision: 8 threads per landmark, thread `sub` owns the
+  // targets t = sub and sub + 8.
+  const bool is_schur = static_cast<int>(blockIdx.x) < a.n_schur_blocks;
+  uint8_t *p_status[2] = {nullptr, nullptr}, *p_cand[2] = {nullptr, nullptr};
+  uint8_t v_status[2] = {0, 0}, v_cand[2] = {0, 0};
+  double *p_idepth = nullptr, *p_istep = nullptr;
+  double v_idepth = 0, v_istep = 0;
+  if (is_schur) {
+    const SchurBlock &be = a.schur_table[blockIdx.x];
+    const int l = tid >> 3, sub = tid & 7;
+    const int i = be.offset + l;
+    if (i < be.n) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = sub + 8 * h;
+        if (t < a.F && be.status[t] != nullptr && i < be.n_res[t]) {
+          p_status[h] = be.status[t] + i;
+          p_cand[h] = be.cand[t] + i;
+          v_status[h] = *p_status[h];
+          v_cand[h] = *p_cand[h];
+        }
+      }
+      if (sub == 0) {
+        p_idepth = be.idepth + i;
+        p_istep = be.idepth_step + i;
+        v_idepth = *p_idepth;
+        v_istep = *p_istep;
+      }
+    }
+  }
+  double st_eps = 0, st_step = 0, st_ab0 = 0;
+  if (tid < kBlk * a.F) {
+    const int f = tid >> 3, c = tid & 7;
+    st_eps = a.st->eps[f][c];
+    st_step = a.st->step[f][c];
+    if (c < 2) st_ab0 = a.st->ab0[f][c];
   }
   // deterministic sums: energy, n_valid, |idepth step|^2, idepth . step (sweep partials) and the frame norms
   double v[6] = {0, 0, 0, 0, 0, 0};
@@ -155,24 +228,46 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /*
       v[3] += p[47];
     }
   }
-  if (tid < kBlk * a.F) {
-    const int f = tid >> 3, c = tid & 7;
-    const double e = a.st->eps[f][c], s = a.st->step[f][c];
-    v[4] = e * e + (c < 2 ? a.st->ab0[f][c] * a.st->ab0[f][c] : 0.0);
-    v[5] = s * s;
+  if (!cin.active) {  // (the loads above are speculative: they overlap the control block's round trip)
+    if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
+    return false;
   }
+  v[4] = st_eps * st_eps + st_ab0 * st_ab0;
+  v[5] = st_step * st_step;
   constexpr int RS = kSchurThreads + 2;
 #pragma unroll
   for (int e = 0; e < 6; ++e) lds[e * RS + tid] = v[e];
-  __syncthreads();
-  if (tid < 6) {
+  ldsBarrier();
+  if (a.dbg && tid == 0) s_dbg[0] = wall_clock64();
+  // three-level tree (8-way per level), fixed order => deterministic
+  static_assert(kSchurThreads == 512, "reduction tree below assumes 512 threads");
+  double *l2 = lds + 6 * RS;  // [6][64]
+  double *l3 = l2 + 6 * 64;   // [6][8]
+  if (tid < 6 * 64) {
+    const int e = tid >> 6, j = tid & 63;
     double s = 0;
-    for (int j = 0; j < kSchurThreads; ++j) s += lds[tid * RS + j];
-    lds[6 * RS + tid] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += lds[e * RS + 8 * j + k];
+    l2[e * 64 + j] = s;
   }
-  __syncthreads();
+  ldsBarrier();
+  if (tid < 6 * 8) {
+    const int e = tid >> 3, j = tid & 7;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += l2[e * 64 + 8 * j + k];
+    l3[e * 8 + j] = s;
+  }
+  ldsBarrier();
   if (tid == 0) {
-    const double *t = lds + 6 * RS;
+    double t[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += l3[e * 8 + k];
+      t[e] = s;
+    }
     LmControl c = cin;
     int accept = 0, proceed = 0;
     const double eval_energy = t[0] + cin.cand_prior;
@@ -224,35 +319,25 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /*
     s_proceed = proceed;
     s_out = c;
   }
-  __syncthreads();
-  const int accept = s_accept;
-  if (cin.pending) {
-    if (static_cast<int>(blockIdx.x) < a.n_schur_blocks) {
-      const SchurBlock be = a.schur_table[blockIdx.x];
-      const FrameDev &fr = a.frames[be.r];
-      const int i = be.offset + tid;
-      if (tid < kSchurLandmarks && i < fr.n) {
-        if (accept) fr.idepth[i] += fr.idepth_step[i];
-        fr.idepth_step[i] = 0;
-        for (int t = 0; t < a.F; ++t) {
-          if (fr.status[t] == nullptr || i >= fr.n_res[t]) continue;
-          if (accept)
-            fr.status[t][i] = fr.cand[t][i];
-          else
-            fr.cand[t][i] = fr.status[t][i];
-        }
-      }
-    }
-    if (blockIdx.x == 0 && tid < kBlk * a.F) {
-      const int f = tid >> 3, c = tid & 7;
-      if (accept) a.st->eps[f][c] += a.st->step[f][c];
-      a.st->step[f][c] = 0;
-    }
-  } else if (!cin.relin) {
-    // first round: candidate statuses of the initial evaluation are NOT promoted (the reference only promotes on accept)
+  ldsBarrier();
+  if (a.dbg && tid == 0) s_dbg[1] = wall_clock64();
+  if (a.dbg && tid == 0) { dbg_out[0] = s_dbg[0]; dbg_out[1] = s_dbg[1]; }
+  ar.accept = s_accept;
+  ar.pending = cin.pending;
+  ar.publish = 1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    ar.p_status[h] = p_status[h];
+    ar.p_cand[h] = p_cand[h];
+    ar.v_status[h] = v_status[h];
+    ar.v_cand[h] = v_cand[h];
   }
-  if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = s_out;
-  __syncthreads();
+  ar.p_idepth = p_idepth;
+  ar.p_istep = p_istep;
+  ar.v_idepth = v_idepth;
+  ar.v_istep = v_istep;
+  ar.st_eps = st_eps;
+  ar.st_step = st_step;
   return s_proceed != 0;
 }
 
@@ -268,9 +353,16 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds /*
  */
 __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  RS_STAMP(0);
+  const long long rs_t0 = a.dbg ? wall_clock64() : 0;
+  long long rs_dbg[2] = {0, 0};
+  ApplyRegs ar;
+  ar.pending = 0;
+  ar.publish = 0;
   if (a.ctrl_out) {
-    if (!fusedDecideApply(a, reinterpret_cast<double *>(smem_raw))) return;
+    if (!fusedDecideApply(a, reinterpret_cast<double *>(smem_raw), rs_dbg, ar)) {
+      applyDecision(a, ar);
+      return;
+    }
   } else if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) {
     return;
   }
@@ -279,15 +371,31 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     // ---- pair block
     const int p = blockIdx.x - a.n_schur_blocks;
     const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
-    const int lane = threadIdx.x;
-    if (lane >= 64) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const PairConst &P = a.pc[pi];
-    if (!P.valid) return;
-    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch + [kPairBlk] derived
+    const int valid = P.valid;
+    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch + [kPairBlk] derived + [8][48] wave sums
+    double *wsum = lds + 48 + 64 + kPairBlk;
+    // partial sums of the sweep's workgroups: wave w takes the blocks w, w + 8, ... (independent loads), the 8 wave sums
+    // are combined in fixed order => deterministic
+    {
+      double sw = 0;
+      if (valid && lane < 44) {
+        const int first = a.pair_first_block[pi], cnt = a.pair_num_blocks[pi];
+        const double *src = a.partials + static_cast<size_t>(first) * kPartial + lane;
+        int b = wave;
+        for (; b + 8 < cnt; b += 16) sw += src[static_cast<size_t>(b) * kPartial] + src[static_cast<size_t>(b + 8) * kPartial];
+        if (b < cnt) sw += src[static_cast<size_t>(b) * kPartial];
+      }
+      if (lane < 48) wsum[wave * 48 + lane] = sw;
+    }
+    applyDecision(a, ar);
+    ldsBarrier();
+    if (threadIdx.x >= 64 || !valid) return;
     double s = 0;
     if (lane < 44) {
-      const int first = a.pair_first_block[pi], cnt = a.pair_num_blocks[pi];
-      for (int b = 0; b < cnt; ++b) s += a.partials[static_cast<size_t>(first + b) * kPartial + lane];
+#pragma unroll
+      for (int w = 0; w < kSchurThreads / 64; ++w) s += wsum[w * 48 + lane];
     }
     if (lane < 48) lds[lane] = s;
     __builtin_amdgcn_s_waitcnt(0);
@@ -313,91 +421,117 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
   double *wgt = hrow + kSchurLandmarks * stride;        // inv per landmark (0 = excluded)
   double *wbd = wgt + kSchurLandmarks;                  // inv * bd
-  const SchurBlock be = a.schur_table[blockIdx.x];
-  const FrameDev &fr = a.frames[be.r];
+  const SchurBlock &be = a.schur_table[blockIdx.x];
   const int r = be.r;
+  const bool bd_in_pad = K < Kp;  // H_schur^T W b_d as one more column of the SYRK when the tiles have a spare column
+  if (a.dbg && threadIdx.x == 0 && blockIdx.x == 1) { a.dbg[0] = rs_t0; a.dbg[6] = rs_dbg[0]; a.dbg[7] = rs_dbg[1]; }
   RS_STAMP(1);
+  // phase 1: 8 threads per landmark, thread `sub` owns the targets t = sub, sub + 8, ...; the loads of its first target,
+  // of the landmark flags and of this thread's share of the per-target constants T = blockdiag(Adj, 1, s0) are issued
+  // before the LDS rows are cleared so that their latency overlaps.
+  const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  const int i = be.offset + l;
+  const unsigned conn = be.conn_mask & ~(1u << r);
+  const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+  const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
+  bool take = false;
+  uint8_t flg = 0;
+  if (i < be.n) {
+    flg = be.flags[i];
+    take = a.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
+  }
+  double ht[kUblk];
+#pragma unroll
+  for (int c = 0; c < kUblk; ++c) ht[c] = 0;
+  const bool first = i < be.n && sub < F && ((conn >> sub) & 1u);
+  if (first) {
+    const double *src = ubase + sub * plane;
+#pragma unroll
+    for (int c = 0; c < kUblk; ++c) ht[c] = src[c];
+  }
+  double tmv = 0;
+  if (static_cast<int>(threadIdx.x) < F * 37) {
+    const int t = threadIdx.x / 37, c = threadIdx.x - 37 * t;
+    const PairConst &P = a.pc[r * kMaxFrames + t];
+    tmv = c < 36 ? P.Adj[c] : P.s0;
+  }
   // zero the tile rows (pad columns must be 0)
   for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;
-  __syncthreads();
+  double *Tm = wbd + kSchurLandmarks;  // [F][40]: Adj (36), s0
+  if (static_cast<int>(threadIdx.x) < F * 37) {
+    const int t = threadIdx.x / 37, c = threadIdx.x - 37 * t;
+    Tm[t * 40 + c] = tmv;
+  }
+  for (int e = threadIdx.x + kSchurThreads; e < F * 37; e += kSchurThreads) {
+    const int t = e / 37, c = e - 37 * t;
+    const PairConst &P = a.pc[r * kMaxFrames + t];
+    Tm[t * 40 + c] = c < 36 ? P.Adj[c] : P.s0;
+  }
+  ldsBarrier();
   RS_STAMP(2);
-  // phase 1: 4 threads per landmark (each handles the targets t = sub, sub+4, ...), combined through LDS atomics-free adds
   {
-    const int l = threadIdx.x >> 2, sub = threadIdx.x & 3;
-    const int i = be.offset + l;
-    bool take = false;
-    uint8_t flg = 0;
-    if (i < fr.n) {
-      flg = fr.flags[i];
-      take = a.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
-    }
     double hr[kBlk];
 #pragma unroll
     for (int c = 0; c < kBlk; ++c) hr[c] = 0;
     double hdd = 0, bd = 0;
+    double *row = hrow + l * stride;
     if (take) {
-      double *row = hrow + l * stride;
-      for (int t = sub; t < F; t += 4) {
-        if (t == r || fr.status[t] == nullptr) continue;
-        const PairConst &P = a.pc[r * kMaxFrames + t];
-        const double *src = fr.ublk + ((static_cast<size_t>(a.ublk_parity) * kMaxFrames + t) * fr.cap + i) * kUblk;
-        double ht[kBlk];
+      for (int t = sub; t < F; t += 8) {
+        if (!((conn >> t) & 1u)) continue;
+        if (t != sub) {
+          const double *src = ubase + t * plane;
 #pragma unroll
-        for (int c = 0; c < kBlk; ++c) {
-          ht[c] = src[c];
-          row[kBlk * t + c] = ht[c];
+          for (int c = 0; c < kUblk; ++c) ht[c] = src[c];
         }
-        hdd += src[8];
-        bd += src[9];
+        const double *Tt = Tm + t * 40;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) row[kBlk * t + c] = ht[c];
+        hdd += ht[8];
+        bd += ht[9];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
           double s = 0;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) s += P.Adj[6 * k + c] * ht[k];
+          for (int k = 0; k < 6; ++k) s += Tt[6 * k + c] * ht[k];
           hr[c] -= s;
         }
         hr[6] -= ht[6];
-        hr[7] -= P.s0 * ht[7];
+        hr[7] -= Tt[36] * ht[7];
       }
     }
-    // combine the 4 sub-threads of a landmark (adjacent lanes)
+    // combine the 8 sub-threads of a landmark (adjacent lanes)
 #pragma unroll
-    for (int c = 0; c < kBlk; ++c) {
-      hr[c] += __shfl_xor(hr[c], 1, 64);
-      hr[c] += __shfl_xor(hr[c], 2, 64);
-    }
-    hdd += __shfl_xor(hdd, 1, 64);
-    hdd += __shfl_xor(hdd, 2, 64);
-    bd += __shfl_xor(bd, 1, 64);
-    bd += __shfl_xor(bd, 2, 64);
+    for (int c = 0; c < kBlk; ++c) hr[c] = sum8(hr[c]);
+    hdd = sum8(hdd);
+    bd = sum8(bd);
     if (sub == 0) {
       double inv = 0, ibd = 0;
       if (take) {
-        double *row = hrow + l * stride;
-        double *dst = fr.ublk + ((static_cast<size_t>(a.ublk_parity) * kMaxFrames + r) * fr.cap + i) * kUblk;
+        double *dst = const_cast<double *>(ubase) + r * plane;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) {
           row[kBlk * r + c] = hr[c];
           dst[c] = hr[c];
         }
-        fr.b_d[i] = bd;
+        be.b_d[i] = bd;
         const double kIdepthNullSpaceThreshold = 1e-15;
         if (hdd > kIdepthNullSpaceThreshold) {
-          if (a.for_marginalized && fr.fixed) hdd += 1e8;  // kScaleNullspaceRegularizer
+          if (a.for_marginalized && be.fixed) hdd += 1e8;  // kScaleNullspaceRegularizer
           inv = 1.0 / hdd;
-          fr.inv_hdd[i] = inv;
+          be.inv_hdd[i] = inv;
           flg &= static_cast<uint8_t>(~kFlagIllConditioned);
           ibd = inv * bd;
         } else {
           flg |= kFlagIllConditioned;
         }
-        fr.flags[i] = flg;
+        be.flags[i] = flg;
       }
       wgt[l] = inv;
       wbd[l] = ibd;
+      if (bd_in_pad && take) row[K] = bd;
     }
   }
-  __syncthreads();
+  ldsBarrier();
   RS_STAMP(3);
   // phase 2: H_schur tiles with v_mfma_f64_16x16x4_f64.  A[i][k] = inv_k * h_k[16*ti + i], B[k][j] = h_k[16*tj + j];
   // lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]  (cdna_hip_programming.md §3)
@@ -429,16 +563,19 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
         const int row = 16 * ti + lk + 4 * reg, col = 16 * tj + li;
         const double v = acc[reg];
         if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.Hsc[row * K + col], v);
+        if (bd_in_pad && row < K && col == K && v != 0) atomicAdd(&a.bsc[row], v);  // b_schur rides in the pad column
       }
     }
     RS_STAMP(4);
-    for (int c = threadIdx.x; c < K; c += kSchurThreads) {
+    for (int c = threadIdx.x; c < (bd_in_pad ? 0 : K); c += kSchurThreads) {
       double s = 0;
+#pragma unroll 1
       for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + c];
       if (s != 0) atomicAdd(&a.bsc[c], s);
     }
     RS_STAMP(5);
   }
+  applyDecision(a, ar);
 }
 
 /** zeroes the Schur accumulation target unless the device-driven loop skips this linearisation */

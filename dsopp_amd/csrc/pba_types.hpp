@@ -77,10 +77,18 @@ struct SweepBlock {
   int pad;
 };
 
-/** one thread block of the Schur kernel = a chunk of landmarks of one frame */
+/** one thread block of the Schur kernel = a chunk of landmarks of one frame.  The descriptor repeats the frame's
+ *  pointers so that a kernel reaches its data with one dependent load (table -> data) instead of two (table -> FrameDev -> data). */
 struct SchurBlock {
   int r;
   int offset;
+  int n, cap;  // landmarks / landmark capacity of frame r
+  int fixed;
+  unsigned conn_mask;  // bit t: frame r has residuals in target slot t
+  double *idepth, *idepth_step, *inv_hdd, *b_d, *ublk;
+  uint8_t *flags;
+  uint8_t *status[kMaxFrames], *cand[kMaxFrames];
+  int n_res[kMaxFrames];
 };
 
 struct SolveParams {

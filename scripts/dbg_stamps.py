@@ -12,3 +12,4 @@ capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
 st = np.array(list(out), dtype=np.int64)
 print("solve phase us:", np.diff(st[:7]) / 100.0, "total", (st[6]-st[0])/100.0)
 print("reduceSchur (wg 1) phase us:", np.diff(st[8:14]) / 100.0, "total", (st[13]-st[8])/100.0)
+print("prologue: loads+lds", (st[14]-st[8])/100.0, "tree+decide", (st[15]-st[14])/100.0, "apply", (st[9]-st[15])/100.0)

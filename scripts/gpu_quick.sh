@@ -8,5 +8,6 @@ d=json.loads(sys.stdin.read())
 print('value', d['value'], 'ms/step', d['ms_per_step'])
 for k,v in d['kernels'].items(): print(f'  {k:18s} {v[\"avg_us\"]:8.2f} us x {v[\"launches\"]}')
 print(d['roofline'])
+print('isolated', d['kernels_isolated_avg_us'])
 "
 tail -5 gpurun_out/bench.err
