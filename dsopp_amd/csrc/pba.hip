@@ -544,7 +544,7 @@ SolveArgs makeSolveArgs(W &w) {
 
 size_t solveSmemBytes(int K) {
   const size_t N = static_cast<size_t>(K) + 1;
-  return (N * (N + 1) + 2 * static_cast<size_t>(K) + 32 + 36 * static_cast<size_t>(kMaxFrames)) * sizeof(double);
+  return (N * (N + 1) + 4 * static_cast<size_t>(K) + 32 + 38 * static_cast<size_t>(kMaxFrames)) * sizeof(double);
 }
 
 /** K3 */

@@ -71,10 +71,12 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
   P.valid = valid ? 1 : 0;
   if (!valid) return;
   Rigid Tr0, Tt0;
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
     Tr0.R[i] = st->T0_R[r][i];
     Tt0.R[i] = st->T0_R[t][i];
   }
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
     Tr0.t[i] = st->T0_t[r][i];
     Tt0.t[i] = st->T0_t[t][i];
@@ -98,6 +100,7 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
   buildProjectionMatrices(T_tr, fr, ft, Ucur, P.M);
   const Rigid &Tlin = fej ? T_tr0 : T_tr;
   buildProjectionMatrices(Tlin, fr, ft, P.U, nullptr);
+#pragma unroll
   for (int i = 0; i < 3; ++i) P.tl[i] = Tlin.t[i];
   rigidAdj(Tlin, P.Adj);
   P.fxt = ft.fx;

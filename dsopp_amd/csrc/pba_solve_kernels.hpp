@@ -654,7 +654,6 @@ __host__ __device__ constexpr int lowIdx(int i, int j) { return i * (i + 1) / 2 
  */
 __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (a.ctrl && (!a.ctrl->active || a.ctrl->relin)) return;
   const int F = a.F, K = kBlk * F;
   const int N = K + 1;   // augmented with the right-hand side row
   const int ld = N + 1;
@@ -662,84 +661,153 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
   double *pv = A + N * ld;                           // K preconditioner
   double *xs = pv + K;                               // K + 16 scratch
   double *Linv = xs + K + 16;                        // F x 36 inverses of the diagonal blocks
+  double *epsl = Linv + 36 * kMaxFrames;             // K: state increment eps of every frame
+  double *stpl = epsl + K;                           // K: the new step (-x), kept in LDS for the pair refresh / prior energy
+  double *ab0l = stpl + K;                           // 2 F: affine brightness at the linearisation point
   const int tid = threadIdx.x;
-  const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
-  const double sc = -1.0 / (1.0 + lam);
+  // Control block, pair-refresh inputs and the first tile batch are all requested before anything waits: the kernel
+  // start costs one memory round trip.  (The early exit is taken after the first barrier, which keeps the loads above it.)
+  int c_active = 1, c_relin = 0;
+  double lam = a.lambda;
+  if (a.ctrl) {
+    c_active = a.ctrl->active;
+    c_relin = a.ctrl->relin;
+    lam = a.ctrl->lambda;
+  }
   DSOPP_STAMP(0);
+  // inputs of refreshPairCurrent for pair (r, t) = (tid / F, tid % F): constant over the solve.  Raw loads only: any
+  // arithmetic on a loaded value here would make the compiler wait for the round trip before issuing the next loads.
+  struct {
+    int valid;
+    Rigid T0;
+    double fxr, fyr, cxr, cyr, fxt, fyt, cxt, cyt, exposure_r, exposure_t;
+  } pp;
+  pp.valid = 0;
+  const bool fast_refresh = a.fej && a.do_solve && a.ctrl;
+  if (fast_refresh && tid < F * F) {
+    const int r = tid / F, t = tid - F * (tid / F);
+    const PairConst &P = a.pc[r * kMaxFrames + t];
+    pp.valid = P.valid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
+      pp.T0.t[i] = P.T0rel[4 * i + 3];
+    }
+    const FrameDev &fr = a.frames[r];
+    const FrameDev &ft = a.frames[t];
+    pp.fxr = fr.fx;
+    pp.fyr = fr.fy;
+    pp.cxr = fr.cx;
+    pp.cyr = fr.cy;
+    pp.fxt = ft.fx;
+    pp.fyt = ft.fy;
+    pp.cxt = ft.cx;
+    pp.cyt = ft.cy;
+    pp.exposure_r = fr.exposure;
+    pp.exposure_t = ft.exposure;
+  }
 
   // ---- system_pose = sums + priors (problem.hpp:39-62)
-  for (int c = tid; c < K; c += kSolveThreads) xs[c] = a.st->eps[c >> 3][c & 7];
-  // per-frame prior diagonal (problem.hpp:39-62) in LDS, so the element loop has no dependent frame-table loads
-  double *prior_diag = Linv;  // the Linv area is not in use yet
-  for (int c = tid; c < K; c += kSolveThreads) {
-    const int f = c >> 3, i = c & 7;
-    double pd = 0;
-    if (a.add_priors && !a.frames[f].to_marginalize) pd = a.frames[f].fixed ? a.fixed_reg : (i >= 6 ? a.affine_reg[i - 6] : 0.0);
-    prior_diag[c] = pd;
+  double eps_c = 0, ab0_c = 0, bpp_c = 0, bsc_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < kSolveThreads)
+  int fixed_c = 0, tomarg_c = 0;
+  if (tid < K) {
+    const int f = tid >> 3, i = tid & 7;
+    eps_c = a.st->eps[f][i];
+    fixed_c = a.frames[f].fixed;
+    tomarg_c = a.frames[f].to_marginalize;
+    ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];
+    bpp_c = a.bpp_raw[tid];
+    bsc_c = a.bsc[tid];
+    if (a.use_marginal) bm_c = a.bm[tid];
   }
-  {
-    // 16 x 16 thread tiles over the lower triangle (diagonal tiles included); the loads of up to 8 tiles are issued
-    // back to back so the phase costs ~one memory round trip per 8 tiles instead of one per tile
-    const int tr = tid >> 4, tc = tid & 15;
-    const int nt = (K + 15) >> 4, n_tiles = nt * (nt + 1) / 2;
-    constexpr int kTileBatch = 12;
-    for (int base = 0; base < n_tiles; base += kTileBatch) {
-      double hp[kTileBatch], hs[kTileBatch], hm[kTileBatch];
-      int rows[kTileBatch], cols[kTileBatch];
+  double *prior_diag = Linv;  // the Linv area is not in use yet
+  // 16 x 16 thread tiles over the lower triangle (diagonal tiles included); the loads of a whole batch of tiles are issued
+  // back to back so the phase costs ~one memory round trip per batch instead of one per tile
+  const int tile_r = tid >> 4, tile_c = tid & 15;
+  const int nt = (K + 15) >> 4, n_tiles = nt * (nt + 1) / 2;
+  constexpr int kTileBatch = 12;
+  double hp[kTileBatch], hs[kTileBatch], hm[kTileBatch];
+  int rows[kTileBatch], cols[kTileBatch];
+  auto loadBatch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kTileBatch; ++u) {
+      int tile = base + u, tr0 = 0;
+      while (tile >= tr0 + 1) {  // tile row tr0 holds tr0 + 1 tiles
+        tile -= tr0 + 1;
+        ++tr0;
+      }
+      const int row = 16 * tr0 + tile_r, col = 16 * tile + tile_c;
+      const bool in = (base + u) < n_tiles && row < K && col < K;
+      rows[u] = in ? row : -1;
+      cols[u] = col;
+      // unconditional loads from clamped addresses (a select around a load makes hipcc branch and drain vmcnt per element)
+      const int rc = min(row, K - 1), cc = min(col, K - 1);
+      hp[u] = a.Hpp_raw[rc * K + cc];
+      hs[u] = a.Hsc[min(rc, cc) * K + max(rc, cc)];
+      hm[u] = 0;
+    }
+    if (a.use_marginal) {
 #pragma unroll
       for (int u = 0; u < kTileBatch; ++u) {
-        int tile = base + u, tr0 = 0;
-        while (tile >= tr0 + 1) {  // tile row tr0 holds tr0 + 1 tiles
-          tile -= tr0 + 1;
-          ++tr0;
-        }
-        const int row = 16 * tr0 + tr, col = 16 * tile + tc;
-        const bool in = (base + u) < n_tiles && row < K && col < K;
-        rows[u] = in ? row : -1;
-        cols[u] = col;
-        // unconditional loads from clamped addresses (a select around a load makes hipcc branch and drain vmcnt per element)
-        const int rc = min(row, K - 1), cc = min(col, K - 1);
-        hp[u] = a.Hpp_raw[rc * K + cc];
-        hs[u] = a.Hsc[min(rc, cc) * K + max(rc, cc)];
+        const int rc = min(rows[u] < 0 ? 0 : rows[u], K - 1), cc = min(cols[u], K - 1);
         hm[u] = a.Hm[rc * K + cc];
       }
-      __syncthreads();  // prior_diag visible (first batch); harmless afterwards
+    }
+  };
+  loadBatch(0);
+  // opaque to the optimiser: stops it from testing these loaded flags (and waiting for them) above the tile loads
+  asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(pp.valid), "+v"(c_active), "+v"(c_relin));
+  int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness
+  if (tid < K) {
+    if (a.add_priors && !tomarg_c) prior_kind = fixed_c ? 1 : ((tid & 7) >= 6 ? 2 : 0);
+    const double pd_c = prior_kind == 1 ? a.fixed_reg : (prior_kind == 2 ? a.affine_reg[(tid & 7) - 6] : 0.0);
+    xs[tid] = eps_c;
+    epsl[tid] = eps_c;
+    prior_diag[tid] = pd_c;
+    if ((tid & 7) >= 6) ab0l[2 * (tid >> 3) + (tid & 7) - 6] = ab0_c;
+  }
+  __syncthreads();  // fence: keeps every load above; prior_diag visible
+  if (!c_active || c_relin) return;
+  const double sc = -1.0 / (1.0 + lam);
+  auto storeBatch = [&]() {
 #pragma unroll
-      for (int u = 0; u < kTileBatch; ++u) {
-        const int row = rows[u], col = cols[u];
-        if (row < 0) continue;
-        double v = hp[u];
-        if (row == col) v += prior_diag[row];
-        if (a.store_system) {
-          a.Hpp_out[row * K + col] = v;
-          a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
-          if (col < row) a.Hsc[row * K + col] = hs[u];
-        }
-        if (col <= row) {
-          // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)
-          if (row == col) v += v * lam;
-          A[row * ld + col] = v + sc * hs[u] + (a.use_marginal ? hm[u] : 0.0);
-        }
+    for (int u = 0; u < kTileBatch; ++u) {
+      const int row = rows[u], col = cols[u];
+      if (row < 0) continue;
+      double v = hp[u];
+      if (row == col) v += prior_diag[row];
+      if (a.store_system) {
+        a.Hpp_out[row * K + col] = v;
+        a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
+        if (col < row) a.Hsc[row * K + col] = hs[u];
+      }
+      if (col <= row) {
+        // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)
+        if (row == col) v += v * lam;
+        A[row * ld + col] = v + sc * hs[u] + hm[u];
       }
     }
+  };
+  storeBatch();
+  for (int base = kTileBatch; base < n_tiles; base += kTileBatch) {
+    loadBatch(base);
+    storeBatch();
   }
   __syncthreads();
-  for (int c = tid; c < K; c += kSolveThreads) {
-    const int f = c >> 3, i = c & 7;
-    double v = a.bpp_raw[c];
-    if (a.add_priors && !a.frames[f].to_marginalize) {
-      if (a.frames[f].fixed)
-        v += a.fixed_reg * xs[c];
-      else if (i >= 6)
-        v += a.affine_reg[i - 6] * (a.st->ab0[f][i - 6] + xs[c]);
-    }
-    (void)i;
+  if (tid < K) {
+    const int c = tid;
+    double v = bpp_c;
+    if (prior_kind == 1)
+      v += a.fixed_reg * eps_c;
+    else if (prior_kind == 2)
+      v += a.affine_reg[(c & 7) - 6] * (ab0_c + eps_c);
     if (a.store_system) a.bpp_out[c] = v;
-    v += sc * a.bsc[c];
+    v += sc * bsc_c;
     if (a.use_marginal) {
       double s = 0;
       for (int k = 0; k < K; ++k) s += a.Hm[c * K + k] * xs[k];
-      v += a.bm[c] + s;
+      v += bm_c + s;
     }
     A[K * ld + c] = v;
     pv[c] = 1.0 / sqrt(A[c * ld + c] + 10.0);  // jacobiPreconditioner — normal_linear_system.cpp:10-16
@@ -910,15 +978,56 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
     }
   }
   __syncthreads();
-  for (int c = tid; c < K; c += kSolveThreads) {
-    const double x = pv[c] * xs[c];
-    a.step[c] = x;
-    a.st->step[c >> 3][c & 7] = -x;  // problem.hpp:353-357
+  if (tid < K) {
+    const double x = pv[tid] * xs[tid];
+    stpl[tid] = -x;
+    a.step[tid] = x;
+    a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
   }
-  __syncthreads();
   DSOPP_STAMP(4);
-  {
+  if (fast_refresh) {
+    // FEJ: only the current reprojection / brightness constants move with the state; all inputs are in registers / LDS
+    ldsBarrier();
     Rigid *E = reinterpret_cast<Rigid *>(A);  // [2][F]: exp(+xi_f), exp(-xi_f); A is free now
+    if (tid < 2 * F) {
+      const int f = tid < F ? tid : tid - F;
+      const double sign = tid < F ? 1.0 : -1.0;
+      double xi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xi[i] = sign * (epsl[kBlk * f + i] + stpl[kBlk * f + i]);
+      E[tid] = rigidExp(xi);
+    }
+    ldsBarrier();
+    if (tid < F * F && pp.valid) {
+      const int r = tid / F, t = tid - F * (tid / F);
+      PairConst &P = a.pc[r * kMaxFrames + t];
+      const Rigid T_tr = rigidMul(E[F + t], rigidMul(pp.T0, E[r]));
+      // ArrayReprojector ctor — camera_reproject.hpp:235-260 (as buildProjectionMatrices)
+      const double ifx = 1.0 / pp.fxr, ify = 1.0 / pp.fyr;
+      const double k02 = -pp.cxr * ifx, k12 = -pp.cyr * ify;
+      double U[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        U[4 * i + 0] = T_tr.R[3 * i + 0] * ifx;
+        U[4 * i + 1] = T_tr.R[3 * i + 1] * ify;
+        U[4 * i + 2] = T_tr.R[3 * i + 0] * k02 + T_tr.R[3 * i + 1] * k12 + T_tr.R[3 * i + 2];
+        U[4 * i + 3] = T_tr.t[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        P.M[0 + j] = pp.fxt * U[0 + j] + pp.cxt * U[8 + j];
+        P.M[4 + j] = pp.fyt * U[4 + j] + pp.cyt * U[8 + j];
+        P.M[8 + j] = U[8 + j];
+      }
+      const double a_r = ab0l[2 * r] + epsl[kBlk * r + 6] + stpl[kBlk * r + 6];
+      const double a_t = ab0l[2 * t] + epsl[kBlk * t + 6] + stpl[kBlk * t + 6];
+      P.s = (pp.exposure_t / pp.exposure_r) * exp(a_t - a_r);
+      P.b_t = ab0l[2 * t + 1] + epsl[kBlk * t + 7] + stpl[kBlk * t + 7];
+      P.b_r = ab0l[2 * r + 1] + epsl[kBlk * r + 7] + stpl[kBlk * r + 7];
+    }
+  } else {
+    __syncthreads();  // the state written above is re-read from memory below
+    Rigid *E = reinterpret_cast<Rigid *>(A);
     if (tid < 2 * F) E[tid] = frameIncrement(a.st, tid % F, tid < F ? 1.0 : -1.0);
     __syncthreads();
     if (tid < F * F) {
@@ -928,12 +1037,30 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
         computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, false, &E[tid / F], &E[F + tid % F]);
     }
   }
-  __syncthreads();
   DSOPP_STAMP(5);
   if (a.ctrl) {
-    const double pe = priorEnergyBlock(a, true, A, tid);
+    // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312)
+    double part = 0;
+    if (tid < K) {
+      const double xc = epsl[tid] + stpl[tid];
+      if (a.use_marginal) {
+        double sacc = 0;
+        for (int k = 0; k < K; ++k) sacc += a.Hm[tid * K + k] * (epsl[k] + stpl[k]);
+        part += bm_c * xc + 0.5 * xc * sacc;
+      }
+      if ((tid & 7) >= 6) {
+        const double ab = ab0_c + xc;
+        part += 0.5 * ab * a.affine_reg[(tid & 7) - 6] * ab;
+      }
+    }
+    part = waveSum(part);
+    ldsBarrier();  // E (in A) fully consumed before the scratch below is written; stpl visible
+    if ((tid & 63) == 0) pv[tid >> 6] = part;
+    ldsBarrier();
     if (tid == 0) {
-      a.ctrl->cand_prior = pe;
+      double total = a.energy_marginalized;
+      for (int w = 0; w < kSolveThreads / 64; ++w) total += pv[w];
+      a.ctrl->cand_prior = total;
       a.ctrl->pending = 1;
     }
   }

@@ -19,6 +19,7 @@ struct Rigid {
 
 DSOPP_HD Rigid rigidIdentity() {
   Rigid T;
+#pragma unroll
   for (int i = 0; i < 9; ++i) T.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
   T.t[0] = T.t[1] = T.t[2] = 0;
   return T;
@@ -128,8 +129,12 @@ DSOPP_HD Rigid rigidMul(const Rigid &a, const Rigid &b) {
 
 DSOPP_HD Rigid rigidInverse(const Rigid &a) {
   Rigid c;
-  for (int i = 0; i < 3; ++i)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * j + i];
+  }
+#pragma unroll
   for (int i = 0; i < 3; ++i) c.t[i] = -(c.R[3 * i] * a.t[0] + c.R[3 * i + 1] * a.t[1] + c.R[3 * i + 2] * a.t[2]);
   return c;
 }
@@ -145,8 +150,11 @@ DSOPP_HD void rigidNormalize(Rigid &T) {
 DSOPP_HD void rigidAdj(const Rigid &T, double *A) {
   const double *t = T.t;
   const double hx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+#pragma unroll
   for (int i = 0; i < 36; ++i) A[i] = 0;
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       A[6 * i + j] = T.R[3 * i + j];
       A[6 * (i + 3) + (j + 3)] = T.R[3 * i + j];
