@@ -84,6 +84,8 @@ struct dsopp_hip_window {
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
   bool state_dirty = true;   // host mirror newer than device
+  bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
+  LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
   bool marg_dirty = true;
   bool pair_valid = false;   // pair constants match the device state
   bool begun = false;
@@ -322,7 +324,8 @@ void uploadState(W &w) {
 }
 
 void downloadState(W &w) {
-  if (w.state_dirty || !w.d_state.ptr) return;
+  if (w.state_dirty || !w.d_state.ptr || !w.host_stale) return;
+  w.host_stale = false;
   w.d_state.download(&w.hst, 1, 0, w.sr.stream);
   w.sr.sync();
 }
@@ -342,6 +345,7 @@ void uploadMarginal(W &w) {
 
 void prepare(W &w) {
   w.sr.use();
+  downloadState(w);  // no-op unless a device-driven solve left the host mirror behind
   syncTopology(w);
   uploadState(w);
   uploadMarginal(w);
@@ -743,13 +747,15 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
   w.pair_valid = false;
   ensurePairConstants(w);
   launchSweep(w, false, true, false);
-  LmControl h;
-  HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(&w.hst, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, st));
+  // one small read-back into pinned memory (a pageable destination makes the copy synchronous and staged); the host
+  // mirror of the frame states is refreshed lazily, by the first reader (downloadState)
+  if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
+  HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  w.host_stale = true;
   w.sr.sync();  // the only host synchronisation of the solve
-  energy_out = h.energy;
-  iterations = h.iteration;
-  n_valid_out = h.n_valid;
+  energy_out = w.h_ctrl->energy;
+  iterations = w.h_ctrl->iteration;
+  n_valid_out = w.h_ctrl->n_valid;
 }
 
 
@@ -777,14 +783,16 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   prm.use_reduced_scalars = w.allreduce ? 1 : 0;
   LmControl *ctrl = w.d_ctrl.ptr;
   ensurePairConstants(w);
-  HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr, 0, 8 * sizeof(double), st));
-  if (w.n_schur_blocks) idepthNormKernel<<<w.n_schur_blocks, kSchurThreads, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_scalars.ptr + 4);
-  if (w.allreduce) allreduceIfNeeded(w, w.d_scalars.ptr + 4, 1);
+  if (w.allreduce) {
+    HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr, 0, 8 * sizeof(double), st));
+    if (w.n_schur_blocks) idepthNormKernel<<<w.n_schur_blocks, kSchurThreads, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_scalars.ptr + 4);
+    allreduceIfNeeded(w, w.d_scalars.ptr + 4, 1);
+  }
   {
     LmInitArgs ia;
     ia.sa = makeSolveArgs(w);
     ia.partials = w.d_partials.ptr;
-    ia.scalars = w.d_scalars.ptr;
+    ia.scalars = w.allreduce ? w.d_scalars.ptr : nullptr;  // single GPU: lmBeginKernel sums idepth^2 itself
     ia.schur_table = w.d_schur_table.ptr;
     ia.n_sweep_blocks = w.n_sweep_blocks;
     ia.n_schur_blocks = w.n_schur_blocks;
@@ -824,13 +832,15 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   }
   HIP_CHECK(hipGetLastError());
   w.pair_valid = false;
-  LmControl h;
-  HIP_CHECK(hipMemcpyAsync(&h, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(&w.hst, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, st));
+  // one small read-back into pinned memory (a pageable destination makes the copy synchronous and staged); the host
+  // mirror of the frame states is refreshed lazily, by the first reader (downloadState)
+  if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
+  HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  w.host_stale = true;
   w.sr.sync();  // the only host synchronisation of the solve
-  energy_out = h.energy;
-  iterations = h.iteration;
-  n_valid_out = h.n_valid;
+  energy_out = w.h_ctrl->energy;
+  iterations = w.h_ctrl->iteration;
+  n_valid_out = w.h_ctrl->n_valid;
 }
 
 }  // namespace
@@ -1267,6 +1277,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->sr.stream) (void)hipStreamSynchronize(w->sr.stream);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
+  if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
   w->frames.clear();
   StreamRef sr = w->sr;
   delete w;
@@ -1790,6 +1801,7 @@ int dsopp_hip_window_restore(dsopp_hip_window *w) {
     }
     w->hst = w->snap_state;
     w->state_dirty = false;
+    w->host_stale = false;
     w->pair_valid = false;
     w->begun = false;
   });

@@ -1365,13 +1365,34 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
 /** fused loop: control block before the first sweep (prior energy of the initial state goes to cand_prior); one workgroup */
 __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // single GPU: the state norm sum idepth^2 (acceptStep, problem.hpp:379) is taken here, in fixed order; with landmark
+  // shards it comes all-reduced in scalars[4] (idepthNormKernel)
+  double idepth_sq = 0;
+  if (a.scalars == nullptr) {
+    __shared__ double wsum[kSolveThreads / 64];
+    double sacc = 0;
+    for (int idx = threadIdx.x; idx < a.n_schur_blocks * kSchurLandmarks; idx += kSolveThreads) {
+      const SchurBlock &be = a.schur_table[idx / kSchurLandmarks];
+      const int i = be.offset + idx % kSchurLandmarks;
+      if (i < be.n) {
+        const double d = be.idepth[i];
+        sacc += d * d;
+      }
+    }
+    sacc = waveSum(sacc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sacc;
+    __syncthreads();
+    for (int wv = 0; wv < kSolveThreads / 64; ++wv) idepth_sq += wsum[wv];
+  } else {
+    idepth_sq = a.scalars[4];
+  }
   const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
   if (threadIdx.x == 0) {
     LmControl c;
     c.lambda = a.prm.lambda0;
     c.energy = 0;
     c.cand_prior = prior;
-    c.idepth_sq = a.scalars[4];
+    c.idepth_sq = idepth_sq;
     c.n_valid = 0;
     c.converged = 0;
     c.active = 1;
