@@ -365,7 +365,11 @@ template <typename S>
 void launchFej(W &w) {
   if (!w.n_sweep_blocks) return;
   timedLaunch(w, DSOPP_HIP_KERNEL_FEJ,
-              [&] { fejKernel<S><<<w.n_sweep_blocks, kSweepThreads, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr); });
+              [&] {
+                const int per_wave = 64 / kItemsPerBlock;
+                fejKernel<S><<<(w.n_sweep_blocks + per_wave - 1) / per_wave, 64, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr,
+                                                                                                   w.n_sweep_blocks);
+              });
   HIP_CHECK(hipGetLastError());
 }
 
@@ -821,15 +825,7 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     launchReduceSchur(w, false, cin, &fr);
     if (r + 1 < rounds) launchAssemble(w, 0.0, true, true, false, cout);
   }
-  // closing problem.calculateEnergy() at the final state: the last sweep already evaluated it unless the last step was
-  // rejected — then the pair constants are rebuilt and a residual sweep re-evaluates energies / candidate statuses
   LmControl *cfin = ctrl + (rounds & 1);
-  pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, st>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), w.fej() ? 1 : 0, &cfin->need_final_setup);
-  {
-    SweepExtras ex;
-    ex.run_flag = &cfin->need_final_setup;
-    launchSweep(w, false, true, false, nullptr, false, 0.0, ex);
-  }
   HIP_CHECK(hipGetLastError());
   w.pair_valid = false;
   // one small read-back into pinned memory (a pageable destination makes the copy synchronous and staged); the host
@@ -837,7 +833,15 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
   HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
   w.host_stale = true;
-  w.sr.sync();  // the only host synchronisation of the solve
+  w.sr.sync();  // the only host synchronisation of the solve (unless the last step was rejected, below)
+  if (w.h_ctrl->need_final_setup) {
+    // closing problem.calculateEnergy() at the final state: the last sweep already evaluated it unless the last step was
+    // rejected — then the pair constants are rebuilt and a residual sweep re-evaluates energies / candidate statuses
+    ensurePairConstants(w);
+    launchSweep(w, false, true, false);
+    HIP_CHECK(hipGetLastError());
+    w.sr.sync();
+  }
   energy_out = w.h_ctrl->energy;
   iterations = w.h_ctrl->iteration;
   n_valid_out = w.h_ctrl->n_valid;

@@ -185,16 +185,21 @@ __device__ __forceinline__ void blockSum(double (&vals)[N], double *lds /* [THRE
   }
 }
 
+constexpr int kItemsPerBlock = kSweepThreads / kPat;  // 8 lanes (one per pattern pixel) per (landmark, target) item
+
 /** firstEstimateJacobians_ (first_estimate_jacobians.hpp:14-71): validity of the reprojection at the linearisation point
  *  + idepth snapshot.  The geometric Jacobians themselves are NOT stored (they are recomputed from the snapshot). */
 template <typename S>
-__global__ void __launch_bounds__(kSweepThreads) fejKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
-                                                           const SweepBlock *__restrict__ table) {
-  const SweepBlock be = table[blockIdx.x];
+__global__ void __launch_bounds__(64) fejKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
+                                                const SweepBlock *__restrict__ table, int n_entries) {
+  // one wave = 4 table entries of kItemsPerBlock (16) landmarks each
+  const int entry = blockIdx.x * (64 / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
+  if (entry >= n_entries) return;
+  const SweepBlock be = table[entry];
   const FrameDev &fr = frames[be.r];
   const FrameDev &ft = frames[be.t];
   const PairConst &P = pc[be.r * kMaxFrames + be.t];
-  const int i = be.offset + threadIdx.x;
+  const int i = be.offset + threadIdx.x % kItemsPerBlock;
   if (i >= fr.n_res[be.t]) return;
   const uint8_t flg = fr.flags[i];
   if ((flg & kFlagMarginalized) && !(flg & kFlagToMarginalize)) return;
@@ -237,7 +242,6 @@ struct SweepParams {
 };
 #define SWEEP_STAMP(i) do { if (prm.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) prm.dbg[i] = wall_clock64(); } while (0)
 
-constexpr int kItemsPerBlock = kSweepThreads / kPat;  // 8 lanes (one per pattern pixel) per (landmark, target) item
 
 /** Workgroup barrier that only orders LDS traffic: unlike __syncthreads() it does not drain outstanding global stores
  *  (vmcnt), which costs 1-2 us when a phase ends with scattered stores nobody in the workgroup reads back. */
