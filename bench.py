@@ -136,6 +136,25 @@ def main():
     kernels = {k: {"avg_us": (v[0] / v[1] * 1e3 if v[1] else 0.0), "launches": v[1]} for k, v in prof.items() if v[1]}
     dominant = max(kernels.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0]
 
+    # HBM traffic of the same launch from the TCC counters: collected by scripts/pmc_traffic.py (rocprofv3, FETCH_SIZE and
+    # WRITE_SIZE in separate --pmc passes, calibrated on a 512 MiB copy in the same pass) and committed under profiles/
+    traffic, traffic_detail = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    default_workload = (F, P, args.width, args.height, args.dtype) == (7, 2000, 640, 480, "f64")
+    if default_workload and os.path.exists(pmc_file):
+        try:
+            with open(pmc_file) as fh:
+                pmc = json.load(fh)
+            k = pmc["per_launch_bytes"]["sweep_linearize"]
+            traffic = k["total"]
+            traffic_detail = {"fetch_bytes": k["fetch"], "write_bytes": k["write"], "source": "profiles/r01_pmc_traffic.json",
+                              "fetch_bytes_per_count": pmc["passes"]["FETCH_SIZE"]["bytes_per_count"],
+                              "write_bytes_per_count": pmc["passes"]["WRITE_SIZE"]["bytes_per_count"],
+                              "note": "per launch of the same kernel on the same window; counters are per XCD-L2 fabric requests, "
+                                      "Infinity-Cache hits included"}
+        except (OSError, KeyError, ValueError):
+            traffic, traffic_detail = None, None
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
@@ -160,7 +179,7 @@ def main():
                        "frames": F, "points_per_gpu": P, "total_points": total_points,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "sweep_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": lin_avg_s * 1e6,
                          "energy_sweep": {"algorithmic_bytes_per_launch": algorithmic_bytes_energy(P_local, F, s_bytes),
                                           "avg_launch_us": en_ms / max(en_n, 1) * 1e3}},

@@ -257,7 +257,30 @@ void syncTopology(W &w) {
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
       for (int off = 0; off < rt.n; off += kItemsPerBlock) {
-        sweep.push_back(SweepBlock{r, t, off, 0});
+        SweepBlock sb;
+        std::memset(&sb, 0, sizeof(sb));
+        sb.r = r;
+        sb.t = t;
+        sb.offset = off;
+        sb.n_res = rt.n;
+        sb.cap = f.cap;
+        sb.owns_landmark_sums = d.first_conn == t ? 1 : 0;
+        sb.width_r = lv.width;
+        sb.height_r = lv.height;
+        sb.uv = d.uv;
+        sb.idepth = d.idepth;
+        sb.patch = d.patch;
+        sb.idepth_fej = d.idepth_fej;
+        sb.b_d = d.b_d;
+        sb.inv_hdd = d.inv_hdd;
+        sb.idepth_step = d.idepth_step;
+        sb.ublk = d.ublk;
+        sb.energy = rt.energy.ptr;
+        sb.flags = d.flags;
+        sb.status = rt.status.ptr;
+        sb.fej_valid = rt.fej_valid.ptr;
+        sb.cand = rt.cand.ptr;
+        sweep.push_back(sb);
         ++cnt;
       }
       pair_count[static_cast<size_t>(r * kMaxFrames + t)] = cnt;
@@ -285,6 +308,14 @@ void syncTopology(W &w) {
       }
       schur.push_back(sb);
     }
+  }
+  for (SweepBlock &sb : sweep) {
+    const FrameDev &dr = fd[static_cast<size_t>(sb.r)], &dt = fd[static_cast<size_t>(sb.t)];
+    sb.width_t = dt.width;
+    sb.height_t = dt.height;
+    sb.texels_t = dt.texels;
+    for (int k = 0; k < F; ++k)
+      if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
   }
   w.d_frames.reserve(kMaxFrames, 0, st);
   w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
@@ -385,7 +416,7 @@ void firstEstimate(W &w) {
 /** extras of the fused device loop (all zero / null for the plain launches) */
 struct SweepExtras {
   int ublk_read = 0, ublk_write = 0;
-  const int *pending_ptr = nullptr;
+  bool gate_on_pending = false;  // fused loop: BACKSUB only when a candidate step is pending (LmControl::pending)
   const int *run_flag = nullptr;
   bool fused_lin_backsub = false;
 };
@@ -400,16 +431,15 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.sigma_huber = w.opt.sigma_huber_loss;
   prm.for_marginalized = for_marg ? 1 : 0;
   prm.use_fej_flag = w.fej() ? 1 : 0;
-  prm.ctrl_active = ctrl ? &ctrl->active : nullptr;
+  prm.ctrl = ctrl;
   prm.clear_buf = lin ? w.d_reduce.ptr : nullptr;
   prm.clear_count = static_cast<int>(w.reduceCount());
   prm.step = w.d_step.ptr;
-  prm.lambda_ptr = ctrl ? &ctrl->lambda : nullptr;
   prm.lambda = lambda;
   prm.F = w.F();
   prm.ublk_read = ex.ublk_read;
   prm.ublk_write = ex.ublk_write;
-  prm.pending_ptr = ex.pending_ptr;
+  prm.gate_on_pending = ex.gate_on_pending ? 1 : 0;
   prm.run_flag = ex.run_flag;
   prm.dbg = (w.dbg_sweep && lin == w.dbg_sweep_lin) ? w.dbg_sweep : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
@@ -811,7 +841,7 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     SweepExtras ex;
     ex.ublk_read = (r + 1) & 1;
     ex.ublk_write = r & 1;
-    ex.pending_ptr = &cin->pending;
+    ex.gate_on_pending = true;
     ex.fused_lin_backsub = true;
     launchSweep(w, true, true, false, cin, true, 0.0, ex);
     if (w.allreduce) {

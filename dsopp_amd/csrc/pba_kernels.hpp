@@ -228,15 +228,14 @@ struct SweepParams {
   double sigma_huber;
   int for_marginalized;  // accumulate only landmarks flagged to_marginalize (FOR_MARGINALIZED of the reference)
   int use_fej_flag;      // FIRST_ESTIMATE_JACOBIANS: success requires reprojection_jacobians_valid
-  const int *ctrl_active;  // nullable: &LmControl::active, followed by linear_system_valid (pba_solve_kernels.hpp)
+  const LmControl *ctrl;   // nullable: device-driven LM loop (active / linear_system_valid / pending / lambda are read here)
   double *clear_buf;       // LIN: buffer the following reduction kernel accumulates into with atomics; zeroed here
   int clear_count;
   const double *step;      // BACKSUB: pose step of calculateStep (K doubles)
-  const double *lambda_ptr;  // BACKSUB: &LmControl::lambda or nullptr (then `lambda`)
-  double lambda;
+  double lambda;             // BACKSUB: damping when ctrl == nullptr
   int F;
   int ublk_read, ublk_write;  // parity of the double-buffered Schur rows read by BACKSUB / written by LIN (0, 0 outside the fused loop)
-  const int *pending_ptr;     // fused loop: &LmControl::pending — BACKSUB only when a candidate step is pending
+  int gate_on_pending;        // fused loop: BACKSUB only when a candidate step is pending (LmControl::pending)
   const int *run_flag;        // nullable: launch is a no-op unless *run_flag != 0 (closing evaluation after a rejected step)
   long long *dbg;  // nullable tuning aid: per-phase wall_clock64 stamps of workgroup 0 / max end stamp
 };
@@ -309,19 +308,25 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
   __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? kPartial : 4) * kRedStride];
-  if (prm.run_flag && !*prm.run_flag) return;
-  if (prm.ctrl_active) {
-    // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
-    // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
-    if (!prm.ctrl_active[0] || (LIN && prm.ctrl_active[1])) return;
+  // ---- round trip 1: block descriptor + LM control block (scalar loads, all requested before any of them is tested)
+  const SweepBlock be = table[blockIdx.x];
+  int c_active = 1, c_lsv = 0, c_pending = 1, run = 1;
+  double lam = prm.lambda;
+  if (prm.ctrl) {
+    c_active = prm.ctrl->active;
+    c_lsv = prm.ctrl->linear_system_valid;
+    c_pending = prm.ctrl->pending;
+    lam = prm.ctrl->lambda;
   }
+  if (prm.run_flag) run = *prm.run_flag;
+  asm volatile("" ::"s"(be.offset), "s"(c_active), "s"(run));
+  // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
+  // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
+  if (!run || !c_active || (LIN && c_lsv)) return;
   if (LIN && prm.clear_buf) {
     for (int k = blockIdx.x * kSweepThreads + threadIdx.x; k < prm.clear_count; k += gridDim.x * kSweepThreads) prm.clear_buf[k] = 0;
   }
   SWEEP_STAMP(0);
-  const SweepBlock be = table[blockIdx.x];
-  const FrameDev &fr = frames[be.r];
-  const FrameDev &ft = frames[be.t];
   const PairConst &P = pc[be.r * kMaxFrames + be.t];
   const int k = threadIdx.x & 7;                  // pattern pixel of this lane
   const int i = be.offset + (threadIdx.x >> 3);   // landmark
@@ -333,55 +338,78 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
 #pragma unroll
   for (int e = 0; e < kPartial; ++e) acc[e] = 0;
 
-  bool active = i < fr.n_res[be.t];
+  // ---- round trip 2: per-item words (identical addresses within the 8 lanes of an item: one request).  Every load is
+  // gated by the index bound only, never by a loaded value, so they all go out together.
+  const bool inb = i < be.n_res;
   uint8_t flg = 0;
-  if (active) {
-    flg = fr.flags[i];
-    active = !((flg & kFlagMarginalized) && !(flg & kFlagToMarginalize));  // evaluate_jacobians.hpp:83-85
-  }
-  const bool accumulate = active && (prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0);
-
-  // ---- per-item words (identical addresses within the 8 lanes of an item: one request)
   S u = S(0), v = S(0);
-  double idepth_d = 0, idepth_step_d = 0;
+  double idepth_d = 0, idepth_step_d = 0, idepth_fej_d = 0, bd_d = 0, inv_hdd_d = 0;
   uint8_t status = DSOPP_HIP_STATUS_OOB, cand = DSOPP_HIP_STATUS_OOB;
-  bool fej_ok = true;
+  uint8_t fej_bit = 1;
   S patch_k = S(0);
-  if (active) {
-    u = static_cast<S>(fr.uv[2 * i]);
-    v = static_cast<S>(fr.uv[2 * i + 1]);
-    idepth_d = fr.idepth[i];
-    idepth_step_d = fr.idepth_step[i];
-    status = fr.status[be.t][i];
-    cand = fr.cand[be.t][i];
-    patch_k = static_cast<S>(fr.patch[kPat * i + k]);
-    if (FEJ && prm.use_fej_flag) fej_ok = fr.fej_valid[be.t][i] != 0;  // evaluate_jacobians.hpp:94
+  double hrow[kBlk], srow[kBlk];  // BACKSUB: Schur row block / pose step block of this lane's frame slot tt = k
+#pragma unroll
+  for (int c = 0; c < kBlk; ++c) hrow[c] = srow[c] = 0;
+  const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+  if (inb) {
+    flg = be.flags[i];
+    u = static_cast<S>(be.uv[2 * i]);
+    v = static_cast<S>(be.uv[2 * i + 1]);
+    idepth_d = be.idepth[i];
+    idepth_step_d = be.idepth_step[i];
+    status = be.status[i];
+    cand = be.cand[i];
+    patch_k = static_cast<S>(be.patch[kPat * i + k]);
+    if (FEJ) {
+      if (prm.use_fej_flag) fej_bit = be.fej_valid[i];  // evaluate_jacobians.hpp:94
+      if (LIN) idepth_fej_d = be.idepth_fej[i];
+    }
+    if (BACKSUB) {
+      bd_d = be.b_d[i];
+      inv_hdd_d = be.inv_hdd[i];
+      if (k < prm.F && (k == be.r || ((be.conn_mask >> k) & 1u))) {
+        const double *src = be.ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + k) * plane + static_cast<size_t>(i) * kUblk;
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          hrow[c] = src[c];
+          srow[c] = prm.step[kBlk * k + c];
+        }
+      }
+    }
+  }
+  bool active = inb && !((flg & kFlagMarginalized) && !(flg & kFlagToMarginalize));  // evaluate_jacobians.hpp:83-85
+  const bool accumulate = active && (prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0);
+  const bool fej_ok = fej_bit != 0;
+  if (!active) {
+    status = DSOPP_HIP_STATUS_OOB;
+    cand = DSOPP_HIP_STATUS_OOB;
   }
   if (BACKSUB) {
     // calculateIdepths — hessian_block_evaluation.hpp:238-263: lane k of the item takes the frame blocks k, k+8, ... of
     // h_p^T step; the 8 partial dot products are summed across the item's lanes
     double d = 0;
-    const bool upd = active && !(flg & (kFlagMarginalized | kFlagIllConditioned)) && (!prm.pending_ptr || *prm.pending_ptr);
+    const bool upd = active && !(flg & (kFlagMarginalized | kFlagIllConditioned)) && (!prm.gate_on_pending || c_pending);
+#pragma unroll
+    for (int c = 0; c < kBlk; ++c) d += hrow[c] * srow[c];
     if (upd) {
-      for (int tt = k; tt < prm.F; tt += kPat) {
-        if (tt != be.r && fr.status[tt] == nullptr) continue;
-        const double *src = fr.ublk + ((static_cast<size_t>(prm.ublk_read) * kMaxFrames + tt) * fr.cap + i) * kUblk;
+      for (int tt = k + kPat; tt < prm.F; tt += kPat) {  // windows of more than 8 frames
+        if (tt != be.r && !((be.conn_mask >> tt) & 1u)) continue;
+        const double *src = be.ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + tt) * plane + static_cast<size_t>(i) * kUblk;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) d += src[c] * prm.step[kBlk * tt + c];
       }
     }
     d = sum8(d);
     if (upd) {
-      const double lam = prm.lambda_ptr ? *prm.lambda_ptr : prm.lambda;
-      idepth_step_d = -((fr.b_d[i] - d) * (1.0 / (1.0 + lam)) * fr.inv_hdd[i]);
-      if (k == 0 && be.t == fr.first_conn) fr.idepth_step[i] = idepth_step_d;
+      idepth_step_d = -((bd_d - d) * (1.0 / (1.0 + lam)) * inv_hdd_d);
+      if (k == 0 && be.owns_landmark_sums) be.idepth_step[i] = idepth_step_d;
     }
   }
   SWEEP_STAMP(1);
   if (prm.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SWEEP_STAMP(2);
   const S idepth = static_cast<S>(idepth_d + idepth_step_d);
-  const S Wr = S(fr.width), Hr = S(fr.height), Wt = S(ft.width), Ht = S(ft.height);
+  const S Wr = S(be.width_r), Hr = S(be.height_r), Wt = S(be.width_t), Ht = S(be.height_t);
 
   // ---- reprojection of this lane's pattern pixel
   const S pu = u + S(ox), pv = v + S(oy);
@@ -410,8 +438,8 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   // (pixel_map.hpp:20-40, camera_mask.hpp:64-66); a lane only touches the image when its own pixel is inside the ROI
   S sI = S(0), sIx = S(0), sIy = S(0);
   if (ok) {
-    const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(ft.texels);
-    const int W = ft.width;
+    const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(be.texels_t);
+    const int W = be.width_t;
     const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
     const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy);
     const S dxdy = dx * dy;
@@ -457,7 +485,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     for (int a = 0; a < kBlk + 2; ++a) gj[a] = 0;
     if (evaluate) {
       // geometric Jacobians at the linearisation point (FEJ: idepth snapshot) — camera_reproject.hpp:339-365
-      const S idj = FEJ ? static_cast<S>(fr.idepth_fej[i]) : idepth;
+      const S idj = FEJ ? static_cast<S>(idepth_fej_d) : idepth;
       const S X = S(P.U[0]) * pu + S(P.U[1]) * pv + (S(P.U[2]) + S(P.U[3]) * idj);
       const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idj);
       const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idj);
@@ -504,20 +532,20 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       double mine = gj[0];
 #pragma unroll
       for (int a = 1; a < kBlk; ++a) mine = (k == a) ? gj[a] : mine;
-      double *dst = fr.ublk + ((static_cast<size_t>(prm.ublk_write) * kMaxFrames + be.t) * fr.cap + i) * kUblk;
+      double *dst = be.ublk + (static_cast<size_t>(prm.ublk_write) * kMaxFrames + be.t) * plane + static_cast<size_t>(i) * kUblk;
       dst[k] = -mine;
       if (k < 2) dst[8 + k] = k == 0 ? gj[8] : gj[9];
     }
   }
   // NEW_EVALUATION_POINT bookkeeping (lane 0 of the item)
   if (active && k == 0) {
-    fr.energy[be.t][i] = energy;
-    fr.cand[be.t][i] = cand;
+    be.energy[i] = energy;
+    be.cand[i] = cand;
     if (accumulate) {
       acc[44] = energy;
       acc[45] = energy > 0 ? 1.0 : 0.0;
     }
-    if ((!LIN || BACKSUB) && be.t == fr.first_conn) {
+    if ((!LIN || BACKSUB) && be.owns_landmark_sums) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
       acc[46] = idepth_step_d * idepth_step_d;
       acc[47] = idepth_d * idepth_step_d;

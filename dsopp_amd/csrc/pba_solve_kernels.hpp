@@ -10,20 +10,7 @@ namespace dsopp_hip {
 // LM control block (lives in HBM; double-buffered by iteration parity so every workgroup of the decide kernel can read
 // the incoming state while workgroup 0 writes the outgoing one)
 // ---------------------------------------------------------------------------------------------------------------
-struct LmControl {
-  double lambda;
-  double energy;           // result.energy
-  double cand_prior;       // prior + marginal energy of the candidate state eps + step (written by the solve kernel)
-  double idepth_sq;        // running sum of idepth^2 over all landmarks of this rank (state norm part)
-  int n_valid;             // result.number_of_valid_residuals
-  int converged;
-  int active;              // loop still running           (sweep kernels read {active, linear_system_valid} as int[2])
-  int linear_system_valid;
-  int iteration;           // loop bodies executed
-  int need_final_setup;    // last step was rejected: pair constants must be rebuilt before the closing energy sweep
-  int pending;             // fused loop: a candidate step is waiting for its energy (0 in the first round / after a re-linearisation)
-  int relin;               // fused loop: the last candidate was rejected, the next sweep re-linearises at the reverted state
-};
+// (struct LmControl: pba_types.hpp)
 
 struct LmParams {
   double function_tolerance, parameter_tolerance;

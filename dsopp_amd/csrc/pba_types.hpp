@@ -70,11 +70,39 @@ struct PairConst {
   double T0rel[12];  // T_tr0 = inv(T_t0) * T_r0 as [R | t] rows (3 x 4): lets the solve kernel refresh M without the frame table
 };
 
-/** one thread block of a sweep = a chunk of landmarks of one ordered pair */
+/** LM control block (lives in HBM; double-buffered by iteration parity so every workgroup of the decide step can read the
+ *  incoming state while workgroup 0 writes the outgoing one) */
+struct LmControl {
+  double lambda;
+  double energy;           // result.energy
+  double cand_prior;       // prior + marginal energy of the candidate state eps + step (written by the solve kernel)
+  double idepth_sq;        // running sum of idepth^2 over all landmarks of this rank (state norm part)
+  int n_valid;             // result.number_of_valid_residuals
+  int converged;
+  int active;              // loop still running           (sweep kernels read {active, linear_system_valid} as int[2])
+  int linear_system_valid;
+  int iteration;           // loop bodies executed
+  int need_final_setup;    // last step was rejected: pair constants must be rebuilt before the closing energy sweep
+  int pending;             // fused loop: a candidate step is waiting for its energy (0 in the first round / after a re-linearisation)
+  int relin;               // fused loop: the last candidate was rejected, the next sweep re-linearises at the reverted state
+};
+
+/** one thread block of a sweep = a chunk of landmarks of one ordered pair.  Like SchurBlock the descriptor repeats every
+ *  pointer the kernel needs: table -> data is one dependent load instead of table -> FrameDev -> data. */
 struct SweepBlock {
   int r, t;    // frame slots
   int offset;  // first landmark
+  int n_res;   // residuals of the pair (== landmarks of r that have a residual in t)
+  int cap;     // landmark capacity of frame r (plane stride of ublk)
+  int owns_landmark_sums;  // t is the first connected target of r: its items own the per-landmark sums / writes
+  int width_r, height_r, width_t, height_t;
+  unsigned conn_mask;  // bit k: frame r has residuals in target slot k
   int pad;
+  const double *uv, *idepth, *patch, *idepth_fej, *b_d, *inv_hdd;
+  double *idepth_step, *ublk, *energy;
+  const uint8_t *flags, *status, *fej_valid;
+  uint8_t *cand;
+  const void *texels_t;  // Texel<S>* of the target frame's level
 };
 
 /** one thread block of the Schur kernel = a chunk of landmarks of one frame.  The descriptor repeats the frame's
