@@ -1726,10 +1726,10 @@ int dsopp_hip_debug_sweep_stamps(dsopp_hip_window *w, int lin, long long *out16)
 int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
   return guarded([&] {
     if (!w->dbg_stamps) {
-      HIP_CHECK(hipMalloc(&w->dbg_stamps, 16 * sizeof(long long)));
-      HIP_CHECK(hipMemset(w->dbg_stamps, 0, 16 * sizeof(long long)));
+      HIP_CHECK(hipMalloc(&w->dbg_stamps, 48 * sizeof(long long)));
+      HIP_CHECK(hipMemset(w->dbg_stamps, 0, 48 * sizeof(long long)));
     }
-    HIP_CHECK(hipMemcpy(out8, w->dbg_stamps, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(out8, w->dbg_stamps, 48 * sizeof(long long), hipMemcpyDeviceToHost));
   });
 }
 

@@ -2,6 +2,7 @@
 // and the LM driver, levenberg_marquardt_algorithm.hpp:77-128, kept on the device so that a whole solve is one stream
 // of launches with no host round trip).
 #pragma once
+#include <type_traits>
 #include "pba_kernels.hpp"
 
 namespace dsopp_hip {
@@ -817,17 +818,31 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
   // the rest of the trailing matrix (columns >= kb+2).  The sequential factor chain is thus off the other waves' path.
   DSOPP_STAMP(2);
   const int wave = tid >> 6, lane = tid & 63;
+  auto readLane = [](double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+  };
   auto factorAndPanel = [&](int kb) {
-    // wave 0 only: Cholesky of the diagonal block kb (redundantly per lane, in registers), then the panel rows below it
+    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below
+    // it): one elimination loop does the Cholesky of the diagonal block and the triangular solve of the panel together.
+    // Per pivot k: d = C[k][k] (v_readlane from lane k), l_ik = c_ik / sqrt(d) in every lane, then for the remaining columns
+    // j the row-k factor l_jk is broadcast by v_readlane and every lane updates its own c_ij.  A wave issues one
+    // instruction per ~4.7 cycles whether or not it depends on the previous one (measured), so what matters is the
+    // instruction count: ~200 here against ~430 for a per-lane redundant 8x8 factorisation + per-row substitution.
     const int k0 = kb * kBlk;
-    double L[36], invd[kBlk];
+    const int row = k0 + lane;
+    const bool valid = row < N;
+    double c[kBlk], invd[kBlk], lj[28];  // lj: strictly-lower factor entries l_jk of the diagonal block (uniform), for rows beyond 64
+    {
+      const double *src = A + (valid ? row : k0) * ld + k0;
 #pragma unroll
-    for (int i = 0; i < kBlk; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) L[lowIdx(i, j)] = A[(k0 + i) * ld + k0 + j];
+      for (int j = 0; j < kBlk; ++j) c[j] = src[j];
+    }
+    int e = 0;
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
-      const double d = L[lowIdx(k, k)];
+      const double d = readLane(c[k], k);
       // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64 (pivots of the Jacobi-scaled system are O(1e-13..1));
       // pivots below 1e-30 are treated as zero, as a rank-revealing factorisation would
       const bool okp = d > 1e-30;
@@ -835,41 +850,45 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = okp ? inv : 0.0;
-      L[lowIdx(k, k)] = okp ? d * inv : 0.0;
       invd[k] = inv;
+      const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik
+      c[k] = l;
 #pragma unroll
-      for (int i = k + 1; i < kBlk; ++i) L[lowIdx(i, k)] *= inv;
-#pragma unroll
-      for (int j = k + 1; j < kBlk; ++j)
-#pragma unroll
-        for (int i = j; i < kBlk; ++i) L[lowIdx(i, j)] -= L[lowIdx(i, k)] * L[lowIdx(j, k)];
+      for (int j = k + 1; j < kBlk; ++j) {
+        const double ljk = readLane(l, j);
+        lj[e++] = ljk;
+        c[j] -= l * ljk;
+      }
     }
-    // panel: L_row = A_row * L_kk^-T by forward substitution (rows k0+8 .. N-1, one or two per lane)
-    for (int row = k0 + kBlk + lane; row < N; row += 64) {
+    if (valid) {
+      double *dst = A + row * ld + k0;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j)
+        if (lane >= kBlk || j <= lane) dst[j] = c[j];  // the diagonal block keeps its lower triangle only
+    }
+    // rows beyond the first 64 of this block column (windows of more than 7 frames): substitution with the broadcast factors
+    for (int r2 = row + 64; r2 < N; r2 += 64) {
       double v[kBlk];
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) v[c] = A[row * ld + k0 + c];
+      for (int j = 0; j < kBlk; ++j) v[j] = A[r2 * ld + k0 + j];
+      int e2 = 0;
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) {
-        double sacc = v[c];
+      for (int k = 0; k < kBlk; ++k) {
+        v[k] *= invd[k];
 #pragma unroll
-        for (int k = 0; k < c; ++k) sacc -= v[k] * L[lowIdx(c, k)];
-        v[c] = sacc * invd[c];
+        for (int j = k + 1; j < kBlk; ++j) v[j] -= v[k] * lj[e2++];
       }
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) A[row * ld + k0 + c] = v[c];
+      for (int j = 0; j < kBlk; ++j) A[r2 * ld + k0 + j] = v[j];
     }
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < kBlk; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) A[(k0 + i) * ld + k0 + j] = L[lowIdx(i, j)];
-#pragma unroll
-      for (int c = 0; c < kBlk; ++c) Linv[kb * 36 + lowIdx(c, c)] = invd[c];  // diagonal of the inverse; completed below
+      for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];  // diagonal of the inverse; completed below
     }
   };
   if (wave == 0) factorAndPanel(0);
   __syncthreads();
+  DSOPP_STAMP(16);
   for (int kb = 0; kb < F; ++kb) {
     const int k0 = kb * kBlk, k1 = k0 + kBlk, k2 = k1 + kBlk;
     if (kb + 1 < F) {
@@ -886,8 +905,10 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
       }
     }
     __syncthreads();
+    DSOPP_STAMP(17 + 3 * kb);
     if (wave == 0) {
       if (kb + 1 < F) factorAndPanel(kb + 1);
+      DSOPP_STAMP(18 + 3 * kb);
     } else {
       // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
       const int t = tid - 64, tr = t >> 4, tc = t & 15;
@@ -906,63 +927,57 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
       }
     }
     __syncthreads();
+    DSOPP_STAMP(19 + 3 * kb);
   }
-  // inverses of the F diagonal factors, all at once (thread f inverts block f): Li_ij = -(sum_{k=j}^{i-1} L_ik Li_kj) / L_ii
-  if (tid < F) {
-    const int k0 = tid * kBlk;
-    double L[36], Li[36];
-#pragma unroll
-    for (int i = 0; i < kBlk; ++i)
-#pragma unroll
-      for (int j = 0; j <= i; ++j) L[lowIdx(i, j)] = A[(k0 + i) * ld + k0 + j];
-#pragma unroll
-    for (int c = 0; c < kBlk; ++c) Li[lowIdx(c, c)] = Linv[tid * 36 + lowIdx(c, c)];
-#pragma unroll
-    for (int j = 0; j < kBlk; ++j)
-#pragma unroll
-      for (int i = j + 1; i < kBlk; ++i) {
-        double sacc = 0;
-#pragma unroll
-        for (int k = j; k < i; ++k) sacc += L[lowIdx(i, k)] * Li[lowIdx(k, j)];
-        Li[lowIdx(i, j)] = -sacc * Li[lowIdx(i, i)];
-      }
-#pragma unroll
-    for (int e = 0; e < 36; ++e) Linv[tid * 36 + e] = Li[e];
-  }
-  __syncthreads();
-  // ---- back substitution x = L^-T y, blocked (y = row K of L); x_k = Linv_kk^T (y_k - sum_{j>k} L_jk^T x_j).
-  // One wave, rows spread over its lanes: no workgroup barriers on this strictly sequential chain.
+  // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
+  // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
+  // 4-7 instructions per unknown, no LDS round trip or barrier inside the chain (L_kj is prefetched a frame block ahead).
   DSOPP_STAMP(3);
-  for (int c = tid; c < K; c += kSolveThreads) xs[c] = A[K * ld + c];
-  __syncthreads();
-  if (tid < 64) {
-    for (int kb = F - 1; kb >= 0; --kb) {
-      const int k0 = kb * kBlk;
-      double xk[kBlk];
+  if (wave == 0) {
+    // No masking anywhere: lane j is consumed at step k = j (x_j = y_j / L_jj); whatever the later steps k < j add to it
+    // (entries on / above the diagonal, uninitialised LDS) is never read again.  x_k leaves the chain as a wave-uniform
+    // value and is written to LDS by lane 0, eight at a time.
+    auto run = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+      const int j0 = lane, j1 = lane + 64;
+      double y0 = j0 < K ? A[K * ld + j0] : 0.0, y1 = (TWO && j1 < K) ? A[K * ld + j1] : 0.0;
+      const double gi0 = j0 < K ? Linv[(j0 >> 3) * 36 + lowIdx(j0 & 7, j0 & 7)] : 0.0;
+      const double gi1 = (TWO && j1 < K) ? Linv[(j1 >> 3) * 36 + lowIdx(j1 & 7, j1 & 7)] : 0.0;
+      double g0[kBlk], g1[kBlk], n0[kBlk], n1[kBlk];
+      auto loadBlock = [&](int kb, double *o0, double *o1) {
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) {
-        double s = 0;
+        for (int c = 0; c < kBlk; ++c) {
+          o0[c] = A[(kb * kBlk + c) * ld + j0];  // lanes beyond the row read into the next row: in bounds, never used
+          if (TWO) o1[c] = j1 < K ? A[(kb * kBlk + c) * ld + j1] : 0.0;
+        }
+      };
+      loadBlock(F - 1, g0, g1);
+      for (int kb = F - 1; kb >= 0; --kb) {
+        if (kb > 0) loadBlock(kb - 1, n0, n1);
+        double xo[kBlk];
 #pragma unroll
-        for (int k = c; k < kBlk; ++k) s += Linv[kb * 36 + lowIdx(k, c)] * xs[k0 + k];
-        xk[c] = s;
+        for (int c = kBlk - 1; c >= 0; --c) {
+          const int k = kb * kBlk + c;
+          const double xk = (!TWO || k < 64) ? readLane(y0 * gi0, k & 63) : readLane(y1 * gi1, k & 63);
+          xo[c] = xk;
+          y0 -= g0[c] * xk;
+          if (TWO) y1 -= g1[c] * xk;
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) xs[kb * kBlk + c] = xo[c];
+        }
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          g0[c] = n0[c];
+          if (TWO) g1[c] = n1[c];
+        }
       }
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      if (tid < kBlk) {
-        double mine = xk[0];
-#pragma unroll
-        for (int c = 1; c < kBlk; ++c) mine = (tid == c) ? xk[c] : mine;
-        xs[k0 + tid] = mine;
-      }
-      for (int rr = tid; rr < k0; rr += 64) {
-        double s = 0;
-#pragma unroll
-        for (int c = 0; c < kBlk; ++c) s += A[(k0 + c) * ld + rr] * xk[c];
-        xs[rr] -= s;
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-    }
+    };
+    if (K > 64)
+      run(std::true_type{});
+    else
+      run(std::false_type{});
   }
   __syncthreads();
   if (tid < K) {
