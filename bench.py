@@ -90,17 +90,12 @@ def main():
     g.snapshot()
 
     def run_iterations(n_target):
-        """executes exactly n_target GN iterations as repeated LM loops from the snapshot; returns iterations done"""
-        done = 0
-        while done < n_target:
-            remaining = n_target - done
-            g.restore()
-            g.set_max_iterations(min(7, remaining))
-            _, it, _ = g.optimize()
-            if it <= 0:
-                raise RuntimeError("LM loop made no progress")
-            done += it
-        g.set_max_iterations(7)
+        """executes exactly n_target GN iterations as repeated LM loops from the snapshot ({restore; optimize} per solve,
+        every solve with its own read-back + stream sync; the loop itself runs inside the library so that the gap between
+        two solves is not Python's call overhead); returns iterations done"""
+        done, _ = g.optimize_repeated(n_target)
+        if done < n_target:
+            raise RuntimeError("LM loop made no progress")
         return done
 
     def barrier():

@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -246,6 +246,13 @@ class HipWindow:
         e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
         _chk(lib().dsopp_hip_window_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
         return e.value, it.value, nv.value
+
+    def optimize_repeated(self, iterations_target: int):
+        """{restore(); optimize()} from the snapshot until exactly `iterations_target` GN iterations ran; returns
+        (iterations_done, last_energy).  Same work as the Python loop, without its per-call overhead between solves."""
+        done, e = C.c_int32(), C.c_double()
+        _chk(lib().dsopp_hip_window_optimize_repeated(self._h, int(iterations_target), C.byref(done), C.byref(e)))
+        return done.value, e.value
 
     def set_max_iterations(self, n: int):
         _chk(lib().dsopp_hip_window_set_max_iterations(self._h, int(n)))

@@ -817,16 +817,11 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   prm.use_reduced_scalars = w.allreduce ? 1 : 0;
   LmControl *ctrl = w.d_ctrl.ptr;
   ensurePairConstants(w);
-  if (w.allreduce) {
-    HIP_CHECK(hipMemsetAsync(w.d_scalars.ptr, 0, 8 * sizeof(double), st));
-    if (w.n_schur_blocks) idepthNormKernel<<<w.n_schur_blocks, kSchurThreads, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_scalars.ptr + 4);
-    allreduceIfNeeded(w, w.d_scalars.ptr + 4, 1);
-  }
   {
     LmInitArgs ia;
     ia.sa = makeSolveArgs(w);
     ia.partials = w.d_partials.ptr;
-    ia.scalars = w.allreduce ? w.d_scalars.ptr : nullptr;  // single GPU: lmBeginKernel sums idepth^2 itself
+    ia.scalars = nullptr;
     ia.schur_table = w.d_schur_table.ptr;
     ia.n_sweep_blocks = w.n_sweep_blocks;
     ia.n_schur_blocks = w.n_schur_blocks;
@@ -1772,6 +1767,27 @@ int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->lm_mode = host_driven;
   });
+}
+
+int dsopp_hip_window_optimize_repeated(dsopp_hip_window *w, int32_t iterations_target, int32_t *iterations_done, double *last_energy) {
+  if (!w || iterations_target < 0) return dsopp_hip_window_restore(nullptr);  // reports the invalid argument
+  const int configured = w->opt.max_iterations;
+  int done = 0, rc = DSOPP_HIP_OK;
+  double e = 0;
+  while (rc == DSOPP_HIP_OK && done < iterations_target) {
+    rc = dsopp_hip_window_restore(w);
+    if (rc != DSOPP_HIP_OK) break;
+    rc = dsopp_hip_window_set_max_iterations(w, std::min(configured, iterations_target - done));
+    if (rc != DSOPP_HIP_OK) break;
+    int32_t it = 0;
+    rc = dsopp_hip_window_optimize(w, &e, &it, nullptr);
+    if (rc == DSOPP_HIP_OK && it <= 0) break;  // no progress: leave the loop, the caller sees iterations_done < target
+    done += it;
+  }
+  const int rc2 = dsopp_hip_window_set_max_iterations(w, configured);
+  if (iterations_done) *iterations_done = done;
+  if (last_energy) *last_energy = e;
+  return rc != DSOPP_HIP_OK ? rc : rc2;
 }
 
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations) {

@@ -547,7 +547,8 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
     if ((!LIN || BACKSUB) && be.owns_landmark_sums) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
-      acc[46] = idepth_step_d * idepth_step_d;
+      // (the opening round of the fused loop has no step yet: slot 46 carries sum idepth^2, the initial state norm)
+      acc[46] = (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;
       acc[47] = idepth_d * idepth_step_d;
     }
   }

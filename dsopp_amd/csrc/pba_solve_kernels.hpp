@@ -267,6 +267,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
         proceed = 1;
       } else {
         // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
+        c.idepth_sq = t[2];  // the opening sweep sums idepth^2 into the step-norm slot
         c.energy = eval_energy;
         c.n_valid = n_valid;
         c.active = (a.prm.max_iterations > 0 && n_valid > 0) ? 1 : 0;
@@ -1367,27 +1368,7 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
 /** fused loop: control block before the first sweep (prior energy of the initial state goes to cand_prior); one workgroup */
 __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  // single GPU: the state norm sum idepth^2 (acceptStep, problem.hpp:379) is taken here, in fixed order; with landmark
-  // shards it comes all-reduced in scalars[4] (idepthNormKernel)
-  double idepth_sq = 0;
-  if (a.scalars == nullptr) {
-    __shared__ double wsum[kSolveThreads / 64];
-    double sacc = 0;
-    for (int idx = threadIdx.x; idx < a.n_schur_blocks * kSchurLandmarks; idx += kSolveThreads) {
-      const SchurBlock &be = a.schur_table[idx / kSchurLandmarks];
-      const int i = be.offset + idx % kSchurLandmarks;
-      if (i < be.n) {
-        const double d = be.idepth[i];
-        sacc += d * d;
-      }
-    }
-    sacc = waveSum(sacc);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sacc;
-    __syncthreads();
-    for (int wv = 0; wv < kSolveThreads / 64; ++wv) idepth_sq += wsum[wv];
-  } else {
-    idepth_sq = a.scalars[4];
-  }
+  const double idepth_sq = 0;  // set by the decide step of the opening round (sum idepth^2 rides in the sweep's partials)
   const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
   if (threadIdx.x == 0) {
     LmControl c;

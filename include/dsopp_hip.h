@@ -187,6 +187,11 @@ int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iter
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int mode);
 /* TrustRegion...Options::max_iterations of an existing window */
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations);
+/* Measurement aid (bench.py): repeats { dsopp_hip_window_restore; dsopp_hip_window_optimize } from the snapshot until exactly
+ * `iterations_target` Gauss-Newton iterations have run (the last solve's max_iterations is capped accordingly, then the
+ * window's setting is put back).  Same work as calling the two entry points in a loop, without the caller's per-call
+ * overhead between solves; every solve still ends with its own read-back + stream synchronisation. */
+int dsopp_hip_window_optimize_repeated(dsopp_hip_window *w, int32_t iterations_target, int32_t *iterations_done, double *last_energy);
 
 /* device-side snapshot / restore of the mutable solver state (poses, affine, idepths, flags, connection statuses);
  * device-to-device copies only.  Lets a caller re-run a solve from the same starting point (benchmark loops, the
