@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the large-window roofline and the tracker (C2) timing")
     args = ap.parse_args()
 
     import torch
@@ -66,9 +67,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("DSOPP_BENCH_FORCE_DIST") == "1"  # exercise the collective path with a single rank (self-test)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     F, P = args.frames, args.points
@@ -84,7 +89,7 @@ def main():
     g = capi.HipWindow(opts, device=local_rank, stream=stream.cuda_stream)
     syn.load_window(g, win)
 
-    if world > 1:
+    if world > 1 or force_dist:
         g.set_allreduce(distributed.make_device_allreduce(dist, torch, stream, local_rank), rank, world)
 
     g.snapshot()
@@ -150,6 +155,12 @@ def main():
         except (OSError, KeyError, ValueError):
             traffic, traffic_detail = None, None
 
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        g.restore()
+        extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
+        extras["tracker"] = run_tracker_timing(capi, syn, torch)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
@@ -182,6 +193,7 @@ def main():
             "kernels_isolated_avg_us": isolated,
             "dominant_kernel_by_total_time": dominant,
         }
+        line.update(extras)
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline
             line["speedup_vs_cpu_port"] = line["value"] / cpu_baseline["value"]
@@ -189,6 +201,95 @@ def main():
     g.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def run_large_window_roofline(capi, syn, dtype, s_bytes):
+    """C4-sized window on one GPU (12 keyframes, 50 000 points, 640x480): the configuration where the sweep moves enough
+    bytes for the HBM fraction to mean something.  Isolated kernel, 50 back-to-back launches per event pair."""
+    F, P = 12, 50000
+    win = syn.make_window(num_frames=F, num_points=P, width=640, height=480, seed=1)
+    g = capi.HipWindow(capi.default_pba_options(dtype=dtype))
+    syn.load_window(g, win)
+    g.snapshot()
+    g.restore()
+    out = {"workload": f"{F}-KF window, {P} points, 640x480, single GPU", "kernels_isolated_avg_us": {}}
+    for k in ("sweep_linearize", "sweep_energy", "schur", "assemble_solve"):
+        out["kernels_isolated_avg_us"][k] = g.time_kernel(k, 50)
+    b_lin = algorithmic_bytes_linearize(P, F, s_bytes)
+    t = out["kernels_isolated_avg_us"]["sweep_linearize"] * 1e-6
+    out.update({"bound": "hbm", "kernel": "sweep_linearize", "algorithmic_bytes_per_launch": b_lin, "achieved": b_lin / t / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_lin / t / 1e9 / HBM_PEAK_GBS})
+    g.restore()
+    g.set_max_iterations(7)
+    t0 = time.perf_counter()
+    _, it, _ = g.optimize()
+    out["gn_iterations_per_s"] = it / (time.perf_counter() - t0)
+    g.close()
+    return out
+
+
+def run_tracker_timing(capi, syn, torch, frames=20):
+    """C2 of BASELINE.json: coarse-to-fine direct image alignment of a new 1280x1024 frame against a reference keyframe,
+    5 pyramid levels (monocular_tracker.cpp:136-248: per level reset / push reference depth map / push target / solve).
+    The 8-bit target image is resident in HBM; per frame = pyramid build (device) + 5 alignments.  The reference points
+    are handed over as point lists (u, v, idepth per level, ~2000 points: what createReferenceDepthMaps + the LocalFrame
+    depth-map constructor produce); the depth-map overload of the C-ABI adds the H2D copy of two H x W planes per level."""
+    W, H, L, n_pts = 1280, 1024, 5, 2000
+    win = syn.make_window(num_frames=2, num_points=16, width=W, height=H, seed=3)
+    fr, ft = win.frames
+    pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
+    pr.build(fr.image_u8)
+    img_dev = torch.from_numpy(ft.image_u8.copy()).cuda()
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(0)
+    pts = []
+    for l in range(L):
+        w, h = W >> l, H >> l
+        n = min(n_pts, (w - 16) * (h - 16) // 4)
+        u = rng.integers(8, w - 8, n).astype(np.float64)
+        v = rng.integers(8, h - 8, n).astype(np.float64)
+        idp = 1.0 / fr.depth[np.minimum(v.astype(int) << l, H - 1), np.minimum(u.astype(int) << l, W - 1)]
+        pts.append((u, v, idp))
+    T_ref = syn.mat_to_params(fr.T_w_c_gt)
+    T_init = syn.mat_to_params(ft.T_w_c_init)
+    a = capi.HipAligner(capi.default_align_options())
+
+    def one_frame():
+        pt.build_device(img_dev.data_ptr())
+        T = T_init
+        its = 0
+        for l in range(L - 1, -1, -1):
+            intr = win.scene.intrinsics / (1 << l)
+            a.reset()
+            a.push_reference_points(1000, T_ref, pr, l, intr, pts[l][0], pts[l][1], pts[l][2], 1.0, np.zeros(2))
+            a.push_target(2000, T, pt, l, intr, 1.0, np.zeros(2))
+            r = a.solve()
+            T = r["T_w_target"]
+            its += r["iterations"]
+        return T, its
+
+    one_frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(frames):
+        T, k = one_frame()
+        its += k
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        pt.build_device(img_dev.data_ptr())
+    torch.cuda.synchronize()
+    pyr_ms = (time.perf_counter() - t0) / frames * 1e3
+    gt = syn.mat_to_params(ft.T_w_c_gt)
+    out = {"metric": "frame-tracking ms/frame (1280x1024, 5 pyramid levels, coarse-to-fine alignment)", "ms_per_frame": ms,
+           "pyramid_ms": pyr_ms, "lm_iterations_per_frame": its / frames, "points_per_level": n_pts,
+           "pose_error_vs_ground_truth": float(np.abs(T - gt).max()), "initial_pose_error": float(np.abs(T_init - gt).max()),
+           "data": "synthetic, target image resident in HBM"}
+    for o in (a, pr, pt):
+        o.close()
+    return out
 
 
 def run_cpu_baseline(args, F, P, win, syn):
@@ -216,6 +317,23 @@ def run_cpu_baseline(args, F, P, win, syn):
         t_used += time.perf_counter() - t0
         its += it
         solves += 1
+    # second figure: all host cores (the reference caps its pool at 7 worker threads; this is the uncapped restatement)
+    all_cores = None
+    if hw > threads:
+        hw = min(hw, 16)  # the pool oversubscribes badly beyond a few dozen threads on this problem size
+        po.set_threads(hw)
+        reset()
+        o.optimize()
+        its2, t2, n2 = 0, 0.0, 0
+        while t2 < min(args.cpu_seconds, 6.0) and n2 < 100:
+            reset()
+            t0 = time.perf_counter()
+            _, it, _ = o.optimize()
+            t2 += time.perf_counter() - t0
+            its2 += it
+            n2 += 1
+        all_cores = {"value": its2 / t2, "cores": hw}
+        po.set_threads(threads)
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as fh:
@@ -225,7 +343,7 @@ def run_cpu_baseline(args, F, P, win, syn):
                     break
     except OSError:
         pass
-    return {"value": its / t_used, "unit": "GN iterations/s", "cores": threads, "kind": "port",
+    return {"value": its / t_used, "unit": "GN iterations/s", "cores": threads, "kind": "port", "all_cores": all_cores,
             "sample": f"{solves} LM solves ({its} GN iterations, {t_used:.1f} s) of the same C1 window ({F} KF, {P} points), "
                       f"oracle = restatement of the reference CPU path, {threads} threads (reference cap), host {cpu_model} ({hw} hw threads)"}
 

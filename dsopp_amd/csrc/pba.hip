@@ -335,7 +335,7 @@ void syncTopology(W &w) {
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
   w.d_Hpp.reserve(KK * KK, 0, st);
   w.d_bpp.reserve(KK, 0, st);
-  w.d_reduce.reserve(2 * (KK * KK + KK), 0, st);
+  w.d_reduce.reserve(2 * (KK * KK + KK) + 8, 0, st);  // + tail: the 4 energy scalars ride in the same collective (sharded windows)
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
@@ -509,7 +509,8 @@ struct FusedReduce {
 
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
  *  in the fused loop it starts with the LM decision for the pending candidate */
-void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr) {
+enum class ReduceMode { kFused, kAccumulateOnly, kDecideOnly };
+void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr, ReduceMode mode = ReduceMode::kFused) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
   static bool attr_set = false;
@@ -533,20 +534,28 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.n_schur_blocks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
   a.for_marginalized = for_marg ? 1 : 0;
   a.ublk_parity = fused ? fused->ublk_parity : 0;
-  a.ctrl_out = fused ? fused->ctrl_out : nullptr;
+  a.ctrl_out = (fused && mode != ReduceMode::kAccumulateOnly) ? fused->ctrl_out : nullptr;
   a.st = w.d_state.ptr;
-  a.scalars = w.d_scalars.ptr;
+  a.scalars = mode == ReduceMode::kDecideOnly ? w.d_reduce.ptr + w.reduceCount() : w.d_scalars.ptr;
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
   if (fused) a.prm = fused->prm;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
+  const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
+  if (mode == ReduceMode::kDecideOnly) {
+    timedLaunch(w, DSOPP_HIP_KERNEL_ACCEPT,
+                [&] { decideApplyKernel<<<std::max(1, a.n_schur_blocks), kSchurThreads, decide_smem, st>>>(a); });
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
-    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8)), st>>>(a);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), decide_smem), st>>>(a);
   });
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
-  allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+  // (in the fused loop the 4 energy scalars of the sweep sit right behind the systems and travel with them)
+  allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount() + (mode == ReduceMode::kAccumulateOnly ? 4 : 0));
   (void)K;
 }
 
@@ -839,15 +848,18 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     ex.gate_on_pending = true;
     ex.fused_lin_backsub = true;
     launchSweep(w, true, true, false, cin, true, 0.0, ex);
-    if (w.allreduce) {
-      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr, cin);
-      allreduceIfNeeded(w, w.d_scalars.ptr, 4);
-    }
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
     fr.prm = prm;
-    launchReduceSchur(w, false, cin, &fr);
+    if (w.allreduce) {
+      // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
+      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.reduceCount(), cin);
+      launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
+      launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
+    } else {
+      launchReduceSchur(w, false, cin, &fr);
+    }
     if (r + 1 < rounds) launchAssemble(w, 0.0, true, true, false, cout);
   }
   LmControl *cfin = ctrl + (rounds & 1);

@@ -567,6 +567,19 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   applyDecision(a, ar);
 }
 
+/** Landmark-sharded windows: the decide / apply prologue of reduceSchurKernel as a kernel of its own.  With shards the
+ *  decision needs the all-reduced energy, so the fused loop accumulates the local systems first (reduceSchurKernel
+ *  without ctrl_out), all-reduces [systems | scalars] in ONE collective and only then decides.  grid = schur blocks (>= 1). */
+__global__ void __launch_bounds__(kSchurThreads) decideApplyKernel(ReduceSchurArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  long long dbg_unused[2] = {0, 0};
+  ApplyRegs ar;
+  ar.pending = 0;
+  ar.publish = 0;
+  fusedDecideApply(a, reinterpret_cast<double *>(smem_raw), dbg_unused, ar);
+  applyDecision(a, ar);
+}
+
 /** zeroes the Schur accumulation target unless the device-driven loop skips this linearisation */
 __global__ void clearSchurKernel(double *buf, int n, const LmControl *ctrl) {
   if (ctrl && (!ctrl->active || ctrl->linear_system_valid)) return;
