@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -168,6 +168,36 @@ class Pyramid:
         return out
 
 
+class DepthMaps:
+    """Device-resident reference depth maps of the newest keyframe (dsopp_hip_depth_maps)."""
+
+    def __init__(self, handle, levels):
+        self._h, self.levels = handle, int(levels)
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_depth_maps_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_depth_maps_level_size(self._h, int(level), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def get_level(self, level):
+        """(idepth_sum, weight), each H x W"""
+        w, h = self.level_size(level)
+        ids, wgt = np.zeros((h, w)), np.zeros((h, w))
+        _chk(lib().dsopp_hip_depth_maps_get_level(self._h, int(level), _p(ids), _p(wgt)))
+        return ids, wgt
+
+
 class HipWindow:
     """Sliding-window photometric BA on the GPU; same Python interface as oracle.pyoracle.OracleWindow."""
 
@@ -246,6 +276,12 @@ class HipWindow:
         e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
         _chk(lib().dsopp_hip_window_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
         return e.value, it.value, nv.value
+
+    def create_reference_depth_maps(self, levels: int) -> DepthMaps:
+        """createReferenceDepthMaps of the window's newest keyframe, on the device"""
+        h = C.c_void_p()
+        _chk(lib().dsopp_hip_window_create_reference_depth_maps(self._h, int(levels), C.byref(h)))
+        return DepthMaps(h, levels)
 
     def optimize_repeated(self, iterations_target: int):
         """{restore(); optimize()} from the snapshot until exactly `iterations_target` GN iterations ran; returns
@@ -407,6 +443,10 @@ class HipAligner:
         _chk(lib().dsopp_hip_aligner_push_reference_depth_map(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),
                                                               _p(_f64(intrinsics)), _p(_f64(idepth_sum)), _p(_f64(weight)), C.c_double(exposure),
                                                               _p(_f64(affine))))
+
+    def push_reference_depth_maps(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, maps: DepthMaps, exposure, affine):
+        _chk(lib().dsopp_hip_aligner_push_reference_depth_maps(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),
+                                                               _p(_f64(intrinsics)), maps._h, C.c_double(exposure), _p(_f64(affine))))
 
     def push_reference_points(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, u, v, idepth, exposure, affine):
         _chk(lib().dsopp_hip_aligner_push_reference_points(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),

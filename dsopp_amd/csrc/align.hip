@@ -16,6 +16,7 @@
 #include <map>
 #include <memory>
 
+#include "depth_maps.hpp"
 #include "device_geom.hpp"
 #include "host_linalg.hpp"
 #include "pyramid.hpp"
@@ -374,6 +375,7 @@ struct dsopp_hip_aligner {
   Rigid T_w_ref = rigidIdentity(), T_w_tgt = rigidIdentity();
   int n_points = 0;
   DeviceBuffer<double> d_u, d_v, d_id, d_int, d_partials[2];
+  DeviceBuffer<int> d_rows;  // row counts / offsets of the device-side depth-map scan
   DeviceBuffer<AlignControl> d_ctrl;
   std::map<int64_t, Rigid> known_poses;
 };
@@ -395,6 +397,17 @@ void setFrame(AlignFrameDev &f, const dsopp_hip_pyramid *p, int level, const dou
   f.ab0[1] = ab[1];
 }
 
+void sampleReferenceIntensitiesImpl(hipStream_t st, const dsopp_hip_pyramid *pyr, int level, const double *u, const double *v, double *out, size_t n) {
+  if (!n) return;
+  const LevelView lv = pyr->view(level);
+  const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+  if (pyr->dtype == DSOPP_HIP_F64)
+    sampleReferenceKernel<double><<<grid, 256, 0, st>>>(static_cast<const Texel<double> *>(lv.texels), lv.width, u, v, out, static_cast<int>(n));
+  else
+    sampleReferenceKernel<float><<<grid, 256, 0, st>>>(static_cast<const Texel<float> *>(lv.texels), lv.width, u, v, out, static_cast<int>(n));
+  HIP_CHECK(hipGetLastError());
+}
+
 void uploadPoints(dsopp_hip_aligner *a, const dsopp_hip_pyramid *pyr, int level, const std::vector<double> &u, const std::vector<double> &v,
                   const std::vector<double> &id) {
   const size_t n = u.size();
@@ -406,18 +419,79 @@ void uploadPoints(dsopp_hip_aligner *a, const dsopp_hip_pyramid *pyr, int level,
   a->d_u.upload(u.data(), n, 0, st);
   a->d_v.upload(v.data(), n, 0, st);
   a->d_id.upload(id.data(), n, 0, st);
-  if (n) {
-    const LevelView lv = pyr->view(level);
-    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
-    if (pyr->dtype == DSOPP_HIP_F64)
-      sampleReferenceKernel<double><<<grid, 256, 0, st>>>(static_cast<const Texel<double> *>(lv.texels), lv.width, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, static_cast<int>(n));
-    else
-      sampleReferenceKernel<float><<<grid, 256, 0, st>>>(static_cast<const Texel<float> *>(lv.texels), lv.width, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, static_cast<int>(n));
-    HIP_CHECK(hipGetLastError());
-  }
+  sampleReferenceIntensitiesImpl(st, pyr, level, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, n);
   a->sr.sync();
   a->n_points = static_cast<int>(n);
 }
+
+// ---- device-side scan of a reference depth map (LocalFrame depth-map ctor, PBA_INT/local_frame.hpp:367-392): a pixel
+// becomes a reference point when it lies inside the 4-px border, its weight is positive and idepth = sum / weight >= 1e-6.
+// The compaction keeps the row-major order of the reference's scan (= its summation order in the alignment).
+__device__ inline bool depthMapPointValid(const double *idsum, const double *weight, int W, int H, int x, int y, double &id) {
+  if (x < 4 || y < 4 || x >= W - 4 || y >= H - 4) return false;
+  const size_t i = static_cast<size_t>(y) * W + x;
+  const double w = weight[i];
+  if (!(w > 0)) return false;
+  id = idsum[i] / w;
+  return !(id < 1e-6);
+}
+
+__global__ void countDepthMapRowsKernel(const double *__restrict__ idsum, const double *__restrict__ weight, int W, int H, int *row_count) {
+  __shared__ int wave_sum[4];
+  const int y = blockIdx.x;
+  int c = 0;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    double id;
+    c += depthMapPointValid(idsum, weight, W, H, x, y, id) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) row_count[y] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+
+/** exclusive scan of the row counts (one workgroup; H <= a few thousand); row_offset[H] = total */
+__global__ void scanDepthMapRowsKernel(const int *row_count, int H, int *row_offset) {
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int y = 0; y < H; ++y) {
+      row_offset[y] = acc;
+      acc += row_count[y];
+    }
+    row_offset[H] = acc;
+  }
+}
+
+__global__ void compactDepthMapRowsKernel(const double *__restrict__ idsum, const double *__restrict__ weight, int W, int H,
+                                          const int *__restrict__ row_offset, double *u, double *v, double *idepth) {
+  __shared__ int wave_cnt[4];
+  __shared__ int running;
+  const int y = blockIdx.x;
+  if (threadIdx.x == 0) running = row_offset[y];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int x0 = 0; x0 < W; x0 += 256) {
+    const int x = x0 + threadIdx.x;
+    double id = 0;
+    const bool ok = x < W && depthMapPointValid(idsum, weight, W, H, x, y, id);
+    const unsigned long long m = __ballot(ok);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = running;
+    for (int k = 0; k < wave; ++k) base += wave_cnt[k];
+    if (ok) {
+      const int dst = base + before;
+      u[dst] = x;
+      v[dst] = y;
+      idepth[dst] = id;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
 
 void checkPyramid(dsopp_hip_aligner *a, const dsopp_hip_pyramid *p, int level) {
   if (!p) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pyramid");
@@ -508,6 +582,47 @@ int dsopp_hip_aligner_push_reference_depth_map(dsopp_hip_aligner *a, int64_t tim
     a->T_w_ref = rigidFromParams(T_world_agent);
     a->ref_time = timestamp;
     uploadPoints(a, pyramid, level, uu, vv, dd);
+    a->have_ref = true;
+  });
+}
+
+int dsopp_hip_aligner_push_reference_depth_maps(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                                const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4],
+                                                const dsopp_hip_depth_maps *maps, double exposure_time, const double affine_brightness[2]) {
+  return guarded([&] {
+    if (!a || !T_world_agent || !intrinsics || !affine_brightness || !maps) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    checkPyramid(a, pyramid, level);
+    if (a->have_ref || a->have_tgt) fail(DSOPP_HIP_ERR_ORDER, "the reference frame must be pushed first after reset()");
+    if (level >= maps->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the depth maps have %d levels, level %d requested", maps->levels, level);
+    if (maps->sr.device != a->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "depth maps live on another device");
+    const int W = pyramid->w(level), H = pyramid->h(level);
+    if (W != maps->width[static_cast<size_t>(level)] || H != maps->height[static_cast<size_t>(level)])
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "depth map level %d is %d x %d, pyramid level is %d x %d", level, maps->width[static_cast<size_t>(level)],
+           maps->height[static_cast<size_t>(level)], W, H);
+    a->sr.use();
+    hipStream_t st = a->sr.stream;
+    if (maps->sr.stream != st) HIP_CHECK(hipStreamSynchronize(maps->sr.stream));  // producer finished (it synchronises at creation anyway)
+    const double *idsum = maps->idepth_sum[static_cast<size_t>(level)].ptr, *wgt = maps->weight[static_cast<size_t>(level)].ptr;
+    a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
+    int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
+    countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
+    scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
+    int total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
+    a->sr.sync();
+    const size_t n = static_cast<size_t>(total);
+    a->d_u.reserve(std::max<size_t>(n, 1), 0, st);
+    a->d_v.reserve(std::max<size_t>(n, 1), 0, st);
+    a->d_id.reserve(std::max<size_t>(n, 1), 0, st);
+    a->d_int.reserve(std::max<size_t>(n, 1), 0, st);
+    if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr);
+    HIP_CHECK(hipGetLastError());
+    setFrame(a->ref, pyramid, level, intrinsics, exposure_time, affine_brightness);
+    a->T_w_ref = rigidFromParams(T_world_agent);
+    a->ref_time = timestamp;
+    sampleReferenceIntensitiesImpl(st, pyramid, level, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, n);
+    a->sr.sync();
+    a->n_points = total;
     a->have_ref = true;
   });
 }

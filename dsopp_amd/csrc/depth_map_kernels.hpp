@@ -1,0 +1,96 @@
+// Kernels of createReferenceDepthMaps (src/tracker/tracker/src/create_depth_maps.cpp:18-147).  Tiny, HBM-streaming work:
+// one splat launch per older keyframe (fp64 atomics into the fine map), one 2x2 sum-pool per coarser level, one dilation
+// per level (ping-pong planes: the reference reads neighbours through a backup of the weights, :94-99).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_geom.hpp"
+#include "pba_types.hpp"
+
+namespace dsopp_hip {
+
+struct SplatArgs {
+  double M[12];        // reproject_ = K [R|t] K^-1 of T_newest^-1 T_source (camera_reproject.hpp:256)
+  double Tz[4];        // row 2 of [R|t]: getDepthScale = Tz . [direction; idepth] (camera_model_base.hpp:102-107)
+  double fx, fy, cx, cy;
+  int width, height;
+  int n;
+  int use_variance;    // 0: every landmark has variance 1e-5 (estimate_uncertainty off, photometric_bundle_adjustment.cpp:254)
+  const double *uv, *idepth, *inv_hdd;
+  const uint8_t *flags, *status;
+};
+
+/** fillFineDepthMap — create_depth_maps.cpp:18-59; one thread per landmark of one older keyframe */
+__global__ void splatDepthMapKernel(SplatArgs a, double *__restrict__ idsum, double *__restrict__ wsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  if (a.status[i] != DSOPP_HIP_STATUS_OK) return;                 // :36
+  const uint8_t flg = a.flags[i];
+  if (flg & (kFlagMarginalized | kFlagOutlier)) return;           // :38
+  double idepth = a.idepth[i];
+  // what updateFrame hands to the keyframe (PROB_SRC/photometric_bundle_adjustment.cpp:233-239): |idepth| < 1e-8 -> 0,
+  // idepth < 0 -> outlier
+  if (fabs(idepth) < 1e-8) idepth = 0;
+  else if (idepth < 0) return;
+  const double u = a.uv[2 * i], v = a.uv[2 * i + 1];
+  const double W = a.width, H = a.height;
+  // ArrayReprojector<..., kCheckSuccess = true>::reproject — camera_reproject.hpp:270-293
+  if (!(validIdepth(idepth) && insideROI(u, v, W, H))) return;
+  const double x = a.M[0] * u + a.M[1] * v + (a.M[2] + a.M[3] * idepth);
+  const double y = a.M[4] * u + a.M[5] * v + (a.M[6] + a.M[7] * idepth);
+  const double z = a.M[8] * u + a.M[9] * v + (a.M[10] + a.M[11] * idepth);
+  const double tu = x / z, tv = y / z;
+  if (!(z > 0) || !insideROI(tu, tv, W, H)) return;
+  const int ix = static_cast<int>(round(tu)), iy = static_cast<int>(round(tv));  // :46
+  const double dx = (u - a.cx) * (1.0 / a.fx), dy = (v - a.cy) * (1.0 / a.fy);
+  const double depth_scale = a.Tz[0] * dx + a.Tz[1] * dy + a.Tz[2] * 1.0 + a.Tz[3] * idepth;  // :49
+  const double variance = a.use_variance ? a.inv_hdd[i] : 1e-5;
+  const double weight = sqrt(1e-3 / (variance + 1e-12));  // :51
+  const size_t cell = static_cast<size_t>(iy) * a.width + ix;
+  atomicAdd(&idsum[cell], idepth / depth_scale * weight);  // :52
+  atomicAdd(&wsum[cell], weight);                          // :53
+}
+
+/** fillCoarseDepthMaps — create_depth_maps.cpp:70-88 */
+__global__ void poolDepthMapKernel(const double *__restrict__ up_id, const double *__restrict__ up_w, int up_width, double *__restrict__ id,
+                                   double *__restrict__ w, int width, int height) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const size_t a = static_cast<size_t>(2 * y) * up_width + 2 * x, b = a + up_width;
+  id[static_cast<size_t>(y) * width + x] = up_id[a] + up_id[a + 1] + up_id[b] + up_id[b + 1];
+  w[static_cast<size_t>(y) * width + x] = up_w[a] + up_w[a + 1] + up_w[b] + up_w[b + 1];
+}
+
+/** dilateDepthMaps — create_depth_maps.cpp:90-122; in -> out planes (out must differ from in) */
+__global__ void dilateDepthMapKernel(const double *__restrict__ in_id, const double *__restrict__ in_w, double *__restrict__ out_id,
+                                     double *__restrict__ out_w, int width, int height, int diagonal) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const size_t c = static_cast<size_t>(y) * width + x;
+  double id = in_id[c], w = in_w[c];
+  if (!(w > 0) && x >= 1 && y >= 1 && x < width - 1 && y < height - 1) {
+    double sum = 0, num = 0, numn = 0;
+    // offsets in the reference's order (:105-109): level > 1: (1,0) (-1,0) (0,1) (0,-1); else (1,1) (-1,-1) (1,-1) (-1,1)
+    constexpr int kAxisX[4] = {1, -1, 0, 0}, kAxisY[4] = {0, 0, 1, -1};
+    constexpr int kDiagX[4] = {1, -1, 1, -1}, kDiagY[4] = {1, -1, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ox = diagonal ? kDiagX[k] : kAxisX[k], oy = diagonal ? kDiagY[k] : kAxisY[k];
+      const size_t n = static_cast<size_t>(y + oy) * width + (x + ox);
+      const double nw = in_w[n];
+      if (nw > 0) {
+        sum += in_id[n];
+        num += nw;
+        numn += 1;
+      }
+    }
+    if (numn > 0) {
+      id = sum / numn;
+      w = num / numn;
+    }
+  }
+  out_id[c] = id;
+  out_w[c] = w;
+}
+
+}  // namespace dsopp_hip

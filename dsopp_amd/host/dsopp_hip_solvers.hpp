@@ -110,6 +110,31 @@ struct TrustRegionOptions {
 };
 
 /** mirror of EigenPhotometricBundleAdjustment<SE3, PinholeCamera, 8, PixelMap, true, true, true, 1> backed by HIP kernels */
+/** Reference depth maps of the newest keyframe, resident on the device: what tracker::createReferenceDepthMaps
+ *  (src/tracker/tracker/src/create_depth_maps.cpp:124-147) returns as std::vector<energy::problem::DepthMap>. */
+class DeviceDepthMaps {
+ public:
+  explicit DeviceDepthMaps(dsopp_hip_depth_maps *m = nullptr) : m_(m) {}
+  ~DeviceDepthMaps() { dsopp_hip_depth_maps_destroy(m_); }
+  DeviceDepthMaps(const DeviceDepthMaps &) = delete;
+  DeviceDepthMaps &operator=(const DeviceDepthMaps &) = delete;
+  DeviceDepthMaps(DeviceDepthMaps &&o) noexcept : m_(o.m_) { o.m_ = nullptr; }
+  const dsopp_hip_depth_maps *handle() const { return m_; }
+  /** host copy of one level: two row-major H x W planes (DepthMap::map(x, y).idepth / .weight) */
+  void level(int level, std::vector<double> &idepth_sum, std::vector<double> &weight, int &width, int &height) const {
+    int32_t w = 0, h = 0;
+    check(dsopp_hip_depth_maps_level_size(m_, level, &w, &h));
+    idepth_sum.assign(static_cast<size_t>(w) * h, 0.0);
+    weight.assign(static_cast<size_t>(w) * h, 0.0);
+    check(dsopp_hip_depth_maps_get_level(m_, level, idepth_sum.data(), weight.data()));
+    width = w;
+    height = h;
+  }
+
+ private:
+  dsopp_hip_depth_maps *m_;
+};
+
 class HipPhotometricBundleAdjustment {
  public:
   /** EigenPhotometricBundleAdjustment(options, estimate_uncertainty, force_accept) — eigen_photometric_bundle_adjustment.cpp:47-57 */
@@ -153,6 +178,13 @@ class HipPhotometricBundleAdjustment {
     uploadLandmarks(frame);
     uploadConnections(frame);
     if (frame.is_marginalized) check(dsopp_hip_window_mark_frame_marginalized(w_, frame.keyframe_id));
+  }
+  /** tracker::createReferenceDepthMaps(active frames, calibration) for the window this solver holds, without leaving the
+   *  device (monocular_tracker.cpp:465,509 call it right after the bundle adjustment, on the same keyframes) */
+  DeviceDepthMaps createReferenceDepthMaps(int levels) {
+    dsopp_hip_depth_maps *m = nullptr;
+    check(dsopp_hip_window_create_reference_depth_maps(w_, levels, &m));
+    return DeviceDepthMaps(m);
   }
   /** solve(number_of_threads) -> final energy; number_of_threads is accepted and ignored, as in the Eigen backend */
   double solve(const size_t number_of_threads = 1) {
@@ -277,6 +309,13 @@ class HipPoseAlignment {
     const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
     check(dsopp_hip_aligner_push_reference_depth_map(a_, timestamp, t_world_agent.data(), pyramids.handle(), static_cast<int>(level), intr,
                                                      depth_idepth_sum, depth_weight, exposure_time, affine_brightness.data()));
+  }
+  /** the same overload fed from device-resident maps (HipPhotometricBundleAdjustment::createReferenceDepthMaps) */
+  void pushFrame(time_point timestamp, const Motion &t_world_agent, const DevicePyramid &pyramids, const DeviceDepthMaps &depth_maps,
+                 double exposure_time, const Vector2 &affine_brightness, size_t level, const PinholeModel &model) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_aligner_push_reference_depth_maps(a_, timestamp, t_world_agent.data(), pyramids.handle(), static_cast<int>(level), intr,
+                                                      depth_maps.handle(), exposure_time, affine_brightness.data()));
   }
   /** pushFrame(timestamp, t_world_agent_init, pyramids, masks, exposure, affine, level, model, kFree) — :131-154 */
   void pushFrame(time_point timestamp, const Motion &t_world_agent_init, const DevicePyramid &pyramids, double exposure_time,

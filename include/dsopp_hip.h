@@ -237,7 +237,21 @@ typedef struct dsopp_hip_align_result {
   int32_t iterations;
   double T_world_target[7];
   double affine_brightness[2];
-  double covariance[36]; /* tTargetReferenceCovariance — eigen_pose_alignment.cpp:320-323 */
+  double covariance[36]; /* ---- reference depth maps of the newest keyframe (row a21) ----
+ * createReferenceDepthMaps (src/tracker/tracker/src/create_depth_maps.cpp:124-147) on the device, from the window's own
+ * state: the active landmarks of every older keyframe (connection status kOk towards the newest keyframe, not outlier, not
+ * marginalized — :36-38) are reprojected into the newest keyframe and splatted with weight sqrt(1e-3 / (variance + 1e-12))
+ * (:51-53; variance = H_dd^-1 of the last linearisation when estimate_uncertainty, else 1e-5 —
+ * PROB_SRC/photometric_bundle_adjustment.cpp:252-254), sum-pooled to `levels` pyramid levels (:70-88) and dilated (:90-122).
+ * The maps stay in HBM; dsopp_hip_aligner_push_reference_depth_maps hands a level to the tracker without a host round trip. */
+typedef struct dsopp_hip_depth_maps dsopp_hip_depth_maps;
+int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t levels, dsopp_hip_depth_maps **out);
+void dsopp_hip_depth_maps_destroy(dsopp_hip_depth_maps *m);
+int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level, int32_t *width, int32_t *height);
+/* copies one level to the host: two row-major H x W planes (energy::problem::DepthMap::map(x, y).{idepth, weight}) */
+int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level, double *idepth_sum, double *weight);
+
+/* tTargetReferenceCovariance — eigen_pose_alignment.cpp:320-323 */
   double H[64];
 } dsopp_hip_align_result;
 
@@ -253,6 +267,11 @@ int dsopp_hip_aligner_push_reference_depth_map(dsopp_hip_aligner *a, int64_t tim
                                                const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4],
                                                const double *idepth_sum, const double *weight, double exposure_time,
                                                const double affine_brightness[2]);
+/* same, from device-resident maps (dsopp_hip_window_create_reference_depth_maps): the scan / compaction of the LocalFrame
+ * depth-map constructor runs on the device and keeps the reference's row-major point order */
+int dsopp_hip_aligner_push_reference_depth_maps(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
+                                                const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4],
+                                                const dsopp_hip_depth_maps *maps, double exposure_time, const double affine_brightness[2]);
 /* same with an explicit point list (u, v, idepth); intensity sampled on the device */
 int dsopp_hip_aligner_push_reference_points(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7],
                                             const dsopp_hip_pyramid *pyramid, int level, const double intrinsics[4], int32_t n,

@@ -7,6 +7,7 @@
 
 #include "pba.hpp"
 #include "pose_alignment.hpp"
+#include "depth_maps.hpp"
 #include "pyramid.hpp"
 
 using namespace oracle;
@@ -307,6 +308,34 @@ int orc_points_from_depth_map(int width, int height, const double *pixelinfo, co
     intensity[i] = pts[static_cast<size_t>(i)].intensity;
   }
   return n;
+}
+
+int orc_create_reference_depth_maps(int n_sources, const double *T_w_sources, const int32_t *counts, const double *uv,
+                                    const double *idepth, const double *variance, const uint8_t *skip, const uint8_t *status,
+                                    const double T_w_newest[7], const double intrinsics[4], int width, int height, int levels,
+                                    double *idepth_sum_out, double *weight_out) {
+  std::vector<DepthMapSource> sources(static_cast<size_t>(n_sources));
+  size_t off = 0;
+  for (int s = 0; s < n_sources; ++s) {
+    DepthMapSource &src = sources[static_cast<size_t>(s)];
+    src.t_world_agent = SE3::fromParams(T_w_sources + 7 * s);
+    src.n = counts[s];
+    src.uv = uv + 2 * off;
+    src.idepth = idepth + off;
+    src.variance = variance + off;
+    src.skip = skip + off;
+    src.status = status + off;
+    off += static_cast<size_t>(counts[s]);
+  }
+  const PinholeModel model{static_cast<double>(width), static_cast<double>(height), intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const auto maps = createReferenceDepthMaps(sources, SE3::fromParams(T_w_newest), model, levels);
+  size_t o = 0;
+  for (const DepthMapLevel &m : maps) {
+    std::copy(m.idepth.begin(), m.idepth.end(), idepth_sum_out + o);
+    std::copy(m.weight.begin(), m.weight.end(), weight_out + o);
+    o += m.idepth.size();
+  }
+  return static_cast<int>(maps.size());
 }
 
 int orc_align_solve(const orc_options *o, int n, const double *u, const double *v, const double *idepth,

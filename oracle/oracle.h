@@ -97,6 +97,14 @@ int orc_align_solve(const orc_options *o, int n, const double *u, const double *
                     int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
                     const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2], orc_align_result *out);
 
+/* createReferenceDepthMaps (create_depth_maps.cpp:18-147) over plain arrays: n_sources older keyframes, source s holds
+ * counts[s] landmarks starting at offsets into the concatenated arrays (uv 2 per landmark).  Outputs: per level row-major
+ * H_l x W_l planes, concatenated level after level (level sizes halve, floor). */
+int orc_create_reference_depth_maps(int n_sources, const double *T_w_sources /* 7 each */, const int32_t *counts, const double *uv,
+                                    const double *idepth, const double *variance, const uint8_t *skip, const uint8_t *status,
+                                    const double T_w_newest[7], const double intrinsics[4], int width, int height, int levels,
+                                    double *idepth_sum_out, double *weight_out);
+
 /* ---- pyramid ---- */
 /* pixelinfo_out[l] must hold 3*w_l*h_l doubles; plane_out[l] (optional) w_l*h_l */
 int orc_build_pyramid(const uint8_t *image, int width, int height, const double *lut256, const uint8_t *vignetting,

@@ -260,6 +260,33 @@ def points_from_depth_map(pixelinfo, idepth_sum, weight):
     return u[:n].copy(), v[:n].copy(), d[:n].copy(), inten[:n].copy()
 
 
+def create_reference_depth_maps(sources, T_w_newest, intrinsics, width, height, levels):
+    """createReferenceDepthMaps (create_depth_maps.cpp:18-147).  sources: list of dicts with T_w (7), uv (n x 2), idepth,
+    variance, skip (outlier | marginalized), status (connection statuses towards the newest keyframe).
+    Returns [(idepth_sum, weight)] per level, H_l x W_l each."""
+    counts = np.array([len(s["idepth"]) for s in sources], dtype=np.int32)
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(s[k], dtype=dt).reshape(len(s["idepth"]), -1) for s in sources]).ravel()
+                                             if len(sources) else np.zeros(0, dtype=dt), dtype=dt)
+    Ts = np.ascontiguousarray(np.concatenate([_f64(s["T_w"]) for s in sources]) if len(sources) else np.zeros(0))
+    sizes, w, h = [], int(width), int(height)
+    for _ in range(levels):
+        sizes.append((h, w))
+        w, h = w // 2, h // 2
+    total = sum(a * b for a, b in sizes)
+    ids, wgt = np.zeros(total), np.zeros(total)
+    uv, idp, var = cat("uv", np.float64), cat("idepth", np.float64), cat("variance", np.float64)
+    skip, status = cat("skip", np.uint8), cat("status", np.uint8)
+    n = lib().orc_create_reference_depth_maps(len(sources), _p(Ts), counts.ctypes.data_as(C.POINTER(C.c_int32)), _p(uv), _p(idp), _p(var),
+                                              _p(skip, np.uint8), _p(status, np.uint8), _p(_f64(T_w_newest)), _p(_f64(intrinsics)),
+                                              int(width), int(height), int(levels), _p(ids), _p(wgt))
+    assert n == levels
+    out, o = [], 0
+    for (hh, ww) in sizes:
+        out.append((ids[o:o + hh * ww].reshape(hh, ww).copy(), wgt[o:o + hh * ww].reshape(hh, ww).copy()))
+        o += hh * ww
+    return out
+
+
 def align_solve(options, u, v, idepth, intensity, ref_intr, ref_size, T_w_ref, ref_exposure, ref_ab, tgt_intr, tgt_pixelinfo,
                 tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab):
     pix = _f64(tgt_pixelinfo)
