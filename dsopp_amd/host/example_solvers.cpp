@@ -107,6 +107,24 @@ int main() {
   const double rmse = align.solve(1);
   const Motion Ta = align.getPose(3000);
   std::printf("alignment: rmse %.3f, tx 0.17000 -> %.5f (ground truth 0.20000)\n", rmse, Ta[4]);
+
+  // reference depth maps of the newest keyframe straight from the window (createReferenceDepthMaps), consumed on the device
+  DeviceDepthMaps maps = pba.createReferenceDepthMaps(1);
+  std::vector<double> dm_id, dm_w;
+  int dm_width = 0, dm_height = 0;
+  maps.level(0, dm_id, dm_w, dm_width, dm_height);
+  int filled = 0;
+  for (double wv : dm_w) filled += wv > 0 ? 1 : 0;
+  std::printf("reference depth map %d x %d: %d cells carry depth\n", dm_width, dm_height, filled);
+  ok = ok && filled > 0;
+  HipPoseAlignment align2(aopt);
+  align2.reset();
+  const KeyframeView &newest = frames[2];
+  align2.pushFrame(newest.timestamp, newest.t_world_agent, *pyramids[2], maps, 1.0, Vector2{0, 0}, 0, model);
+  align2.pushFrame(newest.timestamp + 500, newest.t_world_agent, *pyramids[2], 1.0, Vector2{0, 0}, 0, model);
+  const double rmse2 = align2.solve(1);
+  std::printf("alignment of the newest keyframe against its own depth map: rmse %.3f\n", rmse2);
+  ok = ok && rmse2 >= 0 && rmse2 < 5;
   ok = ok && rmse > 0 && std::abs(Ta[4] - 0.2) < 0.015;
   return ok ? 0 : 1;
 }

@@ -224,20 +224,7 @@ const char *dsopp_hip_kernel_class_name(int kernel_class);
  * short kernel).  Supported: SWEEP_LINEARIZE, SWEEP_ENERGY, SCHUR, ASSEMBLE_SOLVE.  The window state is left unchanged. */
 int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repeats, double *avg_us);
 
-/* ------------------------------------------------------------------------------------------------------------------
- * Two-frame direct image alignment of one pyramid level
- * (replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>, PROB_SRC/eigen_pose_alignment.cpp:26-329)
- * ---------------------------------------------------------------------------------------------------------------- */
-typedef struct dsopp_hip_aligner dsopp_hip_aligner;
-
-typedef struct dsopp_hip_align_result {
-  double rmse; /* sqrt(E / n_valid / PatternSize) — eigen_pose_alignment.cpp:328; -1 (kZeroCost) for a known pose */
-  double energy;
-  int32_t n_valid;
-  int32_t iterations;
-  double T_world_target[7];
-  double affine_brightness[2];
-  double covariance[36]; /* ---- reference depth maps of the newest keyframe (row a21) ----
+/* ---- reference depth maps of the newest keyframe (row a21) ----
  * createReferenceDepthMaps (src/tracker/tracker/src/create_depth_maps.cpp:124-147) on the device, from the window's own
  * state: the active landmarks of every older keyframe (connection status kOk towards the newest keyframe, not outlier, not
  * marginalized — :36-38) are reprojected into the newest keyframe and splatted with weight sqrt(1e-3 / (variance + 1e-12))
@@ -251,7 +238,20 @@ int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level
 /* copies one level to the host: two row-major H x W planes (energy::problem::DepthMap::map(x, y).{idepth, weight}) */
 int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level, double *idepth_sum, double *weight);
 
-/* tTargetReferenceCovariance — eigen_pose_alignment.cpp:320-323 */
+/* ------------------------------------------------------------------------------------------------------------------
+ * Two-frame direct image alignment of one pyramid level
+ * (replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>, PROB_SRC/eigen_pose_alignment.cpp:26-329)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct dsopp_hip_aligner dsopp_hip_aligner;
+
+typedef struct dsopp_hip_align_result {
+  double rmse; /* sqrt(E / n_valid / PatternSize) — eigen_pose_alignment.cpp:328; -1 (kZeroCost) for a known pose */
+  double energy;
+  int32_t n_valid;
+  int32_t iterations;
+  double T_world_target[7];
+  double affine_brightness[2];
+  double covariance[36]; /* tTargetReferenceCovariance — eigen_pose_alignment.cpp:320-323 */
   double H[64];
 } dsopp_hip_align_result;
 

@@ -25,6 +25,12 @@ def test_header_symbols_exported():
     assert set(capi.SYMBOLS) == declared, (set(capi.SYMBOLS) ^ declared)
 
 
+def test_header_is_plain_c():
+    """include/dsopp_hip.h is the C-ABI: it must compile as C (and every declaration must be at file scope)"""
+    import subprocess
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "dsopp_hip.h")], check=True)
+
+
 def test_no_cpu_fallback():
     """without a GPU every compute entry point must fail loudly (DSOPP_HIP_ERR_HIP), never fall back to the CPU"""
     import pytest
