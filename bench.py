@@ -229,52 +229,44 @@ def run_large_window_roofline(capi, syn, dtype, s_bytes):
 
 
 def run_tracker_timing(capi, syn, torch, frames=20):
-    """C2 of BASELINE.json: coarse-to-fine direct image alignment of a new 1280x1024 frame against a reference keyframe,
-    5 pyramid levels (monocular_tracker.cpp:136-248: per level reset / push reference depth map / push target / solve).
-    The 8-bit target image is resident in HBM; per frame = pyramid build (device) + 5 alignments.  The reference points
-    are handed over as point lists (u, v, idepth per level, ~2000 points: what createReferenceDepthMaps + the LocalFrame
-    depth-map constructor produce); the depth-map overload of the C-ABI adds the H2D copy of two H x W planes per level."""
-    W, H, L, n_pts = 1280, 1024, 5, 2000
-    win = syn.make_window(num_frames=2, num_points=16, width=W, height=H, seed=3)
-    fr, ft = win.frames
+    """C2 of BASELINE.json: coarse-to-fine direct image alignment of a new 1280x1024 frame against the last keyframe,
+    5 pyramid levels — estimatePose of the tracker (monocular_tracker.cpp:179-245) on its real inputs: a 7-keyframe /
+    2000-point window is bundle-adjusted, createReferenceDepthMaps runs on the device, then every new frame costs
+    one pyramid build (8-bit image resident in HBM) + one dsopp_hip_aligner_estimate_pose call (all levels)."""
+    W, H, L = 1280, 1024, 5
+    win = syn.make_window(num_frames=8, num_points=2288, width=W, height=H, seed=3)
+    new_frame = win.frames.pop()  # the frame to track; the other 7 are the keyframe window (2002 points)
+    g = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g, win)
+    g.solve()
+    maps = g.create_reference_depth_maps(L)
+    kf = win.frames[-1]
     pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
-    pr.build(fr.image_u8)
-    img_dev = torch.from_numpy(ft.image_u8.copy()).cuda()
+    pr.build(kf.image_u8)
+    img_dev = torch.from_numpy(new_frame.image_u8.copy()).cuda()
     torch.cuda.synchronize()
-    rng = np.random.default_rng(0)
-    pts = []
-    for l in range(L):
-        w, h = W >> l, H >> l
-        n = min(n_pts, (w - 16) * (h - 16) // 4)
-        u = rng.integers(8, w - 8, n).astype(np.float64)
-        v = rng.integers(8, h - 8, n).astype(np.float64)
-        idp = 1.0 / fr.depth[np.minimum(v.astype(int) << l, H - 1), np.minimum(u.astype(int) << l, W - 1)]
-        pts.append((u, v, idp))
-    T_ref = syn.mat_to_params(fr.T_w_c_gt)
-    T_init = syn.mat_to_params(ft.T_w_c_init)
+    T_ref, ab_ref = g.get_pose(kf.frame_id)
+    T_init = syn.mat_to_params(new_frame.T_w_c_init)
     a = capi.HipAligner(capi.default_align_options())
+    rmse_last = np.full(L, 1e10)
+
+    rl_final = rmse_last.copy()
 
     def one_frame():
         pt.build_device(img_dev.data_ptr())
-        T = T_init
-        its = 0
-        for l in range(L - 1, -1, -1):
-            intr = win.scene.intrinsics / (1 << l)
-            a.reset()
-            a.push_reference_points(1000, T_ref, pr, l, intr, pts[l][0], pts[l][1], pts[l][2], 1.0, np.zeros(2))
-            a.push_target(2000, T, pt, l, intr, 1.0, np.zeros(2))
-            r = a.solve()
-            T = r["T_w_target"]
-            its += r["iterations"]
-        return T, its
+        rl = rmse_last.copy()
+        r = a.estimate_pose(kf.timestamp, T_ref, pr, maps, 1.0, ab_ref, new_frame.timestamp, pt, 1.0, win.scene.intrinsics, T_init[None, :],
+                            np.zeros(2), rl)
+        rl_final[:] = rl
+        return r
 
-    one_frame()
+    res = one_frame()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     its = 0
     for _ in range(frames):
-        T, k = one_frame()
-        its += k
+        res = one_frame()
+        its += res["lm_iterations"]
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / frames * 1e3
     t0 = time.perf_counter()
@@ -282,12 +274,16 @@ def run_tracker_timing(capi, syn, torch, frames=20):
         pt.build_device(img_dev.data_ptr())
     torch.cuda.synchronize()
     pyr_ms = (time.perf_counter() - t0) / frames * 1e3
-    gt = syn.mat_to_params(ft.T_w_c_gt)
+    t0 = time.perf_counter()
+    m2 = g.create_reference_depth_maps(L)
+    dm_ms = (time.perf_counter() - t0) * 1e3
+    n0 = int((m2.get_level(0)[1] > 0).sum())
     out = {"metric": "frame-tracking ms/frame (1280x1024, 5 pyramid levels, coarse-to-fine alignment)", "ms_per_frame": ms,
-           "pyramid_ms": pyr_ms, "lm_iterations_per_frame": its / frames, "points_per_level": n_pts,
-           "pose_error_vs_ground_truth": float(np.abs(T - gt).max()), "initial_pose_error": float(np.abs(T_init - gt).max()),
-           "data": "synthetic, target image resident in HBM"}
-    for o in (a, pr, pt):
+           "pyramid_ms": pyr_ms, "lm_iterations_per_frame": its / frames, "success": bool(res["success"]),
+           "reference_depth_maps_ms_per_keyframe": dm_ms, "depth_map_cells_level0": n0,
+           "rmse_per_level": [float(x) for x in rl_final],
+           "data": "synthetic 7-keyframe window + 1 new frame, target image resident in HBM"}
+    for o in (a, maps, m2, pr, pt, g):
         o.close()
     return out
 

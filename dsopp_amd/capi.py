@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -447,6 +447,21 @@ class HipAligner:
     def push_reference_depth_maps(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, maps: DepthMaps, exposure, affine):
         _chk(lib().dsopp_hip_aligner_push_reference_depth_maps(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),
                                                                _p(_f64(intrinsics)), maps._h, C.c_double(exposure), _p(_f64(affine))))
+
+    def estimate_pose(self, ref_time, T_w_ref, ref_pyramid: Pyramid, ref_maps: DepthMaps, ref_exposure, ref_affine, tgt_time,
+                      tgt_pyramid: Pyramid, tgt_exposure, intrinsics, T_w_inits, affine_init, rmse_last):
+        """estimatePose of the tracker (monocular_tracker.cpp:179-245): coarse-to-fine over all levels, one C call per frame.
+        T_w_inits: (n, 7) initialisations; rmse_last: per-level array, updated in place."""
+        inits = _f64(np.atleast_2d(T_w_inits))
+        rl = _f64(rmse_last)
+        T, ab = np.zeros(7), np.zeros(2)
+        ok, tries, its = C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_aligner_estimate_pose(self._h, C.c_int64(int(ref_time)), _p(_f64(T_w_ref)), ref_pyramid._h, ref_maps._h,
+                                                   C.c_double(ref_exposure), _p(_f64(ref_affine)), C.c_int64(int(tgt_time)), tgt_pyramid._h,
+                                                   C.c_double(tgt_exposure), _p(_f64(intrinsics)), len(inits), _p(inits), _p(_f64(affine_init)),
+                                                   _p(rl), _p(T), _p(ab), C.byref(ok), C.byref(tries), C.byref(its)))
+        rmse_last[:] = rl
+        return dict(T_w_target=T, affine_brightness=ab, success=bool(ok.value), tries=tries.value, lm_iterations=its.value)
 
     def push_reference_points(self, timestamp, T_w_agent, pyramid: Pyramid, level, intrinsics, u, v, idepth, exposure, affine):
         _chk(lib().dsopp_hip_aligner_push_reference_points(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent)), pyramid._h, int(level),

@@ -76,11 +76,20 @@ __device__ inline void mat34Compose(const double *A, const double *B, double *C)
   }
 }
 
+/** 1/sqrt(x) for x > 0: f32 estimate + two Newton steps in f64 (~1 ulp); a libm sqrt + division pair costs ~180 cycles on
+ *  the single thread that runs the LM control, this a dozen instructions */
+__device__ inline double rsqrtNewton(double x) {
+  double r = static_cast<double>(__frsqrt_rn(static_cast<float>(x)));
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
 /** 8x8 NormalLinearSystem::solve (Jacobi preconditioner + Cholesky with zero-pivot guard), single thread */
 __device__ inline void solve8(const double *Hin, const double *bin, double *x) {
-  double p[8], A[36], y[8];
+  double p[8], A[36], y[8], linv[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = 1.0 / sqrt(Hin[8 * i + i] + 10.0);
+  for (int i = 0; i < 8; ++i) p[i] = rsqrtNewton(Hin[8 * i + i] + 10.0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -91,8 +100,9 @@ __device__ inline void solve8(const double *Hin, const double *bin, double *x) {
   for (int k = 0; k < 8; ++k) {
     const double d = A[k * (k + 1) / 2 + k];
     const bool ok = d > 1e-300;
-    const double lkk = ok ? sqrt(d) : 0.0, inv = ok ? 1.0 / lkk : 0.0;
-    A[k * (k + 1) / 2 + k] = lkk;
+    const double inv = ok ? rsqrtNewton(ok ? d : 1.0) : 0.0;
+    linv[k] = inv;
+    A[k * (k + 1) / 2 + k] = ok ? d * inv : 0.0;
 #pragma unroll
     for (int i = k + 1; i < 8; ++i) A[i * (i + 1) / 2 + k] *= inv;
 #pragma unroll
@@ -105,16 +115,14 @@ __device__ inline void solve8(const double *Hin, const double *bin, double *x) {
     double s = y[i];
 #pragma unroll
     for (int j = 0; j < i; ++j) s -= A[i * (i + 1) / 2 + j] * y[j];
-    const double l = A[i * (i + 1) / 2 + i];
-    y[i] = l > 0 ? s / l : 0.0;
+    y[i] = s * linv[i];  // 0 for a zero pivot
   }
 #pragma unroll
   for (int i = 7; i >= 0; --i) {
     double s = y[i];
 #pragma unroll
     for (int j = i + 1; j < 8; ++j) s -= A[j * (j + 1) / 2 + i] * y[j];
-    const double l = A[i * (i + 1) / 2 + i];
-    y[i] = l > 0 ? s / l : 0.0;
+    y[i] = s * linv[i];
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = p[i] * y[i];
@@ -151,18 +159,50 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
     if (tid == 0) sc = *cin;  // initial block prepared by the host: candidate == accepted state
     __syncthreads();
   } else {
-    if (!cin->active) {
-      if (blockIdx.x == 0 && tid == 0) *cout = *cin;
+    // the incoming control block is requested first so that its round trip overlaps the partial sums below: all threads
+    // fetch one 8-byte word each into LDS
+    constexpr int kCtrlWords = static_cast<int>(sizeof(AlignControl) / 8);
+    static_assert(sizeof(AlignControl) % 8 == 0 && kCtrlWords <= kAlignThreads, "control block copy assumes one word per thread");
+    double ctrl_word = 0;
+    if (tid < kCtrlWords) ctrl_word = reinterpret_cast<const double *>(cin)[tid];
+    // deterministic sum of the previous launch's partials: thread e < 48 adds column e over all workgroups
+    // (5 thread groups of 48 take the workgroups g, g + 5, ... with four independent loads in flight each — a single
+    // dependent load-add chain over all workgroups costs one memory round trip per workgroup — then a fixed-order combine)
+    {
+      constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
+      const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
+      double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+      if (grp < kGroups) {
+        const double *src = prev_partials + e;
+        int b = grp;
+        for (; b + 3 * kGroups < prm.n_blocks; b += 4 * kGroups) {
+          const double v0 = src[static_cast<size_t>(b) * kAlignPartial], v1 = src[static_cast<size_t>(b + kGroups) * kAlignPartial];
+          const double v2 = src[static_cast<size_t>(b + 2 * kGroups) * kAlignPartial], v3 = src[static_cast<size_t>(b + 3 * kGroups) * kAlignPartial];
+          p0 += v0;
+          p1 += v1;
+          p2 += v2;
+          p3 += v3;
+        }
+        for (; b < prm.n_blocks; b += kGroups) p0 += src[static_cast<size_t>(b) * kAlignPartial];
+        red[kAlignPartial + grp * kAlignPartial + e] = (p0 + p1) + (p2 + p3);
+      }
+      __syncthreads();
+      if (tid < kAlignPartial) {
+        double tot = 0;
+#pragma unroll
+        for (int g2 = 0; g2 < kGroups; ++g2) tot += red[kAlignPartial + g2 * kAlignPartial + tid];
+        red[tid] = tot;
+      }
+    }
+    __syncthreads();
+    if (tid < kCtrlWords) reinterpret_cast<double *>(&sc)[tid] = ctrl_word;
+    __syncthreads();
+    if (!sc.active) {
+      if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = ctrl_word;
       return;
     }
-    // deterministic sum of the previous launch's partials: thread e < 48 adds column e over all workgroups
-    double tot = 0;
-    if (tid < kAlignPartial)
-      for (int b = 0; b < prm.n_blocks; ++b) tot += prev_partials[static_cast<size_t>(b) * kAlignPartial + tid];
-    if (tid < kAlignPartial) red[tid] = tot;
-    __syncthreads();
     if (tid == 0) {
-      AlignControl c = *cin;
+      AlignControl c = sc;
       // evaluated state = candidate (or the initial state): energy with the affine prior (eigen_pose_alignment.cpp:101-104)
       const double tab0 = tgt.ab0[0] + c.cand_ab[0], tab1 = tgt.ab0[1] + c.cand_ab[1];
       const double e_eval = red[44] + 0.5 * (tab0 * prm.affine_reg[0] * tab0 + tab1 * prm.affine_reg[1] * tab1);
@@ -241,7 +281,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
       sc = c;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) *cout = sc;
+    if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = reinterpret_cast<const double *>(&sc)[tid];
     if (!sc.active) return;
     __syncthreads();
   }
@@ -375,6 +415,10 @@ struct dsopp_hip_aligner {
   Rigid T_w_ref = rigidIdentity(), T_w_tgt = rigidIdentity();
   int n_points = 0;
   DeviceBuffer<double> d_u, d_v, d_id, d_int, d_partials[2];
+  // the reference points the solve reads: the aligner's own buffers above or the per-level cache of a dsopp_hip_depth_maps
+  const double *p_u = nullptr, *p_v = nullptr, *p_id = nullptr, *p_int = nullptr;
+  AlignControl *h_ctrl = nullptr;  // pinned staging of the control block (upload + read-back)
+  bool skip_covariance = false;    // estimate_pose: the per-level covariance is not read by the tracker loop
   DeviceBuffer<int> d_rows;  // row counts / offsets of the device-side depth-map scan
   DeviceBuffer<AlignControl> d_ctrl;
   std::map<int64_t, Rigid> known_poses;
@@ -422,6 +466,10 @@ void uploadPoints(dsopp_hip_aligner *a, const dsopp_hip_pyramid *pyr, int level,
   sampleReferenceIntensitiesImpl(st, pyr, level, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, n);
   a->sr.sync();
   a->n_points = static_cast<int>(n);
+  a->p_u = a->d_u.ptr;
+  a->p_v = a->d_v.ptr;
+  a->p_id = a->d_id.ptr;
+  a->p_int = a->d_int.ptr;
 }
 
 // ---- device-side scan of a reference depth map (LocalFrame depth-map ctor, PBA_INT/local_frame.hpp:367-392): a pixel
@@ -522,6 +570,7 @@ void dsopp_hip_aligner_destroy(dsopp_hip_aligner *a) {
   if (!a) return;
   (void)hipSetDevice(a->sr.device);
   if (a->sr.stream) (void)hipStreamSynchronize(a->sr.stream);
+  if (a->h_ctrl) (void)hipHostFree(a->h_ctrl);
   StreamRef sr = a->sr;
   delete a;
   sr.destroy();
@@ -602,26 +651,36 @@ int dsopp_hip_aligner_push_reference_depth_maps(dsopp_hip_aligner *a, int64_t ti
     a->sr.use();
     hipStream_t st = a->sr.stream;
     if (maps->sr.stream != st) HIP_CHECK(hipStreamSynchronize(maps->sr.stream));  // producer finished (it synchronises at creation anyway)
-    const double *idsum = maps->idepth_sum[static_cast<size_t>(level)].ptr, *wgt = maps->weight[static_cast<size_t>(level)].ptr;
-    a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
-    int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
-    countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
-    scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
-    int total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
-    a->sr.sync();
-    const size_t n = static_cast<size_t>(total);
-    a->d_u.reserve(std::max<size_t>(n, 1), 0, st);
-    a->d_v.reserve(std::max<size_t>(n, 1), 0, st);
-    a->d_id.reserve(std::max<size_t>(n, 1), 0, st);
-    a->d_int.reserve(std::max<size_t>(n, 1), 0, st);
-    if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr);
-    HIP_CHECK(hipGetLastError());
+    dsopp_hip_depth_maps::LevelPoints &pts = maps->points[static_cast<size_t>(level)];
+    if (pts.n < 0 || pts.pyramid != pyramid) {
+      const double *idsum = maps->idepth_sum[static_cast<size_t>(level)].ptr, *wgt = maps->weight[static_cast<size_t>(level)].ptr;
+      a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
+      int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
+      countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
+      scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
+      int total = 0;
+      HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
+      a->sr.sync();
+      const size_t n = static_cast<size_t>(total);
+      pts.u.reserve(std::max<size_t>(n, 1), 0, st);
+      pts.v.reserve(std::max<size_t>(n, 1), 0, st);
+      pts.idepth.reserve(std::max<size_t>(n, 1), 0, st);
+      pts.intensity.reserve(std::max<size_t>(n, 1), 0, st);
+      if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
+      HIP_CHECK(hipGetLastError());
+      sampleReferenceIntensitiesImpl(st, pyramid, level, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
+      a->sr.sync();
+      pts.n = total;
+      pts.pyramid = pyramid;
+    }
     setFrame(a->ref, pyramid, level, intrinsics, exposure_time, affine_brightness);
     a->T_w_ref = rigidFromParams(T_world_agent);
     a->ref_time = timestamp;
-    sampleReferenceIntensitiesImpl(st, pyramid, level, a->d_u.ptr, a->d_v.ptr, a->d_int.ptr, n);
-    a->sr.sync();
+    a->p_u = pts.u.ptr;
+    a->p_v = pts.v.ptr;
+    a->p_id = pts.idepth.ptr;
+    a->p_int = pts.intensity.ptr;
+    const int total = pts.n;
     a->n_points = total;
     a->have_ref = true;
   });
@@ -688,7 +747,8 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     prm.max_iterations = a->opt.max_iterations;
     prm.n_points = n;
     prm.n_blocks = n_blocks;
-    AlignControl c;
+    if (!a->h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_ctrl), 2 * sizeof(AlignControl), hipHostMallocDefault));
+    AlignControl &c = a->h_ctrl[0];
     std::memset(&c, 0, sizeof(c));
     const Rigid T_tr = rigidMul(rigidInverse(a->T_w_tgt), a->T_w_ref);  // eigen_pose_alignment.cpp:307-308
     for (int i = 0; i < 3; ++i) {
@@ -697,12 +757,13 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     }
     c.lambda = 1.0 / a->opt.initial_trust_region_radius;
     c.active = 1;
-    a->d_ctrl.upload(&c, 1, 0, st);
-    a->sr.sync();
+    a->d_ctrl.reserve(2, 0, st);
+    a->d_ctrl.upload(&c, 1, 0, st);  // pinned source: stream-ordered, no host wait
     const int total_launches = a->opt.max_iterations + 2;  // initial evaluation + one per iteration + final control pass
     int launch = 0;
-    AlignControl h;
-    const int kBatch = 8;
+    AlignControl &h = a->h_ctrl[1];
+    // launches after the loop has ended are no-ops of ~2 us; a batch covers the typical solve (10-20 iterations) in one sync
+    const int kBatch = 20;
     while (true) {
       const int end = std::min(total_launches, launch + kBatch);
       for (; launch < end; ++launch) {
@@ -712,9 +773,9 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
         const double *prev = a->d_partials[(launch + 1) & 1].ptr;
         double *cur = a->d_partials[launch & 1].ptr;
         if (a->opt.dtype == DSOPP_HIP_F64)
-          alignIterationKernel<double><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr, a->d_int.ptr, cin, cout, prev, cur, prm, launch);
+          alignIterationKernel<double><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->p_u, a->p_v, a->p_id, a->p_int, cin, cout, prev, cur, prm, launch);
         else
-          alignIterationKernel<float><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->d_u.ptr, a->d_v.ptr, a->d_id.ptr, a->d_int.ptr, cin, cout, prev, cur, prm, launch);
+          alignIterationKernel<float><<<n_blocks, kAlignThreads, 0, st>>>(a->ref, a->tgt, a->p_u, a->p_v, a->p_id, a->p_int, cin, cout, prev, cur, prm, launch);
       }
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipMemcpyAsync(&h, a->d_ctrl.ptr + ((launch - 1) & 1), sizeof(AlignControl), hipMemcpyDeviceToHost, st));
@@ -738,12 +799,91 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     rigidToParams(a->T_w_tgt, result->T_world_target);
     result->affine_brightness[0] = a->tgt.ab0[0];
     result->affine_brightness[1] = a->tgt.ab0[1];
-    hostla::Mat Hm(h.H_used, h.H_used + 64);
-    const hostla::Mat pinv = hostla::pinvRankRevealing(Hm, 8);
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) result->covariance[6 * i + j] = pinv[static_cast<size_t>(8 * i + j)];
+    if (!a->skip_covariance) {
+      hostla::Mat Hm(h.H_used, h.H_used + 64);
+      const hostla::Mat pinv = hostla::pinvRankRevealing(Hm, 8);
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) result->covariance[6 * i + j] = pinv[static_cast<size_t>(8 * i + j)];
+    }
     std::memcpy(result->H, h.H_used, sizeof(h.H_used));
   });
+}
+
+
+int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time, const double T_world_reference[7],
+                                    const dsopp_hip_pyramid *reference_pyramid, const dsopp_hip_depth_maps *reference_depth_maps,
+                                    double reference_exposure, const double reference_affine[2], int64_t target_time,
+                                    const dsopp_hip_pyramid *target_pyramid, double target_exposure, const double intrinsics[4],
+                                    int32_t n_initializations, const double *T_world_target_init, const double affine_init[2],
+                                    double *rmse_last_pose_estimation, double T_world_target[7], double affine_brightness[2],
+                                    int32_t *success_out, int32_t *tries_out, int32_t *lm_iterations_out) {
+  if (!a || !T_world_reference || !reference_pyramid || !reference_depth_maps || !reference_affine || !target_pyramid || !intrinsics ||
+      n_initializations < 1 || !T_world_target_init || !affine_init || !rmse_last_pose_estimation || !T_world_target || !affine_brightness) {
+    return guarded([] { fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null / empty argument"); });
+  }
+  // estimatePose — src/tracker/tracker/src/monocular_tracker.cpp:179-245
+  const double kEnergyRatioThreshold = 2.5;
+  const int levels = target_pyramid->levels;
+  if (levels > reference_depth_maps->levels || levels > reference_pyramid->levels)
+    return guarded([&] { fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "target pyramid has %d levels, reference pyramid / depth maps fewer", levels); });
+  std::vector<double> local_rmse(static_cast<size_t>(levels));
+  struct SkipCov {
+    dsopp_hip_aligner *a;
+    explicit SkipCov(dsopp_hip_aligner *x) : a(x) { a->skip_covariance = true; }
+    ~SkipCov() { a->skip_covariance = false; }
+  } skip_cov(a);
+  double T[7], ab[2], T_const[7] = {0, 0, 0, 1, 0, 0, 0}, ab_const[2] = {0, 0};
+  bool success = false;
+  int tries = 0, lm_iterations = 0;
+  for (int try_number = 0; !success && try_number < n_initializations; ++try_number) {
+    ++tries;
+    success = true;
+    std::memcpy(T, T_world_target_init + 7 * try_number, sizeof(T));
+    ab[0] = affine_init[0];
+    ab[1] = affine_init[1];
+    std::copy(rmse_last_pose_estimation, rmse_last_pose_estimation + levels, local_rmse.begin());
+    for (int lvl = levels - 1; success && lvl >= 0; --lvl) {
+      const double s = static_cast<double>(1 << lvl);  // CameraCalibration::cameraModel(level), camera_calibration.cpp:66-70
+      const double intr[4] = {intrinsics[0] / s, intrinsics[1] / s, intrinsics[2] / s, intrinsics[3] / s};
+      int rc = dsopp_hip_aligner_reset(a);
+      if (rc == DSOPP_HIP_OK)
+        rc = dsopp_hip_aligner_push_reference_depth_maps(a, reference_time, T_world_reference, reference_pyramid, lvl, intr, reference_depth_maps,
+                                                         reference_exposure, reference_affine);
+      if (rc == DSOPP_HIP_OK) rc = dsopp_hip_aligner_push_target(a, target_time, T, target_pyramid, lvl, intr, target_exposure, ab);
+      dsopp_hip_align_result r;
+      if (rc == DSOPP_HIP_OK) rc = dsopp_hip_aligner_solve(a, &r);
+      if (rc != DSOPP_HIP_OK) return rc;
+      lm_iterations += r.iterations;
+      if (r.rmse < kEnergyRatioThreshold * local_rmse[static_cast<size_t>(lvl)]) {
+        std::memcpy(T, r.T_world_target, sizeof(T));
+        ab[0] = r.affine_brightness[0];
+        ab[1] = r.affine_brightness[1];
+        if (r.rmse != -1.0) local_rmse[static_cast<size_t>(lvl)] = r.rmse;  // kZeroCost
+      } else {
+        success = false;
+      }
+    }
+    if (try_number == 0) {
+      std::memcpy(T_const, T, sizeof(T));
+      ab_const[0] = ab[0];
+      ab_const[1] = ab[1];
+    }
+  }
+  if (!success) {
+    std::memcpy(T, T_const, sizeof(T));
+    ab[0] = ab_const[0];
+    ab[1] = ab_const[1];
+    for (int l = 0; l < levels; ++l) rmse_last_pose_estimation[l] *= kEnergyRatioThreshold;  // pose invalid: assume maximum energy
+  } else {
+    std::copy(local_rmse.begin(), local_rmse.end(), rmse_last_pose_estimation);
+  }
+  std::memcpy(T_world_target, T, sizeof(T));
+  affine_brightness[0] = ab[0];
+  affine_brightness[1] = ab[1];
+  if (success_out) *success_out = success ? 1 : 0;
+  if (tries_out) *tries_out = tries;
+  if (lm_iterations_out) *lm_iterations_out = lm_iterations;
+  return DSOPP_HIP_OK;
 }
 
 }  // extern "C"

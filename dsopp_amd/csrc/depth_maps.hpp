@@ -12,4 +12,13 @@ struct dsopp_hip_depth_maps {
   std::vector<int> width, height;
   // per level two row-major H x W planes: weighted idepth sum and weight (energy::problem::DepthMap::map, (x, y)-indexed there)
   std::vector<dsopp_hip::DeviceBuffer<double>> idepth_sum, weight;
+  // Reference points of each level as the LocalFrame depth-map constructor extracts them (PBA_INT/local_frame.hpp:367-392),
+  // cached by the first dsopp_hip_aligner_push_reference_depth_maps of that level: the maps belong to one keyframe and
+  // every frame tracked against it scans the same maps.  Intensities are sampled from `pyramid` (the keyframe's own).
+  struct LevelPoints {
+    int n = -1;  // -1: not extracted yet
+    const void *pyramid = nullptr;
+    dsopp_hip::DeviceBuffer<double> u, v, idepth, intensity;
+  };
+  mutable std::vector<LevelPoints> points;
 };

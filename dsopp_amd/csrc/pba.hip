@@ -1719,6 +1719,7 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
     maps->sr = w->sr;
     maps->sr.owned = false;
     maps->levels = levels;
+    maps->points.resize(static_cast<size_t>(levels));
     // initDepthMaps — create_depth_maps.cpp:62-68: one map per pyramid level of the newest keyframe
     std::vector<DeviceBuffer<double>> tmp_id(static_cast<size_t>(levels)), tmp_w(static_cast<size_t>(levels));
     int lw = lv.width, lh = lv.height;

@@ -285,6 +285,19 @@ int dsopp_hip_aligner_push_target(dsopp_hip_aligner *a, int64_t timestamp, const
 int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7]);
 /* solve -> rmse (or kZeroCost = -1) — eigen_pose_alignment.cpp:275-329 */
 int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result);
+/* Coarse-to-fine pose estimation of a new frame against the last keyframe: estimatePose of the tracker
+ * (src/tracker/tracker/src/monocular_tracker.cpp:179-245).  For every initialisation in turn (until one succeeds): from the
+ * coarsest level of the target pyramid down to level 0 { reset; push the keyframe's depth map of that level; push the target
+ * with the current estimate; solve; accept the level when rmse < 2.5 * rmse_last_pose_estimation[level] }.  The camera model
+ * of level l is the level-0 one scaled by 2^-l.  rmse_last_pose_estimation (one per level) is updated as the reference
+ * does (multiplied by 2.5 when every initialisation failed; then the result of the FIRST initialisation is returned). */
+int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time, const double T_world_reference[7],
+                                    const dsopp_hip_pyramid *reference_pyramid, const dsopp_hip_depth_maps *reference_depth_maps,
+                                    double reference_exposure, const double reference_affine[2], int64_t target_time,
+                                    const dsopp_hip_pyramid *target_pyramid, double target_exposure, const double intrinsics[4],
+                                    int32_t n_initializations, const double *T_world_target_init, const double affine_init[2],
+                                    double *rmse_last_pose_estimation, double T_world_target[7], double affine_brightness[2],
+                                    int32_t *success, int32_t *tries, int32_t *lm_iterations);
 int dsopp_hip_aligner_num_points(dsopp_hip_aligner *a, int32_t *n);
 
 #ifdef __cplusplus

@@ -152,3 +152,60 @@ def test_gpu_depth_maps_and_device_scan():
         assert r_dev["energy"] == r_host["energy"] and np.array_equal(r_dev["T_w_target"], r_host["T_w_target"])
     for obj in (maps, pyr, tgt, g):
         obj.close()
+
+
+@pytest.mark.gpu
+def test_gpu_estimate_pose_matches_oracle_chain():
+    """the tracker's coarse-to-fine estimatePose (monocular_tracker.cpp:179-245) in one C call against the same chain
+    stepped by hand through the oracle: window solve -> reference depth maps -> per level {scan, align}"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    W, H, L = 320, 240, 4
+    win = syn.make_window(num_frames=4, num_points=800, width=W, height=H, seed=17)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    o.solve()
+    g.solve()
+    newest, target = win.frames[-1], win.frames[-2]
+    intr = win.scene.intrinsics
+    T_init = syn.mat_to_params(target.T_w_c_init)
+    # oracle chain
+    sources, T_ref_o = _sources_from_window(o, win)
+    maps_o = po.create_reference_depth_maps(sources, T_ref_o, intr, W, H, L)
+    infos_ref, _ = po.build_pyramid(newest.image_u8, levels=L)
+    infos_tgt, _ = po.build_pyramid(target.image_u8, levels=L)
+    _, ab_ref_o = o.get_pose(newest.frame_id)
+    T, ab, its_o, rmse_o = T_init, np.zeros(2), 0, []
+    for lvl in range(L - 1, -1, -1):
+        u, v, idp, inten = po.points_from_depth_map(infos_ref[lvl], *maps_o[lvl])
+        h, w = infos_ref[lvl].shape[:2]
+        r = po.align_solve(po.default_align_options(), u, v, idp, inten, intr / (1 << lvl), (w, h), T_ref_o, 1.0, ab_ref_o, intr / (1 << lvl),
+                           infos_tgt[lvl], None, T, 1.0, ab)
+        T, ab = r["T_w_target"], r["affine_brightness"]
+        its_o += r["iterations"]
+        rmse_o.append(r["rmse"])
+    # HIP: one call
+    maps_g = g.create_reference_depth_maps(L)
+    pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
+    pr.build(newest.image_u8)
+    pt.build(target.image_u8)
+    T_ref_g, ab_ref_g = g.get_pose(newest.frame_id)
+    a = capi.HipAligner(capi.default_align_options())
+    rmse_last = np.full(L, 1e10)
+    res = a.estimate_pose(newest.timestamp, T_ref_g, pr, maps_g, 1.0, ab_ref_g, newest.timestamp + 1, pt, 1.0, intr, T_init[None, :], np.zeros(2),
+                          rmse_last)
+    assert res["success"] and res["tries"] == 1
+    assert res["lm_iterations"] == its_o
+    assert np.abs(res["T_w_target"] - T).max() <= 1e-6, np.abs(res["T_w_target"] - T).max()
+    assert np.abs(res["affine_brightness"] - ab).max() <= 1e-5
+    assert np.allclose(rmse_last[::-1], rmse_o, rtol=1e-6)   # per-level rmse (rmse_last is indexed by level, the chain ran coarse -> fine)
+    # it tracks: closer to the ground truth than the initialisation
+    gt = syn.mat_to_params(target.T_w_c_gt)
+    assert np.abs(res["T_w_target"] - gt).max() < 0.5 * np.abs(T_init - gt).max()
+    # a hopeless rmse bound rejects every initialisation: result of the first one is returned, bounds are relaxed by 2.5
+    rl = np.full(L, 1e-9)
+    res2 = a.estimate_pose(newest.timestamp, T_ref_g, pr, maps_g, 1.0, ab_ref_g, newest.timestamp + 1, pt, 1.0, intr,
+                           np.stack([T_init, T_init]), np.zeros(2), rl)
+    assert not res2["success"] and res2["tries"] == 2 and np.allclose(rl, 2.5e-9)
+    for obj in (a, maps_g, pr, pt, g):
+        obj.close()
