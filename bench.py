@@ -158,6 +158,8 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
         g.restore()
+        extras["stages"] = run_stage_table(g, win, syn, args)
+        g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
         extras["tracker"] = run_tracker_timing(capi, syn, torch)
 
@@ -201,6 +203,48 @@ def main():
     g.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def run_stage_table(g, win, syn, args, repeats=30):
+    """Per-stage wall times of the blocking stage entry points, mirroring the stage list of the reference's benchmark
+    (test/performance/benchmarks/energy/photometric_bundle_adjustment_benchmark.cpp:252-264: Linearize, CalculateStep,
+    CalculateEnergy, AcceptStep, RejectStep), GPU (every call ends with its read-back + synchronisation) beside the CPU
+    port on the same C1 window.  In the fused solve loop these stages are not separate calls (see "kernels")."""
+    def timed(fn, setup=None, n=repeats):
+        tot = 0.0
+        for _ in range(n):
+            if setup:
+                setup()
+            t0 = time.perf_counter()
+            fn()
+            tot += time.perf_counter() - t0
+        return tot / n * 1e6
+
+    def table(w, n):
+        w.begin()
+        w.calculate_energy()
+        out = {"calculate_energy": timed(w.calculate_energy, n=n)}
+        out["linearize"] = timed(w.linearize, n=n)
+        w.linearize()
+        out["calculate_step"] = timed(lambda: w.calculate_step(1e-5), n=n)
+
+        def prep():
+            w.calculate_step(1e-5)
+            w.calculate_energy()
+        out["reject_step"] = timed(w.reject_step, setup=prep, n=n)
+        out["accept_step"] = timed(w.accept_step, setup=lambda: (w.linearize(), prep()), n=max(3, n // 6))
+        return out
+
+    stages = {"gpu_us": table(g, repeats)}
+    if not args.no_cpu:
+        from oracle import pyoracle as po
+        hw = os.cpu_count() or 1
+        po.set_threads(max(1, min(hw, 8) - 1))
+        o = po.OracleWindow(po.default_pba_options())
+        syn.load_window(o, win)
+        stages["cpu_port_us"] = table(o, 5)
+        stages["cpu_threads"] = max(1, min(hw, 8) - 1)
+    return stages
 
 
 def run_large_window_roofline(capi, syn, dtype, s_bytes):
