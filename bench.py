@@ -159,6 +159,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         g.restore()
         extras["stages"] = run_stage_table(g, win, syn, args)
+        # the whole per-keyframe call of the drop-in: solve() = LM loop + relinearizeSystem + pose covariances (pinv of the
+        # K x K system on the host) + updatePointStatuses (device-side radix select of the 3rd quartile)
+        ts = []
+        for _ in range(10):
+            g.restore()
+            t0 = time.perf_counter()
+            g.solve()
+            ts.append(time.perf_counter() - t0)
+        extras["full_solve"] = {"gpu_ms": float(np.median(ts) * 1e3), "what": "dsopp_hip_window_solve on the C1 window (7 LM iterations + uncertainty + point statuses)"}
         g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
         extras["tracker"] = run_tracker_timing(capi, syn, torch)
@@ -243,6 +252,11 @@ def run_stage_table(g, win, syn, args, repeats=30):
         o = po.OracleWindow(po.default_pba_options())
         syn.load_window(o, win)
         stages["cpu_port_us"] = table(o, 5)
+        o2 = po.OracleWindow(po.default_pba_options())
+        syn.load_window(o2, win)
+        t0 = time.perf_counter()
+        o2.solve()
+        stages["cpu_port_full_solve_ms"] = (time.perf_counter() - t0) * 1e3
         stages["cpu_threads"] = max(1, min(hw, 8) - 1)
     return stages
 

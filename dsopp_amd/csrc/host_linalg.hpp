@@ -15,13 +15,16 @@ namespace hostla {
 
 using Mat = std::vector<double>;  // row-major n x n
 
-/** A = Q diag(w) Q^T for symmetric A (cyclic Jacobi rotations) */
+/** A = Q diag(w) Q^T for symmetric A (cyclic Jacobi rotations; chosen over tridiagonal QL because the systems are graded
+ *  over 16 decades — 1e16 fixed-frame prior next to O(1..1e6) photometric terms — and Jacobi keeps the small eigenvalues
+ *  to relative accuracy).  Works on the upper triangle + its mirror with contiguous row updates: a rotation costs two
+ *  row-pair passes (A and the eigenvector rows) instead of three strided ones. */
 inline void symmetricEigen(const Mat &Ain, int n, std::vector<double> &w, Mat &Q) {
   Mat A = Ain;
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j) A[i * n + j] = A[j * n + i] = 0.5 * (A[i * n + j] + A[j * n + i]);
-  Q.assign(static_cast<size_t>(n) * n, 0.0);
-  for (int i = 0; i < n; ++i) Q[i * n + i] = 1;
+  Mat Qt(static_cast<size_t>(n) * n, 0.0);  // rows = eigenvectors
+  for (int i = 0; i < n; ++i) Qt[i * n + i] = 1;
   for (int sweep = 0; sweep < 100; ++sweep) {
     double off = 0, diag = 0;
     for (int i = 0; i < n; ++i) {
@@ -32,41 +35,55 @@ inline void symmetricEigen(const Mat &Ain, int n, std::vector<double> &w, Mat &Q
     for (int p = 0; p < n - 1; ++p)
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[p * n + q];
-        if (std::abs(apq) < 1e-300) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+        const double app = A[p * n + p], aqq = A[q * n + q];
+        // an off-diagonal entry below eps * sqrt(|a_pp a_qq|) no longer moves either eigenvalue in double precision
+        // (de Rijk's criterion for relative accuracy on graded matrices): skip the rotation
+        if (std::abs(apq) < 1e-300 || std::abs(apq) <= 1e-17 * std::sqrt(std::abs(app * aqq))) continue;
+        const double theta = (aqq - app) / (2 * apq);
         const double t = (theta >= 0 ? 1.0 : -1.0) / (std::abs(theta) + std::sqrt(theta * theta + 1));
-        const double c = 1 / std::sqrt(t * t + 1), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq;
-          A[k * n + q] = s * akp + c * akq;
+        const double c = 1 / std::sqrt(t * t + 1), sn = t * c;
+        double *rp = &A[static_cast<size_t>(p) * n], *rq = &A[static_cast<size_t>(q) * n];
+        for (int k = 0; k < n; ++k) {  // rows p, q of J^T A (for k outside {p, q} these are also the final values)
+          const double apk = rp[k], aqk = rq[k];
+          rp[k] = c * apk - sn * aqk;
+          rq[k] = sn * apk + c * aqk;
         }
-        for (int k = 0; k < n; ++k) {
-          const double apk = A[p * n + k], aqk = A[q * n + k];
-          A[p * n + k] = c * apk - s * aqk;
-          A[q * n + k] = s * apk + c * aqk;
+        for (int k = 0; k < n; ++k) {  // mirror into columns p, q
+          A[static_cast<size_t>(k) * n + p] = rp[k];
+          A[static_cast<size_t>(k) * n + q] = rq[k];
         }
+        // the 2 x 2 pivot block of J^T A J in closed form
+        rp[p] = app - t * apq;
+        rq[q] = aqq + t * apq;
+        rp[q] = rq[p] = 0;
+        double *qp = &Qt[static_cast<size_t>(p) * n], *qq = &Qt[static_cast<size_t>(q) * n];
         for (int k = 0; k < n; ++k) {
-          const double qkp = Q[k * n + p], qkq = Q[k * n + q];
-          Q[k * n + p] = c * qkp - s * qkq;
-          Q[k * n + q] = s * qkp + c * qkq;
+          const double a = qp[k], b = qq[k];
+          qp[k] = c * a - sn * b;
+          qq[k] = sn * a + c * b;
         }
       }
   }
   w.resize(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) w[static_cast<size_t>(i)] = A[i * n + i];
+  Q.assign(static_cast<size_t>(n) * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) Q[i * n + j] = Qt[j * n + i];
 }
 
 /** spectral pseudo-inverse keeping the eigenpairs selected by `keep(e)` */
 template <typename Keep>
 Mat spectralPinv(const std::vector<double> &w, const Mat &Q, int n, Keep keep) {
   Mat R(static_cast<size_t>(n) * n, 0.0);
+  std::vector<double> col(static_cast<size_t>(n));
   for (int e = 0; e < n; ++e) {
     if (!keep(e)) continue;
     const double inv = 1.0 / w[static_cast<size_t>(e)];
+    for (int j = 0; j < n; ++j) col[static_cast<size_t>(j)] = Q[j * n + e];  // eigenvector e, gathered once
     for (int i = 0; i < n; ++i) {
-      const double qi = Q[i * n + e] * inv;
-      for (int j = 0; j < n; ++j) R[i * n + j] += qi * Q[j * n + e];
+      const double qi = col[static_cast<size_t>(i)] * inv;
+      double *row = &R[static_cast<size_t>(i) * n];
+      for (int j = 0; j < n; ++j) row[j] += qi * col[static_cast<size_t>(j)];
     }
   }
   return R;

@@ -5,12 +5,15 @@
 // launches the sweeps, and keeps the small dense pieces the reference also keeps in double on the host
 // (marginal prior, covariance pseudo-inverse).  There is no CPU compute path: every stage is a HIP kernel.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <map>
 #include <memory>
 
 #include "host_linalg.hpp"
 #include "pba_solve_kernels.hpp"
 #include "depth_map_kernels.hpp"
+#include "point_status_kernels.hpp"
 #include "depth_maps.hpp"
 
 namespace dsopp_hip {
@@ -88,6 +91,8 @@ struct dsopp_hip_window {
   bool state_dirty = true;   // host mirror newer than device
   bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
+  DeviceBuffer<SelectState> d_select;   // radix-select state of updatePointStatuses
+  DeviceBuffer<double> d_pair_dist;     // camera-centre distances of all frame pairs
   bool marg_dirty = true;
   bool pair_valid = false;   // pair constants match the device state
   bool begun = false;
@@ -902,23 +907,44 @@ Rigid poseOf(const W &w, int f) {
   return rigidMul(T0, rigidExp(w.hst.eps[f]));  // tWorldAgent — local_frame.hpp:525-527
 }
 
-/** relinearizeSystem — PROB_SRC/photometric_bundle_adjustment.cpp:310-316 */
+/** relinearizeSystem — PROB_SRC/photometric_bundle_adjustment.cpp:310-316 (on the device state; the host mirror follows lazily) */
 void relinearize(W &w) {
-  downloadState(w);
-  const int f = w.F() - 1;
-  Rigid T = poseOf(w, f);
-  rigidNormalize(T);
-  for (int i = 0; i < 9; ++i) w.hst.T0_R[f][i] = T.R[i];
-  for (int i = 0; i < 3; ++i) w.hst.T0_t[f][i] = T.t[i];
-  w.hst.ab0[f][0] += w.hst.eps[f][6];
-  w.hst.ab0[f][1] += w.hst.eps[f][7];
-  for (int a = 0; a < kBlk; ++a) w.hst.eps[f][a] = 0;
-  w.state_dirty = true;
+  prepare(w);
+  relinearizeKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F() - 1);
+  HIP_CHECK(hipGetLastError());
+  w.host_stale = true;
+  w.pair_valid = false;
 }
 
-/** updatePointStatuses — PROB_SRC/photometric_bundle_adjustment.cpp:321-406.
- *  Round 1: the 3rd-quartile selection runs on the host over the downloaded energies (once per solve, P*T doubles). */
+/** updatePointStatuses on the device: exact 3rd-quartile order statistic by an 8-pass radix select over the energies where
+ *  they lie, then one pass per landmark.  No host round trip (the sharded multi-rank case keeps the host gather below). */
+void updatePointStatusesDevice(W &w) {
+  prepare(w);
+  hipStream_t st = w.sr.stream;
+  const int F = w.F();
+  w.d_select.reserve(1, 0, st);
+  w.d_pair_dist.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames, 0, st);
+  selectInitKernel<<<1, 256, 0, st>>>(w.d_select.ptr);
+  if (w.n_sweep_blocks) {
+    const int per_wave = 64 / kItemsPerBlock;
+    const int grid = (w.n_sweep_blocks + per_wave - 1) / per_wave;
+    const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
+    for (int pass = 7; pass >= 0; --pass) {
+      selectHistKernel<<<grid, 64, 0, st>>>(w.d_frames.ptr, w.d_sweep_table.ptr, w.n_sweep_blocks, w.d_select.ptr, pass);
+      selectScanKernel<<<1, 64, 0, st>>>(w.d_select.ptr, pass, half_sigma_sq);
+    }
+  }
+  pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr);
+  if (w.n_schur_blocks)
+    applyPointStatusesKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, F, w.d_select.ptr, w.d_pair_dist.ptr);
+  HIP_CHECK(hipGetLastError());
+}
+
 void updatePointStatuses(W &w) {
+  if (!(w.allreduce && w.world > 1)) {
+    updatePointStatusesDevice(w);
+    return;
+  }
   prepare(w);
   downloadState(w);
   const int F = w.F();
@@ -1064,7 +1090,11 @@ void estimateUncertainty(W &w) {
   w.sr.sync();
   hostla::Mat full(static_cast<size_t>(K) * K);
   for (size_t i = 0; i < full.size(); ++i) full[i] = Hpp[i] - Hsc[i] + w.Hm[i];
+  const auto t_pinv0 = std::chrono::steady_clock::now();
   const hostla::Mat cov = hostla::pinvDropSmallest(full, K, w.opt.optimize_idepths ? 1 : 0);
+  if (std::getenv("DSOPP_HIP_TRACE"))
+    std::fprintf(stderr, "[dsopp_hip] estimateUncertainty: pinv of the %d x %d system took %.1f us on the host\n", K, K,
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_pinv0).count());
   downloadState(w);
   for (int r = 0; r < F; ++r)
     for (int t = 0; t < F; ++t) {
@@ -1585,6 +1615,7 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
     relinearize(*w);
     if (w->opt.estimate_uncertainty) estimateUncertainty(*w);
     updatePointStatuses(*w);
+    w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
     collectTimings(*w);
     w->begun = false;
     w->linearized = true;  // the last linearised system stays readable through get_system
