@@ -854,7 +854,8 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     ex.ublk_write = r & 1;
     ex.gate_on_pending = true;
     ex.fused_lin_backsub = true;
-    launchSweep(w, true, true, false, cin, true, 0.0, ex);
+    // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
+    launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
