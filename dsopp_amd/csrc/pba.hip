@@ -616,6 +616,10 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
   a.store_system = store_system ? 1 : 0;
   timedLaunch(w, do_solve ? DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE : DSOPP_HIP_KERNEL_ASSEMBLE,
               [&] { assembleSolveKernel<<<1, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
+  if (do_solve && !w.fej()) {
+    // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
+    pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);
+  }
   HIP_CHECK(hipGetLastError());
 }
 

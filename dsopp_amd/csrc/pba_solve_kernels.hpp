@@ -1046,12 +1046,9 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
     Rigid *E = reinterpret_cast<Rigid *>(A);
     if (tid < 2 * F) E[tid] = frameIncrement(a.st, tid % F, tid < F ? 1.0 : -1.0);
     __syncthreads();
-    if (tid < F * F) {
-      if (a.fej)
-        refreshPairCurrent(a.frames, a.st, a.pc, tid / F, tid % F, E[tid / F], E[F + tid % F]);
-      else
-        computePairConst(a.frames, a.st, a.pc, tid / F, tid % F, F, false, &E[tid / F], &E[F + tid % F]);
-    }
+    // without first-estimate Jacobians every pair constant moves with the state: the host launches pairSetupKernel right
+    // after this kernel (keeping that 15 KB routine and its stack frame out of here spares every launch the scratch setup)
+    if (tid < F * F && a.fej) refreshPairCurrent(a.frames, a.st, a.pc, tid / F, tid % F, E[tid / F], E[F + tid % F]);
   }
   DSOPP_STAMP(5);
   if (a.ctrl) {
