@@ -850,7 +850,9 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     lmBeginKernel<<<1, kSolveThreads, (static_cast<size_t>(w.K()) + 16) * sizeof(double), st>>>(ia);
   }
   HIP_CHECK(hipGetLastError());
-  const int rounds = w.opt.max_iterations + 1;
+  // one round per iteration + the opening evaluation; without force_accept a rejected step costs one more round (the
+  // re-linearisation at the reverted state), so the budget doubles — rounds after the loop has ended are no-op launches
+  const int rounds = (w.opt.force_accept ? w.opt.max_iterations : 2 * w.opt.max_iterations) + 1;
   for (int r = 0; r < rounds; ++r) {
     LmControl *cin = ctrl + (r & 1), *cout = ctrl + ((r + 1) & 1);
     SweepExtras ex;

@@ -136,3 +136,32 @@ def test_snapshot_restore_is_idempotent(small_window):
     done, e = g.optimize_repeated(10)
     assert done == 10
     g.close()
+
+
+@pytest.mark.parametrize("lm_mode", [0, 1, 2])
+@pytest.mark.parametrize("fej", [1, 0])
+def test_reject_path_without_force_accept(lm_mode, fej):
+    """force_accept = false with enough iterations that LM steps get rejected near the optimum: the device-driven loops must
+    follow the reference's reject / re-linearise bookkeeping (levenberg_marquardt_algorithm.hpp:88-128) like the oracle"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    # seed 42: the oracle accepts 4 steps and then rejects every further one (checked with the stage API); seed 41 never rejects
+    win = syn.make_window(num_frames=4, num_points=300, width=320, height=240, seed=42)
+    kw = dict(force_accept=0, max_iterations=14, first_estimate_jacobians=fej)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
+    g.set_lm_mode(lm_mode)
+    eo, ito, nvo = o.optimize()
+    eg, itg, nvg = g.optimize()
+    assert (ito, nvo) == (itg, nvg), (ito, itg, nvo, nvg)
+    assert abs(eo - eg) <= 1e-7 * abs(eo)
+    for f in win.frames:
+        To, abo = o.get_pose(f.frame_id)
+        Tg, abg = g.get_pose(f.frame_id)
+        assert np.abs(To - Tg).max() <= 1e-7 and np.abs(abo - abg).max() <= 1e-7
+        assert np.abs(g.get_landmarks(f.frame_id, False)["idepth"] - o.get_landmarks(f.frame_id)["idepth"]).max() <= 1e-7
+    for fr in win.frames:
+        for ft in win.frames:
+            if fr.frame_id != ft.frame_id:
+                assert np.array_equal(o.get_residuals(fr.frame_id, ft.frame_id)["status"], g.get_residuals(fr.frame_id, ft.frame_id)["status"])
+    g.close()
