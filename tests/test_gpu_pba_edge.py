@@ -165,3 +165,29 @@ def test_reject_path_without_force_accept(lm_mode, fej):
             if fr.frame_id != ft.frame_id:
                 assert np.array_equal(o.get_residuals(fr.frame_id, ft.frame_id)["status"], g.get_residuals(fr.frame_id, ft.frame_id)["status"])
     g.close()
+
+
+@pytest.mark.parametrize("fej", [1, 0])
+def test_affine_brightness_and_exposure(fej):
+    """non-trivial photometric parameters: per-frame affine brightness (a, b) in the images and in the initial state,
+    different exposure times — exercises the a / b Jacobian columns, sigma_r / b_r0 of the FEJ path and the affine priors"""
+    win = syn.make_window(num_frames=4, num_points=320, width=320, height=240, seed=53, affine_jitter=True)
+    rng = np.random.default_rng(8)
+    for f in win.frames:
+        f.exposure = float(rng.uniform(0.7, 1.3))
+        if not f.fixed:
+            f.affine_init = f.affine_gt + rng.normal(0, [0.01, 0.5])
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    # the production regularisers (1e12, 1e8) pin (a, b) to zero; weak ones let the solver really estimate them
+    kw = dict(first_estimate_jacobians=fej, affine_brightness_regularizer=(1e2, 1e-2))
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
+    _compare_solve(o, g, win)
+    assert any(abs(g.get_pose(f.frame_id)[1]).max() > 1e-3 for f in win.frames[1:])
+    g.close()
+    # and with the production regularisers
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(first_estimate_jacobians=fej)), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options(first_estimate_jacobians=fej)), win)
+    _compare_solve(o, g, win)
+    g.close()
