@@ -123,3 +123,44 @@ def test_alignment_known_pose_and_masks(two_frames):
     assert r2["n_valid"] == 0 and r2["iterations"] == 0
     for o in (a, a2, pr, pt):
         o.close()
+
+
+@pytest.mark.parametrize("weak_prior", [False, True])
+def test_alignment_photometric_parameters(two_frames, weak_prior):
+    """exposure ratio != 1, non-zero affine brightness of both frames (the brightness-change scale, the a / b columns of the
+    8x8 system and the affine prior block of eigen_pose_alignment.cpp:101-104,183-187)"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = two_frames
+    fr, ft = win.frames
+    H, W = fr.image_u8.shape
+    level = 1
+    infos_r, _ = po.build_pyramid(fr.image_u8, levels=2)
+    infos_t, _ = po.build_pyramid(ft.image_u8, levels=2)
+    pr, pt = capi.Pyramid(W, H, 2), capi.Pyramid(W, H, 2)
+    pr.build(fr.image_u8)
+    pt.build(ft.image_u8)
+    intr = win.scene.intrinsics / (1 << level)
+    idsum, wgt = _depth_map(fr, level, 1200, seed=11)
+    T_ref, T_init = syn.mat_to_params(fr.T_w_c_gt), syn.mat_to_params(ft.T_w_c_init)
+    ab_ref, ab_tgt = np.array([0.02, 1.5]), np.array([-0.01, -0.7])
+    e_ref, e_tgt = 0.8, 1.1
+    kw = dict(affine_brightness_regularizer=(1e1, 1e-3)) if weak_prior else {}
+    u, v, idp, inten = po.points_from_depth_map(infos_r[level], idsum, wgt)
+    h, w = infos_r[level].shape[:2]
+    ro = po.align_solve(po.default_align_options(**kw), u, v, idp, inten, intr, (w, h), T_ref, e_ref, ab_ref, intr, infos_t[level], None, T_init,
+                        e_tgt, ab_tgt)
+    a = capi.HipAligner(capi.default_align_options(**kw))
+    a.reset()
+    a.push_reference_depth_map(1000, T_ref, pr, level, intr, idsum, wgt, e_ref, ab_ref)
+    a.push_target(2000, T_init, pt, level, intr, e_tgt, ab_tgt)
+    rg = a.solve()
+    assert rg["iterations"] == ro["iterations"] and rg["n_valid"] == ro["n_valid"]
+    assert abs(rg["energy"] - ro["energy"]) <= 1e-8 * abs(ro["energy"])
+    assert np.abs(rg["T_w_target"] - ro["T_w_target"]).max() <= 1e-8
+    assert np.abs(rg["affine_brightness"] - ro["affine_brightness"]).max() <= 1e-7
+    assert np.abs(rg["H"] - ro["H"]).max() <= 1e-8 * np.abs(ro["H"]).max()
+    if weak_prior:
+        assert np.abs(rg["affine_brightness"] - ab_tgt).max() > 1e-3   # the photometric parameters really moved
+    for obj in (a, pr, pt):
+        obj.close()
