@@ -279,7 +279,25 @@ __device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], 
 #pragma unroll
   for (int e = 0; e < COUNT; ++e) lds[e * kRedStride + t] = acc[FIRST + e];
   ldsBarrier();
-  if (t < COUNT) {
+  // two adjacent lanes per row (each sums one half, fixed order), combined with one DPP swap: both waves take part
+  // instead of 48 lanes of one wave walking 128 entries each
+  if (2 * COUNT <= kSweepThreads) {
+    const int row_idx = t >> 1, half = t & 1;
+    double s = 0;
+    if (row_idx < COUNT) {
+      const double2 *row = reinterpret_cast<const double2 *>(lds + row_idx * kRedStride) + half * (kSweepThreads / 4);
+      double s0 = 0, s1 = 0;
+#pragma unroll 8
+      for (int j = 0; j < kSweepThreads / 4; ++j) {
+        const double2 p = row[j];
+        s0 += p.x;
+        s1 += p.y;
+      }
+      s = s0 + s1;
+    }
+    const double other = dppMove<0xB1>(s);  // quad_perm [1,0,3,2]: the neighbour lane's half
+    if (row_idx < COUNT && half == 0) out[FIRST + row_idx] = s + other;
+  } else if (t < COUNT) {
     const double2 *row = reinterpret_cast<const double2 *>(lds + t * kRedStride);
     double s0 = 0, s1 = 0;
 #pragma unroll 8
