@@ -8,6 +8,7 @@
 #include "pba.hpp"
 #include "pose_alignment.hpp"
 #include "depth_maps.hpp"
+#include "depth_estimation.hpp"
 #include "pyramid.hpp"
 
 using namespace oracle;
@@ -306,6 +307,65 @@ int orc_points_from_depth_map(int width, int height, const double *pixelinfo, co
     v[i] = pts[static_cast<size_t>(i)].v;
     idepth[i] = pts[static_cast<size_t>(i)].idepth;
     intensity[i] = pts[static_cast<size_t>(i)].intensity;
+  }
+  return n;
+}
+
+int orc_estimate_depths(int width, int height, const double *target_pixelinfo, const uint8_t *mask, const double intrinsics[4],
+                        const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
+                        double target_exposure, const double target_affine[2], double sigma_huber_loss, int n,
+                        const double *projection, const double *direction, const double *patch, const double *gradient,
+                        double *idepth_min, double *idepth_max, double *uniqueness, double *search_pixel_interval,
+                        uint8_t *status, uint8_t *traced) {
+  DepthEstimationFrame f;
+  f.target = PixelMapView{target_pixelinfo, width, height};
+  f.mask = MaskView{mask, width, height};
+  f.model = PinholeModel{static_cast<double>(width), static_cast<double>(height), intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  f.t_t_r = SE3::fromParams(T_target_reference);
+  f.reference_exposure_time = reference_exposure;
+  f.target_exposure_time = target_exposure;
+  for (int i = 0; i < 2; ++i) {
+    f.reference_affine[i] = reference_affine[i];
+    f.target_affine[i] = target_affine[i];
+  }
+  f.sigma_huber_loss = sigma_huber_loss;
+  for (int i = 0; i < n; ++i) {
+    ImmatureLandmark lm;
+    for (int k = 0; k < 2; ++k) {
+      lm.projection[k] = projection[2 * i + k];
+      lm.gradient[k] = gradient[2 * i + k];
+    }
+    for (int k = 0; k < 3; ++k) lm.direction[k] = direction[3 * i + k];
+    for (int k = 0; k < kPatternSize; ++k) lm.patch[k] = patch[kPatternSize * i + k];
+    lm.idepth_min = idepth_min[i];
+    lm.idepth_max = idepth_max[i];
+    lm.uniqueness = uniqueness[i];
+    lm.search_pixel_interval = search_pixel_interval[i];
+    lm.status = status[i];
+    lm.traced = traced[i] != 0;
+    estimateLandmark(f, lm);
+    idepth_min[i] = lm.idepth_min;
+    idepth_max[i] = lm.idepth_max;
+    uniqueness[i] = lm.uniqueness;
+    search_pixel_interval[i] = lm.search_pixel_interval;
+    status[i] = lm.status;
+    traced[i] = lm.traced ? 1 : 0;
+  }
+  return n;
+}
+
+int orc_build_epipolar_segment(int width, int height, const double intrinsics[4], const double T_target_reference[7],
+                               const double observed[2], double idepth_min, double idepth_max, int cap, double *projections,
+                               double *idepths) {
+  const PinholeModel model{static_cast<double>(width), static_cast<double>(height), intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const SE3 t = SE3::fromParams(T_target_reference);
+  const EpipolarLineBuilder builder(model, t);
+  const EpipolarLine line = builder.buildSegment(observed, idepth_min, idepth_max);
+  const int n = static_cast<int>(line.points.size());
+  for (int i = 0; i < std::min(n, cap); ++i) {
+    projections[2 * i] = line.points[static_cast<size_t>(i)].projection[0];
+    projections[2 * i + 1] = line.points[static_cast<size_t>(i)].projection[1];
+    idepths[i] = line.points[static_cast<size_t>(i)].reference_idepth;
   }
   return n;
 }

@@ -105,6 +105,19 @@ int orc_create_reference_depth_maps(int n_sources, const double *T_w_sources /* 
                                     const double T_w_newest[7], const double intrinsics[4], int width, int height, int levels,
                                     double *idepth_sum_out, double *weight_out);
 
+/* DepthEstimation::estimate (depth_estimation.cpp:363-381) for the immature landmarks of one keyframe against a new frame.
+ * Landmark arrays are in/out (struct-of-arrays view of ImmatureTrackingLandmark). */
+int orc_estimate_depths(int width, int height, const double *target_pixelinfo, const uint8_t *mask, const double intrinsics[4],
+                        const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
+                        double target_exposure, const double target_affine[2], double sigma_huber_loss, int n,
+                        const double *projection, const double *direction, const double *patch, const double *gradient,
+                        double *idepth_min, double *idepth_max, double *uniqueness, double *search_pixel_interval,
+                        uint8_t *status, uint8_t *traced);
+/* EpipolarLineBuilder::buildSegment: returns the number of points, fills up to cap (projection 2 each, reference idepth) */
+int orc_build_epipolar_segment(int width, int height, const double intrinsics[4], const double T_target_reference[7],
+                               const double observed[2], double idepth_min, double idepth_max, int cap, double *projections,
+                               double *idepths);
+
 /* ---- pyramid ---- */
 /* pixelinfo_out[l] must hold 3*w_l*h_l doubles; plane_out[l] (optional) w_l*h_l */
 int orc_build_pyramid(const uint8_t *image, int width, int height, const double *lut256, const uint8_t *vignetting,

@@ -260,6 +260,44 @@ def points_from_depth_map(pixelinfo, idepth_sum, weight):
     return u[:n].copy(), v[:n].copy(), d[:n].copy(), inten[:n].copy()
 
 
+IMMATURE_STATUS = dict(good=0, out_of_boundary=1, outlier=2, skipped=3, ill_conditioned=4, uninitialized=5, delete=6)
+
+
+def new_immature_landmarks(uv, direction, patch, gradient):
+    """struct-of-arrays ImmatureTrackingLandmark set with the constructor defaults (immature_tracking_landmark.hpp:93-106)"""
+    n = len(uv)
+    return dict(projection=_f64(uv).copy(), direction=_f64(direction).copy(), patch=_f64(patch).copy(), gradient=_f64(gradient).copy(),
+                idepth_min=np.zeros(n), idepth_max=np.full(n, 1.0 / 0.001), uniqueness=np.full(n, np.finfo(np.float64).max),
+                search_pixel_interval=np.full(n, np.finfo(np.float64).max), status=np.full(n, IMMATURE_STATUS["uninitialized"], dtype=np.uint8),
+                traced=np.zeros(n, dtype=np.uint8))
+
+
+def estimate_depths(lms, target_pixelinfo, mask, intrinsics, T_target_reference, reference_exposure=1.0, reference_affine=(0, 0),
+                    target_exposure=1.0, target_affine=(0, 0), sigma_huber_loss=20.0):
+    """DepthEstimation::estimate (depth_estimation.cpp:363-381); updates the landmark arrays in place"""
+    pix = _f64(target_pixelinfo)
+    H, W = pix.shape[:2]
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    n = len(lms["status"])
+    for k in ("idepth_min", "idepth_max", "uniqueness", "search_pixel_interval"):
+        lms[k] = _f64(lms[k])
+    for k in ("status", "traced"):
+        lms[k] = np.ascontiguousarray(lms[k], dtype=np.uint8)
+    lib().orc_estimate_depths(W, H, _p(pix), _p(m, np.uint8), _p(_f64(intrinsics)), _p(_f64(T_target_reference)), C.c_double(reference_exposure),
+                              _p(_f64(reference_affine)), C.c_double(target_exposure), _p(_f64(target_affine)), C.c_double(sigma_huber_loss), n,
+                              _p(_f64(lms["projection"])), _p(_f64(lms["direction"])), _p(_f64(lms["patch"])), _p(_f64(lms["gradient"])),
+                              _p(lms["idepth_min"]), _p(lms["idepth_max"]), _p(lms["uniqueness"]), _p(lms["search_pixel_interval"]),
+                              _p(lms["status"], np.uint8), _p(lms["traced"], np.uint8))
+    return lms
+
+
+def build_epipolar_segment(width, height, intrinsics, T_target_reference, observed, idepth_min=0.0, idepth_max=1000.0, cap=8192):
+    proj, idp = np.zeros((cap, 2)), np.zeros(cap)
+    n = lib().orc_build_epipolar_segment(int(width), int(height), _p(_f64(intrinsics)), _p(_f64(T_target_reference)), _p(_f64(observed)),
+                                         C.c_double(idepth_min), C.c_double(idepth_max), cap, _p(proj), _p(idp))
+    return proj[:min(n, cap)].copy(), idp[:min(n, cap)].copy()
+
+
 def create_reference_depth_maps(sources, T_w_newest, intrinsics, width, height, levels):
     """createReferenceDepthMaps (create_depth_maps.cpp:18-147).  sources: list of dicts with T_w (7), uv (n x 2), idepth,
     variance, skip (outlier | marginalized), status (connection statuses towards the newest keyframe).

@@ -1,0 +1,84 @@
+"""Row f-1: the depth estimator of immature landmarks (src/tracker/depth_estimators/src/depth_estimation.cpp,
+src/energy/epipolar_geometry/*).  CPU: the oracle restatement against statements that do not share its code — every
+epipolar-line point must reproject (explicit NumPy 4x4 chain) onto itself at its triangulated inverse depth, the line must
+pass through the true correspondence, and on a synthetic scene the estimated [idepth_min, idepth_max] intervals must bracket
+the ground truth and shrink with a second observation.  GPU: the HIP estimator against the oracle."""
+import numpy as np
+import pytest
+
+from dsopp_amd import synthetic as syn
+
+
+def _rel(T_w_t, T_w_r):
+    return np.linalg.inv(T_w_t) @ T_w_r
+
+
+def _mat_to_params(T):
+    return syn.mat_to_params(T)
+
+
+def _reproject(intr, T, uv, rho):
+    fx, fy, cx, cy = intr
+    d = np.array([(uv[0] - cx) / fx, (uv[1] - cy) / fy, 1.0])
+    X = T[:3, :3] @ d + rho * T[:3, 3]
+    return np.array([fx * X[0] / X[2] + cx, fy * X[1] / X[2] + cy]), X[2]
+
+
+def _landmarks(po, frame, n=None):
+    uv = frame.uv if n is None else frame.uv[:n]
+    ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+    grad = np.stack([frame.pixelinfo[vi, ui, 1], frame.pixelinfo[vi, ui, 2]], axis=1)
+    return uv, grad
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return syn.make_window(num_frames=4, num_points=4 * 150, width=320, height=240, seed=71, pose_noise=False)
+
+
+def test_epipolar_segment_is_consistent(scene):
+    from oracle import pyoracle as po
+    win = scene
+    intr = win.scene.intrinsics
+    fr, ft = win.frames[0], win.frames[2]
+    T = _rel(ft.T_w_c_gt, fr.T_w_c_gt)
+    checked = 0
+    for i in range(0, 60, 3):
+        uv = fr.uv[i]
+        proj, idp = po.build_epipolar_segment(320, 240, intr, _mat_to_params(T), uv)
+        if len(proj) < 3:
+            continue
+        # (a) every point is the reprojection of the observed pixel at the point's own inverse depth
+        for p, rho in zip(proj[::7], idp[::7]):
+            q, z = _reproject(intr, T, uv, rho)
+            assert z > 0 and np.abs(q - p).max() <= 1e-6, (i, p, q)
+        # (b) idepth is monotone along the line and inside the search range
+        assert np.all(np.diff(idp) >= -1e-9) or np.all(np.diff(idp) <= 1e-9)
+        assert idp.min() >= -1e-9 and idp.max() <= 1000 + 1e-9
+        # (c) the true correspondence lies on the polyline (within the 1-px sampling)
+        q, _ = _reproject(intr, T, uv, fr.idepth_gt[i])
+        if 4 <= q[0] <= 315 and 4 <= q[1] <= 235:
+            assert np.min(np.hypot(*(proj - q).T)) <= 1.0, i
+            checked += 1
+    assert checked >= 10
+
+
+def test_estimated_intervals_bracket_ground_truth(scene):
+    from oracle import pyoracle as po
+    win = scene
+    intr = win.scene.intrinsics
+    fr = win.frames[0]
+    uv, grad = _landmarks(po, fr)
+    direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+    lms = po.new_immature_landmarks(uv, direction, fr.patch, grad)
+    widths = []
+    for ft in (win.frames[1], win.frames[3]):
+        T = _rel(ft.T_w_c_gt, fr.T_w_c_gt)
+        po.estimate_depths(lms, ft.pixelinfo, None, intr, _mat_to_params(T))
+        good = lms["status"] == po.IMMATURE_STATUS["good"]
+        assert good.mean() > 0.5
+        inside = (lms["idepth_min"][good] <= fr.idepth_gt[good] * 1.02) & (fr.idepth_gt[good] * 0.98 <= lms["idepth_max"][good])
+        assert inside.mean() > 0.85, inside.mean()
+        widths.append(np.median(lms["idepth_max"][good] - lms["idepth_min"][good]))
+        assert np.all(lms["traced"][good] == 1)
+    assert widths[1] < widths[0]   # a second, wider-baseline observation narrows the interval
