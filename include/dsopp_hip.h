@@ -238,6 +238,22 @@ int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level
 /* copies one level to the host: two row-major H x W planes (energy::problem::DepthMap::map(x, y).{idepth, weight}) */
 int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level, double *idepth_sum, double *weight);
 
+/* ---- depth estimation of immature landmarks (row f-1) ----
+ * DepthEstimation::estimate (src/tracker/depth_estimators/src/depth_estimation.cpp:363-381) for the immature landmarks of one
+ * keyframe against level `level` (0 in the tracker, monocular_tracker.cpp:98-100) of a new frame's device pyramid:
+ * epipolar segment (epipolar_line_builder_pinhole_se3.hpp:296-372), discrete search (findBest, :36-76), sub-pixel
+ * refinement on the epipolar tangent (refine, :184-221), uniqueness, error model and re-triangulated [idepth_min, idepth_max]
+ * (estimateLandmark, :223-357).  T_target_reference = T_new_frame^-1 * T_keyframe.  The landmark arrays are the
+ * struct-of-arrays view of track::landmarks::ImmatureTrackingLandmark and are updated in place:
+ * status: 0 good, 1 out of boundary, 2 outlier, 3 skipped, 4 ill conditioned, 5 uninitialized, 6 delete
+ * (immature_tracking_landmark.hpp:14-22).  One wavefront per landmark. */
+int dsopp_hip_estimate_depths(const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4],
+                              const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
+                              double target_exposure, const double target_affine[2], double sigma_huber_loss, int32_t n,
+                              const double *projection /* 2n */, const double *direction /* 3n */, const double *patch /* 8n */,
+                              const double *gradient /* 2n */, double *idepth_min, double *idepth_max, double *uniqueness,
+                              double *search_pixel_interval, uint8_t *status, uint8_t *traced);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Two-frame direct image alignment of one pyramid level
  * (replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>, PROB_SRC/eigen_pose_alignment.cpp:26-329)

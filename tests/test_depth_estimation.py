@@ -82,3 +82,40 @@ def test_estimated_intervals_bracket_ground_truth(scene):
         widths.append(np.median(lms["idepth_max"][good] - lms["idepth_min"][good]))
         assert np.all(lms["traced"][good] == 1)
     assert widths[1] < widths[0]   # a second, wider-baseline observation narrows the interval
+
+
+@pytest.mark.gpu
+def test_gpu_depth_estimation_matches_oracle(scene):
+    """two consecutive observations (the second one takes the traced path with the narrowed interval): statuses and the
+    traced flags identical, intervals / uniqueness / pixel intervals to 1e-8 (the device evaluates point i of the epipolar
+    segment as start + i * step where the reference accumulates the step i times)"""
+    import copy
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = scene
+    intr = win.scene.intrinsics
+    fr = win.frames[0]
+    uv, grad = _landmarks(po, fr)
+    direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+    lo = po.new_immature_landmarks(uv, direction, fr.patch, grad)
+    lg = copy.deepcopy(lo)
+    for step, ft in enumerate((win.frames[1], win.frames[3], win.frames[2])):
+        T = _mat_to_params(_rel(ft.T_w_c_gt, fr.T_w_c_gt))
+        pyr = capi.Pyramid(320, 240, 1)
+        pyr.set_level(0, ft.pixelinfo)
+        ab_r, ab_t = (0.01 * step, 0.5 * step), (-0.02 * step, 0.3 * step)
+        po.estimate_depths(lo, ft.pixelinfo, None, intr, T, 1.0, ab_r, 1.0 + 0.1 * step, ab_t)
+        capi.estimate_depths(lg, pyr, 0, intr, T, 1.0, ab_r, 1.0 + 0.1 * step, ab_t)
+        pyr.close()
+        assert np.array_equal(lo["status"], lg["status"]), (step, np.flatnonzero(lo["status"] != lg["status"]))
+        assert np.array_equal(lo["traced"], lg["traced"]), step
+        good = lo["status"] == po.IMMATURE_STATUS["good"]
+        if step < 2:   # (the third observation has a short baseline: most landmarks end up skipped / ill conditioned)
+            assert good.sum() > 50, step
+        for k in ("idepth_min", "idepth_max", "search_pixel_interval"):
+            assert np.abs(lo[k] - lg[k]).max() <= 1e-8 * max(1.0, np.abs(lo[k]).max()), (step, k)
+        fin = lo["uniqueness"] < 1e300
+        assert np.array_equal(fin, lg["uniqueness"] < 1e300)
+        assert np.abs(lo["uniqueness"][fin] - lg["uniqueness"][fin]).max() <= 1e-7 * np.abs(lo["uniqueness"][fin]).max(), step
+    # every status class that matters was seen along the way
+    assert len(set(lo["status"].tolist())) >= 3
