@@ -171,6 +171,7 @@ def main():
         g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
         extras["tracker"] = run_tracker_timing(capi, syn, torch)
+        extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -343,6 +344,55 @@ def run_tracker_timing(capi, syn, torch, frames=20):
            "data": "synthetic 7-keyframe window + 1 new frame, target image resident in HBM"}
     for o in (a, maps, m2, pr, pt, g):
         o.close()
+    return out
+
+
+def run_depth_estimation_timing(capi, syn, args, repeats=10):
+    """row f-1: DepthEstimation::estimate for the immature landmarks of the window's keyframes against a new 640x480 frame
+    (monocular_tracker.cpp:74-102 runs it for every frame over all keyframes): 7 keyframes x 2000 immature landmarks.
+    GPU call = upload of the landmark arrays + kernel + download (host buffers at the boundary); CPU port beside it."""
+    from oracle import pyoracle as po
+    W, H, KF, N = 640, 480, 7, 2000
+    win = syn.make_window(num_frames=KF + 1, num_points=(KF + 1) * N, width=W, height=H, seed=5, pose_noise=False)
+    new = win.frames[-1]
+    intr = win.scene.intrinsics
+    pyr = capi.Pyramid(W, H, 1)
+    pyr.set_level(0, new.pixelinfo)
+    sets, Ts = [], []
+    for f in win.frames[:KF]:
+        uv = f.uv
+        ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+        grad = np.stack([f.pixelinfo[vi, ui, 1], f.pixelinfo[vi, ui, 2]], axis=1)
+        direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+        sets.append(po.new_immature_landmarks(uv, direction, f.patch, grad))
+        Ts.append(syn.mat_to_params(np.linalg.inv(new.T_w_c_gt) @ f.T_w_c_gt))
+    import copy
+    t_gpu = []
+    good = 0
+    for rep in range(repeats + 1):
+        dsets = [capi.ImmatureSet(l) for l in sets]   # device-resident: the landmarks persist over frames, only their state moves
+        t0 = time.perf_counter()
+        for ds, T in zip(dsets, Ts):
+            ds.estimate(pyr, 0, intr, T)
+        states = [ds.download() for ds in dsets]      # the tracker reads the statuses back after every frame
+        if rep:
+            t_gpu.append(time.perf_counter() - t0)
+        good = int(sum((s["status"] == 0).sum() for s in states))
+        for ds in dsets:
+            ds.close()
+    out = {"workload": f"{KF} keyframes x {N} immature landmarks against one {W}x{H} frame", "gpu_ms_per_frame": float(np.median(t_gpu) * 1e3),
+           "landmarks": KF * N, "good_after_first_observation": good,
+           "what": "7 estimate launches on device-resident landmark sets + read-back of all estimator states"}
+    if not args.no_cpu:
+        hw = os.cpu_count() or 1
+        po.set_threads(max(1, min(hw, 8) - 1))
+        work = copy.deepcopy(sets)
+        t0 = time.perf_counter()
+        for lms, T in zip(work, Ts):
+            po.estimate_depths(lms, new.pixelinfo, None, intr, T)
+        out["cpu_port_ms_per_frame"] = (time.perf_counter() - t0) * 1e3
+        out["cpu_port_threads"] = 1
+    pyr.close()
     return out
 
 

@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_estimate_depths", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_estimate_depths", "dsopp_hip_immature_set_create", "dsopp_hip_immature_set_destroy", "dsopp_hip_immature_set_upload_state", "dsopp_hip_immature_set_download_state", "dsopp_hip_immature_set_estimate", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -431,6 +431,41 @@ def estimate_depths(lms, target_pyramid: Pyramid, level, intrinsics, T_target_re
                                          _p(lms["idepth_min"]), _p(lms["idepth_max"]), _p(lms["uniqueness"]), _p(lms["search_pixel_interval"]),
                                          _p(lms["status"], np.uint8), _p(lms["traced"], np.uint8)))
     return lms
+
+
+class ImmatureSet:
+    """Device-resident immature landmarks of one keyframe (dsopp_hip_immature_set)."""
+
+    def __init__(self, lms, device=0, stream=None):
+        self._h = C.c_void_p()
+        self.n = len(lms["status"])
+        _chk(lib().dsopp_hip_immature_set_create(int(device), C.c_void_p(stream or 0), self.n, _p(_f64(lms["projection"])), _p(_f64(lms["direction"])),
+                                                 _p(_f64(lms["patch"])), _p(_f64(lms["gradient"])), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_immature_set_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def estimate(self, target_pyramid: Pyramid, level, intrinsics, T_target_reference, reference_exposure=1.0, reference_affine=(0, 0),
+                 target_exposure=1.0, target_affine=(0, 0), sigma_huber_loss=20.0):
+        _chk(lib().dsopp_hip_immature_set_estimate(self._h, target_pyramid._h, int(level), _p(_f64(intrinsics)), _p(_f64(T_target_reference)),
+                                                   C.c_double(reference_exposure), _p(_f64(reference_affine)), C.c_double(target_exposure),
+                                                   _p(_f64(target_affine)), C.c_double(sigma_huber_loss)))
+
+    def download(self):
+        n = self.n
+        out = dict(idepth_min=np.zeros(n), idepth_max=np.zeros(n), uniqueness=np.zeros(n), search_pixel_interval=np.zeros(n),
+                   status=np.zeros(n, dtype=np.uint8), traced=np.zeros(n, dtype=np.uint8))
+        _chk(lib().dsopp_hip_immature_set_download_state(self._h, _p(out["idepth_min"]), _p(out["idepth_max"]), _p(out["uniqueness"]),
+                                                         _p(out["search_pixel_interval"]), _p(out["status"], np.uint8), _p(out["traced"], np.uint8)))
+        return out
 
 
 class HipAligner:

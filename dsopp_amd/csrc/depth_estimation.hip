@@ -13,6 +13,9 @@
 // error model, re-triangulation of the interval) is executed redundantly by all lanes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
+#include <limits>
 #include <memory>
 #include <vector>
 
@@ -570,101 +573,217 @@ __global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLa
 
 using namespace dsopp_hip;
 
-extern "C" int dsopp_hip_estimate_depths(const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4],
-                                         const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
-                                         double target_exposure, const double target_affine[2], double sigma_huber_loss, int32_t n,
-                                         const double *projection, const double *direction, const double *patch, const double *gradient,
-                                         double *idepth_min, double *idepth_max, double *uniqueness, double *search_pixel_interval,
-                                         uint8_t *status, uint8_t *traced) {
+/** the immature landmarks of one keyframe, resident on the device across frames */
+struct dsopp_hip_immature_set {
+  StreamRef sr;
+  int n = 0;
+  DeviceBuffer<double> d_in;      // projection 2n | direction 3n | patch 8n | gradient 2n
+  DeviceBuffer<double> d_io;      // idepth_min | idepth_max | uniqueness | search_pixel_interval
+  DeviceBuffer<uint8_t> d_flags;  // status | traced
+  void *h_stage = nullptr;        // pinned read-back staging
+  size_t h_stage_bytes = 0;
+};
+
+namespace {
+
+DepthFrame makeDepthFrame(const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4], const double T_target_reference[7],
+                          double reference_exposure, const double reference_affine[2], double target_exposure, const double target_affine[2],
+                          double sigma_huber_loss, int n) {
+  const LevelView lv = target_pyramid->view(level);
+  DepthFrame f;
+  f.texels = lv.texels;
+  f.width = lv.width;
+  f.height = lv.height;
+  f.fx = intrinsics[0];
+  f.fy = intrinsics[1];
+  f.cx = intrinsics[2];
+  f.cy = intrinsics[3];
+  const Rigid T = rigidFromParams(T_target_reference);
+  for (int i = 0; i < 9; ++i) f.R[i] = T.R[i];
+  for (int i = 0; i < 3; ++i) f.t[i] = T.t[i];
+  // reproject_ = K [R|t] K^-1 (camera_reproject.hpp:250-258)
+  const double ifx = 1.0 / f.fx, ify = 1.0 / f.fy, k02 = -f.cx / f.fx, k12 = -f.cy / f.fy;
+  double U[12];
+  for (int i = 0; i < 3; ++i) {
+    U[4 * i + 0] = T.R[3 * i + 0] * ifx;
+    U[4 * i + 1] = T.R[3 * i + 1] * ify;
+    U[4 * i + 2] = T.R[3 * i + 0] * k02 + T.R[3 * i + 1] * k12 + T.R[3 * i + 2];
+    U[4 * i + 3] = T.t[i];
+  }
+  for (int j = 0; j < 4; ++j) {
+    f.M[0 + j] = f.fx * U[0 + j] + f.cx * U[8 + j];
+    f.M[4 + j] = f.fy * U[4 + j] + f.cy * U[8 + j];
+    f.M[8 + j] = U[8 + j];
+  }
+  const double K[9] = {f.fx, 0, f.cx, 0, f.fy, f.cy, 0, 0, 1};
+  const double Kinv[9] = {1 / f.fx, 0, -f.cx / f.fx, 0, 1 / f.fy, -f.cy / f.fy, 0, 0, 1};
+  double KR[9];
+  for (int i = 0; i < 3; ++i) {
+    f.Kt[i] = K[3 * i] * T.t[0] + K[3 * i + 1] * T.t[1] + K[3 * i + 2] * T.t[2];
+    for (int j = 0; j < 3; ++j) KR[3 * i + j] = K[3 * i] * T.R[j] + K[3 * i + 1] * T.R[3 + j] + K[3 * i + 2] * T.R[6 + j];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) f.KRKi[3 * i + j] = KR[3 * i] * Kinv[j] + KR[3 * i + 1] * Kinv[3 + j] + KR[3 * i + 2] * Kinv[6 + j];
+  f.scale = (target_exposure / reference_exposure) * std::exp(target_affine[0] - reference_affine[0]);
+  f.b_r = reference_affine[1];
+  f.b_t = target_affine[1];
+  f.sigma = sigma_huber_loss;
+  f.n = n;
+  return f;
+}
+
+DepthLandmarks landmarkPointers(dsopp_hip_immature_set *s) {
+  const size_t N = static_cast<size_t>(s->n);
+  DepthLandmarks L;
+  L.projection = s->d_in.ptr;
+  L.direction = s->d_in.ptr + 2 * N;
+  L.patch = s->d_in.ptr + 5 * N;
+  L.gradient = s->d_in.ptr + 13 * N;
+  L.idepth_min = s->d_io.ptr;
+  L.idepth_max = s->d_io.ptr + N;
+  L.uniqueness = s->d_io.ptr + 2 * N;
+  L.search_pixel_interval = s->d_io.ptr + 3 * N;
+  L.status = s->d_flags.ptr;
+  L.traced = s->d_flags.ptr + N;
+  return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsopp_hip_immature_set_create(int device, void *stream, int32_t n, const double *projection, const double *direction, const double *patch,
+                                  const double *gradient, dsopp_hip_immature_set **out) {
   return guarded([&] {
-    if (!target_pyramid || !intrinsics || !T_target_reference || !reference_affine || !target_affine || n < 0)
-      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    if (n && (!projection || !direction || !patch || !gradient || !idepth_min || !idepth_max || !uniqueness || !search_pixel_interval || !status || !traced))
-      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null landmark array");
-    if (level < 0 || level >= target_pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
-    if (n == 0) return;
-    target_pyramid->sr.use();
-    hipStream_t st = target_pyramid->sr.stream;
-    const LevelView lv = target_pyramid->view(level);
-    DepthFrame f;
-    f.texels = lv.texels;
-    f.width = lv.width;
-    f.height = lv.height;
-    f.fx = intrinsics[0];
-    f.fy = intrinsics[1];
-    f.cx = intrinsics[2];
-    f.cy = intrinsics[3];
-    const Rigid T = rigidFromParams(T_target_reference);
-    for (int i = 0; i < 9; ++i) f.R[i] = T.R[i];
-    for (int i = 0; i < 3; ++i) f.t[i] = T.t[i];
-    {  // reproject_ = K [R|t] K^-1 (camera_reproject.hpp:250-258)
-      const double ifx = 1.0 / f.fx, ify = 1.0 / f.fy, k02 = -f.cx / f.fx, k12 = -f.cy / f.fy;
-      double U[12];
-      for (int i = 0; i < 3; ++i) {
-        U[4 * i + 0] = T.R[3 * i + 0] * ifx;
-        U[4 * i + 1] = T.R[3 * i + 1] * ify;
-        U[4 * i + 2] = T.R[3 * i + 0] * k02 + T.R[3 * i + 1] * k12 + T.R[3 * i + 2];
-        U[4 * i + 3] = T.t[i];
-      }
-      for (int j = 0; j < 4; ++j) {
-        f.M[0 + j] = f.fx * U[0 + j] + f.cx * U[8 + j];
-        f.M[4 + j] = f.fy * U[4 + j] + f.cy * U[8 + j];
-        f.M[8 + j] = U[8 + j];
-      }
-      const double K[9] = {f.fx, 0, f.cx, 0, f.fy, f.cy, 0, 0, 1};
-      const double Kinv[9] = {1 / f.fx, 0, -f.cx / f.fx, 0, 1 / f.fy, -f.cy / f.fy, 0, 0, 1};
-      double KR[9];
-      for (int i = 0; i < 3; ++i) {
-        f.Kt[i] = K[3 * i] * T.t[0] + K[3 * i + 1] * T.t[1] + K[3 * i + 2] * T.t[2];
-        for (int j = 0; j < 3; ++j) KR[3 * i + j] = K[3 * i] * T.R[j] + K[3 * i + 1] * T.R[3 + j] + K[3 * i + 2] * T.R[6 + j];
-      }
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) f.KRKi[3 * i + j] = KR[3 * i] * Kinv[j] + KR[3 * i + 1] * Kinv[3 + j] + KR[3 * i + 2] * Kinv[6 + j];
-    }
-    f.scale = (target_exposure / reference_exposure) * std::exp(target_affine[0] - reference_affine[0]);
-    f.b_r = reference_affine[1];
-    f.b_t = target_affine[1];
-    f.sigma = sigma_huber_loss;
-    f.n = n;
-    // landmark arrays: one upload, one download (the per-keyframe immature set; a device-resident set is the next step)
+    if (!out || n < 0 || (n && (!projection || !direction || !patch || !gradient))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    auto s = std::make_unique<dsopp_hip_immature_set>();
+    s->sr.init(device, stream);
+    s->n = n;
+    hipStream_t st = s->sr.stream;
     const size_t N = static_cast<size_t>(n);
-    DeviceBuffer<double> d_in, d_io;
-    DeviceBuffer<uint8_t> d_flags;
-    d_in.reserve(N * 15, 0, st);
-    d_io.reserve(N * 4, 0, st);
-    d_flags.reserve(N * 2, 0, st);
-    d_in.upload(projection, 2 * N, 0, st);
-    d_in.upload(direction, 3 * N, 2 * N, st);
-    d_in.upload(patch, 8 * N, 5 * N, st);
-    d_in.upload(gradient, 2 * N, 13 * N, st);
-    d_io.upload(idepth_min, N, 0, st);
-    d_io.upload(idepth_max, N, N, st);
-    d_io.upload(uniqueness, N, 2 * N, st);
-    d_io.upload(search_pixel_interval, N, 3 * N, st);
-    d_flags.upload(status, N, 0, st);
-    d_flags.upload(traced, N, N, st);
-    DepthLandmarks L;
-    L.projection = d_in.ptr;
-    L.direction = d_in.ptr + 2 * N;
-    L.patch = d_in.ptr + 5 * N;
-    L.gradient = d_in.ptr + 13 * N;
-    L.idepth_min = d_io.ptr;
-    L.idepth_max = d_io.ptr + N;
-    L.uniqueness = d_io.ptr + 2 * N;
-    L.search_pixel_interval = d_io.ptr + 3 * N;
-    L.status = d_flags.ptr;
-    L.traced = d_flags.ptr + N;
-    if (target_pyramid->dtype == DSOPP_HIP_F64)
-      estimateDepthsKernel<double><<<n, 64, 0, st>>>(f, L);
-    else
-      estimateDepthsKernel<float><<<n, 64, 0, st>>>(f, L);
-    HIP_CHECK(hipGetLastError());
-    d_io.download(idepth_min, N, 0, st);
-    d_io.download(idepth_max, N, N, st);
-    d_io.download(uniqueness, N, 2 * N, st);
-    d_io.download(search_pixel_interval, N, 3 * N, st);
-    d_flags.download(status, N, 0, st);
-    d_flags.download(traced, N, N, st);
-    HIP_CHECK(hipStreamSynchronize(st));
+    s->d_in.reserve(std::max<size_t>(1, N * 15), 0, st);
+    s->d_io.reserve(std::max<size_t>(1, N * 4), 0, st);
+    s->d_flags.reserve(std::max<size_t>(1, N * 2), 0, st);
+    s->d_in.upload(projection, 2 * N, 0, st);
+    s->d_in.upload(direction, 3 * N, 2 * N, st);
+    s->d_in.upload(patch, 8 * N, 5 * N, st);
+    s->d_in.upload(gradient, 2 * N, 13 * N, st);
+    // constructor defaults of ImmatureTrackingLandmark (immature_tracking_landmark.hpp:93-106)
+    std::vector<double> io(4 * N);
+    std::vector<uint8_t> fl(2 * N, 0);
+    for (size_t i = 0; i < N; ++i) {
+      io[i] = 0;
+      io[N + i] = 1. / 0.001;
+      io[2 * N + i] = io[3 * N + i] = std::numeric_limits<double>::max();
+      fl[i] = kImUninitialized;
+    }
+    s->d_io.upload(io.data(), 4 * N, 0, st);
+    s->d_flags.upload(fl.data(), 2 * N, 0, st);
+    s->sr.sync();
+    *out = s.release();
   });
 }
+
+void dsopp_hip_immature_set_destroy(dsopp_hip_immature_set *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->sr.device);
+  if (s->sr.stream) (void)hipStreamSynchronize(s->sr.stream);
+  if (s->h_stage) (void)hipHostFree(s->h_stage);
+  StreamRef sr = s->sr;
+  delete s;
+  sr.destroy();
+}
+
+int dsopp_hip_immature_set_upload_state(dsopp_hip_immature_set *s, const double *idepth_min, const double *idepth_max, const double *uniqueness,
+                                        const double *search_pixel_interval, const uint8_t *status, const uint8_t *traced) {
+  return guarded([&] {
+    if (!s) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null set");
+    s->sr.use();
+    hipStream_t st = s->sr.stream;
+    const size_t N = static_cast<size_t>(s->n);
+    if (idepth_min) s->d_io.upload(idepth_min, N, 0, st);
+    if (idepth_max) s->d_io.upload(idepth_max, N, N, st);
+    if (uniqueness) s->d_io.upload(uniqueness, N, 2 * N, st);
+    if (search_pixel_interval) s->d_io.upload(search_pixel_interval, N, 3 * N, st);
+    if (status) s->d_flags.upload(status, N, 0, st);
+    if (traced) s->d_flags.upload(traced, N, N, st);
+    s->sr.sync();
+  });
+}
+
+int dsopp_hip_immature_set_download_state(dsopp_hip_immature_set *s, double *idepth_min, double *idepth_max, double *uniqueness,
+                                          double *search_pixel_interval, uint8_t *status, uint8_t *traced) {
+  return guarded([&] {
+    if (!s) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null set");
+    s->sr.use();
+    hipStream_t st = s->sr.stream;
+    const size_t N = static_cast<size_t>(s->n);
+    if (N == 0) return;
+    // two contiguous copies into pinned staging (the state planes are adjacent on the device), then a host-side scatter:
+    // six pageable copies cost six staged transfers
+    const size_t bytes = 4 * N * sizeof(double) + 2 * N;
+    if (s->h_stage_bytes < bytes) {
+      if (s->h_stage) (void)hipHostFree(s->h_stage);
+      s->h_stage = nullptr;
+      HIP_CHECK(hipHostMalloc(&s->h_stage, bytes, hipHostMallocDefault));
+      s->h_stage_bytes = bytes;
+    }
+    double *hd = static_cast<double *>(s->h_stage);
+    uint8_t *hf = reinterpret_cast<uint8_t *>(hd + 4 * N);
+    s->d_io.download(hd, 4 * N, 0, st);
+    s->d_flags.download(hf, 2 * N, 0, st);
+    s->sr.sync();
+    if (idepth_min) std::memcpy(idepth_min, hd, N * sizeof(double));
+    if (idepth_max) std::memcpy(idepth_max, hd + N, N * sizeof(double));
+    if (uniqueness) std::memcpy(uniqueness, hd + 2 * N, N * sizeof(double));
+    if (search_pixel_interval) std::memcpy(search_pixel_interval, hd + 3 * N, N * sizeof(double));
+    if (status) std::memcpy(status, hf, N);
+    if (traced) std::memcpy(traced, hf + N, N);
+  });
+}
+
+int dsopp_hip_immature_set_estimate(dsopp_hip_immature_set *s, const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4],
+                                    const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
+                                    double target_exposure, const double target_affine[2], double sigma_huber_loss) {
+  return guarded([&] {
+    if (!s || !target_pyramid || !intrinsics || !T_target_reference || !reference_affine || !target_affine)
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (level < 0 || level >= target_pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
+    if (target_pyramid->sr.device != s->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid lives on another device");
+    if (s->n == 0) return;
+    s->sr.use();
+    hipStream_t st = s->sr.stream;
+    if (target_pyramid->sr.stream != st) HIP_CHECK(hipStreamSynchronize(target_pyramid->sr.stream));  // the pyramid build must have finished
+    const DepthFrame f = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference, reference_exposure, reference_affine, target_exposure,
+                                        target_affine, sigma_huber_loss, s->n);
+    const DepthLandmarks L = landmarkPointers(s);
+    if (target_pyramid->dtype == DSOPP_HIP_F64)
+      estimateDepthsKernel<double><<<s->n, 64, 0, st>>>(f, L);
+    else
+      estimateDepthsKernel<float><<<s->n, 64, 0, st>>>(f, L);
+    HIP_CHECK(hipGetLastError());
+  });
+}
+
+int dsopp_hip_estimate_depths(const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4], const double T_target_reference[7],
+                              double reference_exposure, const double reference_affine[2], double target_exposure, const double target_affine[2],
+                              double sigma_huber_loss, int32_t n, const double *projection, const double *direction, const double *patch,
+                              const double *gradient, double *idepth_min, double *idepth_max, double *uniqueness, double *search_pixel_interval,
+                              uint8_t *status, uint8_t *traced) {
+  if (!target_pyramid) return guarded([] { fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pyramid"); });
+  if (n && (!idepth_min || !idepth_max || !uniqueness || !search_pixel_interval || !status || !traced))
+    return guarded([] { fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null landmark array"); });
+  if (n == 0) return DSOPP_HIP_OK;
+  // one-shot form over host arrays: a temporary device-resident set
+  dsopp_hip_immature_set *s = nullptr;
+  int rc = dsopp_hip_immature_set_create(target_pyramid->sr.device, nullptr, n, projection, direction, patch, gradient, &s);
+  if (rc == DSOPP_HIP_OK) rc = dsopp_hip_immature_set_upload_state(s, idepth_min, idepth_max, uniqueness, search_pixel_interval, status, traced);
+  if (rc == DSOPP_HIP_OK)
+    rc = dsopp_hip_immature_set_estimate(s, target_pyramid, level, intrinsics, T_target_reference, reference_exposure, reference_affine, target_exposure,
+                                         target_affine, sigma_huber_loss);
+  if (rc == DSOPP_HIP_OK) rc = dsopp_hip_immature_set_download_state(s, idepth_min, idepth_max, uniqueness, search_pixel_interval, status, traced);
+  dsopp_hip_immature_set_destroy(s);
+  return rc;
+}
+
+}  // extern "C"

@@ -23,6 +23,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <limits>
+#include <functional>
 
 #include "../../include/dsopp_hip.h"
 
@@ -110,6 +112,61 @@ struct TrustRegionOptions {
 };
 
 /** mirror of EigenPhotometricBundleAdjustment<SE3, PinholeCamera, 8, PixelMap, true, true, true, 1> backed by HIP kernels */
+/** track::landmarks::ImmatureTrackingLandmark as the depth estimator reads and writes it
+ *  (src/track/landmarks/include/track/landmarks/immature_tracking_landmark.hpp:26-106) */
+struct ImmatureLandmarkView {
+  Vector2 projection{};
+  std::array<double, 3> direction{};
+  std::array<double, 8> patch{};
+  Vector2 gradient{};
+  double idepth_min = 0, idepth_max = 1. / 0.001;
+  double uniqueness = std::numeric_limits<double>::max(), search_pixel_interval = std::numeric_limits<double>::max();
+  uint8_t status = 5;  // ImmatureStatus::kUninitialized
+  bool traced = false;
+};
+
+/** tracker::DepthEstimation (src/tracker/depth_estimators/include/tracker/depth_estimators/depth_estimation.hpp:24-58): same
+ *  static entry point, the target frame given as its device pyramid (level 0 is used, as monocular_tracker.cpp:98-100 does) */
+struct HipDepthEstimation {
+  static void estimate(const DevicePyramid &target_frame, std::vector<std::reference_wrapper<ImmatureLandmarkView>> &reference_landmarks,
+                       const Motion &t_t_r, double reference_exposure_time, const Vector2 &reference_affine_brightness,
+                       double target_exposure_time, const Vector2 &target_affine_brightness, const PinholeModel &model,
+                       double sigma_huber_loss) {
+    const size_t n = reference_landmarks.size();
+    std::vector<double> proj(2 * n), dir(3 * n), patch(8 * n), grad(2 * n), imin(n), imax(n), uniq(n), spi(n);
+    std::vector<uint8_t> status(n), traced(n);
+    for (size_t i = 0; i < n; ++i) {
+      const ImmatureLandmarkView &l = reference_landmarks[i];
+      for (int k = 0; k < 2; ++k) {
+        proj[2 * i + k] = l.projection[static_cast<size_t>(k)];
+        grad[2 * i + k] = l.gradient[static_cast<size_t>(k)];
+      }
+      for (int k = 0; k < 3; ++k) dir[3 * i + k] = l.direction[static_cast<size_t>(k)];
+      for (int k = 0; k < 8; ++k) patch[8 * i + k] = l.patch[static_cast<size_t>(k)];
+      imin[i] = l.idepth_min;
+      imax[i] = l.idepth_max;
+      uniq[i] = l.uniqueness;
+      spi[i] = l.search_pixel_interval;
+      status[i] = l.status;
+      traced[i] = l.traced ? 1 : 0;
+    }
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_estimate_depths(target_frame.handle(), 0, intr, t_t_r.data(), reference_exposure_time, reference_affine_brightness.data(),
+                                    target_exposure_time, target_affine_brightness.data(), sigma_huber_loss, static_cast<int32_t>(n), proj.data(),
+                                    dir.data(), patch.data(), grad.data(), imin.data(), imax.data(), uniq.data(), spi.data(), status.data(),
+                                    traced.data()));
+    for (size_t i = 0; i < n; ++i) {
+      ImmatureLandmarkView &l = reference_landmarks[i];
+      l.idepth_min = imin[i];
+      l.idepth_max = imax[i];
+      l.uniqueness = uniq[i];
+      l.search_pixel_interval = spi[i];
+      l.status = status[i];
+      l.traced = traced[i] != 0;
+    }
+  }
+};
+
 /** Reference depth maps of the newest keyframe, resident on the device: what tracker::createReferenceDepthMaps
  *  (src/tracker/tracker/src/create_depth_maps.cpp:124-147) returns as std::vector<energy::problem::DepthMap>. */
 class DeviceDepthMaps {

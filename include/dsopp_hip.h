@@ -247,6 +247,21 @@ int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level,
  * struct-of-arrays view of track::landmarks::ImmatureTrackingLandmark and are updated in place:
  * status: 0 good, 1 out of boundary, 2 outlier, 3 skipped, 4 ill conditioned, 5 uninitialized, 6 delete
  * (immature_tracking_landmark.hpp:14-22).  One wavefront per landmark. */
+/* the same on a device-resident landmark set (the immature landmarks of a keyframe persist over many frames: only their
+ * estimator state changes).  create() initialises the state to the ImmatureTrackingLandmark constructor defaults;
+ * estimate() is asynchronous on the set's stream; upload / download move the state (any pointer may be NULL). */
+typedef struct dsopp_hip_immature_set dsopp_hip_immature_set;
+int dsopp_hip_immature_set_create(int device, void *stream, int32_t n, const double *projection, const double *direction, const double *patch,
+                                  const double *gradient, dsopp_hip_immature_set **out);
+void dsopp_hip_immature_set_destroy(dsopp_hip_immature_set *s);
+int dsopp_hip_immature_set_upload_state(dsopp_hip_immature_set *s, const double *idepth_min, const double *idepth_max, const double *uniqueness,
+                                        const double *search_pixel_interval, const uint8_t *status, const uint8_t *traced);
+int dsopp_hip_immature_set_download_state(dsopp_hip_immature_set *s, double *idepth_min, double *idepth_max, double *uniqueness,
+                                          double *search_pixel_interval, uint8_t *status, uint8_t *traced);
+int dsopp_hip_immature_set_estimate(dsopp_hip_immature_set *s, const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4],
+                                    const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
+                                    double target_exposure, const double target_affine[2], double sigma_huber_loss);
+/* one-shot form over host arrays (temporary set: upload, estimate, download) */
 int dsopp_hip_estimate_depths(const dsopp_hip_pyramid *target_pyramid, int level, const double intrinsics[4],
                               const double T_target_reference[7], double reference_exposure, const double reference_affine[2],
                               double target_exposure, const double target_affine[2], double sigma_huber_loss, int32_t n,

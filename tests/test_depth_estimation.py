@@ -119,3 +119,15 @@ def test_gpu_depth_estimation_matches_oracle(scene):
         assert np.abs(lo["uniqueness"][fin] - lg["uniqueness"][fin]).max() <= 1e-7 * np.abs(lo["uniqueness"][fin]).max(), step
     # every status class that matters was seen along the way
     assert len(set(lo["status"].tolist())) >= 3
+    # the device-resident set driven over the same three frames ends in the same state as the one-shot calls
+    dset = capi.ImmatureSet(po.new_immature_landmarks(uv, direction, fr.patch, grad))
+    for step, ft in enumerate((win.frames[1], win.frames[3], win.frames[2])):
+        T = _mat_to_params(_rel(ft.T_w_c_gt, fr.T_w_c_gt))
+        pyr = capi.Pyramid(320, 240, 1)
+        pyr.set_level(0, ft.pixelinfo)
+        dset.estimate(pyr, 0, intr, T, 1.0, (0.01 * step, 0.5 * step), 1.0 + 0.1 * step, (-0.02 * step, 0.3 * step))
+        st = dset.download()   # (also orders the kernel before the pyramid goes away)
+        pyr.close()
+    for k in ("idepth_min", "idepth_max", "uniqueness", "search_pixel_interval", "status", "traced"):
+        assert np.array_equal(st[k], lg[k]), k
+    dset.close()
