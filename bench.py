@@ -307,6 +307,7 @@ def run_tracker_timing(capi, syn, torch, frames=20):
     T_ref, ab_ref = g.get_pose(kf.frame_id)
     T_init = syn.mat_to_params(new_frame.T_w_c_init)
     a = capi.HipAligner(capi.default_align_options())
+    a.set_lm_path(int(os.environ.get("DSOPP_ALIGN_LM_PATH", "0")))
     rmse_last = np.full(L, 1e10)
 
     rl_final = rmse_last.copy()

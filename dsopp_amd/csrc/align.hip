@@ -86,14 +86,19 @@ __device__ inline double rsqrtNewton(double x) {
 }
 
 /** 8x8 NormalLinearSystem::solve (Jacobi preconditioner + Cholesky with zero-pivot guard), single thread */
-__device__ inline void solve8(const double *Hin, const double *bin, double *x) {
-  double p[8], A[36], y[8], linv[8];
+__device__ inline void solve8(const double *Hin, double lambda, const double *bin, double *x) {
+  // the system is H + lambda * diag(H) (calculateStep, eigen_pose_alignment.cpp:194-198), formed on the fly
+  double p[8], A[36], y[8], linv[8], dg[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p[i] = rsqrtNewton(Hin[8 * i + i] + 10.0);
+  for (int i = 0; i < 8; ++i) {
+    const double hii = Hin[8 * i + i];
+    dg[i] = hii + hii * lambda;
+    p[i] = rsqrtNewton(dg[i] + 10.0);
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) A[i * (i + 1) / 2 + j] = p[i] * Hin[8 * i + j] * p[j];
+    for (int j = 0; j <= i; ++j) A[i * (i + 1) / 2 + j] = p[i] * (i == j ? dg[i] : Hin[8 * i + j]) * p[j];
     y[i] = p[i] * bin[i];
   }
 #pragma unroll
@@ -139,6 +144,213 @@ __global__ void sampleReferenceKernel(const Texel<S> *__restrict__ img, int W, c
   const S dx = x - static_cast<S>(ix), dy = y - static_cast<S>(iy), dxdy = dx * dy;
   const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
   intensity[i] = static_cast<double>(dxdy * p[W + 1].I + (dy - dxdy) * p[W].I + (dx - dxdy) * p[1].I + (S(1) - dx - dy + dxdy) * p[0].I);
+}
+
+/** The LM control step of one iteration (levenberg_marquardt_algorithm.hpp:77-128 unrolled over launches): `red` holds the
+ *  sums of the pass that evaluated the candidate in `c` (H upper 36 | b 8 | energy | n_valid); decides accept / reject,
+ *  keeps or replaces the linear system, solves for the next step and stores the next candidate.  Single thread. */
+__device__ inline void alignDecide(AlignControl &c, const double *red, const AlignFrameDev &tgt, const AlignParams &prm) {
+    // evaluated state = candidate (or the initial state): energy with the affine prior (eigen_pose_alignment.cpp:101-104)
+    const double tab0 = tgt.ab0[0] + c.cand_ab[0], tab1 = tgt.ab0[1] + c.cand_ab[1];
+    const double e_eval = red[44] + 0.5 * (tab0 * prm.affine_reg[0] * tab0 + tab1 * prm.affine_reg[1] * tab1);
+    const int n_eval = static_cast<int>(red[45] + 0.5);
+    bool take_system = false;
+    if (!c.have_candidate) {
+      // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
+      c.energy = e_eval;
+      c.n_valid = n_eval;
+      c.active = (prm.max_iterations > 0 && n_eval > 0) ? 1 : 0;
+      take_system = true;
+    } else {
+      c.iteration += 1;
+      if (n_eval == 0) {
+        c.active = 0;  // rejectStep(); break;
+      } else {
+        if (fabs(c.energy - e_eval) / c.energy < prm.function_tolerance) c.converged = 1;
+        if (e_eval < c.energy) {
+          // acceptStep (eigen_pose_alignment.cpp:208-212)
+          const double a0 = tgt.ab0[0] + c.ab_eps[0], a1 = tgt.ab0[1] + c.ab_eps[1];
+          double step_sq = 0;
+          for (int a = 0; a < 8; ++a) step_sq += c.step[a] * c.step[a];
+          if (step_sq < prm.parameter_tolerance * ((a0 * a0 + a1 * a1) + prm.parameter_tolerance)) c.converged = 1;
+          for (int a = 0; a < 12; ++a) c.T_tr[a] = c.cand_T[a];
+          c.ab_eps[0] = c.cand_ab[0];
+          c.ab_eps[1] = c.cand_ab[1];
+          c.energy = e_eval;
+          c.n_valid = n_eval;
+          c.lambda /= prm.decrease_on_accept;
+          take_system = true;
+        } else {
+          c.lambda *= prm.increase_on_reject;  // rejectStep: the accepted state and its system stay
+        }
+        if (c.converged || c.iteration >= prm.max_iterations) c.active = 0;
+      }
+    }
+    if (take_system) {
+      // system of the evaluated state: symmetric expansion of the 36 sums + affine prior block (eigen_pose_alignment.cpp:183-187)
+      int e = 0;
+      for (int a = 0; a < 8; ++a)
+        for (int b2 = a; b2 < 8; ++b2) {
+          c.H[8 * a + b2] = c.H[8 * b2 + a] = red[e];
+          ++e;
+        }
+      for (int a = 0; a < 8; ++a) c.b[a] = red[36 + a];
+      c.H[8 * 6 + 6] += prm.affine_reg[0];
+      c.H[8 * 7 + 7] += prm.affine_reg[1];
+      c.b[6] += prm.affine_reg[0] * tab0;
+      c.b[7] += prm.affine_reg[1] * tab1;
+    }
+    if (c.active) {
+      // calculateStep (eigen_pose_alignment.cpp:194-206): H + lambda * diag(H), leftIncrement, ab_eps -= step[6:8]
+      for (int a = 0; a < 64; ++a) c.H_used[a] = c.H[a];
+      double step[8];
+      solve8(c.H, c.lambda, c.b, step);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) c.step[a] = step[a];
+      const Rigid E = rigidExp(step);
+      double Em[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Em[4 * i + j] = E.R[3 * i + j];
+        Em[4 * i + 3] = E.t[i];
+      }
+      mat34Compose(Em, c.T_tr, c.cand_T);
+      c.cand_ab[0] = c.ab_eps[0] - step[6];
+      c.cand_ab[1] = c.ab_eps[1] - step[7];
+      c.have_candidate = 1;
+    }
+}
+
+/** PoseAlignerProblem::calculateEnergy + linearize (eigen_pose_alignment.cpp:55-192) at the candidate state of `sc` for the
+ *  points first, first + stride, ...: fills acc with this thread's share of H (36 upper) | b (8) | energy | n_valid */
+template <typename S>
+__device__ __forceinline__ void alignSweep(const AlignFrameDev &ref, const AlignFrameDev &tgt, const double *__restrict__ pu, const double *__restrict__ pv,
+                                           const double *__restrict__ pid, const double *__restrict__ pint, const AlignControl &sc,
+                                           const AlignParams &prm, int first, int stride, double (&acc)[kAlignPartial]) {
+  // ---------------- sweep at the candidate state ----------------
+#pragma unroll
+  for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
+  const double *T = sc.cand_T;
+  // ArrayReprojector ctor — camera_reproject.hpp:235-260
+  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
+  S U[12], M[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double u0 = T[4 * i] * ifx, u1 = T[4 * i + 1] * ify, u2 = T[4 * i] * k02 + T[4 * i + 1] * k12 + T[4 * i + 2], u3 = T[4 * i + 3];
+    U[4 * i] = S(u0);
+    U[4 * i + 1] = S(u1);
+    U[4 * i + 2] = S(u2);
+    U[4 * i + 3] = S(u3);
+  }
+  {
+    const double *Tt = T;
+    double Ud[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Ud[4 * i] = Tt[4 * i] * ifx;
+      Ud[4 * i + 1] = Tt[4 * i + 1] * ify;
+      Ud[4 * i + 2] = Tt[4 * i] * k02 + Tt[4 * i + 1] * k12 + Tt[4 * i + 2];
+      Ud[4 * i + 3] = Tt[4 * i + 3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      M[j] = S(tgt.fx * Ud[j] + tgt.cx * Ud[8 + j]);
+      M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
+      M[8 + j] = S(Ud[8 + j]);
+    }
+  }
+  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
+  const S s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
+  const S b_t = S(tab1), b_r = S(ref.ab0[1]);
+  const S Wr = S(ref.width), Hr_ = S(ref.height), Wt = S(tgt.width), Ht = S(tgt.height);
+  const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(tgt.texels);
+  const int W = tgt.width;
+  // kBatch points of this thread are in flight together: all point words first, then all texel footprints, then the
+  // arithmetic.  Everything is predicated instead of branching (an early `continue` would serialise the memory round trips
+  // of consecutive points): an invalid point reads a safe texel and contributes with weight zero.
+  constexpr int kBatch = 1;  // (4 in flight was tried: the 48 f64 accumulators + 16 texels per lane spill)
+  for (int i0 = first; i0 < prm.n_points; i0 += kBatch * stride) {
+    S u[kBatch], v[kBatch], idepth[kBatch], iref[kBatch];
+    bool ok[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int i = i0 + k * stride;
+      ok[k] = i < prm.n_points;
+      const int ii = ok[k] ? i : prm.n_points - 1;  // (in bounds: the loop runs only when n_points > first >= 0)
+      u[k] = static_cast<S>(pu[ii]);
+      v[k] = static_cast<S>(pv[ii]);
+      idepth[k] = static_cast<S>(pid[ii]);
+      iref[k] = static_cast<S>(pint[ii]);
+    }
+    S tu[kBatch], tv[kBatch];
+    const Texel<S> *p[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      // reproject (checked) — camera_reproject.hpp:270-293
+      bool good = ok[k] && validIdepth(idepth[k]) && insideROI(u[k], v[k], Wr, Hr_);
+      const S x = M[0] * u[k] + M[1] * v[k] + (M[2] + M[3] * idepth[k]);
+      const S y = M[4] * u[k] + M[5] * v[k] + (M[6] + M[7] * idepth[k]);
+      const S z = M[8] * u[k] + M[9] * v[k] + (M[10] + M[11] * idepth[k]);
+      S a = x / z, b = y / z;
+      good = good && (z > S(0)) && insideROI(a, b, Wt, Ht);
+      ok[k] = good;
+      tu[k] = good ? a : S(4);
+      tv[k] = good ? b : S(4);
+      p[k] = img + static_cast<size_t>(static_cast<int>(tv[k])) * W + static_cast<int>(tu[k]);
+    }
+    Texel<S> t00[kBatch], t10[kBatch], t01[kBatch], t11[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      t00[k] = p[k][0];
+      t10[k] = p[k][1];
+      t01[k] = p[k][W];
+      t11[k] = p[k][W + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int ix = static_cast<int>(tu[k]), iy = static_cast<int>(tv[k]);
+      const S dx = tu[k] - static_cast<S>(ix), dy = tv[k] - static_cast<S>(iy), dxdy = dx * dy;
+      const int rx = static_cast<int>(floor(tu[k] + S(0.5))) - ix, ry = static_cast<int>(floor(tv[k] + S(0.5))) - iy;
+      const S m = ry ? (rx ? t11[k].mask : t01[k].mask) : (rx ? t10[k].mask : t00[k].mask);
+      const bool valid = ok[k] && (m != S(0));  // mask_.valid(target_pattern) — eigen_pose_alignment.cpp:78
+      const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+      const S sI = w11 * t11[k].I + w01 * t01[k].I + w10 * t10[k].I + w00 * t00[k].I;
+      const S sIx = w11 * t11[k].Ix + w01 * t01[k].Ix + w10 * t10[k].Ix + w00 * t00[k].Ix;
+      const S sIy = w11 * t11[k].Iy + w01 * t01[k].Iy + w10 * t10[k].Iy + w00 * t00[k].Iy;
+      const S right = s_scale * (iref[k] - b_r);
+      const double r = static_cast<double>((sI - b_t) - right);
+      const double r2 = r * r, sig = prm.sigma_huber;
+      const bool lin = r2 > sig * sig;
+      const double nrm = fabs(r);
+      const double wgt = valid ? (lin ? sig / nrm : 1.0) : 0.0;
+      acc[44] += valid ? (lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2) : 0.0;
+      acc[45] += valid ? 1.0 : 0.0;
+      // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
+      const S X = U[0] * u[k] + U[1] * v[k] + (U[2] + U[3] * idepth[k]);
+      const S Y = U[4] * u[k] + U[5] * v[k] + (U[6] + U[7] * idepth[k]);
+      const S Z = U[8] * u[k] + U[9] * v[k] + (U[10] + U[11] * idepth[k]);
+      const S rho = valid ? S(1) / Z : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth[k] * rho;
+      const S fxt = S(tgt.fx), fyt = S(tgt.fy), b0b1 = b0 * b1;
+      double d[8];
+      d[0] = -static_cast<double>(sIx * (fxt * nid));
+      d[1] = -static_cast<double>(sIy * (fyt * nid));
+      d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
+      d[3] = -static_cast<double>(sIx * (fxt * (-b0b1)) + sIy * (fyt * (-(b1 * b1 + S(1)))));
+      d[4] = -static_cast<double>(sIx * (fxt * (b0 * b0 + S(1))) + sIy * (fyt * b0b1));
+      d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
+      d[6] = -static_cast<double>(right);
+      d[7] = -1.0;
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const double wa = wgt * d[a];
+#pragma unroll
+        for (int b2 = a; b2 < 8; ++b2) acc[e++] += wa * d[b2];
+        acc[36 + a] += wa * r;
+      }
+    }
+  }
 }
 
 /**
@@ -201,85 +413,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
       if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = ctrl_word;
       return;
     }
-    if (tid == 0) {
-      AlignControl c = sc;
-      // evaluated state = candidate (or the initial state): energy with the affine prior (eigen_pose_alignment.cpp:101-104)
-      const double tab0 = tgt.ab0[0] + c.cand_ab[0], tab1 = tgt.ab0[1] + c.cand_ab[1];
-      const double e_eval = red[44] + 0.5 * (tab0 * prm.affine_reg[0] * tab0 + tab1 * prm.affine_reg[1] * tab1);
-      const int n_eval = static_cast<int>(red[45] + 0.5);
-      double Hn[64], bn[8];
-      {
-        int e = 0;
-        for (int a = 0; a < 8; ++a)
-          for (int b2 = a; b2 < 8; ++b2) {
-            Hn[8 * a + b2] = Hn[8 * b2 + a] = red[e];
-            ++e;
-          }
-        for (int a = 0; a < 8; ++a) bn[a] = red[36 + a];
-        // affine prior block (eigen_pose_alignment.cpp:183-187)
-        Hn[8 * 6 + 6] += prm.affine_reg[0];
-        Hn[8 * 7 + 7] += prm.affine_reg[1];
-        bn[6] += prm.affine_reg[0] * tab0;
-        bn[7] += prm.affine_reg[1] * tab1;
-      }
-      bool take_system = false;
-      if (!c.have_candidate) {
-        // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
-        c.energy = e_eval;
-        c.n_valid = n_eval;
-        c.active = (prm.max_iterations > 0 && n_eval > 0) ? 1 : 0;
-        take_system = true;
-      } else {
-        c.iteration += 1;
-        if (n_eval == 0) {
-          c.active = 0;  // rejectStep(); break;
-        } else {
-          if (fabs(c.energy - e_eval) / c.energy < prm.function_tolerance) c.converged = 1;
-          if (e_eval < c.energy) {
-            // acceptStep (eigen_pose_alignment.cpp:208-212)
-            const double a0 = tgt.ab0[0] + c.ab_eps[0], a1 = tgt.ab0[1] + c.ab_eps[1];
-            double step_sq = 0;
-            for (int a = 0; a < 8; ++a) step_sq += c.step[a] * c.step[a];
-            if (step_sq < prm.parameter_tolerance * ((a0 * a0 + a1 * a1) + prm.parameter_tolerance)) c.converged = 1;
-            for (int a = 0; a < 12; ++a) c.T_tr[a] = c.cand_T[a];
-            c.ab_eps[0] = c.cand_ab[0];
-            c.ab_eps[1] = c.cand_ab[1];
-            c.energy = e_eval;
-            c.n_valid = n_eval;
-            c.lambda /= prm.decrease_on_accept;
-            take_system = true;
-          } else {
-            c.lambda *= prm.increase_on_reject;  // rejectStep: the accepted state and its system stay
-          }
-          if (c.converged || c.iteration >= prm.max_iterations) c.active = 0;
-        }
-      }
-      if (take_system) {
-        for (int a = 0; a < 64; ++a) c.H[a] = Hn[a];
-        for (int a = 0; a < 8; ++a) c.b[a] = bn[a];
-      }
-      if (c.active) {
-        // calculateStep (eigen_pose_alignment.cpp:194-206): H + lambda * diag(H), leftIncrement, ab_eps -= step[6:8]
-        double Hr[64];
-        for (int a = 0; a < 64; ++a) Hr[a] = c.H[a];
-        for (int a = 0; a < 8; ++a) Hr[8 * a + a] += c.H[8 * a + a] * c.lambda;
-        for (int a = 0; a < 64; ++a) c.H_used[a] = c.H[a];
-        solve8(Hr, c.b, c.step);
-        const Rigid E = rigidExp(c.step);
-        double Em[12];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int j = 0; j < 3; ++j) Em[4 * i + j] = E.R[3 * i + j];
-          Em[4 * i + 3] = E.t[i];
-        }
-        mat34Compose(Em, c.T_tr, c.cand_T);
-        c.cand_ab[0] = c.ab_eps[0] - c.step[6];
-        c.cand_ab[1] = c.ab_eps[1] - c.step[7];
-        c.have_candidate = 1;
-      }
-      sc = c;
-    }
+    if (tid == 0) alignDecide(sc, red, tgt, prm);  // in place on the LDS copy: no private 1.4 KB struct (= scratch memory)
     __syncthreads();
     if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = reinterpret_cast<const double *>(&sc)[tid];
     if (!sc.active) return;
@@ -289,97 +423,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
 
   // ---------------- sweep at the candidate state ----------------
   double acc[kAlignPartial];
-#pragma unroll
-  for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
-  const double *T = sc.cand_T;
-  // ArrayReprojector ctor — camera_reproject.hpp:235-260
-  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
-  S U[12], M[12];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double u0 = T[4 * i] * ifx, u1 = T[4 * i + 1] * ify, u2 = T[4 * i] * k02 + T[4 * i + 1] * k12 + T[4 * i + 2], u3 = T[4 * i + 3];
-    U[4 * i] = S(u0);
-    U[4 * i + 1] = S(u1);
-    U[4 * i + 2] = S(u2);
-    U[4 * i + 3] = S(u3);
-  }
-  {
-    const double *Tt = T;
-    double Ud[12];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      Ud[4 * i] = Tt[4 * i] * ifx;
-      Ud[4 * i + 1] = Tt[4 * i + 1] * ify;
-      Ud[4 * i + 2] = Tt[4 * i] * k02 + Tt[4 * i + 1] * k12 + Tt[4 * i + 2];
-      Ud[4 * i + 3] = Tt[4 * i + 3];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      M[j] = S(tgt.fx * Ud[j] + tgt.cx * Ud[8 + j]);
-      M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
-      M[8 + j] = S(Ud[8 + j]);
-    }
-  }
-  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
-  const S s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
-  const S b_t = S(tab1), b_r = S(ref.ab0[1]);
-  const S Wr = S(ref.width), Hr_ = S(ref.height), Wt = S(tgt.width), Ht = S(tgt.height);
-  const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(tgt.texels);
-  const int W = tgt.width;
-  for (int i = blockIdx.x * kAlignThreads + tid; i < prm.n_points; i += gridDim.x * kAlignThreads) {
-    const S u = static_cast<S>(pu[i]), v = static_cast<S>(pv[i]), idepth = static_cast<S>(pid[i]);
-    const S iref = static_cast<S>(pint[i]);
-    // reproject (checked) — camera_reproject.hpp:270-293
-    bool ok = validIdepth(idepth) && insideROI(u, v, Wr, Hr_);
-    const S x = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
-    const S y = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
-    const S z = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
-    const S tu = x / z, tv = y / z;
-    ok = ok && (z > S(0)) && insideROI(tu, tv, Wt, Ht);
-    if (!ok) continue;
-    const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
-    const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy), dxdy = dx * dy;
-    const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
-    const Texel<S> t00 = p[0], t10 = p[1], t01 = p[W], t11 = p[W + 1];
-    const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
-    const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
-    if (m == S(0)) continue;  // mask_.valid(target_pattern) — eigen_pose_alignment.cpp:78
-    const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
-    const S sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
-    const S sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
-    const S sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
-    const S right = s_scale * (iref - b_r);
-    const double r = static_cast<double>((sI - b_t) - right);
-    const double r2 = r * r, sig = prm.sigma_huber;
-    const bool lin = r2 > sig * sig;
-    const double nrm = fabs(r);
-    const double wgt = lin ? sig / nrm : 1.0;
-    acc[44] += lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2;
-    acc[45] += 1.0;
-    // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
-    const S X = U[0] * u + U[1] * v + (U[2] + U[3] * idepth);
-    const S Y = U[4] * u + U[5] * v + (U[6] + U[7] * idepth);
-    const S Z = U[8] * u + U[9] * v + (U[10] + U[11] * idepth);
-    const S rho = S(1) / Z, b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
-    const S fxt = S(tgt.fx), fyt = S(tgt.fy), b0b1 = b0 * b1;
-    double d[8];
-    d[0] = -static_cast<double>(sIx * (fxt * nid));
-    d[1] = -static_cast<double>(sIy * (fyt * nid));
-    d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
-    d[3] = -static_cast<double>(sIx * (fxt * (-b0b1)) + sIy * (fyt * (-(b1 * b1 + S(1)))));
-    d[4] = -static_cast<double>(sIx * (fxt * (b0 * b0 + S(1))) + sIy * (fyt * b0b1));
-    d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
-    d[6] = -static_cast<double>(right);
-    d[7] = -1.0;
-    int e = 0;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      const double wa = wgt * d[a];
-#pragma unroll
-      for (int b2 = a; b2 < 8; ++b2) acc[e++] += wa * d[b2];
-      acc[36 + a] += wa * r;
-    }
-  }
+  alignSweep<S>(ref, tgt, pu, pv, pid, pint, sc, prm, blockIdx.x * kAlignThreads + tid, gridDim.x * kAlignThreads, acc);
   // workgroup reduction through an LDS transpose (see blockReduceStore in pba_kernels.hpp)
   {
     constexpr int RS = kAlignThreads + 2;
@@ -400,6 +444,81 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
   }
 }
 
+/**
+ * The whole LM loop of one alignment in ONE launch of ONE workgroup (1024 threads): up to a few thousand reference points
+ * are a latency problem, not a throughput one — a launch per iteration costs more than the iteration.  Per iteration:
+ * control step (thread 0, alignDecide) -> sweep (<= a dozen points per thread) -> deterministic reduction: two DPP steps
+ * fold 4 lanes, an LDS transpose of the 256 remaining columns, 16 lanes per row.  Same state machine and arithmetic as
+ * alignIterationKernel (the multi-workgroup path stays for large point sets).
+ */
+constexpr int kLoopThreads = 512;   // 2 waves per SIMD: the sweep's 48 accumulators + temporaries fit in registers
+constexpr int kAlignLoopMaxPoints = 1024;  // <= 2 points per lane: beyond that one launch per iteration on many workgroups is faster (measured)
+constexpr int kLoopCols = kLoopThreads / 2;  // columns left after the DPP fold of lane pairs
+
+template <int CTRL>
+__device__ __forceinline__ double alignDpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <typename S>
+__global__ void __launch_bounds__(kLoopThreads) alignLoopKernel(AlignFrameDev ref, AlignFrameDev tgt, const double *__restrict__ pu,
+                                                                const double *__restrict__ pv, const double *__restrict__ pid,
+                                                                const double *__restrict__ pint, AlignControl *ctrl_io, AlignParams prm) {
+  extern __shared__ __attribute__((aligned(16))) char loop_smem[];
+  double *red = reinterpret_cast<double *>(loop_smem);  // [kAlignPartial][kLoopCols + 2]
+  double *tot = red + kAlignPartial * (kLoopCols + 2);  // [kAlignPartial]
+  __shared__ AlignControl sc;
+  const int tid = threadIdx.x;
+  constexpr int kCtrlWords = static_cast<int>(sizeof(AlignControl) / 8);
+  if (tid < kCtrlWords) reinterpret_cast<double *>(&sc)[tid] = reinterpret_cast<const double *>(ctrl_io)[tid];
+  __syncthreads();
+  const int total_passes = prm.max_iterations + 2;  // initial evaluation + one per iteration + the closing control step
+  for (int pass = 0; pass < total_passes; ++pass) {
+    if (pass > 0) {
+      if (tid == 0) alignDecide(sc, tot, tgt, prm);
+      __syncthreads();
+      if (!sc.active) break;
+    }
+    double acc[kAlignPartial];
+    alignSweep<S>(ref, tgt, pu, pv, pid, pint, sc, prm, tid, kLoopThreads, acc);
+    // fold lane pairs (quad_perm swap), the sum stays in the even lane: fixed order => deterministic
+#pragma unroll
+    for (int e = 0; e < kAlignPartial; ++e) acc[e] += alignDpp<0xB1>(acc[e]);
+    constexpr int RS = kLoopCols + 2;
+    if ((tid & 1) == 0) {
+#pragma unroll
+      for (int e = 0; e < kAlignPartial; ++e) red[e * RS + (tid >> 1)] = acc[e];
+    }
+    __syncthreads();
+    {
+      // row e: 8 lanes, each sums 32 columns (16 x double2), then the 8-lane DPP tree
+      const int row = tid >> 3, part = tid & 7;
+      double sacc = 0;
+      if (row < kAlignPartial) {
+        const double2 *src = reinterpret_cast<const double2 *>(red + row * RS) + part * (kLoopCols / 16);
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int j = 0; j < kLoopCols / 16; ++j) {
+          const double2 q = src[j];
+          s0 += q.x;
+          s1 += q.y;
+        }
+        sacc = s0 + s1;
+      }
+      sacc += alignDpp<0xB1>(sacc);
+      sacc += alignDpp<0x4E>(sacc);
+      sacc += alignDpp<0x141>(sacc);
+      if (row < kAlignPartial && part == 0) tot[row] = sacc;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < kCtrlWords) reinterpret_cast<double *>(ctrl_io + 1)[tid] = reinterpret_cast<const double *>(&sc)[tid];
+}
+
 }  // namespace
 }  // namespace dsopp_hip
 
@@ -418,6 +537,7 @@ struct dsopp_hip_aligner {
   // the reference points the solve reads: the aligner's own buffers above or the per-level cache of a dsopp_hip_depth_maps
   const double *p_u = nullptr, *p_v = nullptr, *p_id = nullptr, *p_int = nullptr;
   AlignControl *h_ctrl = nullptr;  // pinned staging of the control block (upload + read-back)
+  int lm_path = 0;                 // 0: automatic (single-workgroup loop for small point sets), 1: always one launch per iteration
   bool skip_covariance = false;    // estimate_pose: the per-level covariance is not read by the tracker loop
   DeviceBuffer<int> d_rows;  // row counts / offsets of the device-side depth-map scan
   DeviceBuffer<AlignControl> d_ctrl;
@@ -707,6 +827,13 @@ int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, c
   });
 }
 
+int dsopp_hip_aligner_set_lm_path(dsopp_hip_aligner *a, int path) {
+  return guarded([&] {
+    if (!a || path < 0 || path > 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+    a->lm_path = path;
+  });
+}
+
 int dsopp_hip_aligner_num_points(dsopp_hip_aligner *a, int32_t *n) {
   return guarded([&] {
     if (!a || !n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
@@ -762,9 +889,27 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     const int total_launches = a->opt.max_iterations + 2;  // initial evaluation + one per iteration + final control pass
     int launch = 0;
     AlignControl &h = a->h_ctrl[1];
+    const bool single_workgroup = n <= kAlignLoopMaxPoints && a->lm_path != 1;
+    if (single_workgroup) {
+      // the whole LM loop in one launch of one workgroup (alignLoopKernel): one enqueue, one read-back, one synchronisation
+      static bool attr_set = false;
+      const size_t smem = (static_cast<size_t>(kAlignPartial) * (kLoopCols + 2) + kAlignPartial) * sizeof(double);
+      if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(alignLoopKernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(alignLoopKernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+      }
+      if (a->opt.dtype == DSOPP_HIP_F64)
+        alignLoopKernel<double><<<1, kLoopThreads, smem, st>>>(a->ref, a->tgt, a->p_u, a->p_v, a->p_id, a->p_int, a->d_ctrl.ptr, prm);
+      else
+        alignLoopKernel<float><<<1, kLoopThreads, smem, st>>>(a->ref, a->tgt, a->p_u, a->p_v, a->p_id, a->p_int, a->d_ctrl.ptr, prm);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(&h, a->d_ctrl.ptr + 1, sizeof(AlignControl), hipMemcpyDeviceToHost, st));
+      a->sr.sync();
+    }
     // launches after the loop has ended are no-ops of ~2 us; a batch covers the typical solve (10-20 iterations) in one sync
     const int kBatch = 20;
-    while (true) {
+    while (!single_workgroup) {
       const int end = std::min(total_launches, launch + kBatch);
       for (; launch < end; ++launch) {
         const AlignControl *cin = a->d_ctrl.ptr + ((launch + 1) & 1);

@@ -329,6 +329,10 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
                                     int32_t n_initializations, const double *T_world_target_init, const double affine_init[2],
                                     double *rmse_last_pose_estimation, double T_world_target[7], double affine_brightness[2],
                                     int32_t *success, int32_t *tries, int32_t *lm_iterations);
+/* 0 (default): the whole LM loop of a solve runs in ONE launch of one workgroup when the reference has at most 16384 points
+ * (a launch per iteration costs more than the iteration at that size); 1: always one launch per LM iteration (multi-workgroup).
+ * Same state machine and arithmetic on both paths (parity cross-check in tests/test_gpu_tracker.py). */
+int dsopp_hip_aligner_set_lm_path(dsopp_hip_aligner *a, int path);
 int dsopp_hip_aligner_num_points(dsopp_hip_aligner *a, int32_t *n);
 
 #ifdef __cplusplus

@@ -52,8 +52,9 @@ def _depth_map(frame, level, n, seed):
     return idsum, wgt
 
 
+@pytest.mark.parametrize("lm_path", [0, 1])
 @pytest.mark.parametrize("level", [0, 1, 2])
-def test_alignment_parity(two_frames, level):
+def test_alignment_parity(two_frames, level, lm_path):
     from dsopp_amd import capi
     from oracle import pyoracle as po
     win = two_frames
@@ -65,7 +66,9 @@ def test_alignment_parity(two_frames, level):
     pr.build(fr.image_u8)
     pt.build(ft.image_u8)
     intr = win.scene.intrinsics / (1 << level)  # CameraCalibration::cameraModel(level), camera_calibration.cpp:66-70
-    idsum, wgt = _depth_map(fr, level, 1500, seed=level)
+    # level 2 stays below 1024 reference points: with lm_path 0 it runs the single-workgroup loop kernel, levels 0 / 1 the
+    # launch-per-iteration kernel
+    idsum, wgt = _depth_map(fr, level, 700 if level == 2 else 1500, seed=level)
     T_ref = syn.mat_to_params(fr.T_w_c_gt)
     T_init = syn.mat_to_params(ft.T_w_c_init)
     # oracle
@@ -75,9 +78,10 @@ def test_alignment_parity(two_frames, level):
                         T_init, 1.0, np.zeros(2))
     # HIP
     a = capi.HipAligner(capi.default_align_options())
+    a.set_lm_path(lm_path)   # 0: the whole LM loop in one launch of one workgroup; 1: one launch per iteration
     a.reset()
     a.push_reference_depth_map(1000, T_ref, pr, level, intr, idsum, wgt, 1.0, np.zeros(2))
-    assert a.num_points() == len(u)
+    assert a.num_points() == len(u) and (len(u) <= 1024) == (level == 2)
     a.push_target(2000, T_init, pt, level, intr, 1.0, np.zeros(2))
     rg = a.solve()
     assert rg["iterations"] == ro["iterations"], (rg["iterations"], ro["iterations"])
