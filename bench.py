@@ -65,6 +65,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # self-test hook (tests/test_gpu_distributed.py): all ranks on one device + gloo, to run the N > 1 plumbing of this script on
+    # a single-GPU box (RCCL refuses two ranks on one device)
+    single_device = os.environ.get("DSOPP_BENCH_SINGLE_DEVICE") == "1"
+    if single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("DSOPP_BENCH_FORCE_DIST") == "1"  # exercise the collective path with a single rank (self-test)
@@ -74,7 +79,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if single_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     F, P = args.frames, args.points
     total_points = P * world

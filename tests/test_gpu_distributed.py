@@ -71,3 +71,23 @@ def test_sharded_solve_matches_single_window(lm_mode):
         assert p.exitcode == 0
     res = out.get(timeout=5)
     assert res[0] is True, res
+
+
+def test_bench_script_runs_with_two_ranks():
+    """bench.py's own N > 1 path (sharding, collective callback, MAX-over-ranks timing, rank-0 JSON line) end to end: two
+    ranks on this one GPU over gloo (DSOPP_BENCH_SINGLE_DEVICE=1); the driver runs the same script over RCCL with one GPU per rank"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSOPP_BENCH_SINGLE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "28", "--warmup", "7"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 28 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["total_points"] == 4000 and "roofline" in d
