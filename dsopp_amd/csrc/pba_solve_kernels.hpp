@@ -812,20 +812,16 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
       v += bm_c + s;
     }
     A[K * ld + c] = v;
-    pv[c] = 1.0 / sqrt(A[c * ld + c] + 10.0);  // jacobiPreconditioner — normal_linear_system.cpp:10-16
+    // The reference solves the Jacobi-scaled system p H p, p = 1/sqrt(diag + 10) (normal_linear_system.cpp:10-16,52-59).  A
+    // Cholesky factorisation is invariant under symmetric diagonal scaling (chol(S A S) = S chol(A), and every floating-point
+    // operation keeps its relative error), so the scaling pass is skipped; only the zero-pivot guard refers to the scaled
+    // pivot d / (diag + 10), kept here.
+    pv[c] = A[c * ld + c] + 10.0;
   }
   if (tid == 0) A[K * ld + K] = 0;
   if (!a.do_solve) return;
   __syncthreads();
   DSOPP_STAMP(1);
-  {
-    const int tr = tid >> 4, tc = tid & 15;
-    for (int row = tr; row < N; row += 16) {
-      const double pr = row < K ? pv[row] : 1.0;
-      for (int col = tc; col <= row && col < K; col += 16) A[row * ld + col] *= pr * pv[col];
-    }
-  }
-  __syncthreads();
   // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T.
   // Look-ahead schedule, one barrier per 8x8 frame block: wave 0 ("panel wave") brings block column kb+1 up to date with
   // panel kb, factors its diagonal block in registers and solves the panel below it, WHILE waves 1..3 apply panel kb to
@@ -853,13 +849,16 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) c[j] = src[j];
     }
+    double guard[kBlk];  // zero-pivot thresholds, fetched before the pivot chain starts
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
     int e = 0;
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
       const double d = readLane(c[k], k);
-      // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64 (pivots of the Jacobi-scaled system are O(1e-13..1));
-      // pivots below 1e-30 are treated as zero, as a rank-revealing factorisation would
-      const bool okp = d > 1e-30;
+      // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64; pivots whose Jacobi-scaled value d / (diag + 10) is
+      // below 1e-30 are treated as zero, as a rank-revealing factorisation would
+      const bool okp = d > guard[k];
       double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
       inv = inv * (1.5 - 0.5 * d * inv * inv);
       inv = inv * (1.5 - 0.5 * d * inv * inv);
@@ -995,7 +994,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
   }
   __syncthreads();
   if (tid < K) {
-    const double x = pv[tid] * xs[tid];
+    const double x = xs[tid];
     stpl[tid] = -x;
     a.step[tid] = x;
     a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
