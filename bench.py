@@ -178,6 +178,7 @@ def main():
         extras["full_solve"] = {"gpu_ms": float(np.median(ts) * 1e3), "what": "dsopp_hip_window_solve on the C1 window (7 LM iterations + uncertainty + point statuses)"}
         g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
+        extras["f32_mode"] = run_f32_mode(capi, syn, win, F, P_local)
         extras["tracker"] = run_tracker_timing(capi, syn, torch)
         extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
 
@@ -268,6 +269,25 @@ def run_stage_table(g, win, syn, args, repeats=30):
         stages["cpu_port_full_solve_ms"] = (time.perf_counter() - t0) * 1e3
         stages["cpu_threads"] = max(1, min(hw, 8) - 1)
     return stages
+
+
+def run_f32_mode(capi, syn, win, F, P):
+    """the same C1 loop with images and residual / Jacobian rows in fp32 (fp64 accumulation): the analogue of the reference's
+    -DUSE_FLOAT build.  Not the headline (the reference's default scalar is double); texels are 16 B instead of 32 B."""
+    g = capi.HipWindow(capi.default_pba_options(dtype=capi.F32))
+    syn.load_window(g, win)
+    g.snapshot()
+    g.optimize_repeated(14)
+    t0 = time.perf_counter()
+    done, _ = g.optimize_repeated(140)
+    dt = time.perf_counter() - t0
+    g.restore()
+    t_lin = g.time_kernel("sweep_linearize", 200)
+    b_lin = algorithmic_bytes_linearize(P, F, 4)
+    out = {"gn_iterations_per_s": done / dt, "sweep_linearize_us": t_lin, "algorithmic_bytes_per_launch": b_lin,
+           "achieved_GBs": b_lin / (t_lin * 1e-6) / 1e9, "frac_of_hbm_peak": b_lin / (t_lin * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    g.close()
+    return out
 
 
 def run_large_window_roofline(capi, syn, dtype, s_bytes):

@@ -191,3 +191,22 @@ def test_affine_brightness_and_exposure(fej):
     g = syn.load_window(capi.HipWindow(capi.default_pba_options(first_estimate_jacobians=fej)), win)
     _compare_solve(o, g, win)
     g.close()
+
+
+def test_float_mode_full_solve(small_window):
+    """DSOPP_HIP_F32 (images and residual / Jacobian rows in fp32, fp64 accumulation — the analogue of the reference's
+    -DUSE_FLOAT build) through the fused loop: fp32 round-off class against the fp64 oracle"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = small_window
+    o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options(dtype=capi.F32)), win)
+    eo, ito, nvo = o.optimize()
+    eg, itg, nvg = g.optimize()
+    assert ito == itg and abs(nvo - nvg) <= 3
+    assert abs(eo - eg) <= 2e-3 * abs(eo)
+    for f in win.frames:
+        To, abo = o.get_pose(f.frame_id)
+        Tg, abg = g.get_pose(f.frame_id)
+        assert np.abs(To - Tg).max() <= 2e-4, np.abs(To - Tg).max()
+    g.close()
