@@ -2014,12 +2014,10 @@ int dsopp_hip_window_restore(dsopp_hip_window *w) {
     }
     syncTopology(*w);
     hipStream_t st = w->sr.stream;
-    // two enqueues, no host synchronisation: state block D2D + one kernel over all landmarks
-    HIP_CHECK(hipMemcpyAsync(w->d_state.ptr, w->d_state_snap.ptr, sizeof(WindowState), hipMemcpyDeviceToDevice, st));
-    if (w->n_schur_blocks) {
-      restoreKernel<<<w->n_schur_blocks, kSchurLandmarks, 0, st>>>(w->d_frames.ptr, w->d_schur_table.ptr, w->F());
-      HIP_CHECK(hipGetLastError());
-    }
+    // one enqueue, no host synchronisation: one kernel over all landmarks + the frame-state block
+    restoreKernel<<<w->n_schur_blocks + 1, kSchurLandmarks, 0, st>>>(w->d_frames.ptr, w->d_schur_table.ptr, w->F(), w->d_state.ptr, w->d_state_snap.ptr,
+                                                                 w->n_schur_blocks);
+    HIP_CHECK(hipGetLastError());
     w->hst = w->snap_state;
     w->state_dirty = false;
     w->host_stale = false;

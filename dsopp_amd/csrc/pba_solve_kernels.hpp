@@ -1358,7 +1358,14 @@ __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) 
 }
 
 /** dsopp_hip_window_restore: idepths, flags and connection statuses back to the snapshot; grid = schur blocks */
-__global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F) {
+__global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, WindowState *state,
+                              const WindowState *state_snap, int n_schur_blocks) {
+  if (static_cast<int>(blockIdx.x) == n_schur_blocks) {
+    // last workgroup: the frame states (one launch restores everything; no separate device-to-device copy)
+    constexpr int kWords = static_cast<int>(sizeof(WindowState) / sizeof(double));
+    for (int k = threadIdx.x; k < kWords; k += blockDim.x) reinterpret_cast<double *>(state)[k] = reinterpret_cast<const double *>(state_snap)[k];
+    return;
+  }
   const SchurBlock be = table[blockIdx.x];
   const FrameDev &fr = frames[be.r];
   const int i = be.offset + threadIdx.x;
