@@ -209,3 +209,31 @@ def test_gpu_estimate_pose_matches_oracle_chain():
     assert not res2["success"] and res2["tries"] == 2 and np.allclose(rl, 2.5e-9)
     for obj in (a, maps_g, pr, pt, g):
         obj.close()
+
+
+@pytest.mark.gpu
+def test_tracker_full_size_identity_property():
+    """C2 of BASELINE.json at full size (1280x1024, 5 pyramid levels), checked through a size-independent property: tracking
+    the newest keyframe's OWN image against its reference depth maps from a perturbed initialisation must return the
+    keyframe's own pose (photometric error zero at the identity), whatever the scene."""
+    from dsopp_amd import capi
+    W, H, L = 1280, 1024, 5
+    win = syn.make_window(num_frames=4, num_points=1200, width=W, height=H, seed=23)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    g.solve()
+    maps = g.create_reference_depth_maps(L)
+    kf = win.frames[-1]
+    pyr = capi.Pyramid(W, H, L)
+    pyr.build(kf.image_u8)
+    T_ref, ab_ref = g.get_pose(kf.frame_id)
+    Tm = np.eye(4)
+    Tm[:3, 3] = [0.01, -0.006, 0.004]
+    T_init = syn.mat_to_params(syn.params_to_mat(T_ref) @ Tm) if hasattr(syn, "params_to_mat") else T_ref + np.array([0, 0, 0, 0, 0.01, -0.006, 0.004])
+    a = capi.HipAligner(capi.default_align_options())
+    rmse_last = np.full(L, 1e10)
+    res = a.estimate_pose(kf.timestamp, T_ref, pyr, maps, 1.0, ab_ref, kf.timestamp + 1, pyr, 1.0, win.scene.intrinsics, T_init[None, :], ab_ref, rmse_last)
+    assert res["success"] and res["lm_iterations"] > 5
+    assert np.abs(res["T_w_target"] - T_ref).max() < 2e-4, np.abs(res["T_w_target"] - T_ref).max()
+    assert rmse_last[0] < 1.0   # grey levels: the level-0 residual of a frame against itself
+    for obj in (a, maps, pyr, g):
+        obj.close()
