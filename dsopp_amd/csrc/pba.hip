@@ -546,6 +546,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.scalars = mode == ReduceMode::kDecideOnly ? w.d_reduce.ptr + w.reduceCount() : w.d_scalars.ptr;
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
+  a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + w.reduceCount() : nullptr;
   if (fused) a.prm = fused->prm;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
   const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
@@ -557,7 +558,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   }
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
-    reduceSchurKernel<<<a.n_schur_blocks + F * F, kSchurThreads, std::max(schurSmemBytes(K), decide_smem), st>>>(a);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F + (a.scalars_out ? 1 : 0), kSchurThreads, std::max(schurSmemBytes(K), decide_smem), st>>>(a);
   });
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
@@ -868,7 +869,6 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     fr.prm = prm;
     if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
-      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.reduceCount(), cin);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else {

@@ -101,6 +101,7 @@ struct ReduceSchurArgs {
   const double *scalars;  // multi-GPU: all-reduced {energy, n_valid, step^2, idepth.step}
   int n_sweep_blocks;
   int total_blocks;
+  double *scalars_out;  // nullable: accumulate-only launches of sharded windows write {energy, n_valid, |step|^2, idepth.step} here
   LmParams prm;
   long long *dbg;  // nullable tuning aid
 };
@@ -356,6 +357,28 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     return;
   }
   const int F = a.F, K = kBlk * F;
+  if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {
+    // ---- landmark-sharded windows: one extra workgroup sums the sweep's 4 energy scalars (fixed order) into the tail of
+    // the reduction buffer, so that they travel in the same collective as the systems (no separate kernel for it)
+    double *lds = reinterpret_cast<double *>(smem_raw);
+    double v[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < a.n_sweep_blocks; b += kSchurThreads) {
+      const double *p = a.partials + static_cast<size_t>(b) * kPartial + 44;
+      v[0] += p[0];
+      v[1] += p[1];
+      v[2] += p[2];
+      v[3] += p[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lds[e * (kSchurThreads + 2) + threadIdx.x] = v[e];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double sacc = 0;
+      for (int j = 0; j < kSchurThreads; ++j) sacc += lds[threadIdx.x * (kSchurThreads + 2) + j];
+      a.scalars_out[threadIdx.x] = sacc;
+    }
+    return;
+  }
   if (static_cast<int>(blockIdx.x) >= a.n_schur_blocks) {
     // ---- pair block
     const int p = blockIdx.x - a.n_schur_blocks;

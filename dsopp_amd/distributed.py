@@ -36,17 +36,22 @@ class _DeviceBuffer:
 
 
 def make_device_allreduce(dist, torch, stream, device_index: int):
-    """callback(ptr, count, stream_ptr) for HipWindow.set_allreduce: in-place sum across ranks on `stream`."""
+    """callback(ptr, count, stream_ptr) for HipWindow.set_allreduce: in-place sum across ranks, ordered on `stream`.
+    The callback runs between kernel launches of the solve loop, so its host cost is on the critical path when it exceeds
+    the GPU time of an iteration: `stream` is made the thread's current stream ONCE here (no per-call context manager) and
+    the wrapped tensors are cached per (pointer, count)."""
     cache = {}
+    torch.cuda.set_stream(stream)
+    all_reduce = dist.all_reduce
+    as_tensor = torch.as_tensor
+    dev = f"cuda:{device_index}"
 
     def allreduce(ptr, count, stream_ptr):
-        key = (ptr, count)
-        t = cache.get(key)
+        t = cache.get((ptr, count))
         if t is None:
-            t = torch.as_tensor(_DeviceBuffer(ptr, count), device=f"cuda:{device_index}")
-            cache[key] = t
-        with torch.cuda.stream(stream):
-            dist.all_reduce(t)
+            t = as_tensor(_DeviceBuffer(ptr, count), device=dev)
+            cache[(ptr, count)] = t
+        all_reduce(t)
         return 0
 
     return allreduce
