@@ -46,7 +46,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_aligner_set_lm_path", "dsopp_hip_estimate_depths", "dsopp_hip_immature_set_create", "dsopp_hip_immature_set_destroy", "dsopp_hip_immature_set_upload_state", "dsopp_hip_immature_set_download_state", "dsopp_hip_immature_set_estimate", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_get_frame_update", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_aligner_set_lm_path", "dsopp_hip_estimate_depths", "dsopp_hip_immature_set_create", "dsopp_hip_immature_set_destroy", "dsopp_hip_immature_set_upload_state", "dsopp_hip_immature_set_download_state", "dsopp_hip_immature_set_estimate", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -276,6 +276,22 @@ class HipWindow:
         e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
         _chk(lib().dsopp_hip_window_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
         return e.value, it.value, nv.value
+
+    def get_frame_update(self, frame_id, target_ids):
+        """everything updateFrame reads back for one keyframe in one transfer: dict(idepth, inv_hdd, relative_baseline,
+        n_inliers, flags, status={target_id: array})"""
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_num_landmarks(self._h, int(frame_id), C.byref(n)))
+        n = n.value
+        tids = np.ascontiguousarray(target_ids, dtype=np.int32)
+        out = dict(idepth=np.zeros(n), inv_hdd=np.zeros(n), relative_baseline=np.zeros(n), n_inliers=np.zeros(n, dtype=np.int32),
+                   flags=np.zeros(n, dtype=np.uint8))
+        st = np.zeros((len(tids), n), dtype=np.uint8)
+        _chk(lib().dsopp_hip_window_get_frame_update(self._h, int(frame_id), _p(out["idepth"]), _p(out["inv_hdd"]), _p(out["relative_baseline"]),
+                                                     out["n_inliers"].ctypes.data_as(C.c_void_p), _p(out["flags"], np.uint8), len(tids),
+                                                     tids.ctypes.data_as(C.c_void_p), _p(st, np.uint8)))
+        out["status"] = {int(t): st[k] for k, t in enumerate(tids)}
+        return out
 
     def create_reference_depth_maps(self, levels: int) -> DepthMaps:
         """createReferenceDepthMaps of the window's newest keyframe, on the device"""

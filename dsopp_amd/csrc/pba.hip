@@ -93,6 +93,9 @@ struct dsopp_hip_window {
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
   DeviceBuffer<SelectState> d_select;   // radix-select state of updatePointStatuses
   DeviceBuffer<double> d_pair_dist;     // camera-centre distances of all frame pairs
+  DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
+  void *h_export = nullptr;             // its pinned host staging
+  size_t h_export_bytes = 0;
   bool marg_dirty = true;
   bool pair_valid = false;   // pair constants match the device state
   bool begun = false;
@@ -1358,6 +1361,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
+  if (w->h_export) (void)hipHostFree(w->h_export);
   w->frames.clear();
   StreamRef sr = w->sr;
   delete w;
@@ -1702,6 +1706,56 @@ int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double
           for (int a = 0; a < kBlk; ++a) hpib[i * K + static_cast<size_t>(kBlk * t + a)] = blk[i * kUblk + static_cast<size_t>(a)];
       }
     }
+  });
+}
+
+int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, double *idepth, double *inv_hessian_idepth, double *relative_baseline,
+                                      int32_t *n_inliers, uint8_t *flags_out, int32_t n_targets, const int32_t *target_ids, uint8_t *statuses) {
+  return guarded([&] {
+    if (!w || n_targets < 0 || n_targets > kMaxFrames || (n_targets && (!target_ids || !statuses))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+    w->sr.use();
+    HostFrame &f = w->frameById(frame_id);
+    const size_t n = static_cast<size_t>(f.n);
+    if (n == 0) return;
+    hipStream_t st = w->sr.stream;
+    FrameExportArgs a;
+    a.idepth = f.idepth.ptr;
+    a.inv_hdd = f.inv_hdd.ptr;
+    a.relative_baseline = f.relative_baseline.ptr;
+    a.n_inliers = f.n_inliers.ptr;
+    a.flags = f.dflags.ptr;
+    a.n = f.n;
+    a.n_targets = n_targets;
+    for (int t = 0; t < n_targets; ++t) {
+      auto it = f.residuals.find(target_ids[t]);
+      if (it == f.residuals.end()) fail(DSOPP_HIP_ERR_NOT_FOUND, "no connection %d -> %d", frame_id, target_ids[t]);
+      if (it->second->n != f.n) fail(DSOPP_HIP_ERR_STATE, "connection %d -> %d holds %d residuals, frame has %d landmarks", frame_id, target_ids[t], it->second->n, f.n);
+      a.status[t] = it->second->status.ptr;
+    }
+    const size_t n_bytes = static_cast<size_t>(1 + n_targets) * n;
+    const size_t words = 4 * n + (n_bytes + 7) / 8;
+    w->d_export.reserve(words, 0, st);
+    a.out_d = w->d_export.ptr;
+    a.out_b = reinterpret_cast<uint8_t *>(w->d_export.ptr + 4 * n);
+    exportFrameKernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(a);
+    HIP_CHECK(hipGetLastError());
+    if (w->h_export_bytes < words * 8) {
+      if (w->h_export) (void)hipHostFree(w->h_export);
+      w->h_export = nullptr;
+      HIP_CHECK(hipHostMalloc(&w->h_export, words * 8, hipHostMallocDefault));
+      w->h_export_bytes = words * 8;
+    }
+    HIP_CHECK(hipMemcpyAsync(w->h_export, w->d_export.ptr, words * 8, hipMemcpyDeviceToHost, st));
+    w->sr.sync();
+    const double *hd = static_cast<const double *>(w->h_export);
+    const uint8_t *hb = reinterpret_cast<const uint8_t *>(hd + 4 * n);
+    if (idepth) std::memcpy(idepth, hd, n * sizeof(double));
+    if (inv_hessian_idepth) std::memcpy(inv_hessian_idepth, hd + n, n * sizeof(double));
+    if (relative_baseline) std::memcpy(relative_baseline, hd + 2 * n, n * sizeof(double));
+    if (n_inliers)
+      for (size_t i = 0; i < n; ++i) n_inliers[i] = static_cast<int32_t>(hd[3 * n + i]);
+    if (flags_out) std::memcpy(flags_out, hb, n);
+    if (n_targets) std::memcpy(statuses, hb + n, static_cast<size_t>(n_targets) * n);
   });
 }
 

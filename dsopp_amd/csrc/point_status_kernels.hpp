@@ -151,6 +151,30 @@ __global__ void __launch_bounds__(kSchurLandmarks) applyPointStatusesKernel(cons
   if (valid < 1) be.flags[i] = flg | kFlagOutlier;  // minimum_valid_reprojections_num = 1 (:395-399)
 }
 
+/** what updateFrame reads back for one keyframe (PROB_SRC/photometric_bundle_adjustment.cpp:182-264), packed into one
+ *  contiguous buffer so that it costs one transfer: idepth n | H_dd^-1 n | relative baseline n | inlier counts n (as
+ *  doubles) | then bytes: flags n | statuses of target 0 n | target 1 n | ...  (targets = the frame's connections in the
+ *  order given by the caller) */
+struct FrameExportArgs {
+  const double *idepth, *inv_hdd, *relative_baseline;
+  const int32_t *n_inliers;
+  const uint8_t *flags;
+  const uint8_t *status[kMaxFrames];
+  int n, n_targets;
+  double *out_d;   // 4 n doubles
+  uint8_t *out_b;  // (1 + n_targets) n bytes
+};
+__global__ void exportFrameKernel(FrameExportArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  a.out_d[i] = a.idepth[i];
+  a.out_d[a.n + i] = a.inv_hdd[i];
+  a.out_d[2 * a.n + i] = a.relative_baseline[i];
+  a.out_d[3 * a.n + i] = static_cast<double>(a.n_inliers[i]);
+  a.out_b[i] = a.flags[i];
+  for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][i] : DSOPP_HIP_STATUS_UNKNOWN;
+}
+
 /** relinearizeSystem — :310-316: the newest frame's linearisation point moves to its current estimate */
 __global__ void relinearizeKernel(WindowState *st, int f) {
   if (threadIdx.x != 0) return;

@@ -260,8 +260,13 @@ class HipPhotometricBundleAdjustment {
     std::vector<double> idepth(n), inv_h(n), baseline(n);
     std::vector<int32_t> inliers(n);
     std::vector<uint8_t> flags(n);
-    check(dsopp_hip_window_get_landmarks(w_, frame.keyframe_id, idepth.data(), nullptr, inv_h.data(), nullptr, baseline.data(), inliers.data(),
-                                         flags.data(), nullptr));
+    // one packed transfer for the landmark arrays and the statuses towards every connected frame
+    std::vector<int32_t> targets;
+    for (const auto &kv : frame.reprojection_statuses)
+      if (static_cast<int32_t>(kv.second.size()) == n && n > 0) targets.push_back(kv.first);
+    std::vector<uint8_t> statuses(targets.size() * static_cast<size_t>(n));
+    check(dsopp_hip_window_get_frame_update(w_, frame.keyframe_id, idepth.data(), inv_h.data(), baseline.data(), inliers.data(), flags.data(),
+                                            static_cast<int32_t>(targets.size()), targets.data(), statuses.data()));
     frame.idepth_variance.assign(n, 1e-5);
     frame.inlier_residuals.assign(n, 0);
     frame.relative_baseline.resize(n, 0.0);
@@ -280,11 +285,11 @@ class HipPhotometricBundleAdjustment {
       frame.inlier_residuals[i] = inliers[i];
       if (baseline[i] > frame.relative_baseline[i]) frame.relative_baseline[i] = baseline[i];
     }
+    for (size_t k = 0; k < targets.size(); ++k)
+      frame.reprojection_statuses[targets[k]].assign(statuses.begin() + static_cast<long>(k * static_cast<size_t>(n)),
+                                                     statuses.begin() + static_cast<long>((k + 1) * static_cast<size_t>(n)));
     for (auto &kv : frame.reprojection_statuses) {
-      std::vector<uint8_t> st(kv.second.size());
-      if (st.empty()) continue;
-      if (dsopp_hip_window_get_residuals(w_, frame.keyframe_id, kv.first, static_cast<int32_t>(st.size()), st.data(), nullptr, nullptr) == DSOPP_HIP_OK)
-        kv.second = st;
+      if (kv.second.empty()) continue;
       Matrix6 cov;
       if (estimate_uncertainty_ && dsopp_hip_window_get_covariance(w_, frame.keyframe_id, kv.first, cov.data()) == DSOPP_HIP_OK)
         frame.covariances[kv.first] = cov;

@@ -160,6 +160,13 @@ int dsopp_hip_window_update_point_statuses(dsopp_hip_window *w);                
 int dsopp_hip_window_get_frame_state(dsopp_hip_window *w, int32_t frame_id, double T0[7], double ab0[2], double eps[8], double step[8]);
 int dsopp_hip_window_get_pose(dsopp_hip_window *w, int32_t frame_id, double T_world_agent[7], double affine_brightness[2]);
 int dsopp_hip_window_num_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t *n);
+/* updateFrame in one transfer (PROB_SRC/photometric_bundle_adjustment.cpp:182-264 reads, per keyframe: idepths, H_dd^-1 for the
+ * idepth variance, relative baselines, inlier counts, outlier flags and the connection statuses towards every other frame):
+ * a gather kernel packs everything of one frame, one pinned device-to-host copy, one synchronisation.  Any landmark array may
+ * be NULL; statuses receives n_targets rows of n bytes in the order of target_ids.  (The per-array getters below cost one
+ * copy + wait each.) */
+int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, double *idepth, double *inv_hessian_idepth, double *relative_baseline,
+                                      int32_t *n_inliers, uint8_t *flags_out, int32_t n_targets, const int32_t *target_ids, uint8_t *statuses);
 /* any output may be NULL.  flags_out bit0 marginalized, bit1 outlier, bit2 to_marginalize, bit3 ill_conditioned;
  * hpib (hessian_poses_idepth_block) is n x K */
 int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double *idepth, double *idepth_step, double *inv_hessian_idepth,

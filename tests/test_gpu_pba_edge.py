@@ -210,3 +210,20 @@ def test_float_mode_full_solve(small_window):
         Tg, abg = g.get_pose(f.frame_id)
         assert np.abs(To - Tg).max() <= 2e-4, np.abs(To - Tg).max()
     g.close()
+
+
+def test_frame_update_export_matches_getters(small_window):
+    """dsopp_hip_window_get_frame_update (updateFrame in one transfer) == the per-array getters"""
+    from dsopp_amd import capi
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), small_window)
+    g.solve()
+    ids = [f.frame_id for f in small_window.frames]
+    for fid in ids:
+        targets = [t for t in ids if t != fid]
+        up = g.get_frame_update(fid, targets)
+        lm = g.get_landmarks(fid, False)
+        for k in ("idepth", "inv_hdd", "relative_baseline", "n_inliers", "flags"):
+            assert np.array_equal(up[k], lm[k]), k
+        for t in targets:
+            assert np.array_equal(up["status"][t], g.get_residuals(fid, t)["status"])
+    g.close()
