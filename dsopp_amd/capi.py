@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_window_activate_landmarks",
     "dsopp_hip_last_error", "dsopp_hip_device_count", "dsopp_hip_version", "dsopp_hip_default_pba_options",
     "dsopp_hip_default_align_options", "dsopp_hip_pyramid_create", "dsopp_hip_pyramid_destroy", "dsopp_hip_pyramid_build",
     "dsopp_hip_pyramid_build_device", "dsopp_hip_pyramid_set_level", "dsopp_hip_pyramid_set_mask", "dsopp_hip_pyramid_get_level",
@@ -299,6 +300,25 @@ class HipWindow:
         _chk(lib().dsopp_hip_window_create_reference_depth_maps(self._h, int(levels), C.byref(h)))
         return DepthMaps(h, levels)
 
+    def activate_landmarks(self, frame_ids, immature_sets, newest_pyramid: "Pyramid", T_world_newest, exposure_newest=1.0,
+                           affine_newest=(0, 0), number_of_desired_points=2000, min_distance_to_neighbor=0.0, refine=True,
+                           sigma_huber_loss=20.0):
+        """LandmarksActivator::activate for the listed window keyframes (oldest first) and their device-resident immature
+        sets against a new keyframe.  Returns (statuses per keyframe, idepths per keyframe, result dict)."""
+        n = len(frame_ids)
+        ids = np.ascontiguousarray(frame_ids, dtype=np.int32)
+        sets = (C.c_void_p * n)(*[s._h if s is not None else None for s in immature_sets])
+        st = [np.zeros(s.n if s is not None else 0, dtype=np.uint8) for s in immature_sets]
+        idp = [np.zeros(s.n if s is not None else 0) for s in immature_sets]
+        st_p = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p) for a in st])
+        id_p = (C.c_void_p * n)(*[a.ctypes.data_as(C.c_void_p) for a in idp])
+        dist = C.c_double(min_distance_to_neighbor)
+        res = ActivationResult()
+        _chk(lib().dsopp_hip_window_activate_landmarks(self._h, n, _p(ids, np.int32), sets, newest_pyramid._h, _p(_f64(T_world_newest)),
+                                                       C.c_double(exposure_newest), _p(_f64(affine_newest)), int(number_of_desired_points),
+                                                       C.byref(dist), int(bool(refine)), C.c_double(sigma_huber_loss), st_p, id_p, C.byref(res)))
+        return st, idp, {k: getattr(res, k) for k, _ in ActivationResult._fields_}
+
     def optimize_repeated(self, iterations_target: int):
         """{restore(); optimize()} from the snapshot until exactly `iterations_target` GN iterations ran; returns
         (iterations_done, last_energy).  Same work as the Python loop, without its per-call overhead between solves."""
@@ -449,6 +469,11 @@ def estimate_depths(lms, target_pyramid: Pyramid, level, intrinsics, T_target_re
     return lms
 
 
+class ActivationResult(C.Structure):
+    _fields_ = [("number_of_active_points", C.c_int32), ("n_activated", C.c_int32), ("n_skipped", C.c_int32), ("n_deleted", C.c_int32),
+                ("selection_rounds", C.c_int32), ("min_distance_to_neighbor", C.c_double)]
+
+
 class ImmatureSet:
     """Device-resident immature landmarks of one keyframe (dsopp_hip_immature_set)."""
 
@@ -474,6 +499,12 @@ class ImmatureSet:
         _chk(lib().dsopp_hip_immature_set_estimate(self._h, target_pyramid._h, int(level), _p(_f64(intrinsics)), _p(_f64(T_target_reference)),
                                                    C.c_double(reference_exposure), _p(_f64(reference_affine)), C.c_double(target_exposure),
                                                    _p(_f64(target_affine)), C.c_double(sigma_huber_loss)))
+
+    def upload(self, lms):
+        """replace the estimator state (idepth interval, uniqueness, search interval, status, traced)"""
+        _chk(lib().dsopp_hip_immature_set_upload_state(self._h, _p(_f64(lms["idepth_min"])), _p(_f64(lms["idepth_max"])), _p(_f64(lms["uniqueness"])),
+                                                       _p(_f64(lms["search_pixel_interval"])), _p(np.ascontiguousarray(lms["status"], dtype=np.uint8), np.uint8),
+                                                       _p(np.ascontiguousarray(lms["traced"], dtype=np.uint8), np.uint8)))
 
     def download(self):
         n = self.n

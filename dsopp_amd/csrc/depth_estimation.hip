@@ -21,6 +21,7 @@
 
 #include "common.hpp"
 #include "device_geom.hpp"
+#include "immature_set.hpp"
 #include "pyramid.hpp"
 #include "se3_math.hpp"
 
@@ -572,17 +573,6 @@ __global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLa
 }  // namespace dsopp_hip
 
 using namespace dsopp_hip;
-
-/** the immature landmarks of one keyframe, resident on the device across frames */
-struct dsopp_hip_immature_set {
-  StreamRef sr;
-  int n = 0;
-  DeviceBuffer<double> d_in;      // projection 2n | direction 3n | patch 8n | gradient 2n
-  DeviceBuffer<double> d_io;      // idepth_min | idepth_max | uniqueness | search_pixel_interval
-  DeviceBuffer<uint8_t> d_flags;  // status | traced
-  void *h_stage = nullptr;        // pinned read-back staging
-  size_t h_stage_bytes = 0;
-};
 
 namespace {
 

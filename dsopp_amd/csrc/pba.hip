@@ -15,6 +15,8 @@
 #include "depth_map_kernels.hpp"
 #include "point_status_kernels.hpp"
 #include "depth_maps.hpp"
+#include "activation_kernels.hpp"
+#include "immature_set.hpp"
 
 namespace dsopp_hip {
 namespace {
@@ -96,6 +98,14 @@ struct dsopp_hip_window {
   DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
   void *h_export = nullptr;             // its pinned host staging
   size_t h_export_bytes = 0;
+  struct ActivationScratch {            // work buffers of dsopp_hip_window_activate_landmarks
+    DeviceBuffer<ActKeyframe> keyframes;
+    DeviceBuffer<ActPair> pairs;
+    DeviceBuffer<const void *> texels0;
+    DeviceBuffer<double> px, py, distance, idepth_out;
+    DeviceBuffer<int> counters, state, cell_start, cell_cursor, cell_items, accepted;
+    DeviceBuffer<uint8_t> act_status;
+  } act;
   bool marg_dirty = true;
   bool pair_valid = false;   // pair constants match the device state
   bool begun = false;
@@ -2115,3 +2125,224 @@ int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// activation of immature landmarks (row f-3)
+// ---------------------------------------------------------------------------------------------------------------------
+int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes, const int32_t *frame_ids,
+                                        dsopp_hip_immature_set *const *immature, const dsopp_hip_pyramid *newest_pyramid,
+                                        const double T_world_newest[7], double exposure_newest, const double affine_newest[2],
+                                        int32_t number_of_desired_points, double *min_distance_to_neighbor, int32_t refine,
+                                        double sigma_huber_loss, uint8_t *const *activation_status, double *const *idepth,
+                                        dsopp_hip_activation_result *result) {
+  return guarded([&] {
+    if (!w || !frame_ids || !immature || !newest_pyramid || !T_world_newest || !affine_newest || !min_distance_to_neighbor)
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_keyframes < 1 || n_keyframes > kMaxFrames - 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_keyframes must be in [1, %d]", kMaxFrames - 1);
+    if (number_of_desired_points < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "number_of_desired_points < 0");
+    w->sr.use();
+    prepare(*w);  // device state current, host mirror of the poses current
+    hipStream_t st = w->sr.stream;
+    const int F = n_keyframes + 1;
+    std::vector<int> slots(static_cast<size_t>(n_keyframes));
+    for (int k = 0; k < n_keyframes; ++k) {
+      slots[static_cast<size_t>(k)] = w->slotOf(frame_ids[k]);
+      if (slots[static_cast<size_t>(k)] < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", frame_ids[k]);
+      if (k && slots[static_cast<size_t>(k)] <= slots[static_cast<size_t>(k - 1)])
+        fail(DSOPP_HIP_ERR_ORDER, "keyframes must be listed oldest first (frame %d)", frame_ids[k]);
+    }
+    const HostFrame &f0 = *w->frames[static_cast<size_t>(slots[0])];
+    const dsopp_hip_pyramid *p0 = f0.pyramid;
+    if (f0.level != 0) fail(DSOPP_HIP_ERR_STATE, "the window must hold level-0 frames");
+    if (newest_pyramid->levels < 2) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the newest keyframe needs pyramid level 1 (sparsity level)");
+    if (newest_pyramid->width != p0->width || newest_pyramid->height != p0->height || newest_pyramid->dtype != p0->dtype)
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the newest keyframe's pyramid does not match the window's");
+    for (int k = 0; k < n_keyframes; ++k) {
+      const HostFrame &fr = *w->frames[static_cast<size_t>(slots[static_cast<size_t>(k)])];
+      if (fr.pyramid->width != p0->width || fr.pyramid->height != p0->height || fr.pyramid->dtype != p0->dtype || fr.level != 0)
+        fail(DSOPP_HIP_ERR_STATE, "frame %d: pyramid size / dtype / level differs", fr.id);
+      if (immature[k] && immature[k]->sr.stream != st) immature[k]->sr.sync();  // the depth estimator may still be writing the state
+    }
+    const double *intr = f0.intr;
+    // poses and photometric parameters of track.activeFrames(): window frames from the solver state, the newest as given
+    std::vector<Rigid> T(static_cast<size_t>(F));
+    std::vector<double> expo(static_cast<size_t>(F)), aa(static_cast<size_t>(F)), ab(static_cast<size_t>(F));
+    for (int k = 0; k < n_keyframes; ++k) {
+      const int s = slots[static_cast<size_t>(k)];
+      T[static_cast<size_t>(k)] = poseOf(*w, s);
+      expo[static_cast<size_t>(k)] = w->frames[static_cast<size_t>(s)]->exposure;
+      aa[static_cast<size_t>(k)] = w->hst.ab0[s][0] + w->hst.eps[s][6];
+      ab[static_cast<size_t>(k)] = w->hst.ab0[s][1] + w->hst.eps[s][7];
+    }
+    T[static_cast<size_t>(F - 1)] = rigidFromParams(T_world_newest);
+    expo[static_cast<size_t>(F - 1)] = exposure_newest;
+    aa[static_cast<size_t>(F - 1)] = affine_newest[0];
+    ab[static_cast<size_t>(F - 1)] = affine_newest[1];
+    // [R|t] K^-1 and K [R|t] K^-1 for intrinsics (fx, fy, cx, cy) — camera_reproject.hpp:250-258
+    auto reprojectors = [](const Rigid &Ttr, double fx, double fy, double cx, double cy, double *M, double *U) {
+      const double ifx = 1.0 / fx, ify = 1.0 / fy, k02 = -cx / fx, k12 = -cy / fy;
+      double Ul[12];
+      for (int i = 0; i < 3; ++i) {
+        Ul[4 * i + 0] = Ttr.R[3 * i + 0] * ifx;
+        Ul[4 * i + 1] = Ttr.R[3 * i + 1] * ify;
+        Ul[4 * i + 2] = Ttr.R[3 * i + 0] * k02 + Ttr.R[3 * i + 1] * k12 + Ttr.R[3 * i + 2];
+        Ul[4 * i + 3] = Ttr.t[i];
+      }
+      for (int j = 0; j < 4; ++j) {
+        M[0 + j] = fx * Ul[0 + j] + cx * Ul[8 + j];
+        M[4 + j] = fy * Ul[4 + j] + cy * Ul[8 + j];
+        M[8 + j] = Ul[8 + j];
+      }
+      if (U) std::memcpy(U, Ul, sizeof(Ul));
+    };
+    // ---- tables
+    std::vector<ActKeyframe> kfs(static_cast<size_t>(n_keyframes));
+    std::vector<ActPair> pairs(static_cast<size_t>(F) * F);
+    std::vector<const void *> tex(static_cast<size_t>(F));
+    const Rigid T_newest_inv = rigidInverse(T[static_cast<size_t>(F - 1)]);
+    int n_immature = 0, max_items = 0, n_active_cap = 0;
+    for (int k = 0; k < n_keyframes; ++k) {
+      const HostFrame &fr = *w->frames[static_cast<size_t>(slots[static_cast<size_t>(k)])];
+      ActKeyframe &a = kfs[static_cast<size_t>(k)];
+      std::memset(&a, 0, sizeof(a));
+      reprojectors(rigidMul(T_newest_inv, T[static_cast<size_t>(k)]), intr[0] / 2, intr[1] / 2, intr[2] / 2, intr[3] / 2, a.M, nullptr);  // cameraModel(1)
+      a.n_active = fr.n;
+      a.active_uv = fr.uv.ptr;
+      a.active_idepth = fr.idepth.ptr;
+      a.active_flags = fr.dflags.ptr;
+      a.frame_slot = k;
+      a.immature_offset = n_immature;
+      if (const dsopp_hip_immature_set *s = immature[k]) {
+        const size_t N = static_cast<size_t>(s->n);
+        a.n_immature = s->n;
+        a.projection = s->d_in.ptr;
+        a.patch = s->d_in.ptr + 5 * N;
+        a.idepth_min = s->d_io.ptr;
+        a.idepth_max = s->d_io.ptr + N;
+        a.uniqueness = s->d_io.ptr + 2 * N;
+        a.search_pixel_interval = s->d_io.ptr + 3 * N;
+        a.status = s->d_flags.ptr;
+        a.traced = s->d_flags.ptr + N;
+      }
+      n_immature += a.n_immature;
+      n_active_cap += a.n_active;
+      max_items = std::max(max_items, std::max(a.n_active, a.n_immature));
+      tex[static_cast<size_t>(k)] = fr.pyramid->texels[0];
+    }
+    tex[static_cast<size_t>(F - 1)] = newest_pyramid->texels[0];
+    for (int r = 0; r < F; ++r)
+      for (int t = 0; t < F; ++t) {
+        ActPair &pc = pairs[static_cast<size_t>(r) * F + t];
+        std::memset(&pc, 0, sizeof(pc));
+        if (r == t) continue;
+        const Rigid Ttr = rigidMul(rigidInverse(T[static_cast<size_t>(t)]), T[static_cast<size_t>(r)]);  // :169
+        reprojectors(Ttr, intr[0], intr[1], intr[2], intr[3], pc.M, pc.U);
+        for (int i = 0; i < 3; ++i) pc.t[i] = Ttr.t[i];
+        pc.scale = (expo[static_cast<size_t>(t)] / expo[static_cast<size_t>(r)]) * std::exp(aa[static_cast<size_t>(t)] - aa[static_cast<size_t>(r)]);  // :166-167
+        pc.b_t = ab[static_cast<size_t>(t)];
+        pc.b_r = ab[static_cast<size_t>(r)];
+      }
+    auto &S = w->act;
+    ActArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.swd = static_cast<double>(p0->width) / 2.0;  // CameraCalibration::cameraModel(level): image size / 2^level
+    a.shd = static_cast<double>(p0->height) / 2.0;
+    a.grid_cap = (static_cast<int>(a.swd / kActMinCell) + 1) * (static_cast<int>(a.shd / kActMinCell) + 1);
+    const size_t nI = static_cast<size_t>(std::max(n_immature, 1)), nP = static_cast<size_t>(n_active_cap) + nI;
+    S.keyframes.reserve(static_cast<size_t>(n_keyframes), 0, st);
+    S.pairs.reserve(pairs.size(), 0, st);
+    S.texels0.reserve(static_cast<size_t>(F), 0, st);
+    S.px.reserve(nP, 0, st);
+    S.py.reserve(nP, 0, st);
+    S.distance.reserve(1, 0, st);
+    S.idepth_out.reserve(nI, 0, st);
+    S.counters.reserve(8, 0, st);
+    S.state.reserve(nI, 0, st);
+    S.cell_start.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
+    S.cell_cursor.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
+    S.cell_items.reserve(nP, 0, st);
+    S.accepted.reserve(nI, 0, st);
+    S.act_status.reserve(nI, 0, st);
+    S.keyframes.upload(kfs.data(), kfs.size(), 0, st);
+    S.pairs.upload(pairs.data(), pairs.size(), 0, st);
+    S.texels0.upload(tex.data(), tex.size(), 0, st);
+    S.distance.upload(min_distance_to_neighbor, 1, 0, st);
+    HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 8 * sizeof(int), st));
+    a.keyframes = S.keyframes.ptr;
+    a.pairs = S.pairs.ptr;
+    a.texels0 = S.texels0.ptr;
+    a.newest_sparsity = newest_pyramid->texels[1];
+    a.n_keyframes = n_keyframes;
+    a.n_frames = F;
+    a.n_immature = n_immature;
+    a.active_cap = n_active_cap;
+    a.width = p0->width;
+    a.height = p0->height;
+    a.sw = newest_pyramid->w(1);
+    a.sh = newest_pyramid->h(1);
+    a.fx = intr[0];
+    a.fy = intr[1];
+    a.cx = intr[2];
+    a.cy = intr[3];
+    a.sigma = sigma_huber_loss;
+    a.desired = number_of_desired_points;
+    a.minimum_inliers = std::min(1, F - 1);  // kMinimumInliers, :334
+    a.refine = refine ? 1 : 0;
+    a.px = S.px.ptr;
+    a.py = S.py.ptr;
+    a.counters = S.counters.ptr;
+    a.distance = S.distance.ptr;
+    a.state = S.state.ptr;
+    a.cell_start = S.cell_start.ptr;
+    a.cell_cursor = S.cell_cursor.ptr;
+    a.cell_items = S.cell_items.ptr;
+    a.accepted = S.accepted.ptr;
+    a.act_status = S.act_status.ptr;
+    a.idepth_out = S.idepth_out.ptr;
+    const bool f64 = p0->dtype == DSOPP_HIP_F64;
+    if (max_items > 0) {
+      const dim3 grid(static_cast<unsigned>((max_items + 255) / 256), static_cast<unsigned>(n_keyframes));
+      if (f64) activationProjectKernel<double><<<grid, 256, 0, st>>>(a);
+      else activationProjectKernel<float><<<grid, 256, 0, st>>>(a);
+    }
+    activationSelectKernel<<<1, kActSelectThreads, 0, st>>>(a);
+    if (n_immature > 0) {
+      if (f64) activationRefineKernel<double><<<static_cast<unsigned>(n_immature), 64, 0, st>>>(a);
+      else activationRefineKernel<float><<<static_cast<unsigned>(n_immature), 64, 0, st>>>(a);
+    }
+    HIP_CHECK(hipGetLastError());
+    // ---- one packed read-back: idepth (8 nI) | counters (8 ints) | distance | statuses (nI)
+    const size_t bytes = nI * 8 + 32 + 8 + nI;
+    if (w->h_export_bytes < bytes) {
+      if (w->h_export) (void)hipHostFree(w->h_export);
+      w->h_export = nullptr;
+      HIP_CHECK(hipHostMalloc(&w->h_export, bytes, hipHostMallocDefault));
+      w->h_export_bytes = bytes;
+    }
+    char *h = static_cast<char *>(w->h_export);
+    HIP_CHECK(hipMemcpyAsync(h, S.idepth_out.ptr, nI * 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h + nI * 8, S.counters.ptr, 32, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h + nI * 8 + 32, S.distance.ptr, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h + nI * 8 + 40, S.act_status.ptr, nI, hipMemcpyDeviceToHost, st));
+    w->sr.sync();
+    const double *h_id = reinterpret_cast<const double *>(h);
+    const int *h_cnt = reinterpret_cast<const int *>(h + nI * 8);
+    const uint8_t *h_st = reinterpret_cast<const uint8_t *>(h + nI * 8 + 40);
+    *min_distance_to_neighbor = *reinterpret_cast<const double *>(h + nI * 8 + 32);
+    dsopp_hip_activation_result res;
+    std::memset(&res, 0, sizeof(res));
+    res.number_of_active_points = h_cnt[0];
+    res.selection_rounds = h_cnt[3];
+    res.min_distance_to_neighbor = *min_distance_to_neighbor;
+    for (int k = 0; k < n_keyframes; ++k) {
+      const ActKeyframe &kf = kfs[static_cast<size_t>(k)];
+      for (int i = 0; i < kf.n_immature; ++i) {
+        const uint8_t s = h_st[kf.immature_offset + i];
+        (s == kActActivate ? res.n_activated : s == kActSkip ? res.n_skipped : res.n_deleted)++;
+      }
+      if (activation_status && activation_status[k]) std::memcpy(activation_status[k], h_st + kf.immature_offset, static_cast<size_t>(kf.n_immature));
+      if (idepth && idepth[k]) std::memcpy(idepth[k], h_id + kf.immature_offset, static_cast<size_t>(kf.n_immature) * 8);
+    }
+    if (result) *result = res;
+  });
+}

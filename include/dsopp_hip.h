@@ -276,6 +276,34 @@ int dsopp_hip_estimate_depths(const dsopp_hip_pyramid *target_pyramid, int level
                               const double *gradient /* 2n */, double *idepth_min, double *idepth_max, double *uniqueness,
                               double *search_pixel_interval, uint8_t *status, uint8_t *traced);
 
+/* ---- activation of immature landmarks (row f-3) ----
+ * LandmarksActivator<SE3, PinholeCamera, PixelMap, 1, REFINE>::activate (src/tracker/landmarks_activator/src/landmarks_activator.cpp:351-391),
+ * called once per new keyframe after pushNewKeyframe and before the keyframe enters the bundle adjustment
+ * (monocular_tracker.cpp:491-497).  track.activeFrames() = the listed window keyframes (oldest first; poses, affine
+ * brightness, exposure, level-0 images and active landmarks are the window's own) + the newest keyframe given explicitly.
+ *   1. reprojectActivePoints (:51-87) into the newest keyframe at pyramid level 1, number_of_active_points;
+ *   2. recalculateMinDistanceToNeighbor (:29-39): *min_distance_to_neighbor is LandmarksActivator::min_distance_to_neighbor_ (in/out);
+ *   3. activationStatus (:89-126) of every immature landmark in keyframe / landmark order, the greedy sparsity test
+ *      haveNoNeighbors (:41-49) through a uniform grid (identical result to the sequential O(n^2) loop);
+ *   4. refine != 0: optimizeImmatureLandmark (:279-311), a 3-iteration LM on the inverse depth over all other keyframes.
+ * activation_status[k][i]: 0 activate, 1 skip, 2 delete (ActiveKeyframe::ImmatureLandmarkActivationStatus, active_keyframe.hpp:40-44);
+ * idepth[k][i] = landmark.idepth() after the call (refined for activated landmarks).  Either array (or an entry) may be NULL.
+ * The sets are updated the way applyImmatureLandmarkActivationStatuses (active_keyframe.cpp:209-239) leaves the immature
+ * landmarks: idepth_min = idepth_max = refined value for activated ones, status := delete for activated and deleted ones.
+ * Creating the ActiveTrackingLandmark objects (and dsopp_hip_window_set_landmarks for them) stays with the caller. */
+typedef struct dsopp_hip_activation_result {
+  int32_t number_of_active_points;
+  int32_t n_activated, n_skipped, n_deleted;
+  int32_t selection_rounds; /* parallel rounds the greedy selection needed */
+  double min_distance_to_neighbor;
+} dsopp_hip_activation_result;
+int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes, const int32_t *frame_ids,
+                                        dsopp_hip_immature_set *const *immature /* n_keyframes, entries may be NULL */,
+                                        const dsopp_hip_pyramid *newest_pyramid, const double T_world_newest[7], double exposure_newest,
+                                        const double affine_newest[2], int32_t number_of_desired_points, double *min_distance_to_neighbor,
+                                        int32_t refine, double sigma_huber_loss, uint8_t *const *activation_status, double *const *idepth,
+                                        dsopp_hip_activation_result *result);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Two-frame direct image alignment of one pyramid level
  * (replaces EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true>, PROB_SRC/eigen_pose_alignment.cpp:26-329)

@@ -9,6 +9,7 @@
 #include "pose_alignment.hpp"
 #include "depth_maps.hpp"
 #include "depth_estimation.hpp"
+#include "landmarks_activator.hpp"
 #include "pyramid.hpp"
 
 using namespace oracle;
@@ -352,6 +353,59 @@ int orc_estimate_depths(int width, int height, const double *target_pixelinfo, c
     traced[i] = lm.traced ? 1 : 0;
   }
   return n;
+}
+
+int orc_activate_landmarks(int n_frames, int width, int height, const double *const *pixelinfo, const uint8_t *const *mask0,
+                           const uint8_t *mask_sparsity_newest, const double *T_w, const double *exposure, const double *affine,
+                           const double intrinsics[4], const int32_t *n_active, const double *active_uv, const double *active_idepth,
+                           const uint8_t *active_skip, const int32_t *n_immature, const double *projection, const double *patch,
+                           double *idepth_min, double *idepth_max, const double *uniqueness, const double *search_pixel_interval,
+                           uint8_t *status, const uint8_t *traced, double sigma_huber_loss, int number_of_desired_points,
+                           double *min_distance_to_neighbor, int refine, uint8_t *activation_status) {
+  std::vector<ActivationKeyframe> frames(static_cast<size_t>(n_frames));
+  size_t oa = 0, oi = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    ActivationKeyframe &k = frames[static_cast<size_t>(f)];
+    k.t_world_agent = SE3::fromParams(T_w + 7 * f);
+    k.exposure_time = exposure[f];
+    k.affine_brightness[0] = affine[2 * f];
+    k.affine_brightness[1] = affine[2 * f + 1];
+    k.level0 = PixelMapView{pixelinfo[f], width, height};
+    k.mask0 = MaskView{mask0 ? mask0[f] : nullptr, width, height};
+    k.mask_sparsity = MaskView{f + 1 == n_frames ? mask_sparsity_newest : nullptr, width / 2, height / 2};
+    if (f + 1 == n_frames) break;
+    k.n_active = n_active[f];
+    k.active_uv = active_uv + 2 * oa;
+    k.active_idepth = active_idepth + oa;
+    k.active_skip = active_skip + oa;
+    oa += static_cast<size_t>(n_active[f]);
+    for (int i = 0; i < n_immature[f]; ++i, ++oi) {
+      ImmatureLandmark lm;
+      lm.projection[0] = projection[2 * oi];
+      lm.projection[1] = projection[2 * oi + 1];
+      for (int c = 0; c < kPatternSize; ++c) lm.patch[c] = patch[kPatternSize * oi + c];
+      lm.idepth_min = idepth_min[oi];
+      lm.idepth_max = idepth_max[oi];
+      lm.uniqueness = uniqueness[oi];
+      lm.search_pixel_interval = search_pixel_interval[oi];
+      lm.status = status[oi];
+      lm.traced = traced[oi] != 0;
+      k.immature.push_back(lm);
+    }
+  }
+  const PinholeModel model{static_cast<double>(width), static_cast<double>(height), intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  const ActivationResult r = activateLandmarks(frames, model, sigma_huber_loss, static_cast<size_t>(number_of_desired_points),
+                                               *min_distance_to_neighbor, refine != 0);
+  oi = 0;
+  for (int f = 0; f + 1 < n_frames; ++f)
+    for (size_t i = 0; i < frames[static_cast<size_t>(f)].immature.size(); ++i, ++oi) {
+      const ImmatureLandmark &lm = frames[static_cast<size_t>(f)].immature[i];
+      idepth_min[oi] = lm.idepth_min;
+      idepth_max[oi] = lm.idepth_max;
+      status[oi] = lm.status;
+      activation_status[oi] = r.statuses[static_cast<size_t>(f)][i];
+    }
+  return static_cast<int>(r.number_of_active_points);
 }
 
 int orc_build_epipolar_segment(int width, int height, const double intrinsics[4], const double T_target_reference[7],

@@ -113,6 +113,17 @@ int orc_estimate_depths(int width, int height, const double *target_pixelinfo, c
                         const double *projection, const double *direction, const double *patch, const double *gradient,
                         double *idepth_min, double *idepth_max, double *uniqueness, double *search_pixel_interval,
                         uint8_t *status, uint8_t *traced);
+/* LandmarksActivator::activate (landmarks_activator.cpp:351-391) + the immature-landmark side of
+ * applyImmatureLandmarkActivationStatuses.  Frames oldest first, the newest keyframe last (it has no landmarks yet); all
+ * per-landmark arrays are the concatenation over frames 0..n_frames-2.  idepth_min/max and status are in/out;
+ * activation_status: 0 activate, 1 skip, 2 delete.  Returns number_of_active_points. */
+int orc_activate_landmarks(int n_frames, int width, int height, const double *const *pixelinfo, const uint8_t *const *mask0,
+                           const uint8_t *mask_sparsity_newest, const double *T_w, const double *exposure, const double *affine,
+                           const double intrinsics[4], const int32_t *n_active, const double *active_uv, const double *active_idepth,
+                           const uint8_t *active_skip, const int32_t *n_immature, const double *projection, const double *patch,
+                           double *idepth_min, double *idepth_max, const double *uniqueness, const double *search_pixel_interval,
+                           uint8_t *status, const uint8_t *traced, double sigma_huber_loss, int number_of_desired_points,
+                           double *min_distance_to_neighbor, int refine, uint8_t *activation_status);
 /* EpipolarLineBuilder::buildSegment: returns the number of points, fills up to cap (projection 2 each, reference idepth) */
 int orc_build_epipolar_segment(int width, int height, const double intrinsics[4], const double T_target_reference[7],
                                const double observed[2], double idepth_min, double idepth_max, int cap, double *projections,

@@ -291,6 +291,53 @@ def estimate_depths(lms, target_pixelinfo, mask, intrinsics, T_target_reference,
     return lms
 
 
+ACTIVATION_STATUS = dict(activate=0, skip=1, delete=2)
+
+
+def activate_landmarks(frames, intrinsics, sigma_huber_loss=20.0, number_of_desired_points=2000, min_distance_to_neighbor=0.0, refine=True,
+                       mask_sparsity_newest=None):
+    """LandmarksActivator::activate (landmarks_activator.cpp:351-391).  frames: list of dicts, oldest first, newest keyframe
+    last: pixelinfo (H x W x 3), mask (H x W u8 or None), T_w (7), exposure, affine (2); all but the last also active_uv,
+    active_idepth, active_skip and `immature` (the dict of new_immature_landmarks, updated in place).
+    Returns (statuses per frame, number_of_active_points, new min_distance_to_neighbor)."""
+    F = len(frames)
+    H, W = frames[0]["pixelinfo"].shape[:2]
+    pix = [_f64(f["pixelinfo"]) for f in frames]
+    masks = [None if f.get("mask") is None else np.ascontiguousarray(f["mask"], dtype=np.uint8) for f in frames]
+    pix_arr = (C.c_void_p * F)(*[_p(p) for p in pix])
+    mask_arr = (C.c_void_p * F)(*[_p(m, np.uint8) for m in masks])
+    T_w = _f64(np.concatenate([_f64(f["T_w"]) for f in frames]))
+    expo = _f64([f.get("exposure", 1.0) for f in frames])
+    aff = _f64(np.concatenate([_f64(f.get("affine", (0, 0))) for f in frames]))
+    old = frames[:-1]
+    n_active = np.array([len(f["active_idepth"]) for f in old], dtype=np.int32)
+    n_imm = np.array([len(f["immature"]["status"]) for f in old], dtype=np.int32)
+    cat = lambda arrs, dt, w: np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=dt).reshape(-1, w) for a in arrs]).ravel(), dtype=dt)
+    a_uv, a_id, a_skip = cat([f["active_uv"] for f in old], np.float64, 2), cat([f["active_idepth"] for f in old], np.float64, 1), \
+        cat([f["active_skip"] for f in old], np.uint8, 1)
+    im = lambda k, dt, w: cat([f["immature"][k] for f in old], dt, w)
+    proj, patch = im("projection", np.float64, 2), im("patch", np.float64, 8)
+    imin, imax, uniq, spi = im("idepth_min", np.float64, 1), im("idepth_max", np.float64, 1), im("uniqueness", np.float64, 1), \
+        im("search_pixel_interval", np.float64, 1)
+    status, traced = im("status", np.uint8, 1), im("traced", np.uint8, 1)
+    act = np.zeros(int(n_imm.sum()), dtype=np.uint8)
+    dist = C.c_double(min_distance_to_neighbor)
+    ms = None if mask_sparsity_newest is None else np.ascontiguousarray(mask_sparsity_newest, dtype=np.uint8)
+    fn = lib().orc_activate_landmarks
+    fn.restype = C.c_int
+    n_pts = fn(F, W, H, pix_arr, mask_arr, _p(ms, np.uint8), _p(T_w), _p(expo), _p(aff), _p(_f64(intrinsics)), _p(n_active, np.int32), _p(a_uv),
+               _p(a_id), _p(a_skip, np.uint8), _p(n_imm, np.int32), _p(proj), _p(patch), _p(imin), _p(imax), _p(uniq), _p(spi),
+               _p(status, np.uint8), _p(traced, np.uint8), C.c_double(sigma_huber_loss), int(number_of_desired_points), C.byref(dist),
+               int(bool(refine)), _p(act, np.uint8))
+    out, o = [], 0
+    for f, n in zip(old, n_imm):
+        f["immature"]["idepth_min"], f["immature"]["idepth_max"] = imin[o:o + n].copy(), imax[o:o + n].copy()
+        f["immature"]["status"] = status[o:o + n].copy()
+        out.append(act[o:o + n].copy())
+        o += n
+    return out, n_pts, dist.value
+
+
 def build_epipolar_segment(width, height, intrinsics, T_target_reference, observed, idepth_min=0.0, idepth_max=1000.0, cap=8192):
     proj, idp = np.zeros((cap, 2)), np.zeros(cap)
     n = lib().orc_build_epipolar_segment(int(width), int(height), _p(_f64(intrinsics)), _p(_f64(T_target_reference)), _p(_f64(observed)),

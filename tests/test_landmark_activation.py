@@ -1,0 +1,266 @@
+"""Row f-3: activation of immature landmarks (src/tracker/landmarks_activator/src/landmarks_activator.cpp).
+CPU: the oracle restatement against statements that do not share its code — the sparsity selection must equal a brute-force
+NumPy greedy pass over explicitly reprojected points, the P-regulator its closed form, and the 1-D refinement must move
+the activated landmarks onto the ground-truth inverse depth.  GPU: the HIP activator against the oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from dsopp_amd import synthetic as syn
+
+W, H = 320, 240
+
+
+def _rel(T_w_t, T_w_r):
+    return np.linalg.inv(T_w_t) @ T_w_r
+
+
+def build_case(num_frames=5, per_frame=260, seed=83, observe=True):
+    """a window of `num_frames` keyframes (the last one is the new keyframe without landmarks); the first 100 landmarks of
+    every older keyframe are active, the others immature with the estimator state two depth-estimation passes leave"""
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=num_frames, num_points=num_frames * per_frame, width=W, height=H, seed=seed, pose_noise=False,
+                          affine_jitter=True)
+    intr = win.scene.intrinsics
+    rng = np.random.default_rng(seed)
+    frames = []
+    for i, f in enumerate(win.frames):
+        # the images are rendered as exp(a) * texture + b with exposure 1; a non-trivial exposure is folded out of `a` so that
+        # (e_t / e_r) * exp(a_t - a_r) stays the true brightness ratio
+        expo = 1.0 + 0.05 * i
+        d = dict(pixelinfo=f.pixelinfo, mask=None, T_w=syn.mat_to_params(f.T_w_c_gt), exposure=expo,
+                 affine=np.array([f.affine_gt[0] - np.log(expo), f.affine_gt[1]]), syn=f)
+        if i + 1 < num_frames:
+            na = 100
+            d["active_uv"], d["active_idepth"] = f.uv[:na].copy(), f.idepth_init[:na].copy()
+            skip = np.zeros(na, dtype=np.uint8)
+            skip[rng.choice(na, 7, replace=False)] = 1
+            d["active_skip"] = skip
+            d["active_patch"] = f.patch[:na].copy()
+            uv = f.uv[na:]
+            ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+            grad = np.stack([f.pixelinfo[vi, ui, 1], f.pixelinfo[vi, ui, 2]], axis=1)
+            direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+            lms = po.new_immature_landmarks(uv, direction, f.patch[na:], grad)
+            if observe:   # two observations from later keyframes give the intervals / uniqueness a realistic spread
+                for j in (i + 1, num_frames - 1):
+                    if j == i or j >= num_frames:
+                        continue
+                    g = win.frames[j]
+                    po.estimate_depths(lms, g.pixelinfo, None, intr, syn.mat_to_params(_rel(g.T_w_c_gt, f.T_w_c_gt)), d["exposure"], d["affine"],
+                                       1.0 + 0.05 * j, np.array([g.affine_gt[0] - np.log(1.0 + 0.05 * j), g.affine_gt[1]]))
+            d["immature"] = lms
+            d["idepth_gt"] = f.idepth_gt[na:].copy()
+        frames.append(d)
+    return win, frames, intr
+
+
+def _reproject_half(intr, T, uv, rho):
+    """explicit pinhole chain at pyramid level 1 (intrinsics and pixel coordinates halved)"""
+    fx, fy, cx, cy = np.asarray(intr) / 2
+    u, v = uv[0] / 2, uv[1] / 2
+    ok = -1e-4 < rho < 1010 and 4 <= u <= W / 2 - 5 and 4 <= v <= H / 2 - 5
+    X = T[:3, :3] @ np.array([(u - cx) / fx, (v - cy) / fy, 1.0]) + rho * T[:3, 3]
+    q = np.array([fx * X[0] / X[2] + cx, fy * X[1] / X[2] + cy])
+    ok = ok and X[2] > 0 and 4 <= q[0] <= W / 2 - 5 and 4 <= q[1] <= H / 2 - 5
+    return q, ok
+
+
+def _ready(l, i):
+    return l["status"][i] in (0, 1, 3, 4) and l["search_pixel_interval"][i] < 8 and l["uniqueness"][i] > 3 and \
+        0.5 * l["idepth_min"][i] + 0.5 * l["idepth_max"][i] > 0
+
+
+def _brute_force(frames, intr, distance):
+    T_new = syn.params_to_mat(frames[-1]["T_w"])
+    pts, count = [], 0
+    for f in frames[:-1]:
+        T = _rel(T_new, syn.params_to_mat(f["T_w"]))
+        for uv, rho, skip in zip(f["active_uv"], f["active_idepth"], f["active_skip"]):
+            if skip:
+                continue
+            count += 1
+            q, ok = _reproject_half(intr, T, uv, rho)
+            if ok:
+                pts.append(q)
+    out = []
+    for f in frames[:-1]:
+        T = _rel(T_new, syn.params_to_mat(f["T_w"]))
+        l = f["immature"]
+        st = np.zeros(len(l["status"]), dtype=np.uint8)
+        for i in range(len(st)):
+            if l["status"][i] == 6 or not l["traced"][i] or l["status"][i] == 2:
+                st[i] = 2
+            elif not _ready(l, i):
+                st[i] = 2 if l["status"][i] == 1 else 1
+            else:
+                q, ok = _reproject_half(intr, T, l["projection"][i], 0.5 * l["idepth_min"][i] + 0.5 * l["idepth_max"][i])
+                if not ok:
+                    st[i] = 2
+                elif len(pts) == 0 or np.min(np.hypot(*(np.array(pts) - q).T)) >= distance:
+                    pts.append(q)
+                    st[i] = 0
+                else:
+                    st[i] = 1
+        out.append(st)
+    return out, count
+
+
+@pytest.fixture(scope="module")
+def case():
+    return build_case()
+
+
+def test_sparsity_selection_equals_brute_force(case):
+    from oracle import pyoracle as po
+    _, frames, intr = case
+    for dist0, desired in ((1.2, 372), (0.0, 10000), (9.0, 100)):
+        fr = copy.deepcopy(frames)
+        st, n_active, dist = po.activate_landmarks(fr, intr, 20.0, desired, dist0, refine=False)
+        assert n_active == 4 * 93
+        expect = float(np.clip(dist0 + (n_active - desired) * 0.001, 0, 10))
+        assert abs(dist - expect) < 1e-12
+        ref, count = _brute_force(frames, intr, dist)
+        assert count == n_active
+        for a, b in zip(st, ref):
+            assert np.array_equal(a, b), np.flatnonzero(a != b)
+        allst = np.concatenate(st)
+        assert (allst == 2).sum() > 10
+        if dist0 == 1.2:
+            assert (allst == 0).sum() > 100 and (allst == 1).sum() > 100, np.bincount(allst)   # every class present
+        if dist0 == 0.0:
+            assert dist == 0.0 and (allst == 0).sum() > 400   # distance 0: nothing is ever a neighbour
+        # activated / deleted landmarks are dead afterwards, skipped ones keep their state (active_keyframe.cpp:232-235)
+        for f_old, f_new, s in zip(frames[:-1], fr[:-1], st):
+            assert np.all(f_new["immature"]["status"][s != 1] == 6)
+            assert np.array_equal(f_new["immature"]["status"][s == 1], f_old["immature"]["status"][s == 1])
+
+
+def test_refinement_moves_activated_landmarks_to_ground_truth(case):
+    from oracle import pyoracle as po
+    _, frames, intr = case
+    fr = copy.deepcopy(frames)
+    st0, _, _ = po.activate_landmarks(copy.deepcopy(frames), intr, 20.0, 372, 2.0, refine=False)
+    st, _, _ = po.activate_landmarks(fr, intr, 20.0, 372, 2.0, refine=True)
+    before, after = [], []
+    for f_old, f_new, s0, s in zip(frames[:-1], fr[:-1], st0, st):
+        assert np.all((s == s0) | ((s0 == 0) & (s == 2)))   # the refinement only ever turns an activation into a deletion
+        a = s == 0
+        l0, l1 = f_old["immature"], f_new["immature"]
+        assert np.array_equal(l1["idepth_min"][a], l1["idepth_max"][a])
+        assert np.array_equal(l1["idepth_min"][~a], l0["idepth_min"][~a])
+        gt = f_old["idepth_gt"][a]
+        before.append(np.abs(0.5 * (l0["idepth_min"][a] + l0["idepth_max"][a]) - gt) / gt)
+        after.append(np.abs(l1["idepth_min"][a] - gt) / gt)
+    before, after = np.concatenate(before), np.concatenate(after)
+    assert len(after) > 100
+    assert np.median(after) < 0.5 * np.median(before) and np.median(after) < 5e-3, (np.median(before), np.median(after))
+
+
+def _with_masks(frames):
+    """a masked band in every level-0 image (refinement) and a masked corner of the newest keyframe at level 1 (sparsity)"""
+    fr = copy.deepcopy(frames)
+    for i, f in enumerate(fr):
+        m = np.full((H, W), 255, dtype=np.uint8)
+        m[60 + 10 * i:70 + 10 * i, :] = 0
+        f["mask"] = m
+    ms = np.full((H // 2, W // 2), 255, dtype=np.uint8)
+    ms[:40, :50] = 0
+    return fr, ms
+
+
+def test_masks_delete_and_block(case):
+    from oracle import pyoracle as po
+    _, frames, intr = case
+    fr, ms = _with_masks(frames)
+    st_m, _, _ = po.activate_landmarks(fr, intr, 20.0, 372, 1.2, refine=True, mask_sparsity_newest=ms)
+    st_0, _, _ = po.activate_landmarks(copy.deepcopy(frames), intr, 20.0, 372, 1.2, refine=True)
+    a, b = np.concatenate(st_m), np.concatenate(st_0)
+    assert (a == 2).sum() > (b == 2).sum() + 10   # candidates that land on the masked corner are deleted (:112-115)
+
+
+def _run_gpu(frames, intr, ms, desired, dist0, refine, dtype=None):
+    from dsopp_amd import capi
+    opts = capi.default_pba_options()
+    if dtype is not None:
+        opts.dtype = dtype
+    g = capi.HipWindow(opts)
+    sets = []
+    for i, f in enumerate(frames[:-1]):
+        g.push_frame(i, 1000 * (i + 1), f["pixelinfo"], f.get("mask"), intr, f["T_w"], f["exposure"], f["affine"], i == 0, False)
+        g.set_landmarks(i, f["active_uv"], f["active_idepth"], f["active_patch"], (f["active_skip"] * (1 + (np.arange(len(f["active_skip"])) % 2))).astype(np.uint8))
+        s = capi.ImmatureSet(f["immature"])
+        s.upload(f["immature"])
+        sets.append(s)
+    for i in range(len(frames) - 1):
+        for j in range(len(frames) - 1):
+            if i != j:
+                g.set_connection(i, j, np.zeros(len(frames[i]["active_idepth"]), dtype=np.uint8))
+    new = frames[-1]
+    pyr = capi.Pyramid(W, H, 2, opts.dtype)
+    pyr.set_level(0, new["pixelinfo"])
+    if new.get("mask") is not None:
+        pyr.set_mask(0, new["mask"])
+    if ms is not None:
+        pyr.set_mask(1, ms)
+    st, idp, res = g.activate_landmarks(list(range(len(frames) - 1)), sets, pyr, new["T_w"], new["exposure"], new["affine"], desired, dist0, refine)
+    states = [s.download() for s in sets]
+    for s in sets:
+        s.close()
+    pyr.close()
+    g.close()
+    return st, idp, res, states
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("refine", [False, True])
+def test_gpu_activation_matches_oracle(case, masked, refine):
+    """statuses identical (the sparsity test is a strict `<` on distances of points the two sides compute to ~1e-13 px, ties
+    do not occur), refined inverse depths to 1e-9 relative, set state (interval, status) as the oracle leaves it"""
+    from oracle import pyoracle as po
+    _, frames, intr = case
+    fr, ms = _with_masks(frames) if masked else (copy.deepcopy(frames), None)
+    for dist0, desired in ((1.2, 372), (0.0, 10000), (9.5, 100)):
+        fo = copy.deepcopy(fr)
+        st_o, n_act, dist_o = po.activate_landmarks(fo, intr, 20.0, desired, dist0, refine=refine, mask_sparsity_newest=ms)
+        st_g, idp_g, res, states = _run_gpu(fr, intr, ms, desired, dist0, refine)
+        assert res["number_of_active_points"] == n_act
+        assert abs(res["min_distance_to_neighbor"] - dist_o) < 1e-12
+        for k, (a, b) in enumerate(zip(st_o, st_g)):
+            assert np.array_equal(a, b), (dist0, k, np.flatnonzero(a != b), a[a != b], b[a != b])
+        tot = np.concatenate(st_g)
+        assert res["n_activated"] == (tot == 0).sum() and res["n_skipped"] == (tot == 1).sum() and res["n_deleted"] == (tot == 2).sum()
+        for f_o, s_g, idp, st in zip(fo[:-1], states, idp_g, st_o):
+            lo = f_o["immature"]
+            assert np.array_equal(lo["status"], s_g["status"])
+            for key in ("idepth_min", "idepth_max"):
+                assert np.abs(lo[key] - s_g[key]).max() <= 1e-9 * max(1.0, np.abs(lo[key]).max()), key
+            mid = 0.5 * lo["idepth_min"] + 0.5 * lo["idepth_max"]
+            assert np.abs(mid - idp).max() <= 1e-9 * max(1.0, np.abs(mid).max())
+        if dist0 == 1.2:
+            assert res["n_activated"] > 100 and res["selection_rounds"] >= 2
+
+
+@pytest.mark.gpu
+def test_gpu_activation_f32_pyramids(case):
+    """float texels: the selection does not read intensities (identical statuses without refinement); with it the
+    refined inverse depths agree to float accuracy on the landmarks both sides keep"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    _, frames, intr = case
+    fo = copy.deepcopy(frames)
+    st_o, _, _ = po.activate_landmarks(fo, intr, 20.0, 372, 1.2, refine=False)
+    st_g, _, _, _ = _run_gpu(frames, intr, None, 372, 1.2, False, dtype=capi.F32)
+    for a, b in zip(st_o, st_g):
+        assert np.array_equal(a, b)
+    fo = copy.deepcopy(frames)
+    st_o, _, _ = po.activate_landmarks(fo, intr, 20.0, 372, 1.2, refine=True)
+    st_g, idp_g, _, _ = _run_gpu(frames, intr, None, 372, 1.2, True, dtype=capi.F32)
+    same = np.concatenate(st_o) == np.concatenate(st_g)
+    assert same.mean() > 0.99
+    for f_o, idp, a, b in zip(fo[:-1], idp_g, st_o, st_g):
+        keep = (a == 0) & (b == 0)
+        mid = f_o["immature"]["idepth_min"][keep]
+        assert np.abs(mid - idp[keep]).max() <= 2e-4 * np.abs(mid).max()
