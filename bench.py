@@ -181,6 +181,7 @@ def main():
         extras["f32_mode"] = run_f32_mode(capi, syn, win, F, P_local)
         extras["tracker"] = run_tracker_timing(capi, syn, torch)
         extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
+        extras["landmark_activation"] = run_landmark_activation_timing(capi, syn, args)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -422,6 +423,77 @@ def run_depth_estimation_timing(capi, syn, args, repeats=10):
         out["cpu_port_ms_per_frame"] = (time.perf_counter() - t0) * 1e3
         out["cpu_port_threads"] = 1
     pyr.close()
+    return out
+
+
+def run_landmark_activation_timing(capi, syn, args, repeats=10):
+    """row f-3: LandmarksActivator::activate when a new 640x480 keyframe arrives (monocular_tracker.cpp:495): 6 window
+    keyframes x (286 active + 1500 immature landmarks), sparsity selection at pyramid level 1 + 3-iteration idepth refinement
+    of every selected landmark over the 6 other keyframes.  The immature landmarks carry the estimator state two device
+    depth-estimation passes leave.  GPU call = three launches + one packed read-back of statuses and inverse depths."""
+    W, H, KF, NA, NI = 640, 480, 6, 286, 1500
+    win = syn.make_window(num_frames=KF + 1, num_points=(KF + 1) * (NA + NI), width=W, height=H, seed=9, pose_noise=False)
+    intr = win.scene.intrinsics
+    new = win.frames[-1]
+    pyramids = []
+    for f in win.frames:
+        p = capi.Pyramid(W, H, 2)
+        p.set_level(0, f.pixelinfo)
+        pyramids.append(p)
+    g = capi.HipWindow(capi.default_pba_options())
+    dsets, states = [], []
+    fmax = float(np.finfo(np.float64).max)
+    for i, f in enumerate(win.frames[:KF]):
+        g.push_frame(f.frame_id, f.timestamp, None, None, intr, syn.mat_to_params(f.T_w_c_gt), 1.0, np.zeros(2), i == 0, False, pyramid=pyramids[i])
+        g.set_landmarks(f.frame_id, f.uv[:NA], f.idepth_init[:NA], f.patch[:NA], np.zeros(NA, dtype=np.uint8))
+        uv = f.uv[NA:]
+        ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+        n = len(uv)
+        lms = dict(projection=uv, direction=np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(n)], axis=1),
+                   patch=f.patch[NA:], gradient=np.stack([f.pixelinfo[vi, ui, 1], f.pixelinfo[vi, ui, 2]], axis=1), status=np.full(n, 5, dtype=np.uint8))
+        ds = capi.ImmatureSet(lms)
+        for j in (i + 1, KF):   # traced in the next keyframe and in the new one
+            t = win.frames[j]
+            ds.estimate(pyramids[j], 0, intr, syn.mat_to_params(np.linalg.inv(t.T_w_c_gt) @ f.T_w_c_gt))
+        states.append(ds.download())
+        dsets.append(ds)
+    for a in win.frames[:KF]:
+        for b in win.frames[:KF]:
+            if a is not b:
+                g.set_connection(a.frame_id, b.frame_id, np.zeros(NA, dtype=np.uint8))
+    ids = [f.frame_id for f in win.frames[:KF]]
+    t_gpu, res, st = [], None, None
+    for rep in range(repeats + 1):
+        for ds, s0 in zip(dsets, states):
+            ds.upload(s0)
+        t0 = time.perf_counter()
+        st, _, res = g.activate_landmarks(ids, dsets, pyramids[KF], syn.mat_to_params(new.T_w_c_gt), 1.0, (0, 0), KF * NA, 2.0, True)
+        if rep:
+            t_gpu.append(time.perf_counter() - t0)
+    out = {"workload": f"{KF} keyframes x ({NA} active + {NI} immature landmarks) against a new {W}x{H} keyframe, refinement on",
+           "gpu_ms_per_keyframe": float(np.median(t_gpu) * 1e3), "activated": res["n_activated"], "skipped": res["n_skipped"], "deleted": res["n_deleted"],
+           "selection_rounds": res["selection_rounds"], "min_distance_to_neighbor": res["min_distance_to_neighbor"],
+           "what": "project + grid-hash greedy selection + wave-per-landmark LM refinement + read-back"}
+    if not args.no_cpu:
+        from oracle import pyoracle as po
+        frames = []
+        for i, f in enumerate(win.frames):
+            d = dict(pixelinfo=f.pixelinfo, mask=None, T_w=syn.mat_to_params(f.T_w_c_gt), exposure=1.0, affine=np.zeros(2))
+            if i < KF:
+                lm = {k: np.array(v) for k, v in states[i].items()}
+                lm["projection"], lm["patch"] = f.uv[NA:], f.patch[NA:]
+                d.update(active_uv=f.uv[:NA], active_idepth=f.idepth_init[:NA], active_skip=np.zeros(NA, dtype=np.uint8), immature=lm)
+            frames.append(d)
+        t0 = time.perf_counter()
+        st_o, _, _ = po.activate_landmarks(frames, intr, 20.0, KF * NA, 2.0, refine=True)
+        out["cpu_port_ms_per_keyframe"] = (time.perf_counter() - t0) * 1e3
+        out["cpu_port_threads"] = 1
+        out["statuses_identical_to_cpu_port"] = bool(all(np.array_equal(a, b) for a, b in zip(st, st_o)))
+    for ds in dsets:
+        ds.close()
+    g.close()
+    for p in pyramids:
+        p.close()
     return out
 
 

@@ -412,4 +412,126 @@ class HipPoseAlignment {
   time_point target_time_ = 0;
 };
 
+/** The immature landmarks of one keyframe kept on the device for their lifetime (ActiveKeyframe::immature_landmarks_:
+ *  created by pushImmatureLandmarks, traced every frame by the depth estimator, consumed by the activator). */
+class DeviceImmatureSet {
+ public:
+  explicit DeviceImmatureSet(const std::vector<ImmatureLandmarkView> &landmarks, int device = 0, void *stream = nullptr)
+      : n_(landmarks.size()) {
+    std::vector<double> proj(2 * n_), dir(3 * n_), patch(8 * n_), grad(2 * n_);
+    for (size_t i = 0; i < n_; ++i) {
+      const ImmatureLandmarkView &l = landmarks[i];
+      for (size_t k = 0; k < 2; ++k) {
+        proj[2 * i + k] = l.projection[k];
+        grad[2 * i + k] = l.gradient[k];
+      }
+      for (size_t k = 0; k < 3; ++k) dir[3 * i + k] = l.direction[k];
+      for (size_t k = 0; k < 8; ++k) patch[8 * i + k] = l.patch[k];
+    }
+    check(dsopp_hip_immature_set_create(device, stream, static_cast<int32_t>(n_), proj.data(), dir.data(), patch.data(), grad.data(), &s_));
+    upload(landmarks);
+  }
+  ~DeviceImmatureSet() { dsopp_hip_immature_set_destroy(s_); }
+  DeviceImmatureSet(const DeviceImmatureSet &) = delete;
+  DeviceImmatureSet &operator=(const DeviceImmatureSet &) = delete;
+  dsopp_hip_immature_set *handle() const { return s_; }
+  size_t size() const { return n_; }
+  /** DepthEstimator::estimate on the resident set (asynchronous) */
+  void estimate(const DevicePyramid &target_frame, const Motion &t_t_r, double reference_exposure_time, const Vector2 &reference_affine_brightness,
+                double target_exposure_time, const Vector2 &target_affine_brightness, const PinholeModel &model, double sigma_huber_loss) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    check(dsopp_hip_immature_set_estimate(s_, target_frame.handle(), 0, intr, t_t_r.data(), reference_exposure_time, reference_affine_brightness.data(),
+                                          target_exposure_time, target_affine_brightness.data(), sigma_huber_loss));
+  }
+  void upload(const std::vector<ImmatureLandmarkView> &landmarks) {
+    std::vector<double> imin(n_), imax(n_), uniq(n_), spi(n_);
+    std::vector<uint8_t> status(n_), traced(n_);
+    for (size_t i = 0; i < n_; ++i) {
+      const ImmatureLandmarkView &l = landmarks[i];
+      imin[i] = l.idepth_min;
+      imax[i] = l.idepth_max;
+      uniq[i] = l.uniqueness;
+      spi[i] = l.search_pixel_interval;
+      status[i] = l.status;
+      traced[i] = l.traced ? 1 : 0;
+    }
+    check(dsopp_hip_immature_set_upload_state(s_, imin.data(), imax.data(), uniq.data(), spi.data(), status.data(), traced.data()));
+  }
+  void download(std::vector<ImmatureLandmarkView> &landmarks) const {
+    std::vector<double> imin(n_), imax(n_), uniq(n_), spi(n_);
+    std::vector<uint8_t> status(n_), traced(n_);
+    check(dsopp_hip_immature_set_download_state(s_, imin.data(), imax.data(), uniq.data(), spi.data(), status.data(), traced.data()));
+    for (size_t i = 0; i < n_; ++i) {
+      ImmatureLandmarkView &l = landmarks[i];
+      l.idepth_min = imin[i];
+      l.idepth_max = imax[i];
+      l.uniqueness = uniq[i];
+      l.search_pixel_interval = spi[i];
+      l.status = status[i];
+      l.traced = traced[i] != 0;
+    }
+  }
+
+ private:
+  size_t n_;
+  dsopp_hip_immature_set *s_ = nullptr;
+};
+
+/** ActiveKeyframe::ImmatureLandmarkActivationStatus — src/track/frames/include/track/frames/active_keyframe.hpp:40-44 */
+enum class ImmatureLandmarkActivationStatus : uint8_t { kActivate = 0, kSkip = 1, kDelete = 2 };
+
+/**
+ * tracker::LandmarksActivator<SE3, PinholeCamera, PixelMap, 1, REFINE>
+ * (src/tracker/landmarks_activator/include/tracker/landmarks_activator/landmarks_activator.hpp:31-57): same constructor
+ * arguments and the same persistent min_distance_to_neighbor_.  The track is what the HIP backend holds of it: the window
+ * solver (poses, affine brightness, images and active landmarks of the older keyframes), their device-resident immature
+ * sets, and the new keyframe that pushNewKeyframe just created (monocular_tracker.cpp:491-497 call order).
+ */
+template <bool REFINE = false>
+class HipLandmarksActivator {
+ public:
+  struct Track {
+    HipPhotometricBundleAdjustment *solver;          // holds every keyframe of activeFrames() but the newest
+    std::vector<int32_t> keyframe_ids;               // oldest first
+    std::vector<DeviceImmatureSet *> immature;       // per keyframe, nullptr = no immature landmarks
+    const KeyframeView *newest;                      // pose, exposure, affine brightness, pyramid (>= 2 levels)
+  };
+  explicit HipLandmarksActivator(double sigma_huber_loss = 9, size_t number_of_desired_points = 2000)
+      : sigma_huber_loss_(sigma_huber_loss), number_of_desired_points_(number_of_desired_points) {}
+  /** activate(track): returns the statuses applyImmatureLandmarkActivationStatuses consumes, per keyframe; `idepths` (optional)
+   *  receives landmark.idepth() after the refinement — what the new ActiveTrackingLandmark is constructed with */
+  std::vector<std::vector<ImmatureLandmarkActivationStatus>> activate(const Track &track, std::vector<std::vector<double>> *idepths = nullptr) {
+    const size_t n = track.keyframe_ids.size();
+    std::vector<dsopp_hip_immature_set *> sets(n, nullptr);
+    std::vector<std::vector<ImmatureLandmarkActivationStatus>> statuses(n);
+    std::vector<uint8_t *> st_ptr(n, nullptr);
+    std::vector<double *> id_ptr(n, nullptr);
+    if (idepths) idepths->assign(n, {});
+    for (size_t k = 0; k < n; ++k) {
+      if (!track.immature[k]) continue;
+      sets[k] = track.immature[k]->handle();
+      statuses[k].resize(track.immature[k]->size());
+      st_ptr[k] = reinterpret_cast<uint8_t *>(statuses[k].data());
+      if (idepths) {
+        (*idepths)[k].resize(track.immature[k]->size());
+        id_ptr[k] = (*idepths)[k].data();
+      }
+    }
+    const KeyframeView &nk = *track.newest;
+    check(dsopp_hip_window_activate_landmarks(track.solver->handle(), static_cast<int32_t>(n), track.keyframe_ids.data(), sets.data(),
+                                              nk.pyramids->handle(), nk.t_world_agent.data(), nk.exposure_time, nk.affine_brightness.data(),
+                                              static_cast<int32_t>(number_of_desired_points_), &min_distance_to_neighbor_, REFINE ? 1 : 0,
+                                              sigma_huber_loss_, st_ptr.data(), id_ptr.data(), &last_));
+    return statuses;
+  }
+  double minDistanceToNeighbor() const { return min_distance_to_neighbor_; }
+  const dsopp_hip_activation_result &lastResult() const { return last_; }
+
+ private:
+  double min_distance_to_neighbor_ = 2;  // landmarks_activator.hpp:51
+  const double sigma_huber_loss_;
+  const size_t number_of_desired_points_;
+  dsopp_hip_activation_result last_{};
+};
+
 }  // namespace dsopp_hip_host

@@ -1,6 +1,7 @@
 // Self-contained C++ driver of the host mirror classes (dsopp_hip_solvers.hpp): a 3-keyframe window over an analytic
 // scene (fronto-parallel textured plane at z = 4, camera translating along x), solved with
-// HipPhotometricBundleAdjustment, then one HipPoseAlignment of the third frame against the first.
+// HipPhotometricBundleAdjustment, then one HipPoseAlignment of the third frame against the first, the reference depth
+// maps, and the depth estimation + activation of immature landmarks when a fourth keyframe arrives.
 // Exit code 0 = energies decreased and the perturbed poses moved toward the ground truth.
 //   g++ -std=c++17 example_solvers.cpp -L../lib -ldsopp_hip -Wl,-rpath,$PWD/../lib -o example_solvers
 #include <cmath>
@@ -126,5 +127,51 @@ int main() {
   std::printf("alignment of the newest keyframe against its own depth map: rmse %.3f\n", rmse2);
   ok = ok && rmse2 >= 0 && rmse2 < 5;
   ok = ok && rmse > 0 && std::abs(Ta[4] - 0.2) < 0.015;
+
+  // a fourth keyframe arrives: trace the immature landmarks of keyframe 0 in it (depth estimation on the resident set), then
+  // let the activator pick and refine the ones that become active (LandmarksActivator::activate call order of the tracker)
+  const double tx_new = 0.3;
+  auto pyr_new = std::make_unique<DevicePyramid>(W, H, 2);
+  const std::vector<uint8_t> image_new = render(tx_new);
+  pyr_new->build(image_new.data());
+  std::vector<ImmatureLandmarkView> immature;
+  for (int k = 0; k < 200; ++k) {
+    ImmatureLandmarkView lm;
+    const int u = ux(rng), v = uy(rng);
+    lm.projection = {static_cast<double>(u), static_cast<double>(v)};
+    lm.direction = {(u - cx) / fx, (v - cy) / fy, 1.0};
+    static const int px[8] = {0, -1, 1, -2, 0, 2, -1, 0}, py[8] = {2, 1, 1, 0, 0, 0, -1, -2};
+    for (int p = 0; p < 8; ++p) lm.patch[static_cast<size_t>(p)] = images[0][static_cast<size_t>(v + py[p]) * W + u + px[p]];
+    const auto I0 = [&](int x, int y) { return static_cast<double>(images[0][static_cast<size_t>(y) * W + x]); };
+    lm.gradient = {0.5 * (I0(u + 1, v) - I0(u - 1, v)), 0.5 * (I0(u, v + 1) - I0(u, v - 1))};
+    lm.idepth_min = 0.8 / Z;  // as an earlier observation would have left it (the analytic texture is periodic: a search over
+    lm.idepth_max = 1.25 / Z;  // the whole epipolar line would lock onto the wrong period)
+    immature.push_back(lm);
+  }
+  DeviceImmatureSet dset(immature);
+  pba.updateFrame(frames[0]);
+  const Motion T0 = frames[0].t_world_agent;  // identity rotation in this example: T_new^-1 T_0 is a pure translation
+  dset.estimate(*pyr_new, Motion{0, 0, 0, 1, T0[4] - tx_new, T0[5], T0[6]}, 1.0, Vector2{0, 0}, 1.0, Vector2{0, 0}, model, 20.0);
+  KeyframeView fourth{};
+  fourth.keyframe_id = 3;
+  fourth.timestamp = 4000;
+  fourth.t_world_agent = {0, 0, 0, 1, tx_new, 0, 0};
+  fourth.exposure_time = 1;
+  fourth.affine_brightness = {0, 0};
+  fourth.pyramids = pyr_new.get();
+  HipLandmarksActivator<true> activator(20.0, 2000);
+  HipLandmarksActivator<true>::Track track{&pba, {0, 1, 2}, {&dset, nullptr, nullptr}, &fourth};
+  std::vector<std::vector<double>> new_idepths;
+  const auto act = activator.activate(track, &new_idepths);
+  int n_act = 0;
+  double worst = 0;
+  for (size_t i = 0; i < act[0].size(); ++i)
+    if (act[0][i] == ImmatureLandmarkActivationStatus::kActivate) {
+      ++n_act;
+      worst = std::max(worst, std::abs(new_idepths[0][i] - 1.0 / Z) * Z);
+    }
+  std::printf("activation: %d of %zu immature landmarks activated (%d skipped, %d deleted), worst relative idepth error %.4f, distance %.3f\n", n_act,
+              act[0].size(), activator.lastResult().n_skipped, activator.lastResult().n_deleted, worst, activator.minDistanceToNeighbor());
+  ok = ok && n_act > 20 && worst < 0.05;
   return ok ? 0 : 1;
 }
