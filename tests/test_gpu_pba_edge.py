@@ -118,6 +118,32 @@ def test_bench_configuration_full_size():
     g.close()
 
 
+@pytest.mark.parametrize("frames,points", [(7, 20000), (12, 50000)])
+def test_large_baseline_configurations(frames, points):
+    """the windows of BASELINE.json's 8-GPU configurations (C3: 7 KF / 20 000 points, C4: 12 KF / 50 000 points) solved whole on
+    one GPU against the CPU oracle (16 threads): the full 7-iteration LM solve, energies 1e-7 rel,
+    poses / affine 1e-7, plus the size-independent property that the energy per valid residual decreases"""
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=frames, num_points=points, width=640, height=480, seed=2)
+    from dsopp_amd import capi
+    po.set_threads(16)
+    o = _load(po.OracleWindow(po.default_pba_options()), win)
+    g = _load(capi.HipWindow(capi.default_pba_options()), win)
+    g.begin()
+    e_init, n_init = g.calculate_energy()
+    eo, ito, nvo = o.optimize()
+    eg, itg, nvg = g.optimize()
+    po.set_threads(1)
+    assert (ito, nvo) == (itg, nvg) and ito == 7
+    assert abs(eo - eg) <= 1e-7 * abs(eo)
+    for f in win.frames:
+        To, abo = o.get_pose(f.frame_id)
+        Tg, abg = g.get_pose(f.frame_id)
+        assert np.abs(To - Tg).max() <= 1e-7 and np.abs(abo - abg).max() <= 1e-7
+    assert eg / nvg < e_init / n_init
+    g.close()
+
+
 def test_snapshot_restore_is_idempotent(small_window):
     """restore() + optimize() must reproduce the first solve bit for bit (deterministic reductions, no atomics-order effects
     on the accepted state beyond the stated tolerance)"""
