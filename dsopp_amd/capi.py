@@ -36,6 +36,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_initialization_poses",
+    "dsopp_hip_depth_maps_mean_square_optical_flow",
     "dsopp_hip_window_activate_landmarks",
     "dsopp_hip_last_error", "dsopp_hip_device_count", "dsopp_hip_version", "dsopp_hip_default_pba_options",
     "dsopp_hip_default_align_options", "dsopp_hip_pyramid_create", "dsopp_hip_pyramid_destroy", "dsopp_hip_pyramid_build",
@@ -190,6 +192,13 @@ class DepthMaps:
         w, h = C.c_int32(), C.c_int32()
         _chk(lib().dsopp_hip_depth_maps_level_size(self._h, int(level), C.byref(w), C.byref(h)))
         return w.value, h.value
+
+    def mean_square_optical_flow(self, level, intrinsics, transforms):
+        """calculateMeanSquareOpticalFlow for a list of T_target_reference (7-vectors, at most 4); returns an array"""
+        T = _f64(np.concatenate([_f64(t) for t in transforms]))
+        out = np.zeros(len(transforms))
+        _chk(lib().dsopp_hip_depth_maps_mean_square_optical_flow(self._h, int(level), _p(_f64(intrinsics)), len(transforms), _p(T), _p(out)))
+        return out
 
     def get_level(self, level):
         """(idepth_sum, weight), each H x W"""
@@ -467,6 +476,16 @@ def estimate_depths(lms, target_pyramid: Pyramid, level, intrinsics, T_target_re
                                          _p(lms["idepth_min"]), _p(lms["idepth_max"]), _p(lms["uniqueness"]), _p(lms["search_pixel_interval"]),
                                          _p(lms["status"], np.uint8), _p(lms["traced"], np.uint8)))
     return lms
+
+
+def initialization_poses(T_world_previous, T_world_last, T_world_keyframe):
+    """initializationPoses of the tracker (monocular_tracker.cpp:136-176); T_world_previous None = fewer than two frames"""
+    out, n = np.zeros((128, 7)), C.c_int32()
+    if T_world_previous is None:
+        _chk(lib().dsopp_hip_initialization_poses(None, None, None, 128, _p(out), C.byref(n)))
+    else:
+        _chk(lib().dsopp_hip_initialization_poses(_p(_f64(T_world_previous)), _p(_f64(T_world_last)), _p(_f64(T_world_keyframe)), 128, _p(out), C.byref(n)))
+    return out[:n.value].copy()
 
 
 class ActivationResult(C.Structure):

@@ -827,6 +827,42 @@ int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, c
   });
 }
 
+int dsopp_hip_initialization_poses(const double T_world_previous[7], const double T_world_last[7], const double T_world_keyframe[7],
+                                   int32_t capacity, double *poses, int32_t *n) {
+  return guarded([&] {
+    if (!poses || !n || capacity < 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    std::vector<Rigid> init;
+    if (!T_world_previous || !T_world_last || !T_world_keyframe) {
+      init.push_back(rigidIdentity());  // track.frames().size() < 2, monocular_tracker.cpp:138
+    } else {
+      const double kMin = 1. * M_PI / 180., kMax = 3. * M_PI / 180., kStep = 0.5 * M_PI / 180.;  // :139-141
+      const Rigid t_w_r = rigidFromParams(T_world_last);
+      const Rigid t_r_t_prev = rigidMul(rigidInverse(rigidFromParams(T_world_previous)), t_w_r);  // :145
+      init.push_back(rigidMul(t_w_r, t_r_t_prev));                        // previous motion
+      init.push_back(rigidMul(rigidMul(t_w_r, t_r_t_prev), t_r_t_prev));  // double previous motion (frame skipped)
+      double xi[6];
+      rigidLog(t_r_t_prev, xi);
+      for (double &v : xi) v *= 0.5;
+      init.push_back(rigidMul(t_w_r, rigidExp(xi)));                      // half motion
+      init.push_back(t_w_r);                                              // zero motion
+      init.push_back(rigidFromParams(T_world_keyframe));                  // zero motion from keyframe
+      for (double delta = kMin; delta < kMax; delta += kStep)             // perturbed previous motion, :160-172
+        for (double rx : {0.0, delta, -delta})
+          for (double ry : {0.0, delta, -delta})
+            for (double rz : {0.0, delta, -delta}) {
+              const double rot[6] = {0, 0, 0, rx, ry, rz};
+              init.push_back(rigidMul(init[0], rigidExp(rot)));
+            }
+    }
+    *n = static_cast<int32_t>(init.size());
+    for (size_t i = 0; i < init.size() && static_cast<int32_t>(i) < capacity; ++i) {
+      Rigid T = init[i];
+      rigidNormalize(T);
+      rigidToParams(T, poses + 7 * i);
+    }
+  });
+}
+
 int dsopp_hip_aligner_set_lm_path(dsopp_hip_aligner *a, int path) {
   return guarded([&] {
     if (!a || path < 0 || path > 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");

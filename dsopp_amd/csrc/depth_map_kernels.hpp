@@ -93,4 +93,82 @@ __global__ void dilateDepthMapKernel(const double *__restrict__ in_id, const dou
   out_w[c] = w;
 }
 
+/** calculateMeanSquareOpticalFlow — src/tracker/tracker/src/monocular_tracker.cpp:104-134 — for up to kMaxFlowTransforms
+ *  relative poses in one pass over a depth-map level (the tracker asks for the flow of t_t_r and of t_t_r without its rotation
+ *  on every frame, :474-479).  One thread per pixel, per-workgroup partial sums {sum, count} per transform; the second
+ *  kernel adds the partials in index order (deterministic) and takes sqrt(sum / n). */
+constexpr int kMaxFlowTransforms = 4;
+struct FlowArgs {
+  double M[kMaxFlowTransforms][12];  // reproject_ = K [R|t] K^-1
+  double cx, cy, ifx, ify;
+  int width, height, n_transforms;
+};
+__global__ void __launch_bounds__(256) opticalFlowPartialsKernel(const double *__restrict__ idsum, const double *__restrict__ wgt, FlowArgs a,
+                                                                 double *__restrict__ partials) {
+  __shared__ double lds[4 * 2 * kMaxFlowTransforms];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  double sum[kMaxFlowTransforms], cnt[kMaxFlowTransforms];
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) sum[t] = cnt[t] = 0;
+  if (x >= 4 && x < a.width - 4 && y >= 4 && y < a.height - 4) {
+    const size_t c = static_cast<size_t>(y) * a.width + x;
+    const double w = wgt[c];
+    if (w > 0) {
+      const double idepth = idsum[c] / w;
+      if (!(idepth < 1e-6)) {
+        const double u = x, v = y, W = a.width, H = a.height;
+        const double ax = (u - a.cx) * a.ifx, ay = (v - a.cy) * a.ify;  // PinholeCamera::unproject, pinhole_camera.hpp:129-141
+#pragma unroll
+        for (int t = 0; t < kMaxFlowTransforms; ++t) {
+          if (t >= a.n_transforms) break;
+          const double *M = a.M[t];
+          const double px = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
+          const double py = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
+          const double pz = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
+          const double tu = px / pz, tv = py / pz;
+          if (validIdepth(idepth) && insideROI(u, v, W, H) && (pz > 0) && insideROI(tu, tv, W, H)) {  // camera_reproject.hpp:270-293
+            const double bx = (tu - a.cx) * a.ifx, by = (tv - a.cy) * a.ify;
+            sum[t] = (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+            cnt[t] = 1;
+          }
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) {
+    double s = sum[t], n = cnt[t];
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_down(s, off);
+      n += __shfl_down(n, off);
+    }
+    if (lane == 0) {
+      lds[(wave * kMaxFlowTransforms + t) * 2] = s;
+      lds[(wave * kMaxFlowTransforms + t) * 2 + 1] = n;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kMaxFlowTransforms) {
+    double s = 0;
+    for (int wv = 0; wv < 4; ++wv) s += lds[wv * 2 * kMaxFlowTransforms + threadIdx.x];
+    partials[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 2 * kMaxFlowTransforms + threadIdx.x] = s;
+  }
+}
+__global__ void __launch_bounds__(64) opticalFlowFinishKernel(const double *__restrict__ partials, int n_blocks, int n_transforms, double *__restrict__ out) {
+  const int lane = threadIdx.x;
+  for (int t = 0; t < n_transforms; ++t) {
+    double s = 0, n = 0;
+    for (int b = lane; b < n_blocks; b += 64) {
+      s += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2];
+      n += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2 + 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_down(s, off);
+      n += __shfl_down(n, off);
+    }
+    if (lane == 0) out[t] = sqrt(s / n);  // 0 / 0 = NaN for an empty map, as in the reference
+  }
+}
+
 }  // namespace dsopp_hip

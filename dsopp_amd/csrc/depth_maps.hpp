@@ -21,4 +21,5 @@ struct dsopp_hip_depth_maps {
     dsopp_hip::DeviceBuffer<double> u, v, idepth, intensity;
   };
   mutable std::vector<LevelPoints> points;
+  mutable dsopp_hip::DeviceBuffer<double> flow_scratch;  // per-workgroup partials of the optical-flow measure
 };

@@ -2126,6 +2126,52 @@ int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {
 
 }  // extern "C"
 
+int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m, int32_t level, const double intrinsics[4], int32_t n_transforms,
+                                                  const double *T_target_reference, double *flow) {
+  return guarded([&] {
+    if (!m || !intrinsics || !T_target_reference || !flow) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (level < 0 || level >= m->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level %d out of range (%d levels)", level, m->levels);
+    if (n_transforms < 1 || n_transforms > kMaxFlowTransforms) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_transforms must be in [1, %d]", kMaxFlowTransforms);
+    m->sr.use();
+    hipStream_t st = m->sr.stream;
+    FlowArgs a;
+    std::memset(&a, 0, sizeof(a));
+    const double fx = intrinsics[0], fy = intrinsics[1], cx = intrinsics[2], cy = intrinsics[3];
+    for (int t = 0; t < n_transforms; ++t) {
+      const Rigid T = rigidFromParams(T_target_reference + 7 * t);
+      const double ifx = 1.0 / fx, ify = 1.0 / fy, k02 = -cx / fx, k12 = -cy / fy;
+      double U[12];
+      for (int i = 0; i < 3; ++i) {
+        U[4 * i + 0] = T.R[3 * i + 0] * ifx;
+        U[4 * i + 1] = T.R[3 * i + 1] * ify;
+        U[4 * i + 2] = T.R[3 * i + 0] * k02 + T.R[3 * i + 1] * k12 + T.R[3 * i + 2];
+        U[4 * i + 3] = T.t[i];
+      }
+      for (int j = 0; j < 4; ++j) {
+        a.M[t][0 + j] = fx * U[0 + j] + cx * U[8 + j];
+        a.M[t][4 + j] = fy * U[4 + j] + cy * U[8 + j];
+        a.M[t][8 + j] = U[8 + j];
+      }
+    }
+    a.cx = cx;
+    a.cy = cy;
+    a.ifx = 1 / fx;
+    a.ify = 1 / fy;
+    a.width = m->width[static_cast<size_t>(level)];
+    a.height = m->height[static_cast<size_t>(level)];
+    a.n_transforms = n_transforms;
+    const dim3 grid(static_cast<unsigned>((a.width + 255) / 256), static_cast<unsigned>(a.height));
+    const size_t n_blocks = static_cast<size_t>(grid.x) * grid.y;
+    m->flow_scratch.reserve(n_blocks * 2 * kMaxFlowTransforms + kMaxFlowTransforms, 0, st);
+    double *out = m->flow_scratch.ptr + n_blocks * 2 * kMaxFlowTransforms;
+    opticalFlowPartialsKernel<<<grid, 256, 0, st>>>(m->idepth_sum[static_cast<size_t>(level)].ptr, m->weight[static_cast<size_t>(level)].ptr, a, m->flow_scratch.ptr);
+    opticalFlowFinishKernel<<<1, 64, 0, st>>>(m->flow_scratch.ptr, static_cast<int>(n_blocks), n_transforms, out);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(flow, out, sizeof(double) * static_cast<size_t>(n_transforms), hipMemcpyDeviceToHost, st));
+    m->sr.sync();
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // activation of immature landmarks (row f-3)
 // ---------------------------------------------------------------------------------------------------------------------

@@ -116,6 +116,35 @@ DSOPP_HD Rigid rigidExp(const double *xi) {
   return T;
 }
 
+/** log of a rigid transform, tangent (upsilon, omega): omega from the unit quaternion (2 atan(|v| / w) / |v| * v, series for
+ *  small |v|), upsilon = V^-1 t with V^-1 = I - W/2 + (1 - th cos(th/2) / (2 sin(th/2))) / th^2 W^2 — the inverse of rigidExp
+ *  (reference: SE3::log of Sophus through se3_motion.hpp, call site monocular_tracker.cpp:153) */
+DSOPP_HD void rigidLog(const Rigid &T, double *xi) {
+  double p[7];
+  rigidToParams(T, p);
+  const double kEps = 1e-10;
+  const double squared_n = p[0] * p[0] + p[1] * p[1] + p[2] * p[2], w = p[3];
+  double k;
+  if (squared_n < kEps * kEps) {
+    k = 2.0 / w - (2.0 / 3.0) * squared_n / (w * w * w);
+  } else {
+    const double n = sqrt(squared_n);
+    k = fabs(w) < kEps ? (w > 0 ? 3.14159265358979323846 : -3.14159265358979323846) / n : 2.0 * atan(n / w) / n;
+  }
+  const double wx = k * p[0], wy = k * p[1], wz = k * p[2];
+  const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+  const double c = th < kEps ? 1.0 / 12.0 : (1.0 - 0.5 * th * cos(0.5 * th) / sin(0.5 * th)) / th2;
+  const double *t = T.t;
+  const double c1x = wy * t[2] - wz * t[1], c1y = wz * t[0] - wx * t[2], c1z = wx * t[1] - wy * t[0];
+  const double c2x = wy * c1z - wz * c1y, c2y = wz * c1x - wx * c1z, c2z = wx * c1y - wy * c1x;
+  xi[0] = t[0] - 0.5 * c1x + c * c2x;
+  xi[1] = t[1] - 0.5 * c1y + c * c2y;
+  xi[2] = t[2] - 0.5 * c1z + c * c2z;
+  xi[3] = wx;
+  xi[4] = wy;
+  xi[5] = wz;
+}
+
 DSOPP_HD Rigid rigidMul(const Rigid &a, const Rigid &b) {
   Rigid c;
 #pragma unroll

@@ -177,6 +177,15 @@ class DeviceDepthMaps {
   DeviceDepthMaps &operator=(const DeviceDepthMaps &) = delete;
   DeviceDepthMaps(DeviceDepthMaps &&o) noexcept : m_(o.m_) { o.m_ = nullptr; }
   const dsopp_hip_depth_maps *handle() const { return m_; }
+  /** calculateMeanSquareOpticalFlow(reference_frame_depth_map[level], t_t_r, model) — monocular_tracker.cpp:104-134 — for up
+   *  to four relative poses in one pass over the device-resident map (the tracker needs t_t_r and t_t_r without rotation) */
+  std::vector<double> meanSquareOpticalFlow(int level, const std::vector<Motion> &t_t_r, const PinholeModel &model) const {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    std::vector<double> T(7 * t_t_r.size()), flow(t_t_r.size());
+    for (size_t i = 0; i < t_t_r.size(); ++i) std::copy(t_t_r[i].begin(), t_t_r[i].end(), T.begin() + 7 * static_cast<long>(i));
+    check(dsopp_hip_depth_maps_mean_square_optical_flow(m_, level, intr, static_cast<int32_t>(t_t_r.size()), T.data(), flow.data()));
+    return flow;
+  }
   /** host copy of one level: two row-major H x W planes (DepthMap::map(x, y).idepth / .weight) */
   void level(int level, std::vector<double> &idepth_sum, std::vector<double> &weight, int &width, int &height) const {
     int32_t w = 0, h = 0;
@@ -476,6 +485,19 @@ class DeviceImmatureSet {
   size_t n_;
   dsopp_hip_immature_set *s_ = nullptr;
 };
+
+/** initializationPoses(track) — src/tracker/tracker/src/monocular_tracker.cpp:136-176: the hypotheses estimatePose tries in
+ *  turn (113 for a track with at least two frames, else the identity).  Pass nullptr for a shorter track. */
+inline std::vector<Motion> initializationPoses(const Motion *t_world_previous, const Motion *t_world_last, const Motion *t_world_keyframe) {
+  std::vector<double> buf(7 * 128);
+  int32_t n = 0;
+  const bool two = t_world_previous && t_world_last && t_world_keyframe;
+  check(dsopp_hip_initialization_poses(two ? t_world_previous->data() : nullptr, two ? t_world_last->data() : nullptr,
+                                       two ? t_world_keyframe->data() : nullptr, 128, buf.data(), &n));
+  std::vector<Motion> out(static_cast<size_t>(n));
+  for (int32_t i = 0; i < n; ++i) std::copy(buf.begin() + 7 * i, buf.begin() + 7 * (i + 1), out[static_cast<size_t>(i)].begin());
+  return out;
+}
 
 /** ActiveKeyframe::ImmatureLandmarkActivationStatus — src/track/frames/include/track/frames/active_keyframe.hpp:40-44 */
 enum class ImmatureLandmarkActivationStatus : uint8_t { kActivate = 0, kSkip = 1, kDelete = 2 };

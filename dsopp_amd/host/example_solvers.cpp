@@ -118,6 +118,14 @@ int main() {
   for (double wv : dm_w) filled += wv > 0 ? 1 : 0;
   std::printf("reference depth map %d x %d: %d cells carry depth\n", dm_width, dm_height, filled);
   ok = ok && filled > 0;
+  // the keyframe strategy's parallax measure, straight from the device-resident map (with and without rotation, as the tracker asks)
+  const std::vector<double> flow = maps.meanSquareOpticalFlow(0, {Motion{0, 0, 0, 1, -0.05, 0, 0}, Motion{0, 0, 0, 1, 0, 0, 0}}, model);
+  std::printf("mean square optical flow for a 5 cm step: %.5f (analytic %.5f), for no motion: %.1e\n", flow[0], 0.05 / Z, flow[1]);
+  ok = ok && std::abs(flow[0] - 0.05 / Z) < 2e-3 && flow[1] < 1e-12;
+  const Motion T_prev{0, 0, 0, 1, 0.1, 0, 0}, T_last{0, 0, 0, 1, 0.2, 0, 0};
+  const std::vector<Motion> hypotheses = initializationPoses(&T_prev, &T_last, &T_prev);
+  std::printf("%zu pose hypotheses, constant-motion guess tx = %.3f\n", hypotheses.size(), hypotheses[0][4]);
+  ok = ok && hypotheses.size() == 113 && std::abs(hypotheses[0][4] - 0.3) < 1e-12 && std::abs(hypotheses[2][4] - 0.25) < 1e-12;
   HipPoseAlignment align2(aopt);
   align2.reset();
   const KeyframeView &newest = frames[2];

@@ -243,6 +243,12 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
 void dsopp_hip_depth_maps_destroy(dsopp_hip_depth_maps *m);
 int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level, int32_t *width, int32_t *height);
 /* copies one level to the host: two row-major H x W planes (energy::problem::DepthMap::map(x, y).{idepth, weight}) */
+/* calculateMeanSquareOpticalFlow (src/tracker/tracker/src/monocular_tracker.cpp:104-134) of one level of the device-resident
+ * maps — the parallax measure the keyframe strategy reads for every tracked frame (:474-479: once for t_t_r, once for t_t_r
+ * with the rotation removed) — for n_transforms <= 4 relative poses T_target_reference (7 each) in one pass.
+ * flow[i] = sqrt(mean |bearing(pixel) - bearing(reprojection)|^2) over the map's pixels that reproject (NaN for none). */
+int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m, int32_t level, const double intrinsics[4], int32_t n_transforms,
+                                                  const double *T_target_reference, double *flow);
 int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level, double *idepth_sum, double *weight);
 
 /* ---- depth estimation of immature landmarks (row f-1) ----
@@ -351,6 +357,13 @@ int dsopp_hip_aligner_push_target(dsopp_hip_aligner *a, int64_t timestamp, const
 int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7]);
 /* solve -> rmse (or kZeroCost = -1) — eigen_pose_alignment.cpp:275-329 */
 int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result);
+/* initializationPoses (src/tracker/tracker/src/monocular_tracker.cpp:136-176): the pose hypotheses estimatePose tries in turn —
+ * previous motion, doubled, halved (exp(log/2)), zero motion, the keyframe's pose, then the previous motion perturbed by
+ * rotations of 1, 1.5, 2, 2.5 degrees about every axis combination: 5 + 4 * 27 = 113 poses.  T_world_previous / T_world_last are
+ * track.getFrame(-2) / (-1); any of the three NULL = fewer than two frames in the track -> the single identity pose.
+ * Host arithmetic (no device work); *n receives the count, at most `capacity` poses (7 doubles each) are written. */
+int dsopp_hip_initialization_poses(const double T_world_previous[7], const double T_world_last[7], const double T_world_keyframe[7],
+                                   int32_t capacity, double *poses, int32_t *n);
 /* Coarse-to-fine pose estimation of a new frame against the last keyframe: estimatePose of the tracker
  * (src/tracker/tracker/src/monocular_tracker.cpp:179-245).  For every initialisation in turn (until one succeeds): from the
  * coarsest level of the target pyramid down to level 0 { reset; push the keyframe's depth map of that level; push the target

@@ -452,6 +452,24 @@ int orc_create_reference_depth_maps(int n_sources, const double *T_w_sources, co
   return static_cast<int>(maps.size());
 }
 
+int orc_initialization_poses(int have_two_frames, const double T_w_previous[7], const double T_w_last[7], const double T_w_keyframe[7],
+                             int cap, double *poses) {
+  const auto v = initializationPoses(have_two_frames != 0, have_two_frames ? SE3::fromParams(T_w_previous) : SE3(),
+                                     have_two_frames ? SE3::fromParams(T_w_last) : SE3(), have_two_frames ? SE3::fromParams(T_w_keyframe) : SE3());
+  for (size_t i = 0; i < v.size() && static_cast<int>(i) < cap; ++i) v[i].toParams(poses + 7 * i);
+  return static_cast<int>(v.size());
+}
+void orc_se3_log(const double T[7], double xi[6]) { SE3::fromParams(T).log(xi); }
+
+double orc_mean_square_optical_flow(int width, int height, const double *idepth_sum, const double *weight, const double intrinsics[4],
+                                    const double T_target_reference[7]) {
+  DepthMapLevel m(width, height);
+  std::copy(idepth_sum, idepth_sum + static_cast<size_t>(width) * height, m.idepth.begin());
+  std::copy(weight, weight + static_cast<size_t>(width) * height, m.weight.begin());
+  const PinholeModel model{static_cast<double>(width), static_cast<double>(height), intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
+  return calculateMeanSquareOpticalFlow(m, SE3::fromParams(T_target_reference), model);
+}
+
 int orc_align_solve(const orc_options *o, int n, const double *u, const double *v, const double *idepth,
                     const double *intensity, const double ref_intrinsics[4], int ref_width, int ref_height,
                     const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],

@@ -2,7 +2,7 @@
 // imported here and ships no vectors for this function; this file is a CPU restatement of
 //   createReferenceDepthMaps — src/tracker/tracker/src/create_depth_maps.cpp:18-147
 // (fillFineDepthMap :18-59, fillCoarseDepthMaps :70-88, dilateDepthMaps :90-122), over plain arrays instead of
-// track::ActiveKeyframe.  The product path never links or calls it.
+// track::ActiveKeyframe, and of calculateMeanSquareOpticalFlow — src/tracker/tracker/src/monocular_tracker.cpp:104-134.  The product path never links or calls it.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -119,6 +119,31 @@ inline std::vector<DepthMapLevel> createReferenceDepthMaps(const std::vector<Dep
   fillCoarseDepthMaps(maps);
   dilateDepthMaps(maps);
   return maps;
+}
+
+/** calculateMeanSquareOpticalFlow — monocular_tracker.cpp:104-134: RMS distance between the bearing of every depth-map pixel
+ *  and the bearing of its reprojection under t_t_r (the keyframe strategy's parallax measure) */
+inline double calculateMeanSquareOpticalFlow(const DepthMapLevel &m, const SE3 &t_t_r, const PinholeModel &model) {
+  const int kBorderSize = 4;
+  const double kMinIdepth = 1e-6;
+  double square_optical_flow = 0;
+  size_t n = 0;
+  const ArrayReprojector<true> reprojector(model, model, t_t_r);
+  for (int y = kBorderSize; y < m.height - kBorderSize; y++)
+    for (int x = kBorderSize; x < m.width - kBorderSize; x++) {
+      if (!(m.weight[m.at(x, y)] > 0)) continue;
+      const double idepth = m.idepth[m.at(x, y)] / m.weight[m.at(x, y)];
+      if (idepth < kMinIdepth) continue;
+      const double u = x, v = y;
+      double tu, tv;
+      if (!reprojector.reprojectPattern<1>(&u, &v, idepth, &tu, &tv)) continue;
+      // PinholeCamera::unproject — pinhole_camera.hpp:129-141: (p - c) * (1 / f), z = 1
+      const double ax = (u - model.cx) * (1 / model.fx), ay = (v - model.cy) * (1 / model.fy);
+      const double bx = (tu - model.cx) * (1 / model.fx), by = (tv - model.cy) * (1 / model.fy);
+      square_optical_flow += (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+      ++n;
+    }
+  return std::sqrt(square_optical_flow / static_cast<double>(n));
 }
 
 }  // namespace oracle

@@ -124,6 +124,13 @@ int orc_activate_landmarks(int n_frames, int width, int height, const double *co
                            double *idepth_min, double *idepth_max, const double *uniqueness, const double *search_pixel_interval,
                            uint8_t *status, const uint8_t *traced, double sigma_huber_loss, int number_of_desired_points,
                            double *min_distance_to_neighbor, int refine, uint8_t *activation_status);
+/* initializationPoses (monocular_tracker.cpp:136-176): returns the number of hypotheses, fills up to cap (7 doubles each) */
+int orc_initialization_poses(int have_two_frames, const double T_w_previous[7], const double T_w_last[7], const double T_w_keyframe[7],
+                             int cap, double *poses);
+void orc_se3_log(const double T[7], double xi[6]);
+/* calculateMeanSquareOpticalFlow (monocular_tracker.cpp:104-134) of one depth-map level (row-major H x W planes) */
+double orc_mean_square_optical_flow(int width, int height, const double *idepth_sum, const double *weight, const double intrinsics[4],
+                                    const double T_target_reference[7]);
 /* EpipolarLineBuilder::buildSegment: returns the number of points, fills up to cap (projection 2 each, reference idepth) */
 int orc_build_epipolar_segment(int width, int height, const double intrinsics[4], const double T_target_reference[7],
                                const double observed[2], double idepth_min, double idepth_max, int cap, double *projections,

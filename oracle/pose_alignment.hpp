@@ -212,4 +212,32 @@ inline AlignResult alignSolve(const AlignFrame &reference_frame, AlignFrame &tar
   return out;
 }
 
+/** initializationPoses — src/tracker/tracker/src/monocular_tracker.cpp:136-176: the pose hypotheses estimatePose tries in
+ *  turn.  have_two_frames == false (track.frames().size() < 2) -> {identity}. */
+inline std::vector<SE3> initializationPoses(bool have_two_frames, const SE3 &t_w_previous /* getFrame(-2) */, const SE3 &t_w_last /* getFrame(-1) */,
+                                            const SE3 &t_w_keyframe /* lastKeyframe() */) {
+  if (!have_two_frames) return {SE3()};
+  const double kMinAnglePerturbation = 1. * M_PI / 180.;
+  const double kMaxAnglePerturbation = 3. * M_PI / 180.;
+  const double kAnglePerturbationsStep = 0.5 * M_PI / 180.;
+  std::vector<SE3> initializations;
+  const SE3 t_r_t_prev = t_w_previous.inverse() * t_w_last;
+  initializations.push_back(t_w_last * t_r_t_prev);               // previous motion
+  initializations.push_back(t_w_last * t_r_t_prev * t_r_t_prev);  // double previous motion (frame skipped)
+  double xi[6];
+  t_r_t_prev.log(xi);
+  for (double &v : xi) v *= 0.5;
+  initializations.push_back(t_w_last * SE3::exp(xi));             // half motion
+  initializations.push_back(t_w_last);                            // zero motion
+  initializations.push_back(t_w_keyframe);                        // zero motion from keyframe
+  for (double delta = kMinAnglePerturbation; delta < kMaxAnglePerturbation; delta += kAnglePerturbationsStep)
+    for (double rx : {0.0, delta, -delta})
+      for (double ry : {0.0, delta, -delta})
+        for (double rz : {0.0, delta, -delta}) {
+          const double rot[6] = {0, 0, 0, rx, ry, rz};
+          initializations.push_back(initializations[0] * SE3::exp(rot));  // SE3(SO3::exp(.), 0)
+        }
+  return initializations;
+}
+
 }  // namespace oracle

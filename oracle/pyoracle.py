@@ -372,6 +372,31 @@ def create_reference_depth_maps(sources, T_w_newest, intrinsics, width, height, 
     return out
 
 
+def initialization_poses(T_w_previous, T_w_last, T_w_keyframe):
+    """initializationPoses (monocular_tracker.cpp:136-176); T_w_previous None = fewer than two frames in the track"""
+    out = np.zeros((128, 7))
+    if T_w_previous is None:
+        n = lib().orc_initialization_poses(0, None, None, None, 128, _p(out))
+    else:
+        n = lib().orc_initialization_poses(1, _p(_f64(T_w_previous)), _p(_f64(T_w_last)), _p(_f64(T_w_keyframe)), 128, _p(out))
+    return out[:n].copy()
+
+
+def se3_log(T):
+    xi = np.zeros(6)
+    lib().orc_se3_log(_p(_f64(T)), _p(xi))
+    return xi
+
+
+def mean_square_optical_flow(idepth_sum, weight, intrinsics, T_target_reference):
+    """calculateMeanSquareOpticalFlow (monocular_tracker.cpp:104-134) of one depth-map level"""
+    ids, wgt = _f64(idepth_sum), _f64(weight)
+    H, W = ids.shape
+    fn = lib().orc_mean_square_optical_flow
+    fn.restype = C.c_double
+    return fn(W, H, _p(ids), _p(wgt), _p(_f64(intrinsics)), _p(_f64(T_target_reference)))
+
+
 def align_solve(options, u, v, idepth, intensity, ref_intr, ref_size, T_w_ref, ref_exposure, ref_ab, tgt_intr, tgt_pixelinfo,
                 tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab):
     pix = _f64(tgt_pixelinfo)

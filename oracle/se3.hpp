@@ -79,6 +79,43 @@ struct SE3 {
     s.t[2] = uz + a * c1z + b * c2z;
     return s;
   }
+  /** SE3::log (Sophus @593db47, published algorithm): omega = SO3::log of the unit quaternion (atan-based, series below
+   *  |vec| < 1e-10), upsilon = V^-1 t with V^-1 = I - Omega/2 + (1 - theta cos(theta/2) / (2 sin(theta/2))) / theta^2 Omega^2
+   *  (1/12 for small theta).  Tangent order (upsilon, omega).  Call site: monocular_tracker.cpp:153. */
+  void log(double xi[6]) const {
+    const double kEps = 1e-10;
+    const double squared_n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const double w = q[3];
+    double two_atan_nbyw_by_n;
+    if (squared_n < kEps * kEps) {
+      two_atan_nbyw_by_n = 2.0 / w - (2.0 / 3.0) * squared_n / (w * w * w);
+    } else {
+      const double n = std::sqrt(squared_n);
+      if (std::abs(w) < kEps) {
+        two_atan_nbyw_by_n = (w > 0 ? M_PI : -M_PI) / n;
+      } else {
+        two_atan_nbyw_by_n = 2.0 * std::atan(n / w) / n;
+      }
+    }
+    const double wx = two_atan_nbyw_by_n * q[0], wy = two_atan_nbyw_by_n * q[1], wz = two_atan_nbyw_by_n * q[2];
+    const double theta_sq = wx * wx + wy * wy + wz * wz, theta = std::sqrt(theta_sq);
+    double c;
+    if (theta < kEps) {
+      c = 1.0 / 12.0;
+    } else {
+      const double half = 0.5 * theta;
+      c = (1.0 - 0.5 * theta * std::cos(half) / std::sin(half)) / theta_sq;
+    }
+    // V^-1 t = t - (omega x t)/2 + c * omega x (omega x t)
+    const double c1x = wy * t[2] - wz * t[1], c1y = wz * t[0] - wx * t[2], c1z = wx * t[1] - wy * t[0];
+    const double c2x = wy * c1z - wz * c1y, c2y = wz * c1x - wx * c1z, c2z = wx * c1y - wy * c1x;
+    xi[0] = t[0] - 0.5 * c1x + c * c2x;
+    xi[1] = t[1] - 0.5 * c1y + c * c2y;
+    xi[2] = t[2] - 0.5 * c1z + c * c2z;
+    xi[3] = wx;
+    xi[4] = wy;
+    xi[5] = wz;
+  }
   SE3 inverse() const {
     SE3 s;
     s.q[0] = -q[0];

@@ -102,6 +102,82 @@ def test_oracle_matches_numpy_statement():
         assert np.abs(a - c).max() <= 1e-9 * max(1.0, np.abs(c).max()), lvl   # x/z via the fused 3x4 product vs explicit matrices
 
 
+def _numpy_flow(ids, wgt, intr, T):
+    """calculateMeanSquareOpticalFlow (monocular_tracker.cpp:104-134) with explicit bearing vectors"""
+    fx, fy, cx, cy = intr
+    H, W = ids.shape
+    tot, n = 0.0, 0
+    for y in range(4, H - 4):
+        for x in range(4, W - 4):
+            if wgt[y, x] <= 0:
+                continue
+            rho = ids[y, x] / wgt[y, x]
+            if rho < 1e-6 or not rho < 1010:
+                continue
+            d = np.array([(x - cx) / fx, (y - cy) / fy, 1.0])
+            X = T[:3, :3] @ d + rho * T[:3, 3]
+            if X[2] <= 0:
+                continue
+            q = X / X[2]                                     # bearing of the reprojection, z = 1
+            u, v = fx * q[0] + cx, fy * q[1] + cy
+            if not (4 <= u <= W - 5 and 4 <= v <= H - 5):
+                continue
+            tot += np.sum((d[:2] - q[:2]) ** 2)
+            n += 1
+    return np.sqrt(tot / n), n
+
+
+def _flow_case():
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=4, num_points=900, width=160, height=120, seed=17)
+    sources = [dict(T_w=syn.mat_to_params(f.T_w_c_gt), uv=f.uv, idepth=f.idepth_gt, variance=np.full(len(f.uv), 1e-5),
+                    skip=np.zeros(len(f.uv), dtype=np.uint8), status=np.zeros(len(f.uv), dtype=np.uint8)) for f in win.frames[:-1]]
+    maps = po.create_reference_depth_maps(sources, syn.mat_to_params(win.frames[-1].T_w_c_gt), win.scene.intrinsics, 160, 120, 2)
+    Ts = [syn.se3_exp(np.array([0.05, -0.02, 0.03, 0.01, -0.02, 0.005])), syn.se3_exp(np.array([0.05, -0.02, 0.03, 0, 0, 0])),
+          np.eye(4), syn.se3_exp(np.array([0.3, 0.1, -0.2, 0.05, 0.08, -0.03]))]
+    return win, maps, Ts
+
+
+def test_oracle_optical_flow_matches_numpy_statement():
+    from oracle import pyoracle as po
+    win, maps, Ts = _flow_case()
+    for lvl in (0, 1):
+        ids, wgt = maps[lvl]
+        intr = win.scene.intrinsics / (1 << lvl)
+        for k, T in enumerate(Ts):
+            want, n = _numpy_flow(ids, wgt, intr, T)
+            got = po.mean_square_optical_flow(ids, wgt, intr, syn.mat_to_params(T))
+            assert n > 100
+            assert abs(got - want) <= 1e-10 * max(want, 1e-3), (lvl, k, got, want)
+            if k == 2:
+                assert got < 1e-12     # identity: no flow
+    assert np.isnan(po.mean_square_optical_flow(np.zeros((120, 160)), np.zeros((120, 160)), win.scene.intrinsics, syn.mat_to_params(np.eye(4))))
+
+
+@pytest.mark.gpu
+def test_gpu_optical_flow_matches_oracle():
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    W, H, L = 320, 240, 2
+    win = syn.make_window(num_frames=4, num_points=1200, width=W, height=H, seed=13)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    g.solve()
+    maps = g.create_reference_depth_maps(L)
+    _, _, Ts = _flow_case()
+    for lvl in range(L):
+        ids, wgt = maps.get_level(lvl)
+        intr = win.scene.intrinsics / (1 << lvl)
+        want = np.array([po.mean_square_optical_flow(ids, wgt, intr, syn.mat_to_params(T)) for T in Ts])
+        got = maps.mean_square_optical_flow(lvl, intr, [syn.mat_to_params(T) for T in Ts])
+        assert np.all(np.abs(got - want) <= 1e-12 * np.maximum(want, 1e-3)), (lvl, got, want)
+        one = maps.mean_square_optical_flow(lvl, intr, [syn.mat_to_params(Ts[0])])
+        assert one[0] == got[0]    # deterministic reduction, independent of the batch
+    with pytest.raises(capi.HipError):
+        maps.mean_square_optical_flow(0, win.scene.intrinsics, [syn.mat_to_params(np.eye(4))] * 5)
+    maps.close()
+    g.close()
+
+
 @pytest.mark.gpu
 def test_gpu_depth_maps_and_device_scan():
     from dsopp_amd import capi
