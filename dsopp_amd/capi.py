@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_window_refill_reference_depth_maps",
     "dsopp_hip_initialization_poses",
     "dsopp_hip_depth_maps_mean_square_optical_flow",
     "dsopp_hip_window_activate_landmarks",
@@ -327,6 +328,10 @@ class HipWindow:
                                                        C.c_double(exposure_newest), _p(_f64(affine_newest)), int(number_of_desired_points),
                                                        C.byref(dist), int(bool(refine)), C.c_double(sigma_huber_loss), st_p, id_p, C.byref(res)))
         return st, idp, {k: getattr(res, k) for k, _ in ActivationResult._fields_}
+
+    def refill_reference_depth_maps(self, maps: DepthMaps):
+        """createReferenceDepthMaps into an existing DepthMaps object (no allocation)"""
+        _chk(lib().dsopp_hip_window_refill_reference_depth_maps(self._h, maps._h))
 
     def optimize_repeated(self, iterations_target: int):
         """{restore(); optimize()} from the snapshot until exactly `iterations_target` GN iterations ran; returns

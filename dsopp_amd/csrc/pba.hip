@@ -98,6 +98,7 @@ struct dsopp_hip_window {
   DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
   void *h_export = nullptr;             // its pinned host staging
   size_t h_export_bytes = 0;
+  std::vector<DeviceBuffer<double>> dm_tmp_id, dm_tmp_w;  // undilated reference depth maps (temporaries of createReferenceDepthMaps)
   struct ActivationScratch {            // work buffers of dsopp_hip_window_activate_landmarks
     DeviceBuffer<ActKeyframe> keyframes;
     DeviceBuffer<ActPair> pairs;
@@ -1807,6 +1808,91 @@ int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, i
   });
 }
 
+namespace {
+/** fills `maps` (allocated for `levels` levels of the newest keyframe's size) from the window's landmarks */
+void fillReferenceDepthMaps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
+  hipStream_t st = w->sr.stream;
+  const int levels = maps->levels;
+  const int F = w->F(), newest = F - 1;
+  const HostFrame &fn = *w->frames[static_cast<size_t>(newest)];
+  const LevelView lv = fn.pyramid->view(fn.level);
+  // temporaries (the undilated maps) live with the window: no allocation per keyframe after the first call
+  auto &tmp_id = w->dm_tmp_id, &tmp_w = w->dm_tmp_w;
+  if (tmp_id.size() < static_cast<size_t>(levels)) {
+    tmp_id.resize(static_cast<size_t>(levels));
+    tmp_w.resize(static_cast<size_t>(levels));
+  }
+  for (int l = 0; l < levels; ++l) {
+    const size_t n = static_cast<size_t>(maps->width[static_cast<size_t>(l)]) * maps->height[static_cast<size_t>(l)];
+    tmp_id[static_cast<size_t>(l)].reserve(n, 0, st);
+    tmp_w[static_cast<size_t>(l)].reserve(n, 0, st);
+    maps->points[static_cast<size_t>(l)].n = -1;  // cached reference points of an earlier fill are stale
+  }
+  {
+    const size_t n0 = static_cast<size_t>(maps->width[0]) * maps->height[0];
+    HIP_CHECK(hipMemsetAsync(tmp_id[0].ptr, 0, n0 * sizeof(double), st));  // the splat accumulates; every other plane is overwritten
+    HIP_CHECK(hipMemsetAsync(tmp_w[0].ptr, 0, n0 * sizeof(double), st));
+  }
+  // fillFineDepthMap — :18-59 (into the temporaries; the dilation writes the final planes)
+  const Rigid T_newest_inv = rigidInverse(poseOf(*w, newest));
+  for (int f = 0; f < newest; ++f) {
+    const HostFrame &fr = *w->frames[static_cast<size_t>(f)];
+    auto it = fr.residuals.find(fn.id);
+    if (fr.n == 0 || it == fr.residuals.end() || it->second->n == 0) continue;
+    const Rigid T = rigidMul(T_newest_inv, poseOf(*w, f));  // t_t_r, :28
+    SplatArgs a;
+    const double ifx = 1.0 / fr.intr[0], ify = 1.0 / fr.intr[1];
+    const double k02 = -fr.intr[2] / fr.intr[0], k12 = -fr.intr[3] / fr.intr[1];
+    double U[12];
+    for (int i = 0; i < 3; ++i) {
+      U[4 * i + 0] = T.R[3 * i + 0] * ifx;
+      U[4 * i + 1] = T.R[3 * i + 1] * ify;
+      U[4 * i + 2] = T.R[3 * i + 0] * k02 + T.R[3 * i + 1] * k12 + T.R[3 * i + 2];
+      U[4 * i + 3] = T.t[i];
+    }
+    for (int j = 0; j < 4; ++j) {
+      a.M[0 + j] = fn.intr[0] * U[0 + j] + fn.intr[2] * U[8 + j];
+      a.M[4 + j] = fn.intr[1] * U[4 + j] + fn.intr[3] * U[8 + j];
+      a.M[8 + j] = U[8 + j];
+    }
+    a.Tz[0] = T.R[6];
+    a.Tz[1] = T.R[7];
+    a.Tz[2] = T.R[8];
+    a.Tz[3] = T.t[2];
+    a.fx = fr.intr[0];
+    a.fy = fr.intr[1];
+    a.cx = fr.intr[2];
+    a.cy = fr.intr[3];
+    a.width = lv.width;
+    a.height = lv.height;
+    a.n = std::min(fr.n, it->second->n);
+    a.use_variance = w->opt.estimate_uncertainty ? 1 : 0;
+    a.uv = fr.uv.ptr;
+    a.idepth = fr.idepth.ptr;
+    a.inv_hdd = fr.inv_hdd.ptr;
+    a.flags = fr.dflags.ptr;
+    a.status = it->second->status.ptr;
+    splatDepthMapKernel<<<(a.n + 255) / 256, 256, 0, st>>>(a, tmp_id[0].ptr, tmp_w[0].ptr);
+  }
+  // fillCoarseDepthMaps — :70-88
+  for (int l = 1; l < levels; ++l) {
+    const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
+    poolDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l - 1)].ptr, tmp_w[static_cast<size_t>(l - 1)].ptr,
+                                                                maps->width[static_cast<size_t>(l - 1)], tmp_id[static_cast<size_t>(l)].ptr,
+                                                                tmp_w[static_cast<size_t>(l)].ptr, W, H);
+  }
+  // dilateDepthMaps — :90-122 (after ALL levels were pooled from the undilated maps, as in the reference)
+  for (int l = 0; l < levels; ++l) {
+    const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
+    dilateDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l)].ptr, tmp_w[static_cast<size_t>(l)].ptr,
+                                                                  maps->idepth_sum[static_cast<size_t>(l)].ptr, maps->weight[static_cast<size_t>(l)].ptr, W,
+                                                                  H, l > 1 ? 0 : 1);
+  }
+  HIP_CHECK(hipGetLastError());
+  w->sr.sync();  // consumers may live on other streams
+}
+}  // namespace
+
 int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t levels, dsopp_hip_depth_maps **out) {
   return guarded([&] {
     if (!w || !out) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
@@ -1814,8 +1900,7 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
     if (levels < 1 || levels > 5) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "levels must be in [1, 5]");
     prepare(*w);  // topology / state on the device, host mirror of the poses current
     hipStream_t st = w->sr.stream;
-    const int F = w->F(), newest = F - 1;
-    const HostFrame &fn = *w->frames[static_cast<size_t>(newest)];
+    const HostFrame &fn = *w->frames.back();
     const LevelView lv = fn.pyramid->view(fn.level);
     auto maps = std::make_unique<dsopp_hip_depth_maps>();
     maps->sr = w->sr;
@@ -1823,7 +1908,6 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
     maps->levels = levels;
     maps->points.resize(static_cast<size_t>(levels));
     // initDepthMaps — create_depth_maps.cpp:62-68: one map per pyramid level of the newest keyframe
-    std::vector<DeviceBuffer<double>> tmp_id(static_cast<size_t>(levels)), tmp_w(static_cast<size_t>(levels));
     int lw = lv.width, lh = lv.height;
     for (int l = 0; l < levels; ++l) {
       if (lw < 3 || lh < 3) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level %d of a %d x %d image is too small", l, lv.width, lv.height);
@@ -1832,71 +1916,28 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
       maps->idepth_sum.emplace_back();
       maps->weight.emplace_back();
       const size_t n = static_cast<size_t>(lw) * lh;
-      maps->idepth_sum.back().reserve(n, 0, st);  // reserve() zero-fills
+      maps->idepth_sum.back().reserve(n, 0, st);
       maps->weight.back().reserve(n, 0, st);
-      tmp_id[static_cast<size_t>(l)].reserve(n, 0, st);
-      tmp_w[static_cast<size_t>(l)].reserve(n, 0, st);
       lw /= 2;
       lh /= 2;
     }
-    // fillFineDepthMap — :18-59 (into the temporaries; the dilation writes the final planes)
-    const Rigid T_newest_inv = rigidInverse(poseOf(*w, newest));
-    for (int f = 0; f < newest; ++f) {
-      const HostFrame &fr = *w->frames[static_cast<size_t>(f)];
-      auto it = fr.residuals.find(fn.id);
-      if (fr.n == 0 || it == fr.residuals.end() || it->second->n == 0) continue;
-      const Rigid T = rigidMul(T_newest_inv, poseOf(*w, f));  // t_t_r, :28
-      SplatArgs a;
-      const double ifx = 1.0 / fr.intr[0], ify = 1.0 / fr.intr[1];
-      const double k02 = -fr.intr[2] / fr.intr[0], k12 = -fr.intr[3] / fr.intr[1];
-      double U[12];
-      for (int i = 0; i < 3; ++i) {
-        U[4 * i + 0] = T.R[3 * i + 0] * ifx;
-        U[4 * i + 1] = T.R[3 * i + 1] * ify;
-        U[4 * i + 2] = T.R[3 * i + 0] * k02 + T.R[3 * i + 1] * k12 + T.R[3 * i + 2];
-        U[4 * i + 3] = T.t[i];
-      }
-      for (int j = 0; j < 4; ++j) {
-        a.M[0 + j] = fn.intr[0] * U[0 + j] + fn.intr[2] * U[8 + j];
-        a.M[4 + j] = fn.intr[1] * U[4 + j] + fn.intr[3] * U[8 + j];
-        a.M[8 + j] = U[8 + j];
-      }
-      a.Tz[0] = T.R[6];
-      a.Tz[1] = T.R[7];
-      a.Tz[2] = T.R[8];
-      a.Tz[3] = T.t[2];
-      a.fx = fr.intr[0];
-      a.fy = fr.intr[1];
-      a.cx = fr.intr[2];
-      a.cy = fr.intr[3];
-      a.width = lv.width;
-      a.height = lv.height;
-      a.n = std::min(fr.n, it->second->n);
-      a.use_variance = w->opt.estimate_uncertainty ? 1 : 0;
-      a.uv = fr.uv.ptr;
-      a.idepth = fr.idepth.ptr;
-      a.inv_hdd = fr.inv_hdd.ptr;
-      a.flags = fr.dflags.ptr;
-      a.status = it->second->status.ptr;
-      splatDepthMapKernel<<<(a.n + 255) / 256, 256, 0, st>>>(a, tmp_id[0].ptr, tmp_w[0].ptr);
-    }
-    // fillCoarseDepthMaps — :70-88
-    for (int l = 1; l < levels; ++l) {
-      const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
-      poolDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l - 1)].ptr, tmp_w[static_cast<size_t>(l - 1)].ptr,
-                                                                  maps->width[static_cast<size_t>(l - 1)], tmp_id[static_cast<size_t>(l)].ptr,
-                                                                  tmp_w[static_cast<size_t>(l)].ptr, W, H);
-    }
-    // dilateDepthMaps — :90-122 (after ALL levels were pooled from the undilated maps, as in the reference)
-    for (int l = 0; l < levels; ++l) {
-      const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
-      dilateDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l)].ptr, tmp_w[static_cast<size_t>(l)].ptr,
-                                                                    maps->idepth_sum[static_cast<size_t>(l)].ptr, maps->weight[static_cast<size_t>(l)].ptr, W,
-                                                                    H, l > 1 ? 0 : 1);
-    }
-    HIP_CHECK(hipGetLastError());
-    w->sr.sync();  // the temporaries go out of scope
+    fillReferenceDepthMaps(w, maps.get());
     *out = maps.release();
+  });
+}
+
+int dsopp_hip_window_refill_reference_depth_maps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
+  return guarded([&] {
+    if (!w || !maps) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (w->frames.empty()) fail(DSOPP_HIP_ERR_STATE, "the window holds no keyframe");
+    const HostFrame &fn = *w->frames.back();
+    const LevelView lv = fn.pyramid->view(fn.level);
+    if (maps->levels < 1 || maps->width[0] != lv.width || maps->height[0] != lv.height)
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the maps are %d x %d, the newest keyframe is %d x %d", maps->levels ? maps->width[0] : 0,
+           maps->levels ? maps->height[0] : 0, lv.width, lv.height);
+    if (maps->sr.device != w->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "depth maps live on another device");
+    prepare(*w);
+    fillReferenceDepthMaps(w, maps);
   });
 }
 

@@ -177,6 +177,7 @@ class DeviceDepthMaps {
   DeviceDepthMaps &operator=(const DeviceDepthMaps &) = delete;
   DeviceDepthMaps(DeviceDepthMaps &&o) noexcept : m_(o.m_) { o.m_ = nullptr; }
   const dsopp_hip_depth_maps *handle() const { return m_; }
+  dsopp_hip_depth_maps *mutableHandle() { return m_; }
   /** calculateMeanSquareOpticalFlow(reference_frame_depth_map[level], t_t_r, model) — monocular_tracker.cpp:104-134 — for up
    *  to four relative poses in one pass over the device-resident map (the tracker needs t_t_r and t_t_r without rotation) */
   std::vector<double> meanSquareOpticalFlow(int level, const std::vector<Motion> &t_t_r, const PinholeModel &model) const {
@@ -252,6 +253,8 @@ class HipPhotometricBundleAdjustment {
     check(dsopp_hip_window_create_reference_depth_maps(w_, levels, &m));
     return DeviceDepthMaps(m);
   }
+  /** reference_frame_depth_map_ = createReferenceDepthMaps(...) into the object the tracker already holds (no allocation) */
+  void createReferenceDepthMaps(DeviceDepthMaps &maps) { check(dsopp_hip_window_refill_reference_depth_maps(w_, maps.mutableHandle())); }
   /** solve(number_of_threads) -> final energy; number_of_threads is accepted and ignored, as in the Eigen backend */
   double solve(const size_t number_of_threads = 1) {
     (void)number_of_threads;

@@ -243,6 +243,9 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
 void dsopp_hip_depth_maps_destroy(dsopp_hip_depth_maps *m);
 int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level, int32_t *width, int32_t *height);
 /* copies one level to the host: two row-major H x W planes (energy::problem::DepthMap::map(x, y).{idepth, weight}) */
+/* the same into an existing object of the same image size (the tracker keeps ONE reference_frame_depth_map_ and reassigns it
+ * after every keyframe, monocular_tracker.cpp:465,509): no allocation, cached reference points are invalidated */
+int dsopp_hip_window_refill_reference_depth_maps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps);
 /* calculateMeanSquareOpticalFlow (src/tracker/tracker/src/monocular_tracker.cpp:104-134) of one level of the device-resident
  * maps — the parallax measure the keyframe strategy reads for every tracked frame (:474-479: once for t_t_r, once for t_t_r
  * with the rotation removed) — for n_transforms <= 4 relative poses T_target_reference (7 each) in one pass.

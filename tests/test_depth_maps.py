@@ -174,6 +174,13 @@ def test_gpu_optical_flow_matches_oracle():
         assert one[0] == got[0]    # deterministic reduction, independent of the batch
     with pytest.raises(capi.HipError):
         maps.mean_square_optical_flow(0, win.scene.intrinsics, [syn.mat_to_params(np.eye(4))] * 5)
+    # refilling the same object (what the tracker does after every keyframe) reproduces a fresh creation bit for bit
+    before = [maps.get_level(l) for l in range(L)]
+    g.refill_reference_depth_maps(maps)
+    for l in range(L):
+        a, b = maps.get_level(l)
+        assert np.array_equal(a > 0, before[l][0] > 0) and np.abs(a - before[l][0]).max() <= 1e-12 * np.abs(a).max()   # (atomics order)
+        assert np.abs(b - before[l][1]).max() <= 1e-12 * np.abs(b).max()
     maps.close()
     g.close()
 
