@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Generates tests/golden/pba_tiny.npz — committed input/output vectors of the hot path.
+"""Generates tests/golden/pba_tiny.npz and tests/golden/tracker_tiny.npz — committed input/output vectors of the hot path
+(bundle adjustment, pyramid, alignment) and of the rows around it (depth estimation, landmark activation, depth maps'
+optical flow, pose hypotheses).
 
 The reference ships NO golden vectors for this path and cannot be built or imported in this environment,
 so these vectors do not come from the reference: the expected outputs are produced by the CPU oracle (oracle/*.hpp) and,
@@ -83,5 +85,54 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def tracker_rows():
+    """a 4-keyframe window (the 4th is the new keyframe): immature landmarks traced in two frames, then activated"""
+    W, H = 160, 120
+    win = syn.make_window(num_frames=4, num_points=4 * 110, width=W, height=H, seed=29, pose_noise=False)
+    intr = win.scene.intrinsics
+    out = {"intrinsics": intr, "num_frames": 4}
+    frames = []
+    for i, f in enumerate(win.frames):
+        out[f"image_u8_{i}"] = f.image_u8
+        out[f"T_{i}"] = syn.mat_to_params(f.T_w_c_gt)
+        d = dict(pixelinfo=f.pixelinfo, mask=None, T_w=syn.mat_to_params(f.T_w_c_gt), exposure=1.0, affine=np.zeros(2))
+        if i < 3:
+            na = 40
+            uv = f.uv[na:]
+            ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+            grad = np.stack([f.pixelinfo[vi, ui, 1], f.pixelinfo[vi, ui, 2]], axis=1)
+            direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+            lms = po.new_immature_landmarks(uv, direction, f.patch[na:], grad)
+            out.update({f"active_uv_{i}": f.uv[:na], f"active_idepth_{i}": f.idepth_init[:na], f"active_patch_{i}": f.patch[:na],
+                        f"imm_uv_{i}": uv, f"imm_direction_{i}": direction, f"imm_patch_{i}": f.patch[na:], f"imm_gradient_{i}": grad})
+            for step, j in enumerate((i + 1, 3 if i < 2 else 0)):   # (never the same frame twice: that is a tie generator)
+                g = win.frames[j]
+                po.estimate_depths(lms, g.pixelinfo, None, intr, syn.mat_to_params(np.linalg.inv(g.T_w_c_gt) @ f.T_w_c_gt))
+                for k in ("idepth_min", "idepth_max", "uniqueness", "search_pixel_interval", "status", "traced"):
+                    out[f"depth_{i}_obs{step}_{k}"] = np.array(lms[k])
+            d.update(active_uv=f.uv[:na], active_idepth=f.idepth_init[:na], active_skip=np.zeros(na, dtype=np.uint8), immature=lms)
+        frames.append(d)
+    st, n_act, dist = po.activate_landmarks(frames, intr, 20.0, 120, 1.5, refine=True)
+    out.update(activation_desired=120, activation_distance_in=1.5, activation_distance_out=dist, activation_active_points=n_act)
+    for i in range(3):
+        out[f"activation_status_{i}"] = st[i]
+        out[f"activation_idepth_{i}"] = 0.5 * frames[i]["immature"]["idepth_min"] + 0.5 * frames[i]["immature"]["idepth_max"]
+        out[f"activation_set_status_{i}"] = frames[i]["immature"]["status"]
+    # reference depth maps of keyframe 2 from keyframes 0, 1 and the optical flow of two relative poses
+    sources = [dict(T_w=syn.mat_to_params(f.T_w_c_gt), uv=f.uv, idepth=f.idepth_gt, variance=np.full(len(f.uv), 1e-5),
+                    skip=np.zeros(len(f.uv), dtype=np.uint8), status=np.zeros(len(f.uv), dtype=np.uint8)) for f in win.frames[:2]]
+    maps = po.create_reference_depth_maps(sources, syn.mat_to_params(win.frames[2].T_w_c_gt), intr, W, H, 2)
+    T_rel = np.linalg.inv(win.frames[3].T_w_c_gt) @ win.frames[2].T_w_c_gt
+    T_norot = T_rel.copy()
+    T_norot[:3, :3] = np.eye(3)
+    out.update(maps_idepth_sum_0=maps[0][0], maps_weight_0=maps[0][1], flow_T=np.stack([syn.mat_to_params(T_rel), syn.mat_to_params(T_norot)]),
+               flow=np.array([po.mean_square_optical_flow(maps[0][0], maps[0][1], intr, syn.mat_to_params(T)) for T in (T_rel, T_norot)]))
+    out["hypotheses"] = po.initialization_poses(out["T_1"], out["T_2"], out["T_0"])
+    path = os.path.join(ROOT, "tests", "golden", "tracker_tiny.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
+    tracker_rows()
