@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_aligner_set_rotation_prior",
     "dsopp_hip_window_refill_reference_depth_maps",
     "dsopp_hip_initialization_poses",
     "dsopp_hip_depth_maps_mean_square_optical_flow",
@@ -593,6 +594,11 @@ class HipAligner:
     def push_target(self, timestamp, T_w_agent_init, pyramid: Pyramid, level, intrinsics, exposure, affine):
         _chk(lib().dsopp_hip_aligner_push_target(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent_init)), pyramid._h, int(level),
                                                  _p(_f64(intrinsics)), C.c_double(exposure), _p(_f64(affine))))
+
+    def set_rotation_prior(self, R_target_reference):
+        """setRotationPrior (3x3, None clears); reset() clears it too"""
+        R = None if R_target_reference is None else _f64(np.asarray(R_target_reference).reshape(9))
+        _chk(lib().dsopp_hip_aligner_set_rotation_prior(self._h, _p(R)))
 
     def set_lm_path(self, path: int):
         _chk(lib().dsopp_hip_aligner_set_lm_path(self._h, int(path)))

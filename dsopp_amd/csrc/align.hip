@@ -539,6 +539,12 @@ struct dsopp_hip_aligner {
   AlignControl *h_ctrl = nullptr;  // pinned staging of the control block (upload + read-back)
   int lm_path = 0;                 // 0: automatic (single-workgroup loop for small point sets), 1: always one launch per iteration
   bool skip_covariance = false;    // estimate_pose: the per-level covariance is not read by the tracker loop
+  bool have_rotation_prior = false;  // setRotationPrior, cleared by reset() (eigen_pose_alignment.cpp:254-263)
+  double rotation_prior[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  // launches the previous solve on a target level of this width needed: consecutive frames of a sequence need nearly the same
+  // number of LM iterations per level, so the first batch is sized to that instead of a fixed 20 (launches past the end of
+  // the loop are no-ops, but each still costs a dispatch)
+  std::map<int, int> launches_needed;
   DeviceBuffer<int> d_rows;  // row counts / offsets of the device-side depth-map scan
   DeviceBuffer<AlignControl> d_ctrl;
   std::map<int64_t, Rigid> known_poses;
@@ -701,6 +707,20 @@ int dsopp_hip_aligner_reset(dsopp_hip_aligner *a) {
     if (!a) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null aligner");
     a->have_ref = a->have_tgt = false;
     a->n_points = 0;
+    a->have_rotation_prior = false;  // prior_rotation_t_r_ = std::nullopt, eigen_pose_alignment.cpp:262
+  });
+}
+
+int dsopp_hip_aligner_set_rotation_prior(dsopp_hip_aligner *a, const double *R_target_reference) {
+  return guarded([&] {
+    if (!a) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null aligner");
+    a->have_rotation_prior = R_target_reference != nullptr;
+    if (R_target_reference) {
+      const double *R = R_target_reference;
+      const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+      if (!(det > 0)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "rotation prior has determinant %g", det);
+      fitToSO3(R, a->rotation_prior);
+    }
   });
 }
 
@@ -913,7 +933,9 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     if (!a->h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_ctrl), 2 * sizeof(AlignControl), hipHostMallocDefault));
     AlignControl &c = a->h_ctrl[0];
     std::memset(&c, 0, sizeof(c));
-    const Rigid T_tr = rigidMul(rigidInverse(a->T_w_tgt), a->T_w_ref);  // eigen_pose_alignment.cpp:307-308
+    Rigid T_tr = rigidMul(rigidInverse(a->T_w_tgt), a->T_w_ref);  // eigen_pose_alignment.cpp:307-308
+    if (a->have_rotation_prior)
+      for (int i = 0; i < 9; ++i) T_tr.R[i] = a->rotation_prior[i];  // t_t_r.setRotationMatrix(prior), :309-311
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) c.T_tr[4 * i + j] = c.cand_T[4 * i + j] = T_tr.R[3 * i + j];
       c.T_tr[4 * i + 3] = c.cand_T[4 * i + 3] = T_tr.t[i];
@@ -943,10 +965,16 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
       HIP_CHECK(hipMemcpyAsync(&h, a->d_ctrl.ptr + 1, sizeof(AlignControl), hipMemcpyDeviceToHost, st));
       a->sr.sync();
     }
-    // launches after the loop has ended are no-ops of ~2 us; a batch covers the typical solve (10-20 iterations) in one sync
-    const int kBatch = 20;
+    // launches after the loop has ended are no-ops of ~2 us (plus the dispatch); the first batch covers what the previous
+    // solve on this level needed + 2, follow-up batches are short; every batch ends with one read-back + sync
+    int batch = 20;
+    {
+      auto it = a->launches_needed.find(a->tgt.width);
+      if (it != a->launches_needed.end()) batch = std::max(6, it->second + 2);
+    }
     while (!single_workgroup) {
-      const int end = std::min(total_launches, launch + kBatch);
+      const int end = std::min(total_launches, launch + batch);
+      batch = 8;
       for (; launch < end; ++launch) {
         const AlignControl *cin = a->d_ctrl.ptr + ((launch + 1) & 1);
         AlignControl *cout = a->d_ctrl.ptr + (launch & 1);
@@ -963,6 +991,7 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
       a->sr.sync();
       if (!h.active || launch >= total_launches) break;
     }
+    if (!single_workgroup) a->launches_needed[a->tgt.width] = h.iteration + 2;  // initial evaluation + iterations + closing control pass
     // result — eigen_pose_alignment.cpp:320-328
     Rigid Tfin;
     for (int i = 0; i < 3; ++i) {

@@ -175,6 +175,25 @@ DSOPP_HD void rigidNormalize(Rigid &T) {
   T = rigidFromParams(p);
 }
 
+/** the rotation closest to a 3x3 matrix with positive determinant (SO3::fitToSO3 of Sophus, reached through
+ *  SE3::setRotationMatrix, se3_motion.hpp:215): Newton iteration of the polar decomposition, R <- (R + R^-T) / 2 */
+DSOPP_HD void fitToSO3(const double *Rin, double *R) {
+  for (int i = 0; i < 9; ++i) R[i] = Rin[i];
+  for (int it = 0; it < 30; ++it) {
+    const double c[9] = {R[4] * R[8] - R[5] * R[7], R[5] * R[6] - R[3] * R[8], R[3] * R[7] - R[4] * R[6],
+                         R[2] * R[7] - R[1] * R[8], R[0] * R[8] - R[2] * R[6], R[1] * R[6] - R[0] * R[7],
+                         R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};  // cofactors = det * R^-T
+    const double inv_det = 1.0 / (R[0] * c[0] + R[1] * c[1] + R[2] * c[2]);
+    double delta = 0;
+    for (int i = 0; i < 9; ++i) {
+      const double n = 0.5 * (R[i] + c[i] * inv_det);
+      delta = fmax(delta, fabs(n - R[i]));
+      R[i] = n;
+    }
+    if (delta < 1e-16) break;
+  }
+}
+
 /** Adjoint, row-major 6x6 */
 DSOPP_HD void rigidAdj(const Rigid &T, double *A) {
   const double *t = T.t;

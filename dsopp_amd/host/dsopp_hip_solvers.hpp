@@ -399,6 +399,8 @@ class HipPoseAlignment {
                                         exposure_time, affine_brightness.data()));
     target_time_ = timestamp;
   }
+  /** setRotationPrior(r_t_r) — pose_alignment.hpp:39, eigen_pose_alignment.cpp:254-257 (row-major 3x3) */
+  void setRotationPrior(const std::array<double, 9> &r_t_r) { check(dsopp_hip_aligner_set_rotation_prior(a_, r_t_r.data())); }
   void pushKnownPose(time_point timestamp, const Motion &t_w_agent) { check(dsopp_hip_aligner_push_known_pose(a_, timestamp, t_w_agent.data())); }
   /** solve(number_of_threads) -> rmse, or kZeroCost when the pose was known */
   double solve(const size_t number_of_threads = 1) {

@@ -358,6 +358,9 @@ int dsopp_hip_aligner_push_target(dsopp_hip_aligner *a, int64_t timestamp, const
                                   const double affine_brightness[2]);
 /* pushKnownPose — eigen_pose_alignment.cpp:268-271 */
 int dsopp_hip_aligner_push_known_pose(dsopp_hip_aligner *a, int64_t timestamp, const double T_world_agent[7]);
+/* setRotationPrior — eigen_pose_alignment.cpp:254-257: the rotation of t_target_reference is replaced by fitToSO3(R) (3x3
+ * row-major, det > 0) at the start of solve (:309-311); reset() clears it (:262), as does a NULL pointer */
+int dsopp_hip_aligner_set_rotation_prior(dsopp_hip_aligner *a, const double *R_target_reference);
 /* solve -> rmse (or kZeroCost = -1) — eigen_pose_alignment.cpp:275-329 */
 int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result);
 /* initializationPoses (src/tracker/tracker/src/monocular_tracker.cpp:136-176): the pose hypotheses estimatePose tries in turn —

@@ -475,6 +475,17 @@ int orc_align_solve(const orc_options *o, int n, const double *u, const double *
                     const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],
                     int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
                     const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2], orc_align_result *out) {
+  return orc_align_solve_with_prior(o, n, u, v, idepth, intensity, ref_intrinsics, ref_width, ref_height, T_w_ref, ref_exposure, ref_ab,
+                                    tgt_intrinsics, tgt_width, tgt_height, tgt_pixelinfo, tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab,
+                                    nullptr, out);
+}
+
+int orc_align_solve_with_prior(const orc_options *o, int n, const double *u, const double *v, const double *idepth,
+                               const double *intensity, const double ref_intrinsics[4], int ref_width, int ref_height,
+                               const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],
+                               int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
+                               const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2],
+                               const double *prior_rotation_t_r, orc_align_result *out) {
   std::vector<AlignPoint> pts(static_cast<size_t>(n));
   for (int i = 0; i < n; ++i) pts[static_cast<size_t>(i)] = {u[i], v[i], idepth[i], intensity[i]};
   AlignFrame rf, tf;
@@ -492,7 +503,7 @@ int orc_align_solve(const orc_options *o, int n, const double *u, const double *
                           tgt_intrinsics[1], tgt_intrinsics[2], tgt_intrinsics[3]};
   tf.grid = PixelMapView{tgt_pixelinfo, tgt_width, tgt_height};
   tf.mask = MaskView{tgt_mask, tgt_width, tgt_height};
-  AlignResult r = alignSolve(rf, tf, pts, toOptions(o), nullptr);
+  AlignResult r = alignSolve(rf, tf, pts, toOptions(o), prior_rotation_t_r);
   out->rmse = r.rmse;
   out->energy = r.lm.energy;
   out->n_valid = r.lm.number_of_valid_residuals;

@@ -96,6 +96,14 @@ int orc_align_solve(const orc_options *o, int n, const double *u, const double *
                     const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],
                     int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
                     const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2], orc_align_result *out);
+/* the same with setRotationPrior (eigen_pose_alignment.cpp:254-257,309-311): the rotation of t_t_r is replaced by
+ * fitToSO3(prior_rotation_t_r) (3x3 row-major, nullable) before the solve */
+int orc_align_solve_with_prior(const orc_options *o, int n, const double *u, const double *v, const double *idepth,
+                               const double *intensity, const double ref_intrinsics[4], int ref_width, int ref_height,
+                               const double T_w_ref[7], double ref_exposure, const double ref_ab[2], const double tgt_intrinsics[4],
+                               int tgt_width, int tgt_height, const double *tgt_pixelinfo, const uint8_t *tgt_mask,
+                               const double T_w_tgt_init[7], double tgt_exposure, const double tgt_ab[2],
+                               const double *prior_rotation_t_r, orc_align_result *out);
 
 /* createReferenceDepthMaps (create_depth_maps.cpp:18-147) over plain arrays: n_sources older keyframes, source s holds
  * counts[s] landmarks starting at offsets into the concatenated arrays (uv 2 per landmark).  Outputs: per level row-major

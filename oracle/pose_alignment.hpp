@@ -191,7 +191,7 @@ inline AlignResult alignSolve(const AlignFrame &reference_frame, AlignFrame &tar
   options.levenberg_marquardt_regularizer_decrease_on_accept = 2.;
   options.levenberg_marquardt_regularizer_increase_on_reject = 2.;
   SE3 t_t_r = target_frame.T_w_agent.inverse() * reference_frame.T_w_agent;
-  (void)prior_rotation_t_r;  // setRotationPrior is only used with an IMU prior; not on the benchmarked path
+  if (prior_rotation_t_r) t_t_r.setRotationMatrix(prior_rotation_t_r);  // eigen_pose_alignment.cpp:309-311
   double affine_brightness_eps[2] = {0, 0};
   PoseAlignerProblem problem(reference_frame, target_frame, points, opt.sigma_huber_loss,
                              opt.affine_brightness_regularizer, t_t_r, affine_brightness_eps);

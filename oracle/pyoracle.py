@@ -398,15 +398,16 @@ def mean_square_optical_flow(idepth_sum, weight, intrinsics, T_target_reference)
 
 
 def align_solve(options, u, v, idepth, intensity, ref_intr, ref_size, T_w_ref, ref_exposure, ref_ab, tgt_intr, tgt_pixelinfo,
-                tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab):
+                tgt_mask, T_w_tgt_init, tgt_exposure, tgt_ab, rotation_prior=None):
     pix = _f64(tgt_pixelinfo)
     H, W = pix.shape[:2]
     m = None if tgt_mask is None else np.ascontiguousarray(tgt_mask, dtype=np.uint8)
     out = AlignResult()
-    rc = lib().orc_align_solve(C.byref(options), len(u), _p(_f64(u)), _p(_f64(v)), _p(_f64(idepth)), _p(_f64(intensity)),
-                               _p(_f64(ref_intr)), int(ref_size[0]), int(ref_size[1]), _p(_f64(T_w_ref)), C.c_double(ref_exposure),
-                               _p(_f64(ref_ab)), _p(_f64(tgt_intr)), W, H, _p(pix), _p(m, np.uint8), _p(_f64(T_w_tgt_init)),
-                               C.c_double(tgt_exposure), _p(_f64(tgt_ab)), C.byref(out))
+    prior = None if rotation_prior is None else _f64(np.asarray(rotation_prior).reshape(9))
+    rc = lib().orc_align_solve_with_prior(C.byref(options), len(u), _p(_f64(u)), _p(_f64(v)), _p(_f64(idepth)), _p(_f64(intensity)),
+                                          _p(_f64(ref_intr)), int(ref_size[0]), int(ref_size[1]), _p(_f64(T_w_ref)), C.c_double(ref_exposure),
+                                          _p(_f64(ref_ab)), _p(_f64(tgt_intr)), W, H, _p(pix), _p(m, np.uint8), _p(_f64(T_w_tgt_init)),
+                                          C.c_double(tgt_exposure), _p(_f64(tgt_ab)), _p(prior), C.byref(out))
     if rc < 0:
         raise RuntimeError(f"orc_align_solve failed {rc}")
     return dict(rmse=out.rmse, energy=out.energy, n_valid=out.n_valid, iterations=out.iterations,

@@ -9,6 +9,7 @@
 // (test/test/energy/motion/se3_motion.cpp:51-140, test/test/energy/projector/test_reprojects.cpp:160,196-204)
 // pin derivatives only.
 #pragma once
+#include <algorithm>
 #include <cmath>
 
 namespace oracle {
@@ -115,6 +116,43 @@ struct SE3 {
     xi[3] = wx;
     xi[4] = wy;
     xi[5] = wz;
+  }
+  /** setRotationMatrix — se3_motion.hpp:215: so3() = SO3::fitToSO3(R), the rotation closest to R (Sophus: U diag(1, 1, det) V^T
+   *  of the SVD; here the equivalent polar iteration R <- (R + R^-T) / 2, valid for det R > 0), stored as a unit quaternion */
+  void setRotationMatrix(const double Rin[9]) {
+    double R[9];
+    for (int i = 0; i < 9; ++i) R[i] = Rin[i];
+    for (int it = 0; it < 30; ++it) {
+      const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+      const double c10 = R[2] * R[7] - R[1] * R[8], c11 = R[0] * R[8] - R[2] * R[6], c12 = R[1] * R[6] - R[0] * R[7];
+      const double c20 = R[1] * R[5] - R[2] * R[4], c21 = R[2] * R[3] - R[0] * R[5], c22 = R[0] * R[4] - R[1] * R[3];
+      const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+      const double invT[9] = {c00 / det, c01 / det, c02 / det, c10 / det, c11 / det, c12 / det, c20 / det, c21 / det, c22 / det};  // R^-T
+      double delta = 0;
+      for (int i = 0; i < 9; ++i) {
+        const double n = 0.5 * (R[i] + invT[i]);
+        delta = std::max(delta, std::abs(n - R[i]));
+        R[i] = n;
+      }
+      if (delta < 1e-16) break;
+    }
+    const double tr = R[0] + R[4] + R[8];
+    double x, y, z, w;
+    if (tr > 0) {
+      const double sq = std::sqrt(tr + 1.0) * 2;
+      w = 0.25 * sq, x = (R[7] - R[5]) / sq, y = (R[2] - R[6]) / sq, z = (R[3] - R[1]) / sq;
+    } else if (R[0] > R[4] && R[0] > R[8]) {
+      const double sq = std::sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
+      w = (R[7] - R[5]) / sq, x = 0.25 * sq, y = (R[1] + R[3]) / sq, z = (R[2] + R[6]) / sq;
+    } else if (R[4] > R[8]) {
+      const double sq = std::sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
+      w = (R[2] - R[6]) / sq, x = (R[1] + R[3]) / sq, y = 0.25 * sq, z = (R[5] + R[7]) / sq;
+    } else {
+      const double sq = std::sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
+      w = (R[3] - R[1]) / sq, x = (R[2] + R[6]) / sq, y = (R[5] + R[7]) / sq, z = 0.25 * sq;
+    }
+    const double n = std::sqrt(x * x + y * y + z * z + w * w);
+    q[0] = x / n, q[1] = y / n, q[2] = z / n, q[3] = w / n;
   }
   SE3 inverse() const {
     SE3 s;

@@ -168,3 +168,53 @@ def test_alignment_photometric_parameters(two_frames, weak_prior):
         assert np.abs(rg["affine_brightness"] - ab_tgt).max() > 1e-3   # the photometric parameters really moved
     for obj in (a, pr, pt):
         obj.close()
+
+
+def test_alignment_rotation_prior(two_frames):
+    """setRotationPrior (eigen_pose_alignment.cpp:254-257,309-311): the rotation of t_target_reference is replaced by the prior
+    projected onto SO(3) before the solve; reset() drops it.  The projection is checked against NumPy's SVD statement."""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = two_frames
+    fr, ft = win.frames
+    H, W = fr.image_u8.shape
+    level = 1
+    infos_r, _ = po.build_pyramid(fr.image_u8, levels=2)
+    infos_t, _ = po.build_pyramid(ft.image_u8, levels=2)
+    pr, pt = capi.Pyramid(W, H, 2), capi.Pyramid(W, H, 2)
+    pr.build(fr.image_u8)
+    pt.build(ft.image_u8)
+    intr = win.scene.intrinsics / 2
+    idsum, wgt = _depth_map(fr, level, 1500, seed=3)
+    T_ref, T_init = syn.mat_to_params(fr.T_w_c_gt), syn.mat_to_params(ft.T_w_c_init)
+    R_gt = (np.linalg.inv(ft.T_w_c_gt) @ fr.T_w_c_gt)[:3, :3]
+    rng = np.random.default_rng(0)
+    prior = R_gt + rng.normal(0, 1e-3, (3, 3))                  # not exactly a rotation: fitToSO3 has work to do
+    U, _, Vt = np.linalg.svd(prior)
+    R_fit = U @ np.diag([1, 1, np.linalg.det(U @ Vt)]) @ Vt
+    u, v, idp, inten = po.points_from_depth_map(infos_r[level], idsum, wgt)
+    h, w = infos_r[level].shape[:2]
+    args = (po.default_align_options(), u, v, idp, inten, intr, (w, h), T_ref, 1.0, np.zeros(2), intr, infos_t[level], None, T_init, 1.0, np.zeros(2))
+    r_plain = po.align_solve(*args)
+    r_prior = po.align_solve(*args, rotation_prior=prior)
+    r_fit = po.align_solve(*args, rotation_prior=R_fit)
+    assert np.abs(r_prior["T_w_target"] - r_fit["T_w_target"]).max() <= 1e-9     # oracle's projection == SVD projection
+    assert np.abs(r_prior["T_w_target"] - r_plain["T_w_target"]).max() > 1e-7    # the prior is not a no-op
+    a = capi.HipAligner(capi.default_align_options())
+    a.set_lm_path(1)
+    res = []
+    for use_prior in (True, False):      # the second pass runs after reset(): the prior must be gone
+        a.reset()
+        if use_prior:
+            a.set_rotation_prior(prior)
+        a.push_reference_depth_map(1000, T_ref, pr, level, intr, idsum, wgt, 1.0, np.zeros(2))
+        a.push_target(2000, T_init, pt, level, intr, 1.0, np.zeros(2))
+        res.append(a.solve())
+    for rg, ro in zip(res, (r_prior, r_plain)):
+        assert rg["iterations"] == ro["iterations"] and rg["n_valid"] == ro["n_valid"]
+        assert np.abs(rg["T_w_target"] - ro["T_w_target"]).max() <= 1e-8
+        assert abs(rg["rmse"] - ro["rmse"]) <= 1e-8 * ro["rmse"]
+    with pytest.raises(capi.HipError):
+        a.set_rotation_prior(np.diag([1.0, 1.0, -1.0]))
+    for obj in (a, pr, pt):
+        obj.close()
