@@ -179,7 +179,7 @@ def main():
         g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
         extras["f32_mode"] = run_f32_mode(capi, syn, win, F, P_local)
-        extras["tracker"] = run_tracker_timing(capi, syn, torch)
+        extras["tracker"] = run_tracker_timing(capi, syn, torch, no_cpu=args.no_cpu)
         extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
         extras["landmark_activation"] = run_landmark_activation_timing(capi, syn, args)
 
@@ -316,7 +316,7 @@ def run_large_window_roofline(capi, syn, dtype, s_bytes):
     return out
 
 
-def run_tracker_timing(capi, syn, torch, frames=20):
+def run_tracker_timing(capi, syn, torch, frames=20, no_cpu=False):
     """C2 of BASELINE.json: coarse-to-fine direct image alignment of a new 1280x1024 frame against the last keyframe,
     5 pyramid levels — estimatePose of the tracker (monocular_tracker.cpp:179-245) on its real inputs: a 7-keyframe /
     2000-point window is bundle-adjusted, createReferenceDepthMaps runs on the device, then every new frame costs
@@ -380,6 +380,28 @@ def run_tracker_timing(capi, syn, torch, frames=20):
            "mean_square_optical_flow_ms_per_frame": flow_ms, "mean_square_optical_flow": float(flow[0]),
            "rmse_per_level": [float(x) for x in rl_final],
            "data": "synthetic 7-keyframe window + 1 new frame, target image resident in HBM"}
+    if not no_cpu:
+        # the same frame through the CPU port: pyramid of the new frame + the coarse-to-fine chain stepped level by level
+        # (scan of the depth map, alignment) from the same initialisation, against the same (downloaded) depth maps
+        from oracle import pyoracle as po
+        infos_ref, _ = po.build_pyramid(kf.image_u8, levels=L)
+        t0 = time.perf_counter()
+        infos_tgt, _ = po.build_pyramid(new_frame.image_u8, levels=L)
+        cpu_pyr_ms = (time.perf_counter() - t0) * 1e3
+        T, ab, its = T_init, np.zeros(2), 0
+        t0 = time.perf_counter()
+        for lvl in range(L - 1, -1, -1):
+            ids, wgt = maps.get_level(lvl)
+            u, v, idp, inten = po.points_from_depth_map(infos_ref[lvl], ids, wgt)
+            r = po.align_solve(po.default_align_options(), u, v, idp, inten, win.scene.intrinsics / (1 << lvl), (W >> lvl, H >> lvl), T_ref, 1.0,
+                               ab_ref, win.scene.intrinsics / (1 << lvl), infos_tgt[lvl], None, T, 1.0, ab)
+            T, ab = r["T_w_target"], r["affine_brightness"]
+            its += r["iterations"]
+        out["cpu_port_ms_per_frame"] = cpu_pyr_ms + (time.perf_counter() - t0) * 1e3
+        out["cpu_port_pyramid_ms"] = cpu_pyr_ms
+        out["cpu_port_lm_iterations"] = its
+        out["cpu_port_pose_difference"] = float(np.abs(T - res["T_w_target"]).max())
+        out["cpu_port_threads"] = 1
     for o in (a, maps, m2, pr, pt, g):
         o.close()
     return out
