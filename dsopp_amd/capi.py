@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_immature_sets_estimate",
     "dsopp_hip_aligner_set_rotation_prior",
     "dsopp_hip_window_refill_reference_depth_maps",
     "dsopp_hip_initialization_poses",
@@ -494,6 +495,16 @@ def initialization_poses(T_world_previous, T_world_last, T_world_keyframe):
     return out[:n.value].copy()
 
 
+def estimate_depths_batched(sets, target_pyramid, level, intrinsics, T_target_reference, reference_exposure, reference_affine,
+                            target_exposure=1.0, target_affine=(0, 0), sigma_huber_loss=20.0):
+    """DepthEstimation::estimate for several keyframes' device-resident sets against one new frame in one launch"""
+    n = len(sets)
+    arr = (C.c_void_p * n)(*[s._h for s in sets])
+    _chk(lib().dsopp_hip_immature_sets_estimate(n, arr, target_pyramid._h, int(level), _p(_f64(intrinsics)), _p(_f64(np.asarray(T_target_reference).reshape(-1))),
+                                                _p(_f64(reference_exposure)), _p(_f64(np.asarray(reference_affine).reshape(-1))), C.c_double(target_exposure),
+                                                _p(_f64(target_affine)), C.c_double(sigma_huber_loss)))
+
+
 class ActivationResult(C.Structure):
     _fields_ = [("number_of_active_points", C.c_int32), ("n_activated", C.c_int32), ("n_skipped", C.c_int32), ("n_deleted", C.c_int32),
                 ("selection_rounds", C.c_int32), ("min_distance_to_neighbor", C.c_double)]
@@ -524,6 +535,10 @@ class ImmatureSet:
         _chk(lib().dsopp_hip_immature_set_estimate(self._h, target_pyramid._h, int(level), _p(_f64(intrinsics)), _p(_f64(T_target_reference)),
                                                    C.c_double(reference_exposure), _p(_f64(reference_affine)), C.c_double(target_exposure),
                                                    _p(_f64(target_affine)), C.c_double(sigma_huber_loss)))
+
+    def sync(self):
+        """wait for the set's stream (dsopp_hip_immature_set_download_state with no outputs)"""
+        _chk(lib().dsopp_hip_immature_set_download_state(self._h, None, None, None, None, None, None))
 
     def upload(self, lms):
         """replace the estimator state (idepth interval, uniqueness, search interval, status, traced)"""

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -28,7 +29,10 @@
 namespace dsopp_hip {
 namespace {
 
-constexpr int kDepthMaxLine = 4096;  // epipolar points whose energy is kept (image diagonal of 2896 x 2896 and below)
+// Energies of the epipolar points are kept in LDS for the uniqueness test: one per pixel step of the segment, i.e. at most the
+// image diagonal.  The LDS buffer is sized to that per launch (640x480: 6.6 KB instead of a fixed 32 KB), which is what
+// bounds the occupancy of this one-wavefront-per-landmark kernel (5 -> 24 workgroups per CU).
+inline int depthMaxLine(int W, int H) { return ((static_cast<int>(std::ceil(std::hypot(static_cast<double>(W), static_cast<double>(H)))) + 16 + 63) / 64) * 64; }
 enum : uint8_t { kImGood = 0, kImOutOfBoundary = 1, kImOutlier = 2, kImSkipped = 3, kImIllConditioned = 4, kImUninitialized = 5, kImDelete = 6 };
 
 struct DepthFrame {
@@ -42,6 +46,7 @@ struct DepthFrame {
   double b_r, b_t;
   double sigma;
   int n;
+  int max_line;  // capacity of the LDS energy buffer (depthMaxLine of the target image)
 };
 
 struct DepthLandmarks {
@@ -336,9 +341,8 @@ __device__ inline double sampleI(const Texel<S> *img, int W, double x, double y)
 }
 
 template <typename S>
-__global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLandmarks L) {
-  __shared__ double energies[kDepthMaxLine];
-  const int li = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void estimateDepthsBody(const DepthFrame &f, const DepthLandmarks &L, const int li, double *energies /* LDS [f.max_line] */) {
+  const int lane = threadIdx.x;
   uint8_t status = L.status[li];
   if (status == kImOutOfBoundary || status == kImDelete || status == kImOutlier) return;  // depth_estimation.cpp:246-250
   const Texel<S> *img = static_cast<const Texel<S> *>(f.texels);
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLa
     const unsigned long long lim = static_cast<unsigned long long>(kMaxPixSearch / search_distance * static_cast<double>(seg.n));
     if (lim < static_cast<unsigned long long>(distance)) distance = static_cast<int>(lim);
   }
-  if (distance > kDepthMaxLine) distance = kDepthMaxLine;  // (never on images up to ~2900 px diagonal)
+  if (distance > f.max_line) distance = f.max_line;  // (a segment has one point per pixel step: never longer than the diagonal)
   // ---- findBest :36-76: lane = epipolar point
   double precalc[8];
 #pragma unroll
@@ -569,6 +573,23 @@ __global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLa
   finish(2 * error_step * 10.0, kImGood);
 }
 
+template <typename S>
+__global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLandmarks L) {
+  extern __shared__ double energies[];  // [f.max_line]
+  estimateDepthsBody<S>(f, L, blockIdx.x, energies);
+}
+
+/** the same over several keyframes' sets in one launch (blockIdx.y = set): the estimator runs for every keyframe of the
+ *  window on every frame (monocular_tracker.cpp:74-102), so one dispatch fills the machine instead of seven partial ones */
+template <typename S>
+__global__ void __launch_bounds__(64) estimateDepthsBatchKernel(const DepthFrame *__restrict__ frames, const DepthLandmarks *__restrict__ landmarks) {
+  extern __shared__ double energies[];
+  const DepthFrame f = frames[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= f.n) return;
+  const DepthLandmarks L = landmarks[blockIdx.y];
+  estimateDepthsBody<S>(f, L, blockIdx.x, energies);
+}
+
 }  // namespace
 }  // namespace dsopp_hip
 
@@ -584,6 +605,7 @@ DepthFrame makeDepthFrame(const dsopp_hip_pyramid *target_pyramid, int level, co
   f.texels = lv.texels;
   f.width = lv.width;
   f.height = lv.height;
+  f.max_line = depthMaxLine(lv.width, lv.height);
   f.fx = intrinsics[0];
   f.fy = intrinsics[1];
   f.cx = intrinsics[2];
@@ -679,6 +701,8 @@ void dsopp_hip_immature_set_destroy(dsopp_hip_immature_set *s) {
   (void)hipSetDevice(s->sr.device);
   if (s->sr.stream) (void)hipStreamSynchronize(s->sr.stream);
   if (s->h_stage) (void)hipHostFree(s->h_stage);
+  if (s->h_tables) (void)hipHostFree(s->h_tables);
+  if (s->tables_copied) (void)hipEventDestroy(s->tables_copied);
   StreamRef sr = s->sr;
   delete s;
   sr.destroy();
@@ -708,6 +732,10 @@ int dsopp_hip_immature_set_download_state(dsopp_hip_immature_set *s, double *ide
     s->sr.use();
     hipStream_t st = s->sr.stream;
     const size_t N = static_cast<size_t>(s->n);
+    if (!idepth_min && !idepth_max && !uniqueness && !search_pixel_interval && !status && !traced) {
+      s->sr.sync();  // no output requested: a plain wait for the set's stream (the estimator calls are asynchronous)
+      return;
+    }
     if (N == 0) return;
     // two contiguous copies into pinned staging (the state planes are adjacent on the device), then a host-side scatter:
     // six pageable copies cost six staged transfers
@@ -748,10 +776,68 @@ int dsopp_hip_immature_set_estimate(dsopp_hip_immature_set *s, const dsopp_hip_p
                                         target_affine, sigma_huber_loss, s->n);
     const DepthLandmarks L = landmarkPointers(s);
     if (target_pyramid->dtype == DSOPP_HIP_F64)
-      estimateDepthsKernel<double><<<s->n, 64, 0, st>>>(f, L);
+      estimateDepthsKernel<double><<<s->n, 64, static_cast<size_t>(f.max_line) * sizeof(double), st>>>(f, L);
     else
-      estimateDepthsKernel<float><<<s->n, 64, 0, st>>>(f, L);
+      estimateDepthsKernel<float><<<s->n, 64, static_cast<size_t>(f.max_line) * sizeof(double), st>>>(f, L);
     HIP_CHECK(hipGetLastError());
+  });
+}
+
+int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *const *sets, const dsopp_hip_pyramid *target_pyramid, int level,
+                                     const double intrinsics[4], const double *T_target_reference, const double *reference_exposure,
+                                     const double *reference_affine, double target_exposure, const double target_affine[2],
+                                     double sigma_huber_loss) {
+  return guarded([&] {
+    if (!sets || !target_pyramid || !intrinsics || !T_target_reference || !reference_exposure || !reference_affine || !target_affine)
+      fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_sets < 1 || n_sets > DSOPP_HIP_MAX_FRAMES) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_sets must be in [1, %d]", DSOPP_HIP_MAX_FRAMES);
+    if (level < 0 || level >= target_pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
+    dsopp_hip_immature_set *lead = nullptr;
+    int max_n = 0;
+    for (int k = 0; k < n_sets; ++k) {
+      if (!sets[k]) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null set %d", k);
+      if (target_pyramid->sr.device != sets[k]->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid lives on another device");
+      if (!lead) lead = sets[k];
+      max_n = std::max(max_n, sets[k]->n);
+    }
+    if (max_n == 0) return;
+    lead->sr.use();
+    hipStream_t st = lead->sr.stream;  // the launch runs on the first set's stream, ordered against the others' below
+    if (target_pyramid->sr.stream != st) HIP_CHECK(hipStreamSynchronize(target_pyramid->sr.stream));
+    struct Tables {
+      DepthFrame f[DSOPP_HIP_MAX_FRAMES];
+      DepthLandmarks l[DSOPP_HIP_MAX_FRAMES];
+    };
+    if (!lead->h_tables) {
+      HIP_CHECK(hipHostMalloc(&lead->h_tables, sizeof(Tables), hipHostMallocDefault));
+      HIP_CHECK(hipEventCreateWithFlags(&lead->tables_copied, hipEventDisableTiming));
+    } else {
+      HIP_CHECK(hipEventSynchronize(lead->tables_copied));  // the pinned table is about to be rewritten
+    }
+    lead->d_tables.reserve(sizeof(Tables), 0, st);
+    Tables &t = *static_cast<Tables *>(lead->h_tables);
+    for (int k = 0; k < n_sets; ++k) {
+      dsopp_hip_immature_set *s = sets[k];
+      if (s->sr.stream != st) HIP_CHECK(hipStreamSynchronize(s->sr.stream));  // earlier work on that set's own stream
+      t.f[k] = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference + 7 * k, reference_exposure[k], reference_affine + 2 * k,
+                              target_exposure, target_affine, sigma_huber_loss, s->n);
+      t.l[k] = landmarkPointers(s);
+    }
+    HIP_CHECK(hipMemcpyAsync(lead->d_tables.ptr, &t, sizeof(Tables), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipEventRecord(lead->tables_copied, st));
+    const DepthFrame *df = reinterpret_cast<const DepthFrame *>(lead->d_tables.ptr);
+    const DepthLandmarks *dl = reinterpret_cast<const DepthLandmarks *>(lead->d_tables.ptr + offsetof(Tables, l));
+    const dim3 grid(static_cast<unsigned>(max_n), static_cast<unsigned>(n_sets));
+    const size_t smem = static_cast<size_t>(t.f[0].max_line) * sizeof(double);
+    if (target_pyramid->dtype == DSOPP_HIP_F64)
+      estimateDepthsBatchKernel<double><<<grid, 64, smem, st>>>(df, dl);
+    else
+      estimateDepthsBatchKernel<float><<<grid, 64, smem, st>>>(df, dl);
+    HIP_CHECK(hipGetLastError());
+    // later per-set calls run on the sets' own streams: they must see this launch finished
+    bool other_streams = false;
+    for (int k = 0; k < n_sets; ++k) other_streams = other_streams || sets[k]->sr.stream != st;
+    if (other_streams) HIP_CHECK(hipStreamSynchronize(st));
   });
 }
 

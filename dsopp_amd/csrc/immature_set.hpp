@@ -13,4 +13,7 @@ struct dsopp_hip_immature_set {
   dsopp_hip::DeviceBuffer<uint8_t> d_flags;  // status | traced
   void *h_stage = nullptr;                   // pinned read-back staging
   size_t h_stage_bytes = 0;
+  void *h_tables = nullptr;                  // pinned descriptor tables of a batched estimate led by this set
+  dsopp_hip::DeviceBuffer<char> d_tables;
+  hipEvent_t tables_copied = nullptr;        // the previous batch's table upload has left the pinned buffer
 };

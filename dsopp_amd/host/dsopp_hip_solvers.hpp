@@ -504,6 +504,26 @@ inline std::vector<Motion> initializationPoses(const Motion *t_world_previous, c
   return out;
 }
 
+/** estimateDepths of the tracker (monocular_tracker.cpp:74-102) for all keyframes of the window in one launch:
+ *  DepthEstimator::estimate(target_frame, keyframe k's immature landmarks, t_t_r[k], ...) for every k */
+inline void estimateDepthsOfWindow(const DevicePyramid &target_frame, const std::vector<DeviceImmatureSet *> &keyframe_sets,
+                                   const std::vector<Motion> &t_target_keyframe, const std::vector<double> &keyframe_exposure_times,
+                                   const std::vector<Vector2> &keyframe_affine_brightness, double target_exposure_time,
+                                   const Vector2 &target_affine_brightness, const PinholeModel &model, double sigma_huber_loss) {
+  const size_t n = keyframe_sets.size();
+  std::vector<dsopp_hip_immature_set *> sets(n);
+  std::vector<double> T(7 * n), ab(2 * n);
+  for (size_t k = 0; k < n; ++k) {
+    sets[k] = keyframe_sets[k]->handle();
+    std::copy(t_target_keyframe[k].begin(), t_target_keyframe[k].end(), T.begin() + 7 * static_cast<long>(k));
+    ab[2 * k] = keyframe_affine_brightness[k][0];
+    ab[2 * k + 1] = keyframe_affine_brightness[k][1];
+  }
+  const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+  check(dsopp_hip_immature_sets_estimate(static_cast<int32_t>(n), sets.data(), target_frame.handle(), 0, intr, T.data(), keyframe_exposure_times.data(),
+                                         ab.data(), target_exposure_time, target_affine_brightness.data(), sigma_huber_loss));
+}
+
 /** ActiveKeyframe::ImmatureLandmarkActivationStatus — src/track/frames/include/track/frames/active_keyframe.hpp:40-44 */
 enum class ImmatureLandmarkActivationStatus : uint8_t { kActivate = 0, kSkip = 1, kDelete = 2 };
 

@@ -131,3 +131,44 @@ def test_gpu_depth_estimation_matches_oracle(scene):
     for k in ("idepth_min", "idepth_max", "uniqueness", "search_pixel_interval", "status", "traced"):
         assert np.array_equal(st[k], lg[k]), k
     dset.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batched_estimate_equals_per_set_calls(scene):
+    """dsopp_hip_immature_sets_estimate (all keyframes' sets against the new frame in one launch) leaves every set in exactly
+    the state the per-set calls leave it in; sets of different sizes, shared and separate streams"""
+    import ctypes
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = scene
+    intr = win.scene.intrinsics
+    new = win.frames[3]
+    pyr = capi.Pyramid(320, 240, 1)
+    pyr.set_level(0, new.pixelinfo)
+    lms, Ts = [], []
+    for i, n in zip(range(3), (150, 97, 31)):
+        f = win.frames[i]
+        uv, grad = _landmarks(po, f, n)
+        direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
+        lms.append(po.new_immature_landmarks(uv, direction, f.patch[:n], grad))
+        Ts.append(_mat_to_params(_rel(new.T_w_c_gt, f.T_w_c_gt)))
+    expo, aff = np.array([1.0, 1.1, 0.9]), np.array([[0.0, 0.0], [0.01, 0.5], [-0.02, -0.3]])
+    single = [capi.ImmatureSet(l) for l in lms]
+    for s, T, e, a in zip(single, Ts, expo, aff):
+        s.estimate(pyr, 0, intr, T, e, a, 1.05, (0.01, 0.2))
+    want = [s.download() for s in single]
+    hip = ctypes.CDLL("libamdhip64.so")
+    shared = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(shared)) == 0
+    for streams in (None, shared.value):
+        batch = [capi.ImmatureSet(l, stream=streams) for l in lms]
+        capi.estimate_depths_batched(batch, pyr, 0, intr, np.stack(Ts), expo, aff, 1.05, (0.01, 0.2))
+        for b, w in zip(batch, want):
+            got = b.download()
+            for k in w:
+                assert np.array_equal(got[k], w[k]), k
+            b.close()
+    assert sum((w["status"] == 0).sum() for w in want) > 100
+    for o in single + [pyr]:
+        o.close()
+    hip.hipStreamDestroy(shared)
