@@ -182,6 +182,7 @@ def main():
         extras["tracker"] = run_tracker_timing(capi, syn, torch, no_cpu=args.no_cpu)
         extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
         extras["landmark_activation"] = run_landmark_activation_timing(capi, syn, args)
+        extras["concurrent_windows"] = run_concurrent_windows(capi, syn, torch, win)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -528,6 +529,38 @@ def run_landmark_activation_timing(capi, syn, args, repeats=10):
     for p in pyramids:
         p.close()
     return out
+
+
+def run_concurrent_windows(capi, syn, torch, win, counts=(1, 2, 4, 8), solves=60):
+    """Serving-side view: several INDEPENDENT C1 windows on one GPU, each on its own stream, all driven from one host thread
+    through dsopp_hip_window_optimize_async / _wait ({restore; optimize} per solve like the headline loop).  A single
+    window is latency-bound (3 dependent launches per iteration), so independent windows overlap until the machine
+    fills.  Aggregate GN iterations/s per window count; the headline `value` stays the single-window figure."""
+    out = {}
+    for n in counts:
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        gs = []
+        for st in streams:
+            g = capi.HipWindow(capi.default_pba_options(), stream=st.cuda_stream)
+            syn.load_window(g, win)
+            g.snapshot()
+            g.optimize()
+            gs.append(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        its = 0
+        for _ in range(solves):
+            for g in gs:
+                g.restore()
+                g.optimize_async()
+            for g in gs:
+                its += g.optimize_wait()[1]
+        dt = time.perf_counter() - t0
+        out[str(n)] = its / dt
+        for g in gs:
+            g.close()
+    return {"workload": "n independent C1 windows, one stream each, one host thread (async enqueue, then wait)",
+            "gn_iterations_per_s_by_window_count": out}
 
 
 def run_cpu_baseline(args, F, P, win, syn):

@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_window_optimize_async", "dsopp_hip_window_optimize_wait",
     "dsopp_hip_immature_sets_estimate",
     "dsopp_hip_aligner_set_rotation_prior",
     "dsopp_hip_window_refill_reference_depth_maps",
@@ -334,6 +335,15 @@ class HipWindow:
     def refill_reference_depth_maps(self, maps: DepthMaps):
         """createReferenceDepthMaps into an existing DepthMaps object (no allocation)"""
         _chk(lib().dsopp_hip_window_refill_reference_depth_maps(self._h, maps._h))
+
+    def optimize_async(self):
+        """enqueue the LM loop on the window's stream (no host synchronisation)"""
+        _chk(lib().dsopp_hip_window_optimize_async(self._h))
+
+    def optimize_wait(self):
+        e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_optimize_wait(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
 
     def optimize_repeated(self, iterations_target: int):
         """{restore(); optimize()} from the snapshot until exactly `iterations_target` GN iterations ran; returns

@@ -76,6 +76,8 @@ struct dsopp_hip_window {
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
   DeviceBuffer<LmControl> d_ctrl;
+  const LmControl *fused_final_ctrl = nullptr;  // control block the enqueued fused loop ends in
+  bool async_pending = false;                   // dsopp_hip_window_optimize_async enqueued, _wait not called yet
   int lm_mode = 0;  // 0: fused device loop (3 launches / iteration), 1: host-driven stages, 2: unfused device loop (5 launches)
   double *dHppRaw() const { return d_reduce.ptr; }
   double *dbppRaw() const { return d_reduce.ptr + static_cast<size_t>(K()) * K(); }
@@ -838,7 +840,7 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
  * sweep re-linearises at the reverted state, which reproduces the system the reference keeps via linear_system_valid).
  * The Schur rows are double-buffered because K1 reads the previous round's rows while writing this round's.
  */
-void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+void lmSolveFusedEnqueue(W &w) {
   hipStream_t st = w.sr.stream;
   LmParams prm;
   prm.function_tolerance = w.opt.function_tolerance;
@@ -898,6 +900,13 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
   HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
   w.host_stale = true;
+  w.fused_final_ctrl = cfin;
+}
+
+/** second half of the fused solve: the one host synchronisation, and the rare closing evaluation after a rejected last step */
+void lmSolveFusedFinish(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+  hipStream_t st = w.sr.stream;
+  const LmControl *cfin = w.fused_final_ctrl;
   w.sr.sync();  // the only host synchronisation of the solve (unless the last step was rejected, below)
   if (w.h_ctrl->need_final_setup) {
     // closing problem.calculateEnergy() at the final state: the last sweep already evaluated it unless the last step was
@@ -907,9 +916,16 @@ void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
     HIP_CHECK(hipGetLastError());
     w.sr.sync();
   }
+  (void)st;
+  (void)cfin;
   energy_out = w.h_ctrl->energy;
   iterations = w.h_ctrl->iteration;
   n_valid_out = w.h_ctrl->n_valid;
+}
+
+void lmSolveFused(W &w, double &energy_out, int &iterations, int &n_valid_out) {
+  lmSolveFusedEnqueue(w);
+  lmSolveFusedFinish(w, energy_out, iterations, n_valid_out);
 }
 
 }  // namespace
@@ -1622,6 +1638,36 @@ int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iter
     double e = 0;
     int it = 0, nv = 0;
     runOptimize(w, e, it, nv);
+    if (energy) *energy = e;
+    if (iterations) *iterations = it;
+    if (n_valid) *n_valid = nv;
+  });
+}
+
+int dsopp_hip_window_optimize_async(dsopp_hip_window *w) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (w->F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
+    if (w->lm_mode != 0) fail(DSOPP_HIP_ERR_STATE, "the asynchronous solve exists for the fused device loop only (lm_mode 0)");
+    if (w->async_pending) fail(DSOPP_HIP_ERR_STATE, "an asynchronous solve is already pending: call dsopp_hip_window_optimize_wait first");
+    w->sr.use();
+    prepare(*w);
+    stageBegin(*w);
+    lmSolveFusedEnqueue(*w);
+    w->async_pending = true;
+  });
+}
+
+int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    if (!w->async_pending) fail(DSOPP_HIP_ERR_STATE, "no asynchronous solve is pending");
+    w->sr.use();
+    double e = 0;
+    int it = 0, nv = 0;
+    w->async_pending = false;
+    lmSolveFusedFinish(*w, e, it, nv);
+    collectTimings(*w);
     if (energy) *energy = e;
     if (iterations) *iterations = it;
     if (n_valid) *n_valid = nv;

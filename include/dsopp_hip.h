@@ -187,6 +187,13 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
  * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:83-86) without the post-processing (relinearise, covariance, statuses).
  * One loop body = one Gauss-Newton iteration = linearize + calculateStep + calculateEnergy + accept/reject. */
 int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid);
+/* the same split in two for callers that drive several independent windows from one host thread (a mapping server with many
+ * sessions per GPU): _async enqueues the whole LM loop on the window's stream and returns, _wait is the one host
+ * synchronisation and returns the results.  One window is latency-bound (three dependent launches per iteration), so
+ * windows on different streams overlap: 8 C1 windows reach ~3x the single-window rate on one MI355X (bench.py,
+ * "concurrent_windows").  No other call on this window between the two. */
+int dsopp_hip_window_optimize_async(dsopp_hip_window *w);
+int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid);
 /* 0 (default): fused device-side LM loop — 3 launches per Gauss-Newton iteration, one read-back per solve;
  * 1: control flow on the host through the stage entry points (one small read-back per energy evaluation);
  * 2: unfused device-side loop (5 launches per iteration).  Same arithmetic in all three; 1 and 2 are kept for debugging and

@@ -253,3 +253,38 @@ def test_frame_update_export_matches_getters(small_window):
         for t in targets:
             assert np.array_equal(up["status"][t], g.get_residuals(fid, t)["status"])
     g.close()
+
+
+def test_async_solve_of_concurrent_windows(small_window):
+    """dsopp_hip_window_optimize_async / _wait: several independent windows enqueued from one host thread, each on its own
+    stream, give bit for bit what the blocking call gives; misuse is reported"""
+    import ctypes
+    from dsopp_amd import capi
+    hip = ctypes.CDLL("libamdhip64.so")
+    ref = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(ref, small_window)
+    want = ref.optimize()
+    want_poses = [np.concatenate(ref.get_pose(f.frame_id)) for f in small_window.frames]
+    wins, streams = [], []
+    for _ in range(4):
+        st = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        g = capi.HipWindow(capi.default_pba_options(), stream=st.value)
+        syn.load_window(g, small_window)
+        wins.append(g)
+        streams.append(st)
+    with pytest.raises(capi.HipError):
+        wins[0].optimize_wait()          # nothing pending
+    for g in wins:
+        g.optimize_async()
+    with pytest.raises(capi.HipError):
+        wins[0].optimize_async()         # already pending
+    for g in wins:
+        got = g.optimize_wait()
+        assert got[1:] == want[1:] and abs(got[0] - want[0]) <= 1e-9 * abs(want[0])
+        for f, wp in zip(small_window.frames, want_poses):
+            assert np.abs(np.concatenate(g.get_pose(f.frame_id)) - wp).max() <= 1e-9
+    for g in wins + [ref]:
+        g.close()
+    for st in streams:
+        hip.hipStreamDestroy(st)
