@@ -7,6 +7,8 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -89,8 +91,303 @@ Mat spectralPinv(const std::vector<double> &w, const Mat &Q, int n, Keep keep) {
   return R;
 }
 
-/** pseudoInverse(origin, number_of_nullspaces): invert all but the smallest `nullspaces` singular values */
-inline Mat pinvDropSmallest(const Mat &H, int n, int nullspaces) {
+/**
+ * pinv of a symmetric positive definite matrix with exactly its smallest eigen-direction dropped, without a full
+ * eigendecomposition:  sum_{i != min} v_i v_i^T / l_i  =  H^-1 - v_min v_min^T / l_min.
+ * H^-1 through a Cholesky factorisation of the Jacobi-scaled matrix (entries span 1e16: the fixed-frame prior), the smallest
+ * eigenpair by inverse iteration with that inverse.  Returns false (caller falls back to the Jacobi eigen-solver) when the
+ * matrix is not safely positive definite, the iteration does not converge (no spectral gap), or the subtraction would cancel
+ * more than ~7 digits (l_2 / l_min too large).  ~10x cheaper than the cyclic Jacobi sweep for the 56 x 56 system of a window.
+ */
+inline bool pinvDropSmallestSpd(const Mat &H, int n, Mat &out, int *why = nullptr, double *info = nullptr) {
+  auto no = [&](int code, double v) {
+    if (why) *why = code;
+    if (info) *info = v;
+    return false;
+  };
+  const size_t N = static_cast<size_t>(n);
+  std::vector<double> d(N);
+  for (int i = 0; i < n; ++i) {
+    const double a = H[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+    if (!(a > 0) || !std::isfinite(a)) return no(1, a);
+    d[static_cast<size_t>(i)] = 1.0 / std::sqrt(a);
+  }
+  Mat L(N * N, 0.0);  // Cholesky factor of S = D H D (unit diagonal), lower triangle
+  for (int j = 0; j < n; ++j) {
+    for (int i = j; i < n; ++i) {
+      double s = H[N * static_cast<size_t>(i) + static_cast<size_t>(j)] * d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+      const double *li = &L[N * static_cast<size_t>(i)], *lj = &L[N * static_cast<size_t>(j)];
+      for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
+      if (i == j) {
+        if (!(s > 1e-13)) return no(2, s);
+        L[N * static_cast<size_t>(j) + static_cast<size_t>(j)] = std::sqrt(s);
+      } else {
+        L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = s / L[N * static_cast<size_t>(j) + static_cast<size_t>(j)];
+      }
+    }
+  }
+  Mat Li(N * N, 0.0);  // L^-1 (lower triangular), row by row
+  for (int i = 0; i < n; ++i) {
+    double *ri = &Li[N * static_cast<size_t>(i)];
+    const double *li = &L[N * static_cast<size_t>(i)];
+    const double inv = 1.0 / li[i];
+    for (int j = 0; j <= i; ++j) {
+      double s = i == j ? 1.0 : 0.0;
+      for (int k = j; k < i; ++k) s -= li[k] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
+      ri[j] = s * inv;
+    }
+  }
+  Mat Ainv(N * N, 0.0);  // H^-1 = D (L^-T L^-1) D
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0;
+      for (int k = i; k < n; ++k) s += Li[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
+      s *= d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+      Ainv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = Ainv[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = s;
+    }
+  // inverse iteration for the smallest eigenpair of H = dominant eigenpair of H^-1
+  std::vector<double> x(N), y(N);
+  for (int i = 0; i < n; ++i) x[static_cast<size_t>(i)] = 1.0 + 0.37 * std::sin(1.0 + 2.3 * i);  // fixed, generic start vector
+  double mu = 0;
+  bool converged = false;
+  for (int it = 0; it < 200 && !converged; ++it) {
+    double nrm = 0;
+    for (int i = 0; i < n; ++i) {
+      double s = 0;
+      const double *row = &Ainv[N * static_cast<size_t>(i)];
+      for (int k = 0; k < n; ++k) s += row[k] * x[static_cast<size_t>(k)];
+      y[static_cast<size_t>(i)] = s;
+      nrm += s * s;
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0) || !std::isfinite(nrm)) return no(3, nrm);
+    double diff = 0, dot = 0;
+    for (int i = 0; i < n; ++i) dot += y[static_cast<size_t>(i)] * x[static_cast<size_t>(i)];
+    const double sgn = dot < 0 ? -1.0 : 1.0;
+    for (int i = 0; i < n; ++i) {
+      const double v = sgn * y[static_cast<size_t>(i)] / nrm;
+      diff = std::max(diff, std::abs(v - x[static_cast<size_t>(i)]));
+      x[static_cast<size_t>(i)] = v;
+    }
+    if (it > 0 && diff < 1e-15) {
+      converged = true;
+      mu = nrm;  // |H^-1 x| for the unit eigenvector = 1 / l_min
+    }
+    if (it == 0) {
+      double xn = 0;
+      for (double v : x) xn += v * v;
+      (void)xn;
+    }
+  }
+  if (!converged) return no(4, mu);
+  // refine mu as the Rayleigh quotient of H^-1 and bound the cancellation of the subtraction below
+  {
+    double q = 0;
+    for (int i = 0; i < n; ++i) {
+      double s = 0;
+      const double *row = &Ainv[N * static_cast<size_t>(i)];
+      for (int k = 0; k < n; ++k) s += row[k] * x[static_cast<size_t>(k)];
+      q += s * x[static_cast<size_t>(i)];
+    }
+    mu = q;
+  }
+  out.assign(N * N, 0.0);
+  double rest = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      const double v = Ainv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] - mu * x[static_cast<size_t>(i)] * x[static_cast<size_t>(j)];
+      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = v;
+      rest = std::max(rest, std::abs(v));
+    }
+  if (!(rest > 0) || mu > 1e7 * rest) return no(5, mu / rest);  // l_2 / l_min beyond 1e7: the difference keeps fewer than ~9 digits
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) {
+      const double v = 0.5 * (out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] + out[N * static_cast<size_t>(j) + static_cast<size_t>(i)]);
+      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = v;
+    }
+  return true;
+}
+
+/** lower Cholesky factor of a dense symmetric matrix (row-major n x n, lower triangle read); false if a pivot <= floor */
+inline bool choleskyLower(const Mat &A, int n, double floor, Mat &L) {
+  const size_t N = static_cast<size_t>(n);
+  L.assign(N * N, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) {
+      double s = A[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
+      const double *li = &L[N * static_cast<size_t>(i)], *lj = &L[N * static_cast<size_t>(j)];
+      for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
+      if (i == j) {
+        if (!(s > floor)) return false;
+        L[N * static_cast<size_t>(j) + static_cast<size_t>(j)] = std::sqrt(s);
+      } else {
+        L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = s / lj[j];
+      }
+    }
+  return true;
+}
+/** x <- (L L^T)^-1 x */
+inline void choleskySolveInPlace(const Mat &L, int n, std::vector<double> &x) {
+  const size_t N = static_cast<size_t>(n);
+  for (int i = 0; i < n; ++i) {
+    double s = x[static_cast<size_t>(i)];
+    const double *li = &L[N * static_cast<size_t>(i)];
+    for (int k = 0; k < i; ++k) s -= li[k] * x[static_cast<size_t>(k)];
+    x[static_cast<size_t>(i)] = s / li[i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[static_cast<size_t>(i)];
+    for (int k = i + 1; k < n; ++k) s -= L[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * x[static_cast<size_t>(k)];
+    x[static_cast<size_t>(i)] = s / L[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+  }
+}
+/** (L L^T)^-1 as a dense symmetric matrix */
+inline Mat choleskyInverse(const Mat &L, int n) {
+  const size_t N = static_cast<size_t>(n);
+  Mat Li(N * N, 0.0), out(N * N, 0.0);
+  for (int i = 0; i < n; ++i) {
+    const double *li = &L[N * static_cast<size_t>(i)];
+    const double inv = 1.0 / li[i];
+    for (int j = 0; j <= i; ++j) {
+      double s = i == j ? 1.0 : 0.0;
+      for (int k = j; k < i; ++k) s -= li[k] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
+      Li[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = s * inv;
+    }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0;
+      for (int k = i; k < n; ++k) s += Li[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
+      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = s;
+    }
+  return out;
+}
+
+/**
+ * pinv of a symmetric positive SEMI-definite matrix whose smallest singular direction is a numerical null space (the scale
+ * gauge of a monocular window: l_min / l_max ~ 1e-14 after Jacobi scaling) with exactly that direction dropped:
+ *   v  = null vector: inverse iteration on the Jacobi-scaled matrix S = D H D shifted by tau (z), mapped back v = D z / |D z|;
+ *   pinv = P (H + c v v^T)^-1 P,  P = I - v v^T  (for an exact null vector (H + c v v^T)^-1 = pinv + v v^T / c).
+ * Verified before it is returned (else the caller falls back to the Jacobi eigen-solver): the dropped direction's singular
+ * value |H v| is 1e-6 below every kept one, and H pinv H = H to 1e-7 in the scaled metric.
+ */
+inline bool pinvDropNullDirection(const Mat &H, int n, Mat &out, int *why = nullptr, double *info = nullptr) {
+  auto no = [&](int code, double v) {
+    if (why) *why = code;
+    if (info) *info = v;
+    return false;
+  };
+  const size_t N = static_cast<size_t>(n);
+  std::vector<double> d(N);
+  for (int i = 0; i < n; ++i) {
+    const double a = H[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+    if (!(a > 0) || !std::isfinite(a)) return no(11, a);
+    d[static_cast<size_t>(i)] = 1.0 / std::sqrt(a);
+  }
+  Mat S(N * N);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) S[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = H[N * static_cast<size_t>(i) + static_cast<size_t>(j)] * d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+  Mat St = S, L;
+  const double tau = 1e-9;
+  for (int i = 0; i < n; ++i) St[N * static_cast<size_t>(i) + static_cast<size_t>(i)] += tau;
+  if (!choleskyLower(St, n, 1e-12, L)) return no(12, 0);
+  std::vector<double> z(N), prev(N);
+  for (int i = 0; i < n; ++i) z[static_cast<size_t>(i)] = 1.0 + 0.37 * std::sin(1.0 + 2.3 * i);
+  bool converged = false;
+  for (int it = 0; it < 100 && !converged; ++it) {
+    prev = z;
+    choleskySolveInPlace(L, n, z);
+    double nrm = 0, dot = 0;
+    for (int i = 0; i < n; ++i) nrm += z[static_cast<size_t>(i)] * z[static_cast<size_t>(i)];
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0) || !std::isfinite(nrm)) return no(13, nrm);
+    for (int i = 0; i < n; ++i) dot += z[static_cast<size_t>(i)] * prev[static_cast<size_t>(i)];
+    const double sg = dot < 0 ? -1.0 / nrm : 1.0 / nrm;
+    double diff = 0;
+    for (int i = 0; i < n; ++i) {
+      z[static_cast<size_t>(i)] *= sg;
+      diff = std::max(diff, std::abs(z[static_cast<size_t>(i)] - prev[static_cast<size_t>(i)]));
+    }
+    converged = it > 0 && diff < 1e-13;
+  }
+  if (!converged) return no(14, 0);
+  std::vector<double> v(N), Dv(N);
+  double vn = 0;
+  for (int i = 0; i < n; ++i) {
+    v[static_cast<size_t>(i)] = d[static_cast<size_t>(i)] * z[static_cast<size_t>(i)];
+    vn += v[static_cast<size_t>(i)] * v[static_cast<size_t>(i)];
+  }
+  vn = std::sqrt(vn);
+  double dv2 = 0, sigma = 0;
+  for (int i = 0; i < n; ++i) {
+    v[static_cast<size_t>(i)] /= vn;
+    Dv[static_cast<size_t>(i)] = d[static_cast<size_t>(i)] * v[static_cast<size_t>(i)];
+    dv2 += Dv[static_cast<size_t>(i)] * Dv[static_cast<size_t>(i)];
+  }
+  for (int i = 0; i < n; ++i) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += H[N * static_cast<size_t>(i) + static_cast<size_t>(k)] * v[static_cast<size_t>(k)];
+    sigma += s * s;
+  }
+  sigma = std::sqrt(sigma);  // singular value of the dropped direction
+  // S_M = D (H + c v v^T) D = S + c (Dv)(Dv)^T with c |Dv|^2 = 1
+  const double c = 1.0 / dv2;
+  Mat SM = S;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) SM[N * static_cast<size_t>(i) + static_cast<size_t>(j)] += c * Dv[static_cast<size_t>(i)] * Dv[static_cast<size_t>(j)];
+  if (!choleskyLower(SM, n, 1e-11, L)) return no(15, 0);
+  Mat Minv = choleskyInverse(L, n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) Minv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] *= d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+  // P Minv P
+  std::vector<double> Mv(N, 0.0);
+  double vMv = 0;
+  for (int i = 0; i < n; ++i) {
+    double s = 0;
+    for (int k = 0; k < n; ++k) s += Minv[N * static_cast<size_t>(i) + static_cast<size_t>(k)] * v[static_cast<size_t>(k)];
+    Mv[static_cast<size_t>(i)] = s;
+    vMv += s * v[static_cast<size_t>(i)];
+  }
+  out.assign(N * N, 0.0);
+  double fro = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      const double w = Minv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] - Mv[static_cast<size_t>(i)] * v[static_cast<size_t>(j)] -
+                       v[static_cast<size_t>(i)] * Mv[static_cast<size_t>(j)] + vMv * v[static_cast<size_t>(i)] * v[static_cast<size_t>(j)];
+      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = w;
+      fro += w * w;
+    }
+  fro = std::sqrt(fro);
+  if (!(sigma * fro < 1e-6)) return no(16, sigma * fro);  // the dropped direction is not (numerically) a null space
+  // H pinv H = H in the scaled metric
+  Mat HP(N * N, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < n; ++k) {
+      const double h = H[N * static_cast<size_t>(i) + static_cast<size_t>(k)];
+      if (h == 0) continue;
+      const double *prow = &out[N * static_cast<size_t>(k)];
+      double *orow = &HP[N * static_cast<size_t>(i)];
+      for (int j = 0; j < n; ++j) orow[j] += h * prow[j];
+    }
+  double worst = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      const double *row = &HP[N * static_cast<size_t>(i)];
+      for (int k = 0; k < n; ++k) s += row[k] * H[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
+      worst = std::max(worst, std::abs(s - H[N * static_cast<size_t>(i) + static_cast<size_t>(j)]) * d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)]);
+    }
+  if (!(worst < 1e-7)) return no(17, worst);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) {
+      const double w = 0.5 * (out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] + out[N * static_cast<size_t>(j) + static_cast<size_t>(i)]);
+      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = w;
+    }
+  return true;
+}
+
+/** pseudoInverse(origin, number_of_nullspaces) through the cyclic Jacobi eigen-solver (relative accuracy on graded matrices) */
+inline Mat pinvDropSmallestJacobi(const Mat &H, int n, int nullspaces) {
   std::vector<double> w;
   Mat Q;
   symmetricEigen(H, n, w, Q);
@@ -100,6 +397,23 @@ inline Mat pinvDropSmallest(const Mat &H, int n, int nullspaces) {
   std::vector<char> keep(static_cast<size_t>(n), 0);
   for (int s = 0; s < n - nullspaces; ++s) keep[static_cast<size_t>(order[static_cast<size_t>(s)])] = 1;
   return spectralPinv(w, Q, n, [&](int e) { return keep[static_cast<size_t>(e)] != 0; });
+}
+
+/** pseudoInverse(origin, number_of_nullspaces): invert all but the smallest `nullspaces` singular values */
+inline Mat pinvDropSmallest(const Mat &H, int n, int nullspaces) {
+  if (nullspaces == 1) {
+    Mat fast;
+    int why = 0;
+    double info = 0;
+    if (pinvDropNullDirection(H, n, fast, &why, &info)) return fast;
+    const int why_null = why;
+    const double info_null = info;
+    if (pinvDropSmallestSpd(H, n, fast, &why, &info)) return fast;
+    if (std::getenv("DSOPP_HIP_TRACE"))
+      std::fprintf(stderr, "[dsopp_hip] pinv fast paths declined: null-space path %d (%g), positive-definite path %d (%g)\n", why_null, info_null,
+                   why, info);
+  }
+  return pinvDropSmallestJacobi(H, n, nullspaces);
 }
 
 /** rank-revealing pseudo-inverse with Eigen's default threshold (epsilon * size * largest pivot) */
