@@ -405,6 +405,14 @@ void prepare(W &w) {
   uploadMarginal(w);
 }
 
+/** prepare() for steps that only touch device state: when nothing on the host is newer than the device (no pending state,
+ *  topology or prior upload) the device is current as it is, and the host mirror may stay behind a device-driven solve —
+ *  its refresh (a read-back + synchronisation) is left to the first reader */
+void prepareDevice(W &w) {
+  w.sr.use();
+  if (w.state_dirty || w.topology_dirty || w.marg_dirty || !w.d_state.ptr) prepare(w);
+}
+
 void ensurePairConstants(W &w) {
   if (w.pair_valid) return;
   const int F = w.F();
@@ -946,7 +954,7 @@ Rigid poseOf(const W &w, int f) {
 
 /** relinearizeSystem — PROB_SRC/photometric_bundle_adjustment.cpp:310-316 (on the device state; the host mirror follows lazily) */
 void relinearize(W &w) {
-  prepare(w);
+  prepareDevice(w);
   relinearizeKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F() - 1);
   HIP_CHECK(hipGetLastError());
   w.host_stale = true;
@@ -956,22 +964,20 @@ void relinearize(W &w) {
 /** updatePointStatuses on the device: exact 3rd-quartile order statistic by an 8-pass radix select over the energies where
  *  they lie, then one pass per landmark.  No host round trip (the sharded multi-rank case keeps the host gather below). */
 void updatePointStatusesDevice(W &w) {
-  prepare(w);
+  prepareDevice(w);
   hipStream_t st = w.sr.stream;
   const int F = w.F();
   w.d_select.reserve(1, 0, st);
   w.d_pair_dist.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames, 0, st);
   selectInitKernel<<<1, 256, 0, st>>>(w.d_select.ptr);
+  const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
   if (w.n_sweep_blocks) {
     const int per_wave = 64 / kItemsPerBlock;
     const int grid = (w.n_sweep_blocks + per_wave - 1) / per_wave;
-    const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
-    for (int pass = 7; pass >= 0; --pass) {
+    for (int pass = 7; pass >= 0; --pass)  // each pass advances the select state from the previous pass's histogram itself
       selectHistKernel<<<grid, 64, 0, st>>>(w.d_frames.ptr, w.d_sweep_table.ptr, w.n_sweep_blocks, w.d_select.ptr, pass);
-      selectScanKernel<<<1, 64, 0, st>>>(w.d_select.ptr, pass, half_sigma_sq);
-    }
   }
-  pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr);
+  pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr, w.n_sweep_blocks ? w.d_select.ptr : nullptr, half_sigma_sq);
   if (w.n_schur_blocks)
     applyPointStatusesKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, st>>>(w.d_frames.ptr, w.d_schur_table.ptr, F, w.d_select.ptr, w.d_pair_dist.ptr);
   HIP_CHECK(hipGetLastError());
@@ -1116,16 +1122,32 @@ void updatePointStatuses(W &w) {
 /** covarianceMatrixPosePose + covarianceMatricesOfRelativePoses — problem.hpp:204-242,
  *  PBA_INT/covariance_matrices_of_relative_poses.hpp:23-62, se3_motion.hpp:151-158 */
 void estimateUncertainty(W &w) {
-  prepare(w);
+  prepareDevice(w);
   if (w.fej()) firstEstimate(w);
   w.begun = true;
   stageLinearize(w, /*huber=*/false, false, true);
   const int K = w.K(), F = w.F();
-  std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K);
-  w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
-  w.d_HscDownload(Hsc.data(), Hsc.size(), 0, w.sr.stream);
+  // ONE synchronisation for everything the host needs: both systems and (when a device-driven solve left the host mirror
+  // behind) the frame states, through pinned staging
+  const size_t kk = static_cast<size_t>(K) * K;
+  const bool want_state = w.host_stale && !w.state_dirty;
+  const size_t bytes = 2 * kk * sizeof(double) + sizeof(WindowState);
+  if (w.h_export_bytes < bytes) {
+    if (w.h_export) (void)hipHostFree(w.h_export);
+    w.h_export = nullptr;
+    HIP_CHECK(hipHostMalloc(&w.h_export, bytes, hipHostMallocDefault));
+    w.h_export_bytes = bytes;
+  }
+  double *Hpp = static_cast<double *>(w.h_export), *Hsc = Hpp + kk;
+  w.d_Hpp.download(Hpp, kk, 0, w.sr.stream);
+  w.d_HscDownload(Hsc, kk, 0, w.sr.stream);
+  if (want_state) HIP_CHECK(hipMemcpyAsync(Hsc + kk, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
   w.sr.sync();
-  hostla::Mat full(static_cast<size_t>(K) * K);
+  if (want_state) {
+    std::memcpy(&w.hst, Hsc + kk, sizeof(WindowState));
+    w.host_stale = false;
+  }
+  hostla::Mat full(kk);
   for (size_t i = 0; i < full.size(); ++i) full[i] = Hpp[i] - Hsc[i] + w.Hm[i];
   const auto t_pinv0 = std::chrono::steady_clock::now();
   const hostla::Mat cov = hostla::pinvDropSmallest(full, K, w.opt.optimize_idepths ? 1 : 0);

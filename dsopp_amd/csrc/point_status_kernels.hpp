@@ -11,23 +11,27 @@
 namespace dsopp_hip {
 
 struct SelectState {
-  unsigned long long prefix;  // bits fixed so far (from the most significant byte down)
-  unsigned long long mask;    // which bits of `prefix` are fixed
-  unsigned int rank;          // rank of the wanted element among the keys matching the prefix
-  unsigned int n_ok;
+  // the state after the scan of pass k lives in slot k & 1: a histogram kernel reads one slot and writes the other, so a
+  // workgroup that starts late never sees a half-advanced state
+  unsigned long long prefix[2];  // bits fixed so far (from the most significant byte down)
+  unsigned long long mask[2];    // which bits of `prefix` are fixed
+  unsigned int rank[2];          // rank of the wanted element among the keys matching the prefix
+  unsigned int n_ok[2];
   double threshold;           // result: selected energy + sigma^2 / 2 (0 when there is no kOk residual)
-  unsigned int hist[256];
+  // three histograms in rotation: the kernel of pass p accumulates into hist[p % 3], reads the finished hist[(p + 1) % 3] of the
+  // previous pass (to advance prefix / rank itself: no separate scan launch) and clears hist[(p + 2) % 3] for the next one
+  unsigned int hist[3][256];
 };
 
 __global__ void selectInitKernel(SelectState *s) {
-  if (threadIdx.x == 0) {
-    s->prefix = 0;
-    s->mask = 0;
-    s->rank = 0;
-    s->n_ok = 0;
+  if (threadIdx.x < 2) {
+    s->prefix[threadIdx.x] = 0;
+    s->mask[threadIdx.x] = 0;
+    s->rank[threadIdx.x] = 0;
+    s->n_ok[threadIdx.x] = 0;
     s->threshold = 0;
   }
-  s->hist[threadIdx.x] = 0;
+  for (int b = 0; b < 3; ++b) s->hist[b][threadIdx.x] = 0;
 }
 
 /** eligible = residual status kOk of a non-marginalised landmark towards a non-marginalised target frame (:340-352) */
@@ -40,62 +44,101 @@ __device__ inline bool eligibleEnergy(const SweepBlock &be, const FrameDev *fram
   return true;
 }
 
-/** one histogram pass of the radix select; byte index `pass` (7 = most significant) */
-__global__ void __launch_bounds__(64) selectHistKernel(const FrameDev *__restrict__ frames, const SweepBlock *__restrict__ table, int n_entries,
-                                                       SelectState *s, int pass) {
-  const int entry = blockIdx.x * (64 / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
-  if (entry >= n_entries) return;
-  const SweepBlock be = table[entry];
-  const int i = be.offset + threadIdx.x % kItemsPerBlock;
-  unsigned long long key;
-  if (!eligibleEnergy(be, frames, i, key)) return;
-  if ((key & s->mask) != s->prefix) return;
-  atomicAdd(&s->hist[(key >> (8 * pass)) & 0xFFull], 1u);
-}
-
-/** picks the bucket that holds the wanted rank, narrows the prefix, clears the histogram (one wave) */
-__global__ void selectScanKernel(SelectState *s, int pass, double half_sigma_sq) {
-  __shared__ unsigned int h[256];
-  const int t = threadIdx.x;
-  for (int k = t; k < 256; k += 64) h[k] = s->hist[k];
-  __syncthreads();
-  if (t == 0) {
-    unsigned int rank = s->rank;
-    if (pass == 7) {
-      unsigned int n = 0;
-      for (int k = 0; k < 256; ++k) n += h[k];
-      s->n_ok = n;
-      rank = static_cast<unsigned int>(static_cast<double>(n) * 0.75);  // third_quartile index, :358
-      if (n == 0) {
-        s->threshold = 0;
-        s->mask = ~0ull;     // nothing matches any more
-        s->prefix = 1;
-      }
-    }
-    if (s->n_ok > 0) {
-      unsigned int cum = 0;
-      int bucket = 255;
-      for (int k = 0; k < 256; ++k) {
-        if (rank < cum + h[k]) {
-          bucket = k;
-          break;
-        }
-        cum += h[k];
-      }
-      s->rank = rank - cum;
-      s->prefix |= static_cast<unsigned long long>(bucket) << (8 * pass);
-      s->mask |= 0xFFull << (8 * pass);
-      if (pass == 0) s->threshold = __longlong_as_double(static_cast<long long>(s->prefix)) + half_sigma_sq;  // :360
+/** what the scan step of pass `done` does to the select state: picks the bucket of hist that holds the wanted rank and
+ *  narrows prefix / mask / rank (pass 7 also fixes n_ok and the third-quartile rank, :358).  Executed by one lane; every
+ *  workgroup of the next pass computes it for itself from the stored state + the finished histogram. */
+struct SelectLocal {
+  unsigned long long prefix, mask;
+  unsigned int rank, n_ok;
+};
+__device__ inline SelectLocal selectAdvance(const SelectState *s, int done) {
+  const int in = (done + 1) & 1;  // S_{done + 1}; for done == 7 that is the initial all-zero state
+  SelectLocal l{s->prefix[in], s->mask[in], s->rank[in], s->n_ok[in]};
+  const unsigned int *h = s->hist[done % 3];
+  if (done == 7) {
+    l = SelectLocal{0, 0, 0, 0};
+    unsigned int n = 0;
+    for (int k = 0; k < 256; ++k) n += h[k];
+    l.n_ok = n;
+    l.rank = static_cast<unsigned int>(static_cast<double>(n) * 0.75);  // third_quartile index, :358
+    if (n == 0) {
+      l.mask = ~0ull;  // nothing matches any more
+      l.prefix = 1;
     }
   }
+  if (l.n_ok > 0) {
+    unsigned int cum = 0;
+    int bucket = 255;
+    for (int k = 0; k < 256; ++k) {
+      if (l.rank < cum + h[k]) {
+        bucket = k;
+        break;
+      }
+      cum += h[k];
+    }
+    l.rank -= cum;
+    l.prefix |= static_cast<unsigned long long>(bucket) << (8 * done);
+    l.mask |= 0xFFull << (8 * done);
+  }
+  return l;
+}
+
+/** one histogram pass of the radix select; byte index `pass` (7 = most significant).  For pass < 7 the workgroup first
+ *  advances the select state by the previous pass's histogram (workgroup 0 also stores it and clears the histogram of the
+ *  next pass): 8 launches per select instead of 16. */
+__global__ void __launch_bounds__(64) selectHistKernel(const FrameDev *__restrict__ frames, const SweepBlock *__restrict__ table, int n_entries,
+                                                       SelectState *s, int pass) {
+  __shared__ SelectLocal sl;
+  if (threadIdx.x == 0) {
+    sl = pass == 7 ? SelectLocal{0, 0, 0, 0} : selectAdvance(s, pass + 1);
+  }
   __syncthreads();
-  for (int k = t; k < 256; k += 64) s->hist[k] = 0;
+  const SelectLocal l = sl;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0 && pass < 7) {  // S_{pass + 1}
+      const int out = (pass + 1) & 1;
+      s->prefix[out] = l.prefix;
+      s->mask[out] = l.mask;
+      s->rank[out] = l.rank;
+      s->n_ok[out] = l.n_ok;
+    }
+    for (int k = threadIdx.x; k < 256; k += 64) s->hist[(pass + 2) % 3][k] = 0;
+  }
+  const int entry = blockIdx.x * (64 / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
+  const bool in_range = entry < n_entries;
+  const SweepBlock be = table[in_range ? entry : 0];
+  const int i = be.offset + threadIdx.x % kItemsPerBlock;
+  unsigned long long key = 0;
+  const bool counts = in_range && eligibleEnergy(be, frames, i, key) && (key & l.mask) == l.prefix;
+  // The upper bytes of the energies are nearly constant (same sign / exponent range), so almost every key of a pass lands in
+  // ONE bucket: 12 000 atomics on one address took 109 us.  The wavefront first counts the lanes that share the bucket of
+  // its first counting lane and adds them with one atomic; only the rest uses per-lane atomics.
+  const unsigned int bucket = static_cast<unsigned int>((key >> (8 * pass)) & 0xFFull);
+  const unsigned long long active = __ballot(counts);
+  if (active == 0) return;
+  const int leader = __ffsll(static_cast<long long>(active)) - 1;
+  const unsigned int common = static_cast<unsigned int>(__shfl(static_cast<int>(bucket), leader));
+  const unsigned long long same = __ballot(counts && bucket == common);
+  if (static_cast<int>(threadIdx.x & 63) == leader) atomicAdd(&s->hist[pass % 3][common], static_cast<unsigned int>(__popcll(same)));
+  if (counts && bucket != common) atomicAdd(&s->hist[pass % 3][bucket], 1u);
+}
+
+/** closing step of the select (after the pass-0 histogram): the selected key is the threshold energy (:360) */
+__device__ inline void selectFinish(SelectState *s, double half_sigma_sq) {
+  const SelectLocal l = selectAdvance(s, 0);
+  s->prefix[0] = l.prefix;
+  s->mask[0] = l.mask;
+  s->rank[0] = l.rank;
+  s->n_ok[0] = l.n_ok;
+  s->threshold = l.n_ok > 0 ? __longlong_as_double(static_cast<long long>(l.prefix)) + half_sigma_sq : 0.0;
 }
 
 /** current camera-centre distances between all frame pairs: |t_r - t_t| of T = T0 exp(eps) (:380-382) */
-__global__ void pairDistanceKernel(const WindowState *st, int F, double *dist /* [kMaxFrames][kMaxFrames] */) {
+__global__ void pairDistanceKernel(const WindowState *st, int F, double *dist /* [kMaxFrames][kMaxFrames] */, SelectState *select,
+                                   double half_sigma_sq) {
   __shared__ double c[kMaxFrames][3];
   const int f = threadIdx.x;
+  if (select && threadIdx.x == 255) selectFinish(select, half_sigma_sq);  // the single-workgroup step between select and apply
   if (f < F) {
     Rigid T0;
 #pragma unroll
