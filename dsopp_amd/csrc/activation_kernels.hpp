@@ -3,14 +3,17 @@
 //   LandmarkActivationProblem, optimizeImmatureLandmark   — src/tracker/landmarks_activator/src/landmarks_activator.cpp:29-391
 //   ImmatureTrackingLandmark::readyForActivation           — src/track/landmarks/src/immature_tracking_landmark.cpp:46-52
 //
-// Three launches, no host round trip in between:
+// Seven launches, no host round trip in between:
 //   1. activationProjectKernel — one thread per active / immature landmark: reprojection into the newest keyframe at the
 //      sparsity level (pyramid level 1), the per-landmark part of activationStatus, number_of_active_points.
-//   2. activationSelectKernel  — one workgroup: P-regulator for min_distance_to_neighbor, a uniform grid over all reprojected
-//      points (cell >= distance, 3 x 3 neighbourhood), and the reference's sequential greedy selection
-//      ("activate if no earlier accepted point is closer than the distance") resolved in parallel rounds: a candidate is
-//      decided as soon as every earlier candidate within the distance is decided; the lowest undecided index always
-//      is, so the loop terminates with exactly the sequential result (the reference's haveNoNeighbors is O(n^2)).
+//   2. the selection — P-regulator for min_distance_to_neighbor (recomputed by every kernel from the device-side count), a
+//      uniform grid over all reprojected points (cell >= distance, 3 x 3 neighbourhood; counting sort: activationCellCount /
+//      CellScan / CellFill), activationNeighboursKernel (one thread per candidate: blocked by an active landmark? which earlier
+//      candidates are within the distance?) and activationResolveKernel: the reference's sequential greedy selection
+//      ("activate if no earlier accepted point is closer than the distance") resolved in parallel rounds by one workgroup
+//      over those short lists — a candidate is decided as soon as every earlier candidate within the distance is decided;
+//      the lowest undecided index always is, so the loop terminates with exactly the sequential result (the reference's
+//      haveNoNeighbors is O(n^2)).  [First version: everything in one workgroup — 545 us of the call's 670.]
 //   3. activationRefineKernel  — one wavefront per accepted candidate: the 3-iteration Levenberg-Marquardt on the inverse
 //      depth over all other keyframes; 8 lanes per target keyframe (one per pattern pixel), DPP sums inside a target,
 //      target sums accumulated in keyframe order like the reference's loop.
@@ -64,9 +67,13 @@ struct ActArgs {
   // work
   double *px, *py;               // [0, active_cap): reprojected active landmarks; active_cap + g: immature landmark g
   int *counters;                 // 0 number_of_active_points, 1 reprojected active points, 2 accepted, 3 rounds, 4 grid_w, 5 grid_h
-  double *distance;              // [0] in: LandmarksActivator::min_distance_to_neighbor_, out: regulated value
+  double distance_in;            // LandmarksActivator::min_distance_to_neighbor_ before the regulator
+  double *distance;              // [0] out: regulated value
   int *state;                    // per immature landmark
-  int *cell_start, *cell_cursor, *cell_items;
+  int *cell_start, *cell_cursor;  // counting sort of the reprojected points into grid cells
+  double *sx, *sy;               // the points in cell order ...
+  int *sid;                      // ... and who they are: -1 - k active landmark slot k, g >= 0 immature landmark g
+  int *nbr, *nbr_count;          // per candidate: the earlier candidates within the distance (kActNbrCap kept)
   int *accepted;
   uint8_t *act_status;           // per immature landmark
   double *idepth_out;            // per immature landmark: idepth() after the call
@@ -164,96 +171,157 @@ __global__ void __launch_bounds__(256) activationProjectKernel(ActArgs a) {
 __device__ __forceinline__ int actLoad(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void actStore(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ void __launch_bounds__(kActSelectThreads) activationSelectKernel(ActArgs a) {
-  __shared__ double s_distance;
+constexpr int kActNbrCap = 12;  // earlier candidates within the distance kept per candidate (more: that candidate rescans its cells)
+
+/** regulated distance (recalculateMinDistanceToNeighbor :29-39) and the uniform grid derived from it; every kernel of the
+ *  selection recomputes it from the same inputs instead of reading it back from a prologue launch */
+struct ActGrid {
+  double distance, inv_cell;
+  int gw, gh, ncell;
+};
+__device__ __forceinline__ ActGrid actGrid(const ActArgs &a) {
+  ActGrid g;
+  double d = a.distance_in + (static_cast<double>(a.counters[0]) - static_cast<double>(a.desired)) * 0.001;
+  d = d < 0.0 ? 0.0 : (d > 10.0 ? 10.0 : d);
+  g.distance = d;
+  const double cell = d > kActMinCell ? d : kActMinCell;
+  g.inv_cell = 1.0 / cell;
+  g.gw = static_cast<int>(a.swd * g.inv_cell) + 1;
+  g.gh = static_cast<int>(a.shd * g.inv_cell) + 1;
+  g.ncell = g.gw * g.gh;  // <= grid_cap by construction of the host (cell >= kActMinCell)
+  return g;
+}
+__device__ __forceinline__ int actCellOf(const ActGrid &g, double x, double y) {
+  int cx = static_cast<int>(x * g.inv_cell), cy = static_cast<int>(y * g.inv_cell);
+  cx = cx < 0 ? 0 : (cx >= g.gw ? g.gw - 1 : cx);
+  cy = cy < 0 ? 0 : (cy >= g.gh ? g.gh - 1 : cy);
+  return cy * g.gw + cx;
+}
+/** slot of point k in px / py (k < active_cap: reprojected active landmark, else immature landmark k - active_cap) and
+ *  whether it takes part in the selection */
+__device__ __forceinline__ bool actPointLive(const ActArgs &a, int k) {
+  return k < a.active_cap ? k < a.counters[1] : a.state[k - a.active_cap] == kCandUndecided;
+}
+
+/** counting sort, step 1: points per cell (cell_start zeroed by the host) */
+__global__ void __launch_bounds__(256) activationCellCountKernel(ActArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.active_cap + a.n_immature || !actPointLive(a, k)) return;
+  const ActGrid g = actGrid(a);
+  atomicAdd(&a.cell_start[actCellOf(g, a.px[k], a.py[k])], 1);
+}
+
+/** step 2: exclusive scan of the cell counts (one workgroup: the grid has a few thousand cells) */
+__global__ void __launch_bounds__(kActSelectThreads) activationCellScanKernel(ActArgs a) {
   __shared__ int s_scan[kActSelectThreads];
   const int tid = threadIdx.x;
-  if (tid == 0) {  // recalculateMinDistanceToNeighbor :29-39
-    double d = a.distance[0] + (static_cast<double>(a.counters[0]) - static_cast<double>(a.desired)) * 0.001;
-    d = d < 0.0 ? 0.0 : (d > 10.0 ? 10.0 : d);
-    a.distance[0] = d;
-    s_distance = d;
-  }
+  const ActGrid g = actGrid(a);
+  const int ncell = g.ncell;
+  const int chunk = (ncell + kActSelectThreads - 1) / kActSelectThreads;
+  const int c0 = tid * chunk, c1 = c0 + chunk < ncell ? c0 + chunk : ncell;
+  int sum = 0;
+  for (int c = c0; c < c1; ++c) sum += a.cell_start[c];
+  s_scan[tid] = sum;
   __syncthreads();
-  const double distance = s_distance;
-  const double cell = distance > kActMinCell ? distance : kActMinCell, inv_cell = 1.0 / cell;
-  const int gw = static_cast<int>(a.swd * inv_cell) + 1, gh = static_cast<int>(a.shd * inv_cell) + 1;
-  const int ncell = gw * gh;  // <= grid_cap by construction of the host (cell >= kActMinCell)
-  const int n_active = a.counters[1], nI = a.n_immature;
-  auto cellOf = [&](double x, double y) {
-    int cx = static_cast<int>(x * inv_cell), cy = static_cast<int>(y * inv_cell);
-    cx = cx < 0 ? 0 : (cx >= gw ? gw - 1 : cx);
-    cy = cy < 0 ? 0 : (cy >= gh ? gh - 1 : cy);
-    return cy * gw + cx;
-  };
-  // ---- counting sort of the points into cells
-  for (int c = tid; c < ncell + 1; c += kActSelectThreads) a.cell_start[c] = 0;
-  __syncthreads();
-  for (int k = tid; k < n_active; k += kActSelectThreads) atomicAdd(&a.cell_start[cellOf(a.px[k], a.py[k])], 1);
-  for (int g = tid; g < nI; g += kActSelectThreads)
-    if (a.state[g] == kCandUndecided) atomicAdd(&a.cell_start[cellOf(a.px[a.active_cap + g], a.py[a.active_cap + g])], 1);
-  __syncthreads();
-  {  // exclusive scan: contiguous chunk per thread, then the chunk totals
-    const int chunk = (ncell + kActSelectThreads - 1) / kActSelectThreads;
-    const int c0 = tid * chunk, c1 = c0 + chunk < ncell ? c0 + chunk : ncell;
-    int sum = 0;
-    for (int c = c0; c < c1; ++c) sum += a.cell_start[c];
-    s_scan[tid] = sum;
+  for (int off = 1; off < kActSelectThreads; off <<= 1) {
+    const int v = tid >= off ? s_scan[tid - off] : 0;
     __syncthreads();
-    for (int off = 1; off < kActSelectThreads; off <<= 1) {
-      const int v = tid >= off ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
-    }
-    int run = s_scan[tid] - sum;
-    for (int c = c0; c < c1; ++c) {
-      const int n = a.cell_start[c];
-      a.cell_start[c] = run;
-      a.cell_cursor[c] = run;
-      run += n;
-    }
-    if (tid == kActSelectThreads - 1) a.cell_start[ncell] = s_scan[tid];
+    s_scan[tid] += v;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int k = tid; k < n_active; k += kActSelectThreads) a.cell_items[atomicAdd(&a.cell_cursor[cellOf(a.px[k], a.py[k])], 1)] = -1 - k;
-  for (int g = tid; g < nI; g += kActSelectThreads)
-    if (a.state[g] == kCandUndecided) a.cell_items[atomicAdd(&a.cell_cursor[cellOf(a.px[a.active_cap + g], a.py[a.active_cap + g])], 1)] = g;
-  __syncthreads();
-  // ---- greedy selection in rounds (haveNoNeighbors :41-49 against the points pushed before this candidate)
+  int run = s_scan[tid] - sum;
+  for (int c = c0; c < c1; ++c) {
+    const int n = a.cell_start[c];
+    a.cell_start[c] = run;
+    a.cell_cursor[c] = run;
+    run += n;
+  }
+  if (tid == kActSelectThreads - 1) a.cell_start[ncell] = s_scan[tid];
+}
+
+/** step 3: points into cell order (coordinates and identity side by side: a cell scan reads three contiguous arrays) */
+__global__ void __launch_bounds__(256) activationCellFillKernel(ActArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.active_cap + a.n_immature || !actPointLive(a, k)) return;
+  const ActGrid g = actGrid(a);
+  const double x = a.px[k], y = a.py[k];
+  const int pos = atomicAdd(&a.cell_cursor[actCellOf(g, x, y)], 1);
+  a.sx[pos] = x;
+  a.sy[pos] = y;
+  a.sid[pos] = k < a.active_cap ? -1 - k : k - a.active_cap;
+}
+
+/** scan of the 3 x 3 cell neighbourhood of candidate g; calls f(id) for every point closer than the distance (id < 0: an
+ *  active landmark) until f returns false */
+template <typename F>
+__device__ __forceinline__ void actForNeighbours(const ActArgs &a, const ActGrid &g, double x, double y, F f) {
+  const int c = actCellOf(g, x, y), cx = c % g.gw, cy = c / g.gw;
+  for (int yy = (cy > 0 ? cy - 1 : 0); yy <= (cy + 1 < g.gh ? cy + 1 : g.gh - 1); ++yy) {
+    const int lo = a.cell_start[yy * g.gw + (cx > 0 ? cx - 1 : 0)], hi = a.cell_start[yy * g.gw + (cx + 1 < g.gw ? cx + 1 : g.gw - 1) + 1];
+    for (int it = lo; it < hi; ++it) {  // the three cells of a grid row are contiguous in cell order
+      const double dx = a.sx[it] - x, dy = a.sy[it] - y;
+      if (sqrt(dx * dx + dy * dy) < g.distance)
+        if (!f(a.sid[it])) return;
+    }
+  }
+}
+
+/** haveNoNeighbors (:41-49), the order-independent part: a candidate within the distance of a reprojected ACTIVE landmark
+ *  is blocked whatever the order; the earlier candidates within the distance are remembered for the greedy rounds */
+__global__ void __launch_bounds__(256) activationNeighboursKernel(ActArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.n_immature || a.state[g] != kCandUndecided) return;
+  const ActGrid grid = actGrid(a);
+  const double x = a.px[a.active_cap + g], y = a.py[a.active_cap + g];
+  bool blocked = false;
+  int cnt = 0;
+  int *list = a.nbr + static_cast<size_t>(g) * kActNbrCap;
+  actForNeighbours(a, grid, x, y, [&](int id) {
+    if (id < 0) {
+      blocked = true;
+      return false;
+    }
+    if (id < g) {
+      if (cnt < kActNbrCap) list[cnt] = id;
+      ++cnt;
+    }
+    return true;
+  });
+  if (blocked) a.state[g] = kCandBlocked;
+  a.nbr_count[g] = cnt;
+}
+
+/** the reference's sequential greedy selection ("activate if no earlier accepted point is closer than the distance")
+ *  resolved in parallel rounds by one workgroup: a candidate is decided as soon as every earlier candidate within the distance
+ *  is decided; the lowest undecided index always is, so the loop terminates with exactly the sequential result */
+__global__ void __launch_bounds__(kActSelectThreads) activationResolveKernel(ActArgs a) {
+  const int tid = threadIdx.x;
+  const ActGrid grid = actGrid(a);
+  const int nI = a.n_immature;
   int rounds = 0;
   for (;;) {
     int undecided = 0;
     for (int g = tid; g < nI; g += kActSelectThreads) {
       if (actLoad(&a.state[g]) != kCandUndecided) continue;
-      const double x = a.px[a.active_cap + g], y = a.py[a.active_cap + g];
-      const int cx = cellOf(x, y) % gw, cy = cellOf(x, y) / gw;
       bool blocked = false, wait = false;
-      for (int yy = (cy > 0 ? cy - 1 : 0); yy <= (cy + 1 < gh ? cy + 1 : gh - 1) && !blocked; ++yy)
-        for (int xx = (cx > 0 ? cx - 1 : 0); xx <= (cx + 1 < gw ? cx + 1 : gw - 1) && !blocked; ++xx) {
-          const int c = yy * gw + xx;
-          for (int it = a.cell_start[c]; it < a.cell_start[c + 1]; ++it) {
-            const int id = a.cell_items[it];
-            int sj = kCandAccepted;
-            int slot;
-            if (id < 0) {
-              slot = -1 - id;
-            } else {
-              if (id >= g) continue;
-              sj = actLoad(&a.state[id]);
-              if (sj == kCandBlocked) continue;
-              slot = a.active_cap + id;
-            }
-            const double dx = a.px[slot] - x, dy = a.py[slot] - y;
-            if (sqrt(dx * dx + dy * dy) < distance) {
-              if (sj == kCandAccepted) {
-                blocked = true;
-                break;
-              }
-              wait = true;
-            }
-          }
+      const int cnt = a.nbr_count[g];
+      if (cnt <= kActNbrCap) {
+        const int *list = a.nbr + static_cast<size_t>(g) * kActNbrCap;
+        for (int k = 0; k < cnt; ++k) {
+          const int sj = actLoad(&a.state[list[k]]);
+          blocked = blocked || sj == kCandAccepted;
+          wait = wait || sj == kCandUndecided;
         }
+      } else {  // more neighbours than the list holds: rescan the cells
+        actForNeighbours(a, grid, a.px[a.active_cap + g], a.py[a.active_cap + g], [&](int id) {
+          if (id >= 0 && id < g) {
+            const int sj = actLoad(&a.state[id]);
+            blocked = blocked || sj == kCandAccepted;
+            wait = wait || sj == kCandUndecided;
+          }
+          return true;
+        });
+      }
       if (blocked) actStore(&a.state[g], kCandBlocked);
       else if (!wait) actStore(&a.state[g], kCandAccepted);
       else undecided = 1;
@@ -268,8 +336,9 @@ __global__ void __launch_bounds__(kActSelectThreads) activationSelectKernel(ActA
     }
   if (tid == 0) {
     a.counters[3] = rounds;
-    a.counters[4] = gw;
-    a.counters[5] = gh;
+    a.counters[4] = grid.gw;
+    a.counters[5] = grid.gh;
+    a.distance[0] = grid.distance;
   }
 }
 

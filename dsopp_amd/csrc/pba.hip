@@ -106,7 +106,8 @@ struct dsopp_hip_window {
     DeviceBuffer<ActPair> pairs;
     DeviceBuffer<const void *> texels0;
     DeviceBuffer<double> px, py, distance, idepth_out;
-    DeviceBuffer<int> counters, state, cell_start, cell_cursor, cell_items, accepted;
+    DeviceBuffer<double> sx, sy;
+    DeviceBuffer<int> counters, state, cell_start, cell_cursor, sid, accepted, nbr, nbr_count;
     DeviceBuffer<uint8_t> act_status;
   } act;
   bool marg_dirty = true;
@@ -2415,14 +2416,19 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     S.state.reserve(nI, 0, st);
     S.cell_start.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
     S.cell_cursor.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
-    S.cell_items.reserve(nP, 0, st);
+    S.sx.reserve(nP, 0, st);
+    S.sy.reserve(nP, 0, st);
+    S.sid.reserve(nP, 0, st);
+    S.nbr.reserve(nI * kActNbrCap, 0, st);
+    S.nbr_count.reserve(nI, 0, st);
     S.accepted.reserve(nI, 0, st);
     S.act_status.reserve(nI, 0, st);
     S.keyframes.upload(kfs.data(), kfs.size(), 0, st);
     S.pairs.upload(pairs.data(), pairs.size(), 0, st);
     S.texels0.upload(tex.data(), tex.size(), 0, st);
-    S.distance.upload(min_distance_to_neighbor, 1, 0, st);
     HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 8 * sizeof(int), st));
+    HIP_CHECK(hipMemsetAsync(S.cell_start.ptr, 0, (static_cast<size_t>(a.grid_cap) + 1) * sizeof(int), st));
+    a.distance_in = *min_distance_to_neighbor;
     a.keyframes = S.keyframes.ptr;
     a.pairs = S.pairs.ptr;
     a.texels0 = S.texels0.ptr;
@@ -2450,7 +2456,11 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     a.state = S.state.ptr;
     a.cell_start = S.cell_start.ptr;
     a.cell_cursor = S.cell_cursor.ptr;
-    a.cell_items = S.cell_items.ptr;
+    a.sx = S.sx.ptr;
+    a.sy = S.sy.ptr;
+    a.sid = S.sid.ptr;
+    a.nbr = S.nbr.ptr;
+    a.nbr_count = S.nbr_count.ptr;
     a.accepted = S.accepted.ptr;
     a.act_status = S.act_status.ptr;
     a.idepth_out = S.idepth_out.ptr;
@@ -2460,7 +2470,14 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
       if (f64) activationProjectKernel<double><<<grid, 256, 0, st>>>(a);
       else activationProjectKernel<float><<<grid, 256, 0, st>>>(a);
     }
-    activationSelectKernel<<<1, kActSelectThreads, 0, st>>>(a);
+    {
+      const unsigned pts = static_cast<unsigned>((n_active_cap + n_immature + 255) / 256);
+      if (pts) activationCellCountKernel<<<pts, 256, 0, st>>>(a);
+      activationCellScanKernel<<<1, kActSelectThreads, 0, st>>>(a);
+      if (pts) activationCellFillKernel<<<pts, 256, 0, st>>>(a);
+      if (n_immature > 0) activationNeighboursKernel<<<static_cast<unsigned>((n_immature + 255) / 256), 256, 0, st>>>(a);
+      activationResolveKernel<<<1, kActSelectThreads, 0, st>>>(a);
+    }
     if (n_immature > 0) {
       if (f64) activationRefineKernel<double><<<static_cast<unsigned>(n_immature), 64, 0, st>>>(a);
       else activationRefineKernel<float><<<static_cast<unsigned>(n_immature), 64, 0, st>>>(a);
