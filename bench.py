@@ -412,7 +412,6 @@ def run_depth_estimation_timing(capi, syn, args, repeats=10):
     """row f-1: DepthEstimation::estimate for the immature landmarks of the window's keyframes against a new 640x480 frame
     (monocular_tracker.cpp:74-102 runs it for every frame over all keyframes): 7 keyframes x 2000 immature landmarks.
     GPU call = upload of the landmark arrays + kernel + download (host buffers at the boundary); CPU port beside it."""
-    from oracle import pyoracle as po
     W, H, KF, N = 640, 480, 7, 2000
     win = syn.make_window(num_frames=KF + 1, num_points=(KF + 1) * N, width=W, height=H, seed=5, pose_noise=False)
     new = win.frames[-1]
@@ -425,7 +424,11 @@ def run_depth_estimation_timing(capi, syn, args, repeats=10):
         ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
         grad = np.stack([f.pixelinfo[vi, ui, 1], f.pixelinfo[vi, ui, 2]], axis=1)
         direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
-        sets.append(po.new_immature_landmarks(uv, direction, f.patch, grad))
+        # ImmatureTrackingLandmark constructor defaults (immature_tracking_landmark.hpp:93-106), as struct-of-arrays
+        sets.append(dict(projection=uv.copy(), direction=direction, patch=f.patch.copy(), gradient=grad, idepth_min=np.zeros(N),
+                         idepth_max=np.full(N, 1000.0), uniqueness=np.full(N, np.finfo(np.float64).max),
+                         search_pixel_interval=np.full(N, np.finfo(np.float64).max), status=np.full(N, 5, dtype=np.uint8),
+                         traced=np.zeros(N, dtype=np.uint8)))
         Ts.append(syn.mat_to_params(np.linalg.inv(new.T_w_c_gt) @ f.T_w_c_gt))
     import copy
     t_gpu, t_rb = [], []
@@ -447,7 +450,8 @@ def run_depth_estimation_timing(capi, syn, args, repeats=10):
            "landmarks": KF * N, "good_after_first_observation": good, "state_read_back_ms": float(np.median(t_rb) * 1e3),
            "what": "dsopp_hip_immature_sets_estimate: one launch over the 7 device-resident landmark sets, then a stream sync; "
                    "state_read_back_ms = download of all estimator states (needed at keyframe time only)"}
-    if not args.no_cpu:
+    if not args.no_cpu:   # the CPU port is imported by this leg only
+        from oracle import pyoracle as po
         hw = os.cpu_count() or 1
         po.set_threads(max(1, min(hw, 8) - 1))
         work = copy.deepcopy(sets)
