@@ -97,3 +97,50 @@ def test_aligner_and_pyramid_contract_violations(tiny_window):
     assert _code(e) == -1
     for o in (a, pyr, f32):
         o.close()
+
+
+def test_empty_and_degenerate_inputs_of_the_tracker_side_calls(tiny_window):
+    """empty sets, keyframes without immature landmarks, an empty depth map, a window without active landmarks: every call
+    returns cleanly with the reference's result for the empty case"""
+    from dsopp_amd import capi
+    win = tiny_window
+    intr = win.scene.intrinsics
+    H, W = win.frames[0].image_u8.shape
+    g = capi.HipWindow(capi.default_pba_options())
+    pyrs = []
+    for i, f in enumerate(win.frames):
+        p = capi.Pyramid(W, H, 2)
+        p.build(f.image_u8)
+        pyrs.append(p)
+        if i < 2:
+            g.push_frame(f.frame_id, f.timestamp, None, None, intr, syn.mat_to_params(f.T_w_c_gt), 1.0, np.zeros(2), i == 0, False, pyramid=p)
+            g.set_landmarks(f.frame_id, np.zeros((0, 2)), np.zeros(0), np.zeros((0, 8)), np.zeros(0, dtype=np.uint8))
+    new = win.frames[2]
+    empty = dict(projection=np.zeros((0, 2)), direction=np.zeros((0, 3)), patch=np.zeros((0, 8)), gradient=np.zeros((0, 2)),
+                 status=np.zeros(0, dtype=np.uint8))
+    s_empty = capi.ImmatureSet(empty)
+    # activation: no active landmarks, one keyframe with an empty set, one without a set
+    st, idp, res = g.activate_landmarks([win.frames[0].frame_id, win.frames[1].frame_id], [s_empty, None], pyrs[2], syn.mat_to_params(new.T_w_c_gt),
+                                        1.0, (0, 0), 2000, 2.0, True)
+    assert res["number_of_active_points"] == 0 and res["n_activated"] == 0 and len(st[0]) == 0 and len(st[1]) == 0
+    assert abs(res["min_distance_to_neighbor"] - 0.0) < 1e-15        # 2.0 + (0 - 2000) * 0.001 clamps at 0 (:34-38)
+    # depth estimation on an empty set, alone and inside a batch
+    T = syn.mat_to_params(np.linalg.inv(new.T_w_c_gt) @ win.frames[0].T_w_c_gt)
+    s_empty.estimate(pyrs[2], 0, intr, T)
+    capi.estimate_depths_batched([s_empty, s_empty], pyrs[2], 0, intr, np.stack([T, T]), np.ones(2), np.zeros((2, 2)))
+    assert len(s_empty.download()["status"]) == 0
+    with pytest.raises(capi.HipError):
+        capi.estimate_depths_batched([], pyrs[2], 0, intr, np.zeros((0, 7)), np.zeros(0), np.zeros((0, 2)))
+    # reference depth maps of a window without landmarks: all-zero maps, optical flow of nothing = NaN (0 / 0 in the reference)
+    maps = g.create_reference_depth_maps(2)
+    ids, wgt = maps.get_level(0)
+    assert not ids.any() and not wgt.any()
+    assert np.isnan(maps.mean_square_optical_flow(0, intr, [T])[0])
+    # aligning against the empty maps: no valid residual, zero iterations, failure reported through rmse
+    a = capi.HipAligner()
+    rl = np.full(2, 1e10)
+    r = a.estimate_pose(win.frames[1].timestamp, syn.mat_to_params(win.frames[1].T_w_c_gt), pyrs[1], maps, 1.0, np.zeros(2), new.timestamp, pyrs[2], 1.0,
+                        intr, syn.mat_to_params(new.T_w_c_gt)[None, :], np.zeros(2), rl)
+    assert r["lm_iterations"] == 0 and not r["success"]
+    for o in [a, maps, s_empty, g] + pyrs:
+        o.close()
