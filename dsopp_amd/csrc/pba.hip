@@ -100,6 +100,18 @@ struct dsopp_hip_window {
   DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
   void *h_export = nullptr;             // its pinned host staging
   size_t h_export_bytes = 0;
+  // Pinned bump allocator for the per-keyframe uploads (landmarks, connection statuses, flags): the caller's arrays are
+  // copied here and leave with asynchronous transfers, so set_landmarks / set_connection need no synchronisation of their own.
+  // When the ring wraps the stream is synchronised once (every transfer that read the old contents has finished then).
+  struct StageRing {
+    char *base = nullptr;
+    size_t capacity = 0, offset = 0;
+  } stage;
+  DeviceBuffer<uint8_t> d_flag_stage;  // host-side flag bits of one frame on their way into the merge kernel
+  // device buffers of keyframes / connections that left the window, kept for the next keyframe: a new keyframe needs ~12
+  // landmark arrays and 12 connection tables of 5 arrays each — about 70 hipMallocs (0.5 ms) when allocated afresh
+  std::vector<std::unique_ptr<HostFrame>> frame_pool;
+  std::vector<std::unique_ptr<ResidualTable>> table_pool;
   std::vector<DeviceBuffer<double>> dm_tmp_id, dm_tmp_w;  // undilated reference depth maps (temporaries of createReferenceDepthMaps)
   struct ActivationScratch {            // work buffers of dsopp_hip_window_activate_landmarks
     DeviceBuffer<ActKeyframe> keyframes;
@@ -223,6 +235,50 @@ void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   }
   f.cap = cap;
   w.topology_dirty = true;
+}
+
+/** `bytes` of pinned staging whose previous contents are no longer in flight */
+void *stageAcquire(W &w, size_t bytes) {
+  bytes = (bytes + 63) & ~static_cast<size_t>(63);
+  if (bytes > w.stage.capacity) {
+    if (w.stage.base) {
+      w.sr.sync();
+      (void)hipHostFree(w.stage.base);
+      w.stage.base = nullptr;
+    }
+    const size_t cap = std::max<size_t>(bytes * 2, size_t(1) << 21);
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.stage.base), cap, hipHostMallocDefault));
+    w.stage.capacity = cap;
+    w.stage.offset = 0;
+  }
+  if (w.stage.offset + bytes > w.stage.capacity) {
+    w.sr.sync();
+    w.stage.offset = 0;
+  }
+  void *p = w.stage.base + w.stage.offset;
+  w.stage.offset += bytes;
+  return p;
+}
+/** asynchronous upload of caller memory through the pinned ring */
+template <typename T>
+void uploadStaged(W &w, DeviceBuffer<T> &dst, const T *host, size_t count, size_t offset) {
+  if (!count) return;
+  void *p = stageAcquire(w, count * sizeof(T));
+  std::memcpy(p, host, count * sizeof(T));
+  HIP_CHECK(hipMemcpyAsync(dst.ptr + offset, p, count * sizeof(T), hipMemcpyHostToDevice, w.sr.stream));
+}
+
+/** landmark flags: {marginalized, to_marginalize} are decided on the host (LocalFrame::update), {outlier, ill_conditioned}
+ *  live on the device (point statuses, Schur kernel): old landmarks keep the device bits, new ones take the host's outlier bit */
+__global__ void mergeLandmarkFlagsKernel(uint8_t *__restrict__ dflags, const uint8_t *__restrict__ host_bits, int n_old, int n_total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  const uint8_t h = host_bits[i];
+  dflags[i] = i < n_old ? static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize))) : h;
+}
+__global__ void clearLandmarkFlagKernel(uint8_t *__restrict__ dflags, int n, uint8_t mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dflags[i] &= static_cast<uint8_t>(~mask);
 }
 
 /** rebuild the FrameDev table, the sweep / Schur block tables and upload them */
@@ -1248,15 +1304,8 @@ void foldMarginalized(W &w) {
         fl &= static_cast<uint8_t>(~kFlagToMarginalize);
         changed = true;
       }
-    if (changed) {
-      // device flags may carry ill_conditioned bits set by the Schur kernel: merge
-      std::vector<uint8_t> dev(static_cast<size_t>(f.n));
-      f.dflags.download(dev.data(), dev.size(), 0, w.sr.stream);
-      w.sr.sync();
-      for (int i = 0; i < f.n; ++i) dev[static_cast<size_t>(i)] &= static_cast<uint8_t>(~kFlagToMarginalize);
-      f.dflags.upload(dev.data(), dev.size(), 0, w.sr.stream);
-      w.sr.sync();
-    }
+    if (changed && f.n)  // on the device too (its other bits — outlier, ill_conditioned — are the device's own)
+      clearLandmarkFlagKernel<<<(f.n + 255) / 256, 256, 0, w.sr.stream>>>(f.dflags.ptr, f.n, kFlagToMarginalize);
   }
   std::vector<int> marginalized_part;
   for (int f = 0; f < F; ++f)
@@ -1293,9 +1342,20 @@ void foldMarginalized(W &w) {
   // erase the marginalised frames (:201-202) — state rows shift down
   WindowState ns = w.hst;
   std::vector<std::unique_ptr<HostFrame>> kept;
+  std::vector<int> erased_ids;
   int dst = 0;
   for (int f = 0; f < F; ++f) {
-    if (w.frames[static_cast<size_t>(f)]->to_marginalize) continue;
+    if (w.frames[static_cast<size_t>(f)]->to_marginalize) {
+      // recycle the device buffers of the leaving frame: its own connection tables and landmark arrays
+      std::unique_ptr<HostFrame> gone = std::move(w.frames[static_cast<size_t>(f)]);
+      for (auto &kv : gone->residuals)
+        if (kv.second) w.table_pool.push_back(std::move(kv.second));
+      gone->residuals.clear();
+      gone->covariance.clear();
+      erased_ids.push_back(gone->id);
+      w.frame_pool.push_back(std::move(gone));
+      continue;
+    }
     std::memcpy(ns.T0_R[dst], w.hst.T0_R[f], sizeof(ns.T0_R[dst]));
     std::memcpy(ns.T0_t[dst], w.hst.T0_t[f], sizeof(ns.T0_t[dst]));
     std::memcpy(ns.ab0[dst], w.hst.ab0[f], sizeof(ns.ab0[dst]));
@@ -1304,6 +1364,13 @@ void foldMarginalized(W &w) {
     kept.push_back(std::move(w.frames[static_cast<size_t>(f)]));
     ++dst;
   }
+  for (auto &kf : kept)  // ... and the remaining frames' tables towards it
+    for (int id : erased_ids) {
+      auto it = kf->residuals.find(id);
+      if (it == kf->residuals.end()) continue;
+      if (it->second) w.table_pool.push_back(std::move(it->second));
+      kf->residuals.erase(it);
+    }
   w.hst = ns;
   w.frames = std::move(kept);
   w.marg_size = kBlk * w.F();
@@ -1412,6 +1479,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
   if (w->h_export) (void)hipHostFree(w->h_export);
+  if (w->stage.base) (void)hipHostFree(w->stage.base);
   w->frames.clear();
   StreamRef sr = w->sr;
   delete w;
@@ -1433,7 +1501,17 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
     if (w->frames.size() > 1) foldMarginalized(*w);
     if (w->F() >= kMaxFrames) fail(DSOPP_HIP_ERR_CAPACITY, "window holds %d frames already", kMaxFrames);
     downloadState(*w);
-    auto f = std::make_unique<HostFrame>();
+    std::unique_ptr<HostFrame> f;
+    if (!w->frame_pool.empty()) {  // device arrays of a keyframe that left the window (capacity kept, contents dead)
+      f = std::move(w->frame_pool.back());
+      w->frame_pool.pop_back();
+      f->n = 0;
+      f->snap_n = 0;
+      f->flags.clear();
+      f->to_marginalize = false;
+    } else {
+      f = std::make_unique<HostFrame>();
+    }
     f->id = frame_id;
     f->timestamp = timestamp;
     f->pyramid = pyramid;
@@ -1477,30 +1555,31 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     hipStream_t st = w->sr.stream;
     ensureLandmarkCapacity(*w, f, n_total);
     const int old = f.n;
-    // existing landmarks: only flags move (LocalFrame::update, local_frame.hpp:492-497); device flags may carry the
-    // ill_conditioned bit which is preserved
-    std::vector<uint8_t> dev(static_cast<size_t>(old));
-    if (old) {
-      f.dflags.download(dev.data(), dev.size(), 0, st);
-      w->sr.sync();
-    }
+    // existing landmarks: only flags move (LocalFrame::update, local_frame.hpp:492-497).  The host mirror holds the bits the
+    // host decides (marginalized, to_marginalize); the device flags also carry outlier / ill_conditioned, which stay
     f.flags.resize(static_cast<size_t>(n_total));
     for (int i = 0; i < old; ++i) {
-      const bool was_marg = dev[static_cast<size_t>(i)] & kFlagMarginalized;
+      const bool was_marg = f.flags[static_cast<size_t>(i)] & kFlagMarginalized;
       const bool marg = flags[i] & 1, outl = flags[i] & 2;
-      uint8_t v = static_cast<uint8_t>(dev[static_cast<size_t>(i)] & (kFlagOutlier | kFlagIllConditioned));
+      uint8_t v = 0;  // (to_marginalize is ASSIGNED by every update, local_frame.hpp:493-496: a pending one does not survive a second update)
       if (marg) v |= kFlagMarginalized;
       if (!was_marg && marg && !outl) v |= kFlagToMarginalize;
       f.flags[static_cast<size_t>(i)] = v;
     }
     for (int i = old; i < n_total; ++i)
       f.flags[static_cast<size_t>(i)] = static_cast<uint8_t>(((flags[i] & 1) ? kFlagMarginalized : 0) | ((flags[i] & 2) ? kFlagOutlier : 0));
-    f.dflags.upload(f.flags.data(), static_cast<size_t>(n_total), 0, st);
+    if (n_total) {
+      w->d_flag_stage.reserve(static_cast<size_t>(n_total), 0, st);
+      uploadStaged(*w, w->d_flag_stage, f.flags.data(), static_cast<size_t>(n_total), 0);
+      mergeLandmarkFlagsKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total);
+      HIP_CHECK(hipGetLastError());
+    }
+    for (int i = old; i < n_total; ++i) f.flags[static_cast<size_t>(i)] &= kFlagMarginalized;  // the mirror keeps host-decided bits only
     const size_t add = static_cast<size_t>(n_total - old);
     if (add) {
-      f.uv.upload(uv + 2 * old, 2 * add, 2 * static_cast<size_t>(old), st);
-      f.idepth.upload(idepth + old, add, static_cast<size_t>(old), st);
-      f.patch.upload(patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old), st);
+      uploadStaged(*w, f.uv, uv + 2 * old, 2 * add, 2 * static_cast<size_t>(old));
+      uploadStaged(*w, f.idepth, idepth + old, add, static_cast<size_t>(old));
+      uploadStaged(*w, f.patch, patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old));
       HIP_CHECK(hipMemsetAsync(f.idepth_step.ptr + old, 0, add * sizeof(double), st));
       HIP_CHECK(hipMemsetAsync(f.idepth_fej.ptr + old, 0, add * sizeof(double), st));
       HIP_CHECK(hipMemsetAsync(f.inv_hdd.ptr + old, 0, add * sizeof(double), st));
@@ -1508,7 +1587,6 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       HIP_CHECK(hipMemsetAsync(f.relative_baseline.ptr + old, 0, add * sizeof(double), st));
       HIP_CHECK(hipMemsetAsync(f.n_inliers.ptr + old, 0, add * sizeof(int32_t), st));
     }
-    w->sr.sync();
     f.n = n_total;
     w->topology_dirty = true;
     w->begun = false;
@@ -1522,7 +1600,16 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     HostFrame &f = w->frameById(reference_id);
     if (n > f.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection has %d entries, frame %d only %d landmarks", n, reference_id, f.n);
     auto &slot = f.residuals[target_id];
-    if (!slot) slot = std::make_unique<ResidualTable>();
+    if (!slot) {
+      if (!w->table_pool.empty()) {
+        slot = std::move(w->table_pool.back());
+        w->table_pool.pop_back();
+        slot->n = 0;
+        slot->snap_n = 0;
+      } else {
+        slot = std::make_unique<ResidualTable>();
+      }
+    }
     ResidualTable &rt = *slot;
     hipStream_t st = w->sr.stream;
     const size_t cap = static_cast<size_t>(std::max(f.cap, 1));
@@ -1533,11 +1620,10 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     rt.energy.reserve(cap, keep, st);
     if (n > rt.n) {
       const size_t add = static_cast<size_t>(n - rt.n);
-      rt.status.upload(statuses + rt.n, add, keep, st);
-      rt.cand.upload(statuses + rt.n, add, keep, st);
+      uploadStaged(*w, rt.status, statuses + rt.n, add, keep);
+      HIP_CHECK(hipMemcpyAsync(rt.cand.ptr + keep, rt.status.ptr + keep, add, hipMemcpyDeviceToDevice, st));
       HIP_CHECK(hipMemsetAsync(rt.fej_valid.ptr + keep, 0, add, st));
       HIP_CHECK(hipMemsetAsync(rt.energy.ptr + keep, 0, add * sizeof(double), st));
-      w->sr.sync();
       rt.n = n;
     }
     w->topology_dirty = true;
