@@ -276,6 +276,38 @@ __global__ void mergeLandmarkFlagsKernel(uint8_t *__restrict__ dflags, const uin
   const uint8_t h = host_bits[i];
   dflags[i] = i < n_old ? static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize))) : h;
 }
+/** the same for a frame that gained landmarks [n_old, n_total): also clears their solver state (one launch instead of six fills) */
+struct NewLandmarkArrays {
+  double *idepth_step, *idepth_fej, *inv_hdd, *b_d, *relative_baseline;
+  int32_t *n_inliers;
+};
+__global__ void mergeFlagsInitLandmarksKernel(uint8_t *__restrict__ dflags, const uint8_t *__restrict__ host_bits, int n_old, int n_total,
+                                              NewLandmarkArrays a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  const uint8_t h = host_bits[i];
+  if (i < n_old) {
+    dflags[i] = static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize)));
+    return;
+  }
+  dflags[i] = h;
+  a.idepth_step[i] = 0;
+  a.idepth_fej[i] = 0;
+  a.inv_hdd[i] = 0;
+  a.b_d[i] = 0;
+  a.relative_baseline[i] = 0;
+  a.n_inliers[i] = 0;
+}
+/** new entries [keep, keep + add) of a connection: candidate = status, no FEJ cache, zero energy (one launch instead of a
+ *  copy and two fills) */
+__global__ void initConnectionKernel(const uint8_t *__restrict__ status, uint8_t *__restrict__ cand, uint8_t *__restrict__ fej_valid,
+                                     double *__restrict__ energy, int keep, int add) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= add) return;
+  cand[keep + i] = status[keep + i];
+  fej_valid[keep + i] = 0;
+  energy[keep + i] = 0;
+}
 __global__ void clearLandmarkFlagKernel(uint8_t *__restrict__ dflags, int n, uint8_t mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dflags[i] &= static_cast<uint8_t>(~mask);
@@ -1571,7 +1603,12 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     if (n_total) {
       w->d_flag_stage.reserve(static_cast<size_t>(n_total), 0, st);
       uploadStaged(*w, w->d_flag_stage, f.flags.data(), static_cast<size_t>(n_total), 0);
-      mergeLandmarkFlagsKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total);
+      if (n_total > old) {
+        const NewLandmarkArrays na{f.idepth_step.ptr, f.idepth_fej.ptr, f.inv_hdd.ptr, f.b_d.ptr, f.relative_baseline.ptr, f.n_inliers.ptr};
+        mergeFlagsInitLandmarksKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total, na);
+      } else {
+        mergeLandmarkFlagsKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total);
+      }
       HIP_CHECK(hipGetLastError());
     }
     for (int i = old; i < n_total; ++i) f.flags[static_cast<size_t>(i)] &= kFlagMarginalized;  // the mirror keeps host-decided bits only
@@ -1580,12 +1617,6 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       uploadStaged(*w, f.uv, uv + 2 * old, 2 * add, 2 * static_cast<size_t>(old));
       uploadStaged(*w, f.idepth, idepth + old, add, static_cast<size_t>(old));
       uploadStaged(*w, f.patch, patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old));
-      HIP_CHECK(hipMemsetAsync(f.idepth_step.ptr + old, 0, add * sizeof(double), st));
-      HIP_CHECK(hipMemsetAsync(f.idepth_fej.ptr + old, 0, add * sizeof(double), st));
-      HIP_CHECK(hipMemsetAsync(f.inv_hdd.ptr + old, 0, add * sizeof(double), st));
-      HIP_CHECK(hipMemsetAsync(f.b_d.ptr + old, 0, add * sizeof(double), st));
-      HIP_CHECK(hipMemsetAsync(f.relative_baseline.ptr + old, 0, add * sizeof(double), st));
-      HIP_CHECK(hipMemsetAsync(f.n_inliers.ptr + old, 0, add * sizeof(int32_t), st));
     }
     f.n = n_total;
     w->topology_dirty = true;
@@ -1621,9 +1652,9 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     if (n > rt.n) {
       const size_t add = static_cast<size_t>(n - rt.n);
       uploadStaged(*w, rt.status, statuses + rt.n, add, keep);
-      HIP_CHECK(hipMemcpyAsync(rt.cand.ptr + keep, rt.status.ptr + keep, add, hipMemcpyDeviceToDevice, st));
-      HIP_CHECK(hipMemsetAsync(rt.fej_valid.ptr + keep, 0, add, st));
-      HIP_CHECK(hipMemsetAsync(rt.energy.ptr + keep, 0, add * sizeof(double), st));
+      initConnectionKernel<<<static_cast<unsigned>((add + 255) / 256), 256, 0, st>>>(rt.status.ptr, rt.cand.ptr, rt.fej_valid.ptr, rt.energy.ptr,
+                                                                                    static_cast<int>(keep), static_cast<int>(add));
+      HIP_CHECK(hipGetLastError());
       rt.n = n;
     }
     w->topology_dirty = true;
