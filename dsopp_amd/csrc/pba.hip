@@ -108,6 +108,19 @@ struct dsopp_hip_window {
     size_t capacity = 0, offset = 0;
   } stage;
   DeviceBuffer<uint8_t> d_flag_stage;  // host-side flag bits of one frame on their way into the merge kernel
+  // updateFrame read-back prefetched by solve(): the tracker calls updateFrame for every keyframe right after the solve
+  // (refinePoses), so solve() packs all frames behind its own final synchronisation and the getters become host copies.
+  // Valid until the next call that can change the window (every such entry point clears it).
+  struct ExportEntry {
+    int frame_id, n;
+    size_t word_offset;               // into h_update (doubles)
+    std::vector<int> target_ids;      // status rows in this order
+  };
+  std::vector<ExportEntry> export_entries;
+  DeviceBuffer<double> d_update;
+  void *h_update = nullptr;
+  size_t h_update_bytes = 0;
+  bool export_valid = false;
   // device buffers of keyframes / connections that left the window, kept for the next keyframe: a new keyframe needs ~12
   // landmark arrays and 12 connection tables of 5 arrays each — about 70 hipMallocs (0.5 ms) when allocated afresh
   std::vector<std::unique_ptr<HostFrame>> frame_pool;
@@ -1512,6 +1525,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
   if (w->h_export) (void)hipHostFree(w->h_export);
   if (w->stage.base) (void)hipHostFree(w->stage.base);
+  if (w->h_update) (void)hipHostFree(w->h_update);
   w->frames.clear();
   StreamRef sr = w->sr;
   delete w;
@@ -1522,6 +1536,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
                                 const double intrinsics[4], const double T_world_agent[7], double exposure_time,
                                 const double affine_brightness[2], int fixed, int is_marginalized) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w || !pyramid || !intrinsics || !T_world_agent || !affine_brightness) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (level < 0 || level >= pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
     if (pyramid->dtype != w->opt.dtype) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid dtype differs from the window's");
@@ -1580,6 +1595,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
 int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
                                    const double *patch, const uint8_t *flags) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w || n_total < 0 || (n_total && (!uv || !idepth || !patch || !flags))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     w->sr.use();
     HostFrame &f = w->frameById(frame_id);
@@ -1626,6 +1642,7 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
 
 int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w || n < 0 || (n && !statuses)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     w->sr.use();
     HostFrame &f = w->frameById(reference_id);
@@ -1664,6 +1681,7 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
 
 int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_id) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     HostFrame &f = w->frameById(frame_id);
     f.to_marginalize = !f.is_marginalized;
@@ -1681,6 +1699,7 @@ int dsopp_hip_window_num_frames(dsopp_hip_window *w, int32_t *n) {
 
 int dsopp_hip_window_begin(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     stageBegin(*w);
   });
@@ -1688,6 +1707,7 @@ int dsopp_hip_window_begin(dsopp_hip_window *w) {
 
 int dsopp_hip_window_calculate_energy(dsopp_hip_window *w, double *energy, int32_t *n_valid) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
     auto r = stageEnergy(*w);
@@ -1698,6 +1718,7 @@ int dsopp_hip_window_calculate_energy(dsopp_hip_window *w, double *energy, int32
 
 int dsopp_hip_window_linearize(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
     stageLinearize(*w);
@@ -1722,6 +1743,7 @@ int dsopp_hip_window_get_system(dsopp_hip_window *w, double *H_pp, double *b_pp,
 
 int dsopp_hip_window_calculate_step(dsopp_hip_window *w, double lambda, double *step) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
     stageStep(*w, lambda);
@@ -1731,6 +1753,7 @@ int dsopp_hip_window_calculate_step(dsopp_hip_window *w, double lambda, double *
 
 int dsopp_hip_window_accept_step(dsopp_hip_window *w, double *state_sq, double *step_sq) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
     auto r = stageAccept(*w, true);
@@ -1741,6 +1764,7 @@ int dsopp_hip_window_accept_step(dsopp_hip_window *w, double *state_sq, double *
 
 int dsopp_hip_window_reject_step(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
     stageAccept(*w, false);
@@ -1749,6 +1773,7 @@ int dsopp_hip_window_reject_step(dsopp_hip_window *w) {
 
 int dsopp_hip_window_update_point_statuses(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     updatePointStatuses(*w);
   });
@@ -1774,6 +1799,7 @@ static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
 
 int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     double e = 0;
     int it = 0, nv = 0;
@@ -1784,8 +1810,60 @@ int dsopp_hip_window_optimize(dsopp_hip_window *w, double *energy, int32_t *iter
   });
 }
 
+namespace {
+/** packs the updateFrame data of every keyframe (exportFrameKernel per frame, statuses towards all other frames of the window)
+ *  and starts ONE transfer into pinned memory; the caller synchronises */
+void prefetchFrameUpdates(dsopp_hip_window &w) {
+  hipStream_t st = w.sr.stream;
+  w.export_entries.clear();
+  size_t words = 0;
+  for (auto &fp : w.frames) {
+    HostFrame &f = *fp;
+    if (f.n == 0) continue;
+    dsopp_hip_window::ExportEntry e;
+    e.frame_id = f.id;
+    e.n = f.n;
+    e.word_offset = words;
+    for (auto &gp : w.frames) {
+      if (gp.get() == &f) continue;
+      auto it = f.residuals.find(gp->id);
+      if (it != f.residuals.end() && it->second && it->second->n == f.n) e.target_ids.push_back(gp->id);
+    }
+    const size_t n = static_cast<size_t>(f.n);
+    words += 4 * n + ((1 + e.target_ids.size()) * n + 7) / 8;
+    w.export_entries.push_back(std::move(e));
+  }
+  if (!words) return;
+  w.d_update.reserve(words, 0, st);
+  for (const auto &e : w.export_entries) {
+    HostFrame &f = w.frameById(e.frame_id);
+    FrameExportArgs a;
+    a.idepth = f.idepth.ptr;
+    a.inv_hdd = f.inv_hdd.ptr;
+    a.relative_baseline = f.relative_baseline.ptr;
+    a.n_inliers = f.n_inliers.ptr;
+    a.flags = f.dflags.ptr;
+    a.n = f.n;
+    a.n_targets = static_cast<int>(e.target_ids.size());
+    for (int t = 0; t < a.n_targets; ++t) a.status[t] = f.residuals[e.target_ids[static_cast<size_t>(t)]]->status.ptr;
+    a.out_d = w.d_update.ptr + e.word_offset;
+    a.out_b = reinterpret_cast<uint8_t *>(a.out_d + 4 * static_cast<size_t>(f.n));
+    exportFrameKernel<<<static_cast<unsigned>((f.n + 255) / 256), 256, 0, st>>>(a);
+  }
+  HIP_CHECK(hipGetLastError());
+  if (w.h_update_bytes < words * 8) {
+    if (w.h_update) (void)hipHostFree(w.h_update);
+    w.h_update = nullptr;
+    HIP_CHECK(hipHostMalloc(&w.h_update, words * 8, hipHostMallocDefault));
+    w.h_update_bytes = words * 8;
+  }
+  HIP_CHECK(hipMemcpyAsync(w.h_update, w.d_update.ptr, words * 8, hipMemcpyDeviceToHost, st));
+}
+}  // namespace
+
 int dsopp_hip_window_optimize_async(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (w->F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
     if (w->lm_mode != 0) fail(DSOPP_HIP_ERR_STATE, "the asynchronous solve exists for the fused device loop only (lm_mode 0)");
@@ -1800,6 +1878,7 @@ int dsopp_hip_window_optimize_async(dsopp_hip_window *w) {
 
 int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (!w->async_pending) fail(DSOPP_HIP_ERR_STATE, "no asynchronous solve is pending");
     w->sr.use();
@@ -1816,6 +1895,7 @@ int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t 
 
 int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterations, int32_t *n_valid) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     double e = 0;
     int it = 0, nv = 0;
@@ -1823,7 +1903,10 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
     relinearize(*w);
     if (w->opt.estimate_uncertainty) estimateUncertainty(*w);
     updatePointStatuses(*w);
+    const bool prefetch = !(w->allreduce && w->world > 1);
+    if (prefetch) prefetchFrameUpdates(*w);
     w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
+    w->export_valid = prefetch;
     collectTimings(*w);
     w->begun = false;
     w->linearized = true;  // the last linearised system stays readable through get_system
@@ -1914,6 +1997,29 @@ int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, dou
     HostFrame &f = w->frameById(frame_id);
     const size_t n = static_cast<size_t>(f.n);
     if (n == 0) return;
+    if (w->export_valid) {  // packed by the last solve(): a host copy
+      for (const auto &e : w->export_entries) {
+        if (e.frame_id != frame_id || e.n != f.n) continue;
+        std::vector<int> row(static_cast<size_t>(n_targets), -1);
+        bool all = true;
+        for (int t = 0; t < n_targets && all; ++t) {
+          auto it = std::find(e.target_ids.begin(), e.target_ids.end(), target_ids[t]);
+          all = it != e.target_ids.end();
+          if (all) row[static_cast<size_t>(t)] = static_cast<int>(it - e.target_ids.begin());
+        }
+        if (!all) break;
+        const double *hd = static_cast<const double *>(w->h_update) + e.word_offset;
+        const uint8_t *hb = reinterpret_cast<const uint8_t *>(hd + 4 * n);
+        if (idepth) std::memcpy(idepth, hd, n * sizeof(double));
+        if (inv_hessian_idepth) std::memcpy(inv_hessian_idepth, hd + n, n * sizeof(double));
+        if (relative_baseline) std::memcpy(relative_baseline, hd + 2 * n, n * sizeof(double));
+        if (n_inliers)
+          for (size_t i = 0; i < n; ++i) n_inliers[i] = static_cast<int32_t>(hd[3 * n + i]);
+        if (flags_out) std::memcpy(flags_out, hb, n);
+        for (int t = 0; t < n_targets; ++t) std::memcpy(statuses + static_cast<size_t>(t) * n, hb + n * (1 + static_cast<size_t>(row[static_cast<size_t>(t)])), n);
+        return;
+      }
+    }
     hipStream_t st = w->sr.stream;
     FrameExportArgs a;
     a.idepth = f.idepth.ptr;
@@ -2155,6 +2261,7 @@ int dsopp_hip_depth_maps_get_level(const dsopp_hip_depth_maps *m, int32_t level,
 
 int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user, int rank, int world_size) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (fn && (world_size < 1 || rank < 0 || rank >= world_size)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad rank %d / world %d", rank, world_size);
     w->allreduce = fn;
@@ -2192,6 +2299,7 @@ int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
 
 int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repeats, double *avg_us) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w || !avg_us || repeats < 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
     w->sr.use();
     if (!w->begun) stageBegin(*w);
@@ -2226,6 +2334,7 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
 
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->lm_mode = host_driven;
   });
@@ -2254,6 +2363,7 @@ int dsopp_hip_window_optimize_repeated(dsopp_hip_window *w, int32_t iterations_t
 
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w || max_iterations < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
     w->opt.max_iterations = max_iterations;
   });
@@ -2295,6 +2405,7 @@ int dsopp_hip_window_snapshot(dsopp_hip_window *w) {
 
 int dsopp_hip_window_restore(dsopp_hip_window *w) {
   return guarded([&] {
+    if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (!w->snap_valid || w->snap_F != w->F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
     w->sr.use();

@@ -239,19 +239,31 @@ def test_float_mode_full_solve(small_window):
 
 
 def test_frame_update_export_matches_getters(small_window):
-    """dsopp_hip_window_get_frame_update (updateFrame in one transfer) == the per-array getters"""
+    """dsopp_hip_window_get_frame_update (updateFrame in one transfer) == the per-array getters: served from what solve()
+    prefetched behind its own synchronisation (all targets, a subset, a permuted subset), and packed on demand once another
+    call has touched the window"""
     from dsopp_amd import capi
     g = syn.load_window(capi.HipWindow(capi.default_pba_options()), small_window)
-    g.solve()
     ids = [f.frame_id for f in small_window.frames]
-    for fid in ids:
-        targets = [t for t in ids if t != fid]
-        up = g.get_frame_update(fid, targets)
-        lm = g.get_landmarks(fid, False)
-        for k in ("idepth", "inv_hdd", "relative_baseline", "n_inliers", "flags"):
-            assert np.array_equal(up[k], lm[k]), k
-        for t in targets:
-            assert np.array_equal(up["status"][t], g.get_residuals(fid, t)["status"])
+
+    def check():
+        for fid in ids:
+            others = [t for t in ids if t != fid]
+            for targets in (others, others[:1], others[::-1]):
+                up = g.get_frame_update(fid, targets)
+                lm = g.get_landmarks(fid, False)
+                for k in ("idepth", "inv_hdd", "relative_baseline", "n_inliers", "flags"):
+                    assert np.array_equal(up[k], lm[k]), k
+                for t in targets:
+                    assert np.array_equal(up["status"][t], g.get_residuals(fid, t)["status"])
+
+    g.solve()
+    check()                      # prefetched by solve()
+    g.optimize()                 # moves idepths / statuses: the prefetched copy is stale and must not be served
+    check()
+    g.solve()
+    g.update_point_statuses()
+    check()
     g.close()
 
 
