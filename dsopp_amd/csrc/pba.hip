@@ -1295,7 +1295,7 @@ void estimateUncertainty(W &w) {
 
 /** updateMarginalizedLinearSystem — problem.hpp:146-203, called from pushFrame before the new frame is appended */
 void foldMarginalized(W &w) {
-  prepare(w);
+  prepareDevice(w);
   firstEstimate(w);  // pushFrame calls firstEstimateJacobians unconditionally (eigen_photometric_bundle_adjustment.cpp:123)
   w.begun = true;
   // evaluateJacobians<..., true, true, true> then changeResidualStatuses (accept), :124-126
@@ -1313,15 +1313,23 @@ void foldMarginalized(W &w) {
   HIP_CHECK(hipGetLastError());
   allreduceIfNeeded(w, w.d_scalars.ptr, 2);
   const int K = w.K(), F = w.F();
-  std::vector<double> Hpp(static_cast<size_t>(K) * K), Hsc(static_cast<size_t>(K) * K), bpp(static_cast<size_t>(K)), bsc(static_cast<size_t>(K));
-  double scal[2];
-  w.d_Hpp.download(Hpp.data(), Hpp.size(), 0, w.sr.stream);
-  w.d_HscDownload(Hsc.data(), Hsc.size(), 0, w.sr.stream);
-  w.d_bpp.download(bpp.data(), bpp.size(), 0, w.sr.stream);
-  w.d_bscDownload(bsc.data(), bsc.size(), 0, w.sr.stream);
+  // both systems, the energy scalars and (if a device-driven solve left the host mirror behind) the frame states in ONE
+  // synchronisation, through pinned staging (five pageable read-backs cost five staged transfers)
+  const size_t kk = static_cast<size_t>(K) * K, k1 = static_cast<size_t>(K);
+  const bool want_state = w.host_stale && !w.state_dirty;
+  double *stg = static_cast<double *>(stageAcquire(w, (2 * kk + 2 * k1 + 2) * sizeof(double) + sizeof(WindowState)));
+  double *Hpp = stg, *Hsc = Hpp + kk, *bpp = Hsc + kk, *bsc = bpp + k1, *scal = bsc + k1;
+  w.d_Hpp.download(Hpp, kk, 0, w.sr.stream);
+  w.d_HscDownload(Hsc, kk, 0, w.sr.stream);
+  w.d_bpp.download(bpp, k1, 0, w.sr.stream);
+  w.d_bscDownload(bsc, k1, 0, w.sr.stream);
   w.d_scalars.download(scal, 2, 0, w.sr.stream);
+  if (want_state) HIP_CHECK(hipMemcpyAsync(scal + 2, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
   w.sr.sync();
-  downloadState(w);
+  if (want_state) {
+    std::memcpy(&w.hst, scal + 2, sizeof(WindowState));
+    w.host_stale = false;
+  }
   std::vector<double> state(static_cast<size_t>(K));
   for (int f = 0; f < F; ++f)
     for (int a = 0; a < kBlk; ++a) state[static_cast<size_t>(kBlk * f + a)] = w.hst.eps[f][a];
