@@ -183,6 +183,7 @@ def main():
         extras["depth_estimation"] = run_depth_estimation_timing(capi, syn, args)
         extras["landmark_activation"] = run_landmark_activation_timing(capi, syn, args)
         extras["concurrent_windows"] = run_concurrent_windows(capi, syn, torch, win)
+        extras["keyframe_step"] = run_keyframe_step_timing(capi, syn)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -565,6 +566,61 @@ def run_concurrent_windows(capi, syn, torch, win, counts=(1, 2, 4, 8), solves=60
             g.close()
     return {"workload": "n independent C1 windows, one stream each, one host thread (async enqueue, then wait)",
             "gn_iterations_per_s_by_window_count": out}
+
+
+def run_keyframe_step_timing(capi, syn):
+    """One keyframe step as the tracker drives the backend (monocular_tracker.cpp:497-507), in steady state: a 7-frame
+    window of 286 landmarks per frame, 12 keyframes streamed through it.  pushFrame (incl. the fold-in of the frame that was
+    marginalised, updateMarginalizedLinearSystem) -> landmarks + connections of the new keyframe -> solve() -> updateFrame
+    read-back of every keyframe -> marginalisation flags.  Device pyramids exist already (the tracker built them when the
+    frames arrived).  Median of the steady-state keyframes, ms per call group."""
+    W, H = 640, 480
+    win = syn.make_window(num_frames=12, num_points=12 * 286, width=W, height=H, seed=61)
+    intr = win.scene.intrinsics
+    g = capi.HipWindow(capi.default_pba_options())
+    pyramids = []
+    for f in win.frames:
+        p = capi.Pyramid(W, H, 1)
+        p.set_level(0, f.pixelinfo)
+        pyramids.append(p)
+    alive, rows = [], []
+    for k, f in enumerate(win.frames):
+        t0 = time.perf_counter()
+        g.push_frame(f.frame_id, f.timestamp, None, None, intr, syn.mat_to_params(f.T_w_c_init), f.exposure, f.affine_init, f.fixed, False,
+                     pyramid=pyramids[k])
+        t1 = time.perf_counter()
+        g.set_landmarks(f.frame_id, f.uv, f.idepth_init, f.patch, np.zeros(len(f.uv), dtype=np.uint8))
+        for a in alive:
+            g.set_connection(a.frame_id, f.frame_id, np.zeros(len(a.uv), dtype=np.uint8))
+            g.set_connection(f.frame_id, a.frame_id, np.zeros(len(f.uv), dtype=np.uint8))
+        alive.append(f)
+        t2 = time.perf_counter()
+        if len(alive) < 2:
+            continue
+        g.solve()
+        t3 = time.perf_counter()
+        for a in alive:
+            g.get_pose(a.frame_id)
+            g.get_frame_update(a.frame_id, [b.frame_id for b in alive if b is not a])
+        t4 = time.perf_counter()
+        if len(alive) == 7 and k + 1 < len(win.frames):
+            victim = alive[1]
+            for a in alive:
+                fl = np.zeros(len(a.uv), dtype=np.uint8)
+                fl[::4 if a is victim else 9] = 1
+                g.set_landmarks(a.frame_id, a.uv, a.idepth_init, a.patch, fl)
+            g.mark_frame_marginalized(victim.frame_id)
+            alive.remove(victim)
+        t5 = time.perf_counter()
+        if k >= 8:
+            rows.append([t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4])
+    med = np.median(np.array(rows), axis=0) * 1e3
+    g.close()
+    for p in pyramids:
+        p.close()
+    return {"workload": "7-frame window, 286 landmarks per keyframe, steady state with one marginalisation per keyframe",
+            "push_frame_incl_fold_in_ms": float(med[0]), "landmarks_and_connections_ms": float(med[1]), "solve_ms": float(med[2]),
+            "update_frame_read_back_ms": float(med[3]), "marginalisation_flags_ms": float(med[4]), "total_ms": float(med.sum())}
 
 
 def run_cpu_baseline(args, F, P, win, syn):
