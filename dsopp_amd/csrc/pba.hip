@@ -1074,10 +1074,10 @@ void updatePointStatusesDevice(W &w) {
   selectInitKernel<<<1, 256, 0, st>>>(w.d_select.ptr);
   const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
   if (w.n_sweep_blocks) {
-    const int per_wave = 64 / kItemsPerBlock;
-    const int grid = (w.n_sweep_blocks + per_wave - 1) / per_wave;
+    const int per_group = kSelectThreads / kItemsPerBlock;
+    const int grid = (w.n_sweep_blocks + per_group - 1) / per_group;
     for (int pass = 7; pass >= 0; --pass)  // each pass advances the select state from the previous pass's histogram itself
-      selectHistKernel<<<grid, 64, 0, st>>>(w.d_frames.ptr, w.d_sweep_table.ptr, w.n_sweep_blocks, w.d_select.ptr, pass);
+      selectHistKernel<<<grid, kSelectThreads, 0, st>>>(w.d_frames.ptr, w.d_sweep_table.ptr, w.n_sweep_blocks, w.d_select.ptr, pass);
   }
   pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr, w.n_sweep_blocks ? w.d_select.ptr : nullptr, half_sigma_sq);
   if (w.n_schur_blocks)

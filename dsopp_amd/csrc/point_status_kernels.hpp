@@ -51,14 +51,24 @@ struct SelectLocal {
   unsigned long long prefix, mask;
   unsigned int rank, n_ok;
 };
-__device__ inline SelectLocal selectAdvance(const SelectState *s, int done) {
+/** cooperative: called by ALL threads of a workgroup of >= 256 threads; `scan` is 256 words of LDS.  (A single lane walking
+ *  the histogram in global memory paid one dependent round trip per bin: 10 - 15 us per pass.) */
+__device__ inline SelectLocal selectAdvance(const SelectState *s, int done, unsigned int *scan) {
+  const int t = threadIdx.x;
   const int in = (done + 1) & 1;  // S_{done + 1}; for done == 7 that is the initial all-zero state
   SelectLocal l{s->prefix[in], s->mask[in], s->rank[in], s->n_ok[in]};
-  const unsigned int *h = s->hist[done % 3];
+  const unsigned int mine = t < 256 ? s->hist[done % 3][t] : 0u;
+  if (t < 256) scan[t] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
+    const unsigned int v = (t < 256 && t >= off) ? scan[t - off] : 0u;
+    __syncthreads();
+    if (t < 256) scan[t] += v;
+    __syncthreads();
+  }
   if (done == 7) {
     l = SelectLocal{0, 0, 0, 0};
-    unsigned int n = 0;
-    for (int k = 0; k < 256; ++k) n += h[k];
+    const unsigned int n = scan[255];
     l.n_ok = n;
     l.rank = static_cast<unsigned int>(static_cast<double>(n) * 0.75);  // third_quartile index, :358
     if (n == 0) {
@@ -66,34 +76,35 @@ __device__ inline SelectLocal selectAdvance(const SelectState *s, int done) {
       l.prefix = 1;
     }
   }
+  __shared__ int s_bucket;
+  if (t == 0) s_bucket = 255;
+  __syncthreads();
   if (l.n_ok > 0) {
-    unsigned int cum = 0;
-    int bucket = 255;
-    for (int k = 0; k < 256; ++k) {
-      if (l.rank < cum + h[k]) {
-        bucket = k;
-        break;
-      }
-      cum += h[k];
-    }
+    // the first bin whose inclusive count exceeds the rank (bins with that property form a suffix: take the smallest index)
+    if (t < 256 && l.rank < scan[t] && (t == 0 || !(l.rank < scan[t - 1]))) s_bucket = t;
+  }
+  __syncthreads();
+  if (l.n_ok > 0) {
+    const int bucket = s_bucket;
+    const unsigned int cum = bucket > 0 ? scan[bucket - 1] : 0u;
     l.rank -= cum;
     l.prefix |= static_cast<unsigned long long>(bucket) << (8 * done);
     l.mask |= 0xFFull << (8 * done);
   }
+  __syncthreads();
   return l;
 }
 
 /** one histogram pass of the radix select; byte index `pass` (7 = most significant).  For pass < 7 the workgroup first
  *  advances the select state by the previous pass's histogram (workgroup 0 also stores it and clears the histogram of the
  *  next pass): 8 launches per select instead of 16. */
-__global__ void __launch_bounds__(64) selectHistKernel(const FrameDev *__restrict__ frames, const SweepBlock *__restrict__ table, int n_entries,
-                                                       SelectState *s, int pass) {
-  __shared__ SelectLocal sl;
-  if (threadIdx.x == 0) {
-    sl = pass == 7 ? SelectLocal{0, 0, 0, 0} : selectAdvance(s, pass + 1);
-  }
+constexpr int kSelectThreads = 1024;
+__global__ void __launch_bounds__(kSelectThreads) selectHistKernel(const FrameDev *__restrict__ frames, const SweepBlock *__restrict__ table, int n_entries,
+                                                                  SelectState *s, int pass) {
+  __shared__ unsigned int lh[256];  // workgroup-private histogram: one global atomic per non-empty bin and workgroup
+  const SelectLocal l = pass == 7 ? SelectLocal{0, 0, 0, 0} : selectAdvance(s, pass + 1, lh);
+  if (threadIdx.x < 256) lh[threadIdx.x] = 0;
   __syncthreads();
-  const SelectLocal l = sl;
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0 && pass < 7) {  // S_{pass + 1}
       const int out = (pass + 1) & 1;
@@ -102,35 +113,41 @@ __global__ void __launch_bounds__(64) selectHistKernel(const FrameDev *__restric
       s->rank[out] = l.rank;
       s->n_ok[out] = l.n_ok;
     }
-    for (int k = threadIdx.x; k < 256; k += 64) s->hist[(pass + 2) % 3][k] = 0;
+    for (int k = threadIdx.x; k < 256; k += kSelectThreads) s->hist[(pass + 2) % 3][k] = 0;
   }
-  const int entry = blockIdx.x * (64 / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
+  const int entry = blockIdx.x * (kSelectThreads / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
   const bool in_range = entry < n_entries;
   const SweepBlock be = table[in_range ? entry : 0];
   const int i = be.offset + threadIdx.x % kItemsPerBlock;
   unsigned long long key = 0;
   const bool counts = in_range && eligibleEnergy(be, frames, i, key) && (key & l.mask) == l.prefix;
   // The upper bytes of the energies are nearly constant (same sign / exponent range), so almost every key of a pass lands in
-  // ONE bucket: 12 000 atomics on one address took 109 us.  The wavefront first counts the lanes that share the bucket of
-  // its first counting lane and adds them with one atomic; only the rest uses per-lane atomics.
+  // ONE bucket: per-lane atomics on one address serialise (12 000 of them took 109 us; one per wavefront from 190 wavefronts
+  // still 50 us across the XCDs).  A wavefront adds the lanes sharing the bucket of its first counting lane with one LDS
+  // atomic, the rest per lane, and the workgroup flushes its non-empty bins once.
   const unsigned int bucket = static_cast<unsigned int>((key >> (8 * pass)) & 0xFFull);
   const unsigned long long active = __ballot(counts);
-  if (active == 0) return;
-  const int leader = __ffsll(static_cast<long long>(active)) - 1;
-  const unsigned int common = static_cast<unsigned int>(__shfl(static_cast<int>(bucket), leader));
-  const unsigned long long same = __ballot(counts && bucket == common);
-  if (static_cast<int>(threadIdx.x & 63) == leader) atomicAdd(&s->hist[pass % 3][common], static_cast<unsigned int>(__popcll(same)));
-  if (counts && bucket != common) atomicAdd(&s->hist[pass % 3][bucket], 1u);
+  if (active != 0) {
+    const int leader = __ffsll(static_cast<long long>(active)) - 1;
+    const unsigned int common = static_cast<unsigned int>(__shfl(static_cast<int>(bucket), leader));
+    const unsigned long long same = __ballot(counts && bucket == common);
+    if (static_cast<int>(threadIdx.x & 63) == leader) atomicAdd(&lh[common], static_cast<unsigned int>(__popcll(same)));
+    if (counts && bucket != common) atomicAdd(&lh[bucket], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&s->hist[pass % 3][threadIdx.x], lh[threadIdx.x]);
 }
 
 /** closing step of the select (after the pass-0 histogram): the selected key is the threshold energy (:360) */
-__device__ inline void selectFinish(SelectState *s, double half_sigma_sq) {
-  const SelectLocal l = selectAdvance(s, 0);
-  s->prefix[0] = l.prefix;
-  s->mask[0] = l.mask;
-  s->rank[0] = l.rank;
-  s->n_ok[0] = l.n_ok;
-  s->threshold = l.n_ok > 0 ? __longlong_as_double(static_cast<long long>(l.prefix)) + half_sigma_sq : 0.0;
+__device__ inline void selectFinish(SelectState *s, double half_sigma_sq, unsigned int *scan) {
+  const SelectLocal l = selectAdvance(s, 0, scan);
+  if (threadIdx.x == 0) {
+    s->prefix[0] = l.prefix;
+    s->mask[0] = l.mask;
+    s->rank[0] = l.rank;
+    s->n_ok[0] = l.n_ok;
+    s->threshold = l.n_ok > 0 ? __longlong_as_double(static_cast<long long>(l.prefix)) + half_sigma_sq : 0.0;
+  }
 }
 
 /** current camera-centre distances between all frame pairs: |t_r - t_t| of T = T0 exp(eps) (:380-382) */
@@ -138,7 +155,8 @@ __global__ void pairDistanceKernel(const WindowState *st, int F, double *dist /*
                                    double half_sigma_sq) {
   __shared__ double c[kMaxFrames][3];
   const int f = threadIdx.x;
-  if (select && threadIdx.x == 255) selectFinish(select, half_sigma_sq);  // the single-workgroup step between select and apply
+  __shared__ unsigned int scan[256];
+  if (select) selectFinish(select, half_sigma_sq, scan);  // the single-workgroup step between select and apply (256 threads)
   if (f < F) {
     Rigid T0;
 #pragma unroll
