@@ -143,6 +143,7 @@ struct dsopp_hip_window {
   double last_lambda = 0;
   std::vector<double> last_step;
   float last_solve_ms = 0;
+  bool solve_events_pending = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   dsopp_hip_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
@@ -1800,8 +1801,7 @@ static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
   else
     lmSolveFused(*w, e, it, nv);
   HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
-  HIP_CHECK(hipEventSynchronize(w->ev1));
-  HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
+  w->solve_events_pending = true;  // the elapsed time is read when somebody asks for it (dsopp_hip_window_last_solve_ms)
   collectTimings(*w);
 }
 
@@ -2466,6 +2466,12 @@ const char *dsopp_hip_kernel_class_name(int kernel_class) {
 int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {
   return guarded([&] {
     if (!w || !ms) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    if (w->solve_events_pending) {
+      w->sr.use();
+      HIP_CHECK(hipEventSynchronize(w->ev1));
+      HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
+      w->solve_events_pending = false;
+    }
     *ms = w->last_solve_ms;
   });
 }
