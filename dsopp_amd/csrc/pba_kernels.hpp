@@ -321,11 +321,13 @@ __device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], 
  * 1 reprojection -> 4 texel loads (2 x 64 B segments) -> 1 Jacobian row -> reductions, so a C1-sized sweep is one
  * memory round trip deep per stage instead of eight.
  */
-template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false>
+template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool SMALL_LDS = false>
 __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
-  __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? kPartial : 4) * kRedStride];
+  // SMALL_LDS (large windows: many workgroups per CU): the 48 partials cross LDS in two halves of 24 — 25 KB instead of 50 KB
+  // per workgroup, which is what bounds the occupancy of the linearisation sweep (3 -> 6 workgroups per CU)
+  __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? (SMALL_LDS ? kPartial / 2 : kPartial) : 4) * kRedStride];
   // ---- round trip 1: block descriptor + LM control block (scalar loads, all requested before any of them is tested)
   const SweepBlock be = table[blockIdx.x];
   int c_active = 1, c_lsv = 0, c_pending = 1, run = 1;
@@ -572,7 +574,11 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   }
   SWEEP_STAMP(4);
   double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
-  if (LIN) {
+  if (LIN && SMALL_LDS) {
+    blockReduceStore<0, kPartial / 2>(acc, red_lds, out);
+    ldsBarrier();  // the first half has been read
+    blockReduceStore<kPartial / 2, kPartial / 2>(acc, red_lds, out);
+  } else if (LIN) {
     blockReduceStore<0, kPartial>(acc, red_lds, out);
   } else {
     blockReduceStore<44, 4>(acc, red_lds, out);
