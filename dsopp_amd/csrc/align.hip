@@ -430,17 +430,31 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
 #pragma unroll
     for (int e = 0; e < kAlignPartial; ++e) red[e * RS + tid] = acc[e];
     __syncthreads();
-    if (tid < kAlignPartial) {
-      const double2 *row = reinterpret_cast<const double2 *>(red + tid * RS);
+    // four adjacent lanes per row (each sums a quarter, fixed order), combined with two DPP swaps: 192 lanes read 32 entries
+    // each instead of 48 lanes walking 128
+    static_assert(4 * kAlignPartial <= kAlignThreads, "four lanes per row");
+    const int row_idx = tid >> 2, quarter = tid & 3;
+    double s = 0;
+    if (row_idx < kAlignPartial) {
+      const double2 *row = reinterpret_cast<const double2 *>(red + row_idx * RS) + quarter * (kAlignThreads / 8);
       double s0 = 0, s1 = 0;
 #pragma unroll 8
-      for (int j = 0; j < kAlignThreads / 2; ++j) {
+      for (int j = 0; j < kAlignThreads / 8; ++j) {
         const double2 q = row[j];
         s0 += q.x;
         s1 += q.y;
       }
-      partials[static_cast<size_t>(blockIdx.x) * kAlignPartial + tid] = s0 + s1;
+      s = s0 + s1;
     }
+    auto dpp = [](double v, auto ctrl) {
+      int lo = __double2loint(v), hi = __double2hiint(v);
+      lo = __builtin_amdgcn_mov_dpp(lo, decltype(ctrl)::value, 0xF, 0xF, true);
+      hi = __builtin_amdgcn_mov_dpp(hi, decltype(ctrl)::value, 0xF, 0xF, true);
+      return __hiloint2double(hi, lo);
+    };
+    s += dpp(s, std::integral_constant<int, 0xB1>{});  // quad_perm [1,0,3,2]
+    s += dpp(s, std::integral_constant<int, 0x4E>{});  // quad_perm [2,3,0,1]
+    if (row_idx < kAlignPartial && quarter == 0) partials[static_cast<size_t>(blockIdx.x) * kAlignPartial + row_idx] = s;
   }
 }
 
