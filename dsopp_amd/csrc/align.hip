@@ -386,16 +386,22 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
       double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
       if (grp < kGroups) {
         const double *src = prev_partials + e;
-        int b = grp;
-        for (; b + 3 * kGroups < prm.n_blocks; b += 4 * kGroups) {
-          const double v0 = src[static_cast<size_t>(b) * kAlignPartial], v1 = src[static_cast<size_t>(b + kGroups) * kAlignPartial];
-          const double v2 = src[static_cast<size_t>(b + 2 * kGroups) * kAlignPartial], v3 = src[static_cast<size_t>(b + 3 * kGroups) * kAlignPartial];
-          p0 += v0;
-          p1 += v1;
-          p2 += v2;
-          p3 += v3;
+        // the first 8 workgroups of this group in ONE round trip: clamped indices + a 0 / 1 factor instead of predicated loads
+        // (a level of the tracker has <= 40 workgroups: this is the whole sum)
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int b = grp + j * kGroups;
+          const int bc = b < prm.n_blocks ? b : prm.n_blocks - 1;
+          v[j] = src[static_cast<size_t>(bc) * kAlignPartial];
         }
-        for (; b < prm.n_blocks; b += kGroups) p0 += src[static_cast<size_t>(b) * kAlignPartial];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (grp + j * kGroups < prm.n_blocks) ? v[j] : 0.0;
+        p0 = v[0] + v[4];
+        p1 = v[1] + v[5];
+        p2 = v[2] + v[6];
+        p3 = v[3] + v[7];
+        for (int b = grp + 8 * kGroups; b < prm.n_blocks; b += kGroups) p0 += src[static_cast<size_t>(b) * kAlignPartial];
         red[kAlignPartial + grp * kAlignPartial + e] = (p0 + p1) + (p2 + p3);
       }
       __syncthreads();
