@@ -159,7 +159,9 @@ int main() {
   DeviceImmatureSet dset(immature);
   pba.updateFrame(frames[0]);
   const Motion T0 = frames[0].t_world_agent;  // identity rotation in this example: T_new^-1 T_0 is a pure translation
-  dset.estimate(*pyr_new, Motion{0, 0, 0, 1, T0[4] - tx_new, T0[5], T0[6]}, 1.0, Vector2{0, 0}, 1.0, Vector2{0, 0}, model, 20.0);
+  // (the tracker's estimateDepths loop over all keyframes of the window is one call: here the window contributes one set)
+  estimateDepthsOfWindow(*pyr_new, {&dset}, {Motion{0, 0, 0, 1, T0[4] - tx_new, T0[5], T0[6]}}, {1.0}, {Vector2{0, 0}}, 1.0, Vector2{0, 0}, model, 20.0);
+  pba.createReferenceDepthMaps(maps);  // refill of the map object the tracker keeps (no allocation)
   KeyframeView fourth{};
   fourth.keyframe_id = 3;
   fourth.timestamp = 4000;
