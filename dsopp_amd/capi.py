@@ -36,6 +36,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_window_frame_ids",
     "dsopp_hip_window_optimize_async", "dsopp_hip_window_optimize_wait",
     "dsopp_hip_immature_sets_estimate",
     "dsopp_hip_aligner_set_rotation_prior",
@@ -228,8 +229,9 @@ class HipWindow:
         if self._h:
             lib().dsopp_hip_window_destroy(self._h)
             self._h = C.c_void_p()
-        for p in self._pyramids.values():
-            p.close()
+        for p, owned in self._pyramids.values():
+            if owned:
+                p.close()
         self._pyramids = {}
 
     def __del__(self):
@@ -251,6 +253,7 @@ class HipWindow:
     def push_frame(self, frame_id, timestamp, pixelinfo, mask, intrinsics, T_w_agent, exposure, affine, fixed, is_marginalized,
                    pyramid: Pyramid | None = None, level=0):
         """pixelinfo: H x W x 3 host array (uploaded into a 1-level pyramid owned by this wrapper) unless `pyramid` given."""
+        owned = pyramid is None
         if pyramid is None:
             pix = _f64(pixelinfo)
             H, W = pix.shape[:2]
@@ -259,10 +262,23 @@ class HipWindow:
             if mask is not None:
                 pyramid.set_mask(0, mask)
             level = 0
-        self._pyramids[int(frame_id)] = pyramid
+        self._pyramids[int(frame_id)] = (pyramid, owned)
         _chk(lib().dsopp_hip_window_push_frame(self._h, int(frame_id), C.c_int64(int(timestamp)), pyramid._h, int(level),
                                                _p(_f64(intrinsics)), _p(_f64(T_w_agent)), C.c_double(exposure), _p(_f64(affine)),
                                                int(bool(fixed)), int(bool(is_marginalized))))
+        # pushFrame folds the frames flagged for marginalisation into the prior and erases them: their pyramids are no longer
+        # borrowed.  Wrapper-owned ones are freed here (a long sliding-window run would otherwise keep one per keyframe, ~10 MB each)
+        alive = set(self.frame_ids())
+        for fid in [k for k in self._pyramids if k not in alive]:
+            p, was_owned = self._pyramids.pop(fid)
+            if was_owned:
+                p.close()
+
+    def frame_ids(self):
+        ids = np.zeros(16, dtype=np.int32)
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_frame_ids(self._h, 16, ids.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return [int(x) for x in ids[:n.value]]
 
     def set_landmarks(self, frame_id, uv, idepth, patch, flags):
         n = len(idepth)

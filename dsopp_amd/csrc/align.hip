@@ -559,6 +559,7 @@ struct dsopp_hip_aligner {
   AlignControl *h_ctrl = nullptr;  // pinned staging of the control block (upload + read-back)
   int lm_path = 0;                 // 0: automatic (single-workgroup loop for small point sets), 1: always one launch per iteration
   bool skip_covariance = false;    // estimate_pose: the per-level covariance is not read by the tracker loop
+  bool pyramids_ordered = false;   // estimate_pose already ordered this stream behind both pyramids' builds (one wait per frame, not per level)
   bool have_rotation_prior = false;  // setRotationPrior, cleared by reset() (eigen_pose_alignment.cpp:254-263)
   double rotation_prior[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   // launches the previous solve on a target level of this width needed: consecutive frames of a sequence need nearly the same
@@ -692,6 +693,9 @@ void checkPyramid(dsopp_hip_aligner *a, const dsopp_hip_pyramid *p, int level) {
   if (level < 0 || level >= p->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
   if (p->dtype != a->opt.dtype) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid dtype differs from the aligner's");
   if (p->sr.device != a->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "pyramid lives on another device");
+  // dsopp_hip_pyramid_build_device only enqueues on the pyramid's stream: everything this aligner launches from here on must
+  // see the finished texels
+  if (!a->pyramids_ordered) p->waitReady(a->sr.stream);
 }
 
 }  // namespace
@@ -970,13 +974,11 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
     const bool single_workgroup = n <= kAlignLoopMaxPoints && a->lm_path != 1;
     if (single_workgroup) {
       // the whole LM loop in one launch of one workgroup (alignLoopKernel): one enqueue, one read-back, one synchronisation
-      static bool attr_set = false;
       const size_t smem = (static_cast<size_t>(kAlignPartial) * (kLoopCols + 2) + kAlignPartial) * sizeof(double);
-      if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(alignLoopKernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(alignLoopKernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
-      }
+      if (a->opt.dtype == DSOPP_HIP_F64)
+        ensureDynamicLds(reinterpret_cast<const void *>(alignLoopKernel<double>), a->sr.device, 128 * 1024);
+      else
+        ensureDynamicLds(reinterpret_cast<const void *>(alignLoopKernel<float>), a->sr.device, 128 * 1024);
       if (a->opt.dtype == DSOPP_HIP_F64)
         alignLoopKernel<double><<<1, kLoopThreads, smem, st>>>(a->ref, a->tgt, a->p_u, a->p_v, a->p_id, a->p_int, a->d_ctrl.ptr, prm);
       else
@@ -1062,6 +1064,20 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
     explicit SkipCov(dsopp_hip_aligner *x) : a(x) { a->skip_covariance = true; }
     ~SkipCov() { a->skip_covariance = false; }
   } skip_cov(a);
+  struct OrderedOnce {
+    dsopp_hip_aligner *a;
+    explicit OrderedOnce(dsopp_hip_aligner *x) : a(x) {}
+    ~OrderedOnce() { a->pyramids_ordered = false; }
+  } ordered_once(a);
+  {
+    const int rc = guarded([&] {
+      a->sr.use();
+      reference_pyramid->waitReady(a->sr.stream);
+      target_pyramid->waitReady(a->sr.stream);
+    });
+    if (rc != DSOPP_HIP_OK) return rc;
+    a->pyramids_ordered = true;
+  }
   double T[7], ab[2], T_const[7] = {0, 0, 0, 1, 0, 0, 0}, ab_const[2] = {0, 0};
   bool success = false;
   int tries = 0, lm_iterations = 0;

@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -36,6 +38,17 @@ struct Error : std::runtime_error {
     if (_e != hipSuccess)                                                                                   \
       ::dsopp_hip::fail(DSOPP_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
+
+/** hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device, handles may live on
+ *  different devices and be driven from different threads */
+inline void ensureDynamicLds(const void *kernel, int device, int bytes) {
+  static std::mutex mtx;
+  static std::set<std::pair<const void *, int>> done;
+  std::lock_guard<std::mutex> lock(mtx);
+  if (done.count({kernel, device})) return;
+  HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({kernel, device});
+}
 
 /** run `body`, translate exceptions into the C-ABI's error codes */
 template <typename F>

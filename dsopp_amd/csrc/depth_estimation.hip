@@ -771,7 +771,7 @@ int dsopp_hip_immature_set_estimate(dsopp_hip_immature_set *s, const dsopp_hip_p
     if (s->n == 0) return;
     s->sr.use();
     hipStream_t st = s->sr.stream;
-    if (target_pyramid->sr.stream != st) HIP_CHECK(hipStreamSynchronize(target_pyramid->sr.stream));  // the pyramid build must have finished
+    target_pyramid->waitReady(st);  // the pyramid build (enqueued on the pyramid's stream) must have finished
     const DepthFrame f = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference, reference_exposure, reference_affine, target_exposure,
                                         target_affine, sigma_huber_loss, s->n);
     const DepthLandmarks L = landmarkPointers(s);
@@ -803,7 +803,7 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     if (max_n == 0) return;
     lead->sr.use();
     hipStream_t st = lead->sr.stream;  // the launch runs on the first set's stream, ordered against the others' below
-    if (target_pyramid->sr.stream != st) HIP_CHECK(hipStreamSynchronize(target_pyramid->sr.stream));
+    target_pyramid->waitReady(st);
     struct Tables {
       DepthFrame f[DSOPP_HIP_MAX_FRAMES];
       DepthLandmarks l[DSOPP_HIP_MAX_FRAMES];

@@ -654,11 +654,7 @@ enum class ReduceMode { kFused, kAccumulateOnly, kDecideOnly };
 void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr, ReduceMode mode = ReduceMode::kFused) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(reduceSchurKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
+  ensureDynamicLds(reinterpret_cast<const void *>(reduceSchurKernel), w.sr.device, 96 * 1024);
   ReduceSchurArgs a;
   a.frames = w.d_frames.ptr;
   a.pc = w.d_pc.ptr;
@@ -738,11 +734,7 @@ size_t solveSmemBytes(int K) {
 
 /** K3 */
 void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool store_system, LmControl *ctrl) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(assembleSolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
-  }
+  ensureDynamicLds(reinterpret_cast<const void *>(assembleSolveKernel), w.sr.device, 150 * 1024);
   SolveArgs a = makeSolveArgs(w);
   a.lambda = lambda;
   a.ctrl = ctrl;
@@ -1578,6 +1570,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
     f->id = frame_id;
     f->timestamp = timestamp;
     f->pyramid = pyramid;
+    pyramid->waitReady(w->sr.stream);  // a build_device still in flight on the pyramid's stream
     f->level = level;
     for (int i = 0; i < 4; ++i) f->intr[i] = intrinsics[i];
     f->exposure = exposure_time;
@@ -1710,6 +1703,14 @@ int dsopp_hip_window_num_frames(dsopp_hip_window *w, int32_t *n) {
   return guarded([&] {
     if (!w || !n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     *n = w->F();
+  });
+}
+
+int dsopp_hip_window_frame_ids(dsopp_hip_window *w, int32_t capacity, int32_t *ids, int32_t *n) {
+  return guarded([&] {
+    if (!w || !n || (capacity > 0 && !ids)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    *n = w->F();
+    for (int i = 0; i < w->F() && i < capacity; ++i) ids[i] = w->frames[static_cast<size_t>(i)]->id;
   });
 }
 
@@ -2562,6 +2563,7 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     if (newest_pyramid->levels < 2) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the newest keyframe needs pyramid level 1 (sparsity level)");
     if (newest_pyramid->width != p0->width || newest_pyramid->height != p0->height || newest_pyramid->dtype != p0->dtype)
       fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the newest keyframe's pyramid does not match the window's");
+    newest_pyramid->waitReady(st);  // its build_device may still be in flight on the pyramid's stream
     for (int k = 0; k < n_keyframes; ++k) {
       const HostFrame &fr = *w->frames[static_cast<size_t>(slots[static_cast<size_t>(k)])];
       if (fr.pyramid->width != p0->width || fr.pyramid->height != p0->height || fr.pyramid->dtype != p0->dtype || fr.level != 0)

@@ -208,6 +208,7 @@ void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p) {
   if (p->staging_u8) (void)hipFree(p->staging_u8);
   if (p->staging_vig) (void)hipFree(p->staging_vig);
   if (p->lut_dev) (void)hipFree(p->lut_dev);
+  if (p->ready) (void)hipEventDestroy(p->ready);
   p->sr.destroy();
   delete p;
 }
@@ -226,6 +227,7 @@ int dsopp_hip_pyramid_build_device(dsopp_hip_pyramid *p, const void *image_dev, 
       buildTyped<double>(p, static_cast<const uint8_t *>(image_dev), static_cast<const uint8_t *>(vignetting_dev), lut_dev, vignetting_max);
     else
       buildTyped<float>(p, static_cast<const uint8_t *>(image_dev), static_cast<const uint8_t *>(vignetting_dev), lut_dev, vignetting_max);
+    p->markReady();
   });
 }
 
@@ -262,6 +264,7 @@ int dsopp_hip_pyramid_set_level(dsopp_hip_pyramid *p, int level, const double *p
     else
       setLevelKernel<float><<<grid, 256, 0, p->sr.stream>>>(static_cast<Texel<float> *>(p->texels[level]), static_cast<float *>(p->planes[level]), tmp, n);
     HIP_CHECK(hipGetLastError());
+    p->markReady();
     p->sr.sync();
     (void)hipFree(tmp);
   });
@@ -281,6 +284,7 @@ int dsopp_hip_pyramid_set_mask(dsopp_hip_pyramid *p, int level, const uint8_t *m
       fillMask<double>(p, level, mask_dev);
     else
       fillMask<float>(p, level, mask_dev);
+    p->markReady();
     p->sr.sync();
   });
 }

@@ -33,6 +33,18 @@ struct dsopp_hip_pyramid {
   void *staging_u8 = nullptr;                       // level-0 u8 image / vignette / mask staging
   void *staging_vig = nullptr;
   double *lut_dev = nullptr;                        // 256 doubles
+  // Recorded on the pyramid's stream behind every write of the texels (build / build_device / set_level / set_mask).  A
+  // consumer that reads the texels on another stream orders itself behind it with waitReady(): build_device only ENQUEUES
+  // work, so without this a solve on the aligner's or the window's own stream could sample a half-built image.
+  hipEvent_t ready = nullptr;
+  void markReady() {
+    if (!ready) HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ready, sr.stream));
+  }
+  /** everything enqueued on `consumer` after this call sees the texels of the last build (no host synchronisation) */
+  void waitReady(hipStream_t consumer) const {
+    if (ready && consumer != sr.stream) HIP_CHECK(hipStreamWaitEvent(consumer, ready, 0));
+  }
   int w(int l) const { return width >> l; }
   int h(int l) const { return height >> l; }
   size_t elemSize() const { return dtype == DSOPP_HIP_F64 ? sizeof(double) : sizeof(float); }

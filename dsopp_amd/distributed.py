@@ -45,8 +45,12 @@ def make_device_allreduce(dist, torch, stream, device_index: int):
     all_reduce = dist.all_reduce
     as_tensor = torch.as_tensor
     dev = f"cuda:{device_index}"
+    expected_stream = int(stream.cuda_stream)
 
     def allreduce(ptr, count, stream_ptr):
+        # the collective is ordered on torch's current stream: it must be the stream the library launches on
+        if stream_ptr and int(stream_ptr) != expected_stream:
+            return -1
         t = cache.get((ptr, count))
         if t is None:
             t = as_tensor(_DeviceBuffer(ptr, count), device=dev)

@@ -279,8 +279,10 @@ class HipPhotometricBundleAdjustment {
     std::vector<uint8_t> statuses(targets.size() * static_cast<size_t>(n));
     check(dsopp_hip_window_get_frame_update(w_, frame.keyframe_id, idepth.data(), inv_h.data(), baseline.data(), inliers.data(), flags.data(),
                                             static_cast<int32_t>(targets.size()), targets.data(), statuses.data()));
-    frame.idepth_variance.assign(n, 1e-5);
-    frame.inlier_residuals.assign(n, 0);
+    // entries of landmarks the solver has not written yet start at the reference's defaults; entries of marginalised
+    // landmarks are left as they are (photometric_bundle_adjustment.cpp:232-262 `continue`s before touching them)
+    frame.idepth_variance.resize(n, 1e-5);
+    frame.inlier_residuals.resize(n, 0);
     frame.relative_baseline.resize(n, 0.0);
     const double kIdepthEps = 1e-8;
     for (int32_t i = 0; i < n && i < static_cast<int32_t>(frame.active_landmarks.size()); ++i) {
@@ -293,7 +295,7 @@ class HipPhotometricBundleAdjustment {
         lm.is_outlier = true;
       else
         lm.idepth = idepth[i];
-      if (estimate_uncertainty_) frame.idepth_variance[i] = inv_h[i];
+      frame.idepth_variance[i] = estimate_uncertainty_ ? inv_h[i] : 1e-5;  // :252-254
       frame.inlier_residuals[i] = inliers[i];
       if (baseline[i] > frame.relative_baseline[i]) frame.relative_baseline[i] = baseline[i];
     }

@@ -139,6 +139,10 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
 /* updateLocalFrame's frame flags (PROB_SRC/eigen_photometric_bundle_adjustment.cpp:106-113) */
 int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_id);
 int dsopp_hip_window_num_frames(dsopp_hip_window *w, int32_t *n);
+/* ids of the frames currently in the window, oldest first (frames_ of PBA_INC/photometric_bundle_adjustment.hpp:181 after
+ * the fold-in of pushFrame erased the marginalised ones): a caller that owns the borrowed pyramids learns here which of them the
+ * window has let go of.  At most `capacity` ids are written, *n receives the count. */
+int dsopp_hip_window_frame_ids(dsopp_hip_window *w, int32_t capacity, int32_t *ids, int32_t *n);
 
 /* solve(number_of_threads) -> final energy — PBA_INC/photometric_bundle_adjustment.hpp:154,
  * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:61-101 (FEJ, LM loop on device, relinearise, covariances, point statuses) */

@@ -1,0 +1,89 @@
+"""Cross-stream ordering of the image pyramids.  dsopp_hip_pyramid_build_device only ENQUEUES work on the pyramid's stream;
+the aligner, the window and the depth estimator read the texels on their own streams and order themselves behind the build
+through the pyramid's `ready` event (pyramid.hpp).  The test rebuilds a pyramid with a DIFFERENT image and consumes it
+immediately, with no host synchronisation in between: the result must be the one of the new image."""
+import numpy as np
+import pytest
+
+from dsopp_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_build_device_then_align_immediately():
+    import torch
+    from dsopp_amd import capi
+    W, H, L = 1280, 1024, 5
+    win = syn.make_window(num_frames=3, num_points=30, width=W, height=H, seed=13)
+    fr, fa, fb = win.frames
+    pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
+    pr.build(fr.image_u8)
+    imgs = {k: torch.from_numpy(f.image_u8.copy()).cuda() for k, f in (("a", fa), ("b", fb))}
+    torch.cuda.synchronize()
+    intr = win.scene.intrinsics
+    rng = np.random.default_rng(2)
+    n = 3000
+    xs, ys = rng.integers(8, W - 8, n), rng.integers(8, H - 8, n)
+    idsum, wgt = np.zeros((H, W)), np.zeros((H, W))
+    idsum[ys, xs] = 1.0 / fr.depth[ys, xs]
+    wgt[ys, xs] = 1.0
+    T_ref = syn.mat_to_params(fr.T_w_c_gt)
+
+    def solve(target, sync_first):
+        a = capi.HipAligner(capi.default_align_options())
+        a.set_lm_path(1)
+        a.reset()
+        a.push_reference_depth_map(1000, T_ref, pr, 0, intr, idsum, wgt, 1.0, np.zeros(2))
+        pt.build_device(imgs[target].data_ptr())       # enqueue only
+        if sync_first:
+            torch.cuda.synchronize()
+        a.push_target(2000, syn.mat_to_params({"a": fa, "b": fb}[target].T_w_c_init), pt, 0, intr, 1.0, np.zeros(2))
+        r = a.solve()
+        a.close()
+        return r
+
+    ref = {k: solve(k, True) for k in ("a", "b")}
+    assert np.abs(ref["a"]["T_w_target"] - ref["b"]["T_w_target"]).max() > 1e-3   # the two images give different answers
+    for _ in range(5):                        # alternate the image, consume without synchronising
+        for k in ("a", "b"):
+            r = solve(k, False)
+            assert r["iterations"] == ref[k]["iterations"] and r["n_valid"] == ref[k]["n_valid"]
+            assert r["energy"] == ref[k]["energy"]
+            assert np.array_equal(r["T_w_target"], ref[k]["T_w_target"])
+    pr.close()
+    pt.close()
+
+
+def test_build_device_then_push_frame_immediately():
+    """the window reads the texels on ITS stream: a frame pushed right behind build_device must see the finished image"""
+    import torch
+    from dsopp_amd import capi
+    W, H = 640, 480
+    win = syn.make_window(num_frames=3, num_points=600, width=W, height=H, seed=17)
+    intr = win.scene.intrinsics
+    devs = [torch.from_numpy(f.image_u8.copy()).cuda() for f in win.frames]
+    torch.cuda.synchronize()
+
+    def run(sync_first):
+        g = capi.HipWindow(capi.default_pba_options())
+        pyrs = []
+        for i, f in enumerate(win.frames):
+            p = capi.Pyramid(W, H, 1)
+            p.build_device(devs[i].data_ptr())
+            if sync_first:
+                torch.cuda.synchronize()
+            pyrs.append(p)
+            g.push_frame(f.frame_id, f.timestamp, None, None, intr, syn.mat_to_params(f.T_w_c_init), 1.0, np.zeros(2), i == 0, False, pyramid=p)
+            g.set_landmarks(f.frame_id, f.uv, f.idepth_init, f.patch, np.zeros(len(f.uv), dtype=np.uint8))
+            for j in range(i):
+                o = win.frames[j]
+                g.set_connection(o.frame_id, f.frame_id, np.zeros(len(o.uv), dtype=np.uint8))
+                g.set_connection(f.frame_id, o.frame_id, np.zeros(len(f.uv), dtype=np.uint8))
+        g.begin()
+        e = g.calculate_energy()
+        g.close()
+        for p in pyrs:
+            p.close()
+        return e
+
+    assert run(False) == run(True)
