@@ -7,10 +7,14 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
   workload  = C1 of BASELINE.json (configs[1]): 7-keyframe window, 2000 active points per GPU, 640x480, full clique,
               production solver settings (7 LM iterations, lambda = 1e-5, Huber 20, force_accept), synthetic scene.
               All inputs (images, landmarks, statuses) are resident in HBM before the timed region starts.
-  N > 1     = landmarks sharded across ranks (weak scaling: 2000 points PER GPU, the window grows with N); frames and
-              images replicated; one RCCL all-reduce of the reduced normal equations per linearisation + one of
-              (energy, n_valid) per energy sweep, through torch.distributed (backend nccl = RCCL).
-  value     = world_size * GN iterations / wall time  (2000-point-window GN iterations per second, whole job)
+  N > 1     = landmarks sharded across ranks, frames and images replicated; ONE RCCL all-reduce per GN iteration over
+              [H_pp | b_pp | H_schur | b_schur | energy scalars], enqueued by the library itself (dsopp_hip_comm: ncclAllReduce on the
+              window's stream; --comm torch routes it through a torch.distributed callback instead).  Default = weak scaling
+              (2000 points PER GPU, the window grows with N; value = world_size * GN iterations / wall time).
+              `--workload c3|c4` (or --scaling strong) fixes the TOTAL landmark count (20 000 / 7 KF, 50 000 / 12 KF) and shards
+              it: value = GN iterations of the whole window / wall time.  Every default run also reports both strong-scaling
+              configurations at its world size under "strong_scaling".  Without a launcher `--gpus N` spawns its own ranks
+              (torch.distributed.run) and refuses to run when the node has fewer than N GPUs.
 Extra objects on the same line: roofline (linearisation sweep kernel, measured live with HIP events on the library's
 stream) and cpu_baseline (the oracle = CPU port of the reference algorithm, timed on the host cores of this box).
 """
@@ -40,66 +44,205 @@ def algorithmic_bytes_energy(P, F, s):
     return s * P * (12 + (F - 1) * 35)
 
 
+WORKLOADS = {
+    # name: (frames, total points or None = per-GPU count, scaling, description) — BASELINE.json configs[1], [3], [4]
+    "c1": (7, None, "weak", "C1: 7-KF window, 2000 active points per GPU"),
+    "c3": (7, 20000, "strong", "C3: 7-KF window, 20000 active points in total, landmark-sharded"),
+    "c4": (12, 50000, "strong", "C4: 12-KF window, 50000 active points in total, landmark-sharded"),
+}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU the way the driver does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...) and pass its exit code on.
+    Fails loudly when the node has fewer GPUs than ranks — never a silent single-GPU run."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus and os.environ.get("DSOPP_BENCH_SINGLE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {n_dev} GPU(s); one rank per GPU is required "
+                         "(RCCL refuses two ranks on one device) — not running a smaller job under the same label")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+class Job:
+    """rank / world / process group / native communicator of this process"""
+
+    def __init__(self, args, torch):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # self-test hook (tests/test_gpu_distributed.py): all ranks on one device + gloo, to run the N > 1 plumbing of this script
+        # on a single-GPU box (RCCL refuses two ranks on one device)
+        self.single_device = os.environ.get("DSOPP_BENCH_SINGLE_DEVICE") == "1"
+        self.force_dist = os.environ.get("DSOPP_BENCH_FORCE_DIST") == "1"  # collective path with a single rank (self-test)
+        if self.single_device:
+            self.local_rank = 0
+        n_dev = torch.cuda.device_count()
+        if self.local_rank >= n_dev:
+            raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} but only {n_dev} GPU(s) visible")
+        torch.cuda.set_device(self.local_rank)
+        self.dist = None
+        self.comm = None
+        self.transport = "none"
+        if self.world > 1 or self.force_dist:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            if self.single_device:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
+            self.torch = torch
+            if not self.single_device and args.comm == "native":
+                from dsopp_amd import capi
+
+                def exchange(raw):
+                    box = [raw]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+                self.comm = capi.Comm(self.rank, self.world, self.local_rank, exchange)
+                self.transport = "native ncclAllReduce (dsopp_hip_comm, RCCL)"
+            else:
+                self.transport = "torch.distributed callback (gloo)" if self.single_device else "torch.distributed callback (nccl = RCCL)"
+
+    def attach(self, g, stream):
+        if self.dist is None:
+            return
+        if self.comm is not None:
+            g.set_comm(self.comm)
+        else:
+            from dsopp_amd import distributed
+            g.set_allreduce(distributed.make_device_allreduce(self.dist, self.torch, stream, self.local_rank), self.rank, self.world)
+
+    def barrier(self, torch):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, torch, x):
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], device="cpu" if self.single_device else "cuda", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def timed_blocks(job, torch, run_iterations, steps, min_seconds=0.2, max_blocks=200):
+    """Times blocks of EXACTLY `steps` GN iterations, each bracketed by barrier + torch.cuda.synchronize() on both sides, max
+    over ranks per block; blocks are repeated until min_seconds of timed work have accumulated (one block at the driver's
+    --steps 20 is 1 ms: a single sample).  Returns (median block seconds, all block seconds)."""
+    times = []
+    n_blocks = 1
+    while len(times) < n_blocks:
+        job.barrier(torch)
+        t0 = time.perf_counter()
+        done = run_iterations(steps)
+        job.barrier(torch)
+        dt = job.max_over_ranks(torch, time.perf_counter() - t0)
+        assert done == steps
+        times.append(dt)
+        if len(times) == 1:   # every rank derives the same count from the all-reduced first block
+            n_blocks = int(min(max_blocks, max(1, np.ceil(min_seconds / max(dt, 1e-6)))))
+    return float(np.median(times)), times
+
+
+def make_sharded_window(syn, distributed, job, frames, total_points, width, height, seed):
+    """identical synthetic window on every rank (seeded); each rank keeps its landmark shard of every frame"""
+    win = syn.make_window(num_frames=frames, num_points=total_points, width=width, height=height, seed=seed)
+    distributed.shard_window(win, job.rank, job.world)
+    return win
+
+
+def run_strong_scaling(job, torch, capi, syn, distributed, name, args, dtype):
+    """BASELINE.json configs[3] / [4] with the TOTAL landmark count fixed and sharded over the ranks: whole-window GN
+    iterations / s at this world size (the driver's SCALE run collects one such figure per N)."""
+    F, total, _, desc = WORKLOADS[name]
+    win = make_sharded_window(syn, distributed, job, F, total, 640, 480, seed=1 if name == "c4" else 0)
+    stream = torch.cuda.Stream()
+    g = capi.HipWindow(capi.default_pba_options(dtype=dtype), device=job.local_rank, stream=stream.cuda_stream)
+    syn.load_window(g, win)
+    job.attach(g, stream)
+    g.snapshot()
+
+    def run(n):
+        return g.optimize_repeated(n)[0]
+    run(7)
+    med, times = timed_blocks(job, torch, run, 14, min_seconds=0.1, max_blocks=50)
+    out = {"workload": f"{desc}, 640x480, {win.num_points} on this rank", "frames": F, "total_points": total, "n_gpus": job.world,
+           "gn_iterations_per_s": 14 / med, "ms_per_iteration": med / 14 * 1e3, "timed_blocks": len(times), "scaling": "strong"}
+    g.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=140)
     ap.add_argument("--warmup", type=int, default=14)
-    ap.add_argument("--frames", type=int, default=7)
-    ap.add_argument("--points", type=int, default=2000, help="active points per GPU")
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 (default; the metric's configuration), c3, c4")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: --points per GPU (default for c1); strong: the window's total is fixed and sharded (default for c3 / c4)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None, help="active points per GPU (weak) or in total (strong)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="N > 1 exchange: native = the library's own ncclAllReduce (dsopp_hip_comm), torch = torch.distributed callback")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the large-window roofline and the tracker (C2) timing")
+    ap.add_argument("--no-extras", action="store_true", help="skip the large-window roofline, the tracker (C2) timing and the other extras")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
 
     import torch
     from dsopp_amd import capi, distributed, synthetic as syn
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # self-test hook (tests/test_gpu_distributed.py): all ranks on one device + gloo, to run the N > 1 plumbing of this script on
-    # a single-GPU box (RCCL refuses two ranks on one device)
-    single_device = os.environ.get("DSOPP_BENCH_SINGLE_DEVICE") == "1"
-    if single_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    force_dist = os.environ.get("DSOPP_BENCH_FORCE_DIST") == "1"  # exercise the collective path with a single rank (self-test)
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if single_device:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report one under the other's label")
+    job = Job(args, torch)
+    world, rank = job.world, job.rank
 
-    F, P = args.frames, args.points
-    total_points = P * world
-    # identical synthetic window on every rank (seeded); each rank keeps its landmark shard of every frame
-    win = syn.make_window(num_frames=F, num_points=total_points, width=args.width, height=args.height, seed=0)
-    distributed.shard_window(win, rank, world)
+    Fw, total_w, scaling_w, desc = WORKLOADS[args.workload]
+    F = args.frames or Fw
+    scaling = args.scaling or scaling_w
+    if scaling == "weak":
+        P = args.points or 2000
+        total_points = P * world
+    else:
+        total_points = args.points or total_w or 2000
+        P = total_points // world
+    win = make_sharded_window(syn, distributed, job, F, total_points, args.width, args.height, seed=0)
     P_local = win.num_points
 
     stream = torch.cuda.Stream()
     dtype = capi.F64 if args.dtype == "f64" else capi.F32
     opts = capi.default_pba_options(dtype=dtype)
-    g = capi.HipWindow(opts, device=local_rank, stream=stream.cuda_stream)
+    g = capi.HipWindow(opts, device=job.local_rank, stream=stream.cuda_stream)
     syn.load_window(g, win)
-
-    if world > 1 or force_dist:
-        g.set_allreduce(distributed.make_device_allreduce(dist, torch, stream, local_rank), rank, world)
-
+    job.attach(g, stream)
     g.snapshot()
 
     def run_iterations(n_target):
@@ -111,21 +254,10 @@ def main():
             raise RuntimeError("LM loop made no progress")
         return done
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_iterations(max(args.warmup, 7))
-    barrier()
-    t0 = time.perf_counter()
-    steps_done = run_iterations(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    warmup = max(args.warmup, 7)
+    run_iterations(warmup)
+    block_s, block_times = timed_blocks(job, torch, run_iterations, args.steps)
+    steps_done = args.steps
 
     # ---- live per-kernel timing (HIP events on the library's stream) -> roofline of the dominant kernel
     g.set_profiling(True)
@@ -134,36 +266,27 @@ def main():
     g.set_profiling(False)
     s_bytes = 8 if dtype == capi.F64 else 4
     # dominant HBM-bound kernel: average over 200 back-to-back launches inside ONE HIP event pair on the library's stream
-    # (an event pair around a single ~6 us launch adds ~5 us; the per-class numbers in "kernels" carry that overhead)
+    # (an event pair around a single ~6 us launch adds ~5 us; the per-class numbers in "kernels" carry that overhead).
+    # sweep_linearize_loop is the variant the LM loop actually runs (back-substitution of the pending step fused in);
+    # sweep_linearize is the plain linearisation that opens a solve.
     g.restore()
-    isolated = {k: g.time_kernel(k, 200) for k in ("sweep_linearize", "sweep_energy", "schur", "assemble_solve")}
-    lin_avg_s = isolated["sweep_linearize"] * 1e-6
-    en_ms, en_n = isolated["sweep_energy"] * 1e-3, 1
+    isolated = {k: g.time_kernel(k, 200) for k in ("sweep_linearize_loop", "sweep_linearize", "sweep_energy", "schur", "assemble_solve")}
+    lin_avg_s = isolated["sweep_linearize_loop"] * 1e-6
     b_lin = algorithmic_bytes_linearize(P_local, F, s_bytes)
+    b_en = algorithmic_bytes_energy(P_local, F, s_bytes)
     achieved = b_lin / lin_avg_s / 1e9 if lin_avg_s > 0 else 0.0
     kernels = {k: {"avg_us": (v[0] / v[1] * 1e3 if v[1] else 0.0), "launches": v[1]} for k, v in prof.items() if v[1]}
     dominant = max(kernels.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches"])[0]
 
     # HBM traffic of the same launch from the TCC counters: collected by scripts/pmc_traffic.py (rocprofv3, FETCH_SIZE and
-    # WRITE_SIZE in separate --pmc passes, calibrated on a 512 MiB copy in the same pass) and committed under profiles/
-    traffic, traffic_detail = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    default_workload = (F, P, args.width, args.height, args.dtype) == (7, 2000, 640, 480, "f64")
-    if default_workload and os.path.exists(pmc_file):
-        try:
-            with open(pmc_file) as fh:
-                pmc = json.load(fh)
-            k = pmc["per_launch_bytes"]["sweep_linearize"]
-            traffic = k["total"]
-            traffic_detail = {"fetch_bytes": k["fetch"], "write_bytes": k["write"], "source": "profiles/r01_pmc_traffic.json",
-                              "fetch_bytes_per_count": pmc["passes"]["FETCH_SIZE"]["bytes_per_count"],
-                              "write_bytes_per_count": pmc["passes"]["WRITE_SIZE"]["bytes_per_count"],
-                              "note": "per launch of the same kernel on the same window; counters are per XCD-L2 fabric requests, "
-                                      "Infinity-Cache hits included"}
-        except (OSError, KeyError, ValueError):
-            traffic, traffic_detail = None, None
+    # WRITE_SIZE in separate --pmc passes, calibrated on copies AND on a 64-byte-segment gather in the same pass) and committed
+    # under profiles/
+    traffic, traffic_detail = load_pmc_traffic(F, P, args)
 
     extras = {}
+    if not args.no_extras and args.workload == "c1" and scaling == "weak":
+        # BASELINE.json configs[3] / [4] at THIS world size (total landmark count fixed, sharded): the strong-scaling figures
+        extras["strong_scaling"] = {name: run_strong_scaling(job, torch, capi, syn, distributed, name, args, dtype) for name in ("c3", "c4")}
     if rank == 0 and world == 1 and not args.no_extras:
         g.restore()
         extras["stages"] = run_stage_table(g, win, syn, args)
@@ -190,29 +313,41 @@ def main():
         cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
 
     if rank == 0:
-        ms_per_step = elapsed / steps_done * 1e3
+        ms_per_step = block_s / steps_done * 1e3
+        per_job = world if scaling == "weak" else 1   # weak: every rank advances its own 2000-point share of the window
         line = {
             "metric": "Gauss-Newton iters/sec (7-KF window, 2k active pts)",
-            "value": world * steps_done / elapsed,
+            "value": per_job * steps_done / block_s,
             "unit": "GN iterations/s",
             "n_gpus": world,
             "steps": steps_done,
-            "warmup": max(args.warmup, 7),
+            "warmup": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"C1: {F}-KF window, {P} active points per GPU ({total_points} total), "
-                                   f"{args.width}x{args.height}, full clique, production LM settings",
+            "timing": {"what": f"median over {len(block_times)} timed blocks of {steps_done} GN iterations each (barrier + synchronize on both sides "
+                               "of every block, max over ranks per block)",
+                       "blocks": len(block_times), "block_ms_min": min(block_times) * 1e3, "block_ms_median": block_s * 1e3,
+                       "block_ms_max": max(block_times) * 1e3},
+            "config": {"workload": f"{desc} ({total_points} total, {P_local} on rank 0), {args.width}x{args.height}, full clique, "
+                                   "production LM settings", "name": args.workload,
                        "frames": F, "points_per_gpu": P, "total_points": total_points,
-                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "sweep_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+                       "exchange": job.transport, "ranks": world},
+            "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN, FEJ, HUBER, BACKSUB>: the in-loop variant)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": lin_avg_s * 1e6,
-                         "energy_sweep": {"algorithmic_bytes_per_launch": algorithmic_bytes_energy(P_local, F, s_bytes),
-                                          "avg_launch_us": en_ms / max(en_n, 1) * 1e3}},
+                         # whole Gauss-Newton iteration against the same roof: SURVEY.md §8d's B_gn = B_lin + B_en over the
+                         # driver-timed time per iteration (launch gaps, reduction and dense solve included)
+                         "iteration_frac": (b_lin + b_en) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "iteration_algorithmic_bytes": b_lin + b_en,
+                         "opening_linearisation": {"avg_launch_us": isolated["sweep_linearize"],
+                                                   "frac": b_lin / (isolated["sweep_linearize"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                         "energy_sweep": {"algorithmic_bytes_per_launch": b_en, "avg_launch_us": isolated["sweep_energy"]}},
             "kernels": kernels,
             "kernels_isolated_avg_us": isolated,
             "dominant_kernel_by_total_time": dominant,
@@ -221,10 +356,35 @@ def main():
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline
             line["speedup_vs_cpu_port"] = line["value"] / cpu_baseline["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     g.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
+
+
+def load_pmc_traffic(F, P, args):
+    """per-launch HBM bytes of the in-loop linearisation sweep from the committed counter run (profiles/, newest round first)"""
+    if (F, P, args.width, args.height, args.dtype, args.workload) != (7, 2000, 640, 480, "f64", "c1"):
+        return None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        pmc_file = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pmc_file):
+            continue
+        try:
+            with open(pmc_file) as fh:
+                pmc = json.load(fh)
+            per = pmc["per_launch_bytes"]
+            k = per.get("sweep_linearize_loop") or per["sweep_linearize"]
+            detail = {"fetch_bytes": k["fetch"], "write_bytes": k["write"], "source": f"profiles/{name}",
+                      "kernel": "sweep_linearize_loop" if "sweep_linearize_loop" in per else "sweep_linearize",
+                      "fetch_bytes_per_count": pmc["passes"]["FETCH_SIZE"]["bytes_per_count"],
+                      "write_bytes_per_count": pmc["passes"]["WRITE_SIZE"]["bytes_per_count"],
+                      "calibration": pmc.get("calibration"),
+                      "note": "per launch of the same kernel on the same window; counters are per XCD-L2 fabric requests, "
+                              "Infinity-Cache hits included"}
+            return k["total"], detail
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def run_stage_table(g, win, syn, args, repeats=30):

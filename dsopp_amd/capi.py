@@ -37,6 +37,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "dsopp_hip_window_frame_ids",
+    "dsopp_hip_comm_unique_id", "dsopp_hip_comm_create", "dsopp_hip_comm_adopt", "dsopp_hip_comm_destroy", "dsopp_hip_comm_rank",
+    "dsopp_hip_comm_allreduce", "dsopp_hip_window_set_comm",
     "dsopp_hip_window_optimize_async", "dsopp_hip_window_optimize_wait",
     "dsopp_hip_immature_sets_estimate",
     "dsopp_hip_aligner_set_rotation_prior",
@@ -213,6 +215,37 @@ class DepthMaps:
         return ids, wgt
 
 
+class Comm:
+    """One rank of the native RCCL communicator (dsopp_hip_comm): one process per GPU.  `exchange(id_bytes_or_None) -> bytes`
+    moves the 128-byte id from rank 0 to every rank (e.g. torch.distributed.broadcast_object_list, MPI, a file)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank: int, world_size: int, device: int, exchange):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * self.ID_BYTES)()
+        if rank == 0:
+            _chk(lib().dsopp_hip_comm_unique_id(buf))
+        raw = exchange(bytes(buf) if rank == 0 else None)
+        buf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(raw)
+        _chk(lib().dsopp_hip_comm_create(buf, int(rank), int(world_size), int(device), C.byref(self._h)))
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    def allreduce(self, device_ptr: int, count: int, stream: int = 0):
+        _chk(lib().dsopp_hip_comm_allreduce(self._h, C.c_void_p(device_ptr), C.c_size_t(count), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipWindow:
     """Sliding-window photometric BA on the GPU; same Python interface as oracle.pyoracle.OracleWindow."""
 
@@ -301,6 +334,12 @@ class HipWindow:
         self._cb = ALLREDUCE_FN(lambda user, ptr, count, stream: int(fn(ptr, count, stream) or 0))
         _chk(lib().dsopp_hip_window_set_allreduce(self._h, self._cb, None, int(rank), int(world_size)))
 
+    def set_comm(self, comm: "Comm | None"):
+        """native multi-GPU exchange: the library enqueues ncclAllReduce itself (no Python in the solve loop)"""
+        self._comm = comm
+        self._cb = None
+        _chk(lib().dsopp_hip_window_set_comm(self._h, comm._h if comm is not None else None))
+
     def optimize(self):
         """LM loop only (no relinearisation / covariance / point statuses)."""
         e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
@@ -373,7 +412,8 @@ class HipWindow:
         self.options.max_iterations = int(n)
 
     KERNEL_CLASSES = {"pair_setup": 0, "fej": 1, "sweep_linearize": 2, "sweep_energy": 3, "schur": 4, "assemble": 5, "assemble_solve": 6,
-                      "backsub": 7, "energy_reduce": 8, "accept_decide": 9}
+                      "backsub": 7, "energy_reduce": 8, "accept_decide": 9,
+                      "sweep_linearize_loop": 10}
 
     def time_kernel(self, name: str, repeats: int = 50) -> float:
         """average microseconds of `repeats` back-to-back launches of one kernel class (one HIP event pair)"""

@@ -183,6 +183,10 @@ namespace {
 
 using W = dsopp_hip_window;
 
+}  // namespace
+int nativeAllreduce(void *user, void *device_buffer, size_t count, void *stream);  // comm.hip
+namespace {
+
 hipEvent_t takeEvent(W &w) {
   if (!w.event_pool.empty()) {
     hipEvent_t e = w.event_pool.back();
@@ -2287,9 +2291,19 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
   });
 }
 
+int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm) {
+  int rank = 0, world = 1;
+  if (comm) {
+    const int rc = dsopp_hip_comm_rank(comm, &rank, &world);
+    if (rc != DSOPP_HIP_OK) return rc;
+  }
+  return dsopp_hip_window_set_allreduce(w, comm ? &dsopp_hip::nativeAllreduce : nullptr, comm, rank, world);
+}
+
 /* tuning aid (not declared in the public header): stamps of the sweep kernel (workgroup grid/2) */
 int dsopp_hip_debug_sweep_stamps(dsopp_hip_window *w, int lin, long long *out16) {
   return guarded([&] {
+    if (!kStamps) fail(DSOPP_HIP_ERR_STATE, "phase stamps are not compiled in (build with -DDSOPP_HIP_STAMPS)");
     if (!w->dbg_sweep) {
       HIP_CHECK(hipMalloc(&w->dbg_sweep, 16 * sizeof(long long)));
     } else {
@@ -2305,6 +2319,7 @@ int dsopp_hip_debug_sweep_stamps(dsopp_hip_window *w, int lin, long long *out16)
 /* tuning aid (not declared in the public header): wall_clock64 stamps of the solve kernel's phases (100 MHz ticks) */
 int dsopp_hip_debug_solve_stamps(dsopp_hip_window *w, long long *out8) {
   return guarded([&] {
+    if (!kStamps) fail(DSOPP_HIP_ERR_STATE, "phase stamps are not compiled in (build with -DDSOPP_HIP_STAMPS)");
     if (!w->dbg_stamps) {
       HIP_CHECK(hipMalloc(&w->dbg_stamps, 48 * sizeof(long long)));
       HIP_CHECK(hipMemset(w->dbg_stamps, 0, 48 * sizeof(long long)));
@@ -2326,13 +2341,25 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
       switch (kernel_class) {
         case DSOPP_HIP_KERNEL_SWEEP_LINEARIZE: launchSweep(*w, true, true, false); break;
         case DSOPP_HIP_KERNEL_SWEEP_ENERGY: launchSweep(*w, false, true, false); break;
+        case DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP: {
+          // exactly the launch of lmSolveFusedEnqueue's rounds >= 1: reads the Schur rows / pose step of the previous round,
+          // back-substitutes the inverse depths, linearises at the candidate state
+          SweepExtras ex;
+          ex.ublk_read = 0;
+          ex.ublk_write = 1;
+          ex.fused_lin_backsub = true;
+          launchSweep(*w, true, true, false, nullptr, true, 1e-5, ex);
+          break;
+        }
         case DSOPP_HIP_KERNEL_SCHUR: launchReduceSchur(*w, false, nullptr); break;
         case DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE: launchAssemble(*w, 1e-5, true, true, false, nullptr); break;
         default: fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "kernel class %d cannot be timed in isolation", kernel_class);
       }
     };
-    if (kernel_class == DSOPP_HIP_KERNEL_SCHUR || kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) launchSweep(*w, true, true, false);
-    if (kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) launchReduceSchur(*w, false, nullptr);
+    const bool needs_step = kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE || kernel_class == DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP;
+    if (kernel_class == DSOPP_HIP_KERNEL_SCHUR || needs_step) launchSweep(*w, true, true, false);
+    if (needs_step) launchReduceSchur(*w, false, nullptr);
+    if (kernel_class == DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP) launchAssemble(*w, 1e-5, true, true, false, nullptr);  // a pose step to back-substitute
     once();  // warm
     HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
     for (int i = 0; i < repeats; ++i) once();
@@ -2343,7 +2370,10 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
     *avg_us = static_cast<double>(ms) * 1e3 / repeats;
     w->profiling = saved;
     // the repeated solve launches moved the candidate step: drop it so the window state is unchanged
-    if (kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE) stageAccept(*w, false);
+    if (needs_step) {
+      stageAccept(*w, false);
+      w->pair_valid = false;
+    }
     w->linearized = false;
   });
 }
@@ -2467,7 +2497,8 @@ int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *
 
 const char *dsopp_hip_kernel_class_name(int kernel_class) {
   static const char *names[DSOPP_HIP_NUM_KERNEL_CLASSES] = {"pair_setup", "fej", "sweep_linearize", "sweep_energy", "schur",
-                                                            "assemble", "assemble_solve", "backsub", "energy_reduce", "accept_decide"};
+                                                            "assemble", "assemble_solve", "backsub", "energy_reduce", "accept_decide",
+                                                            "sweep_linearize_loop"};
   return (kernel_class >= 0 && kernel_class < DSOPP_HIP_NUM_KERNEL_CLASSES) ? names[kernel_class] : "?";
 }
 

@@ -239,7 +239,14 @@ struct SweepParams {
   const int *run_flag;        // nullable: launch is a no-op unless *run_flag != 0 (closing evaluation after a rejected step)
   long long *dbg;  // nullable tuning aid: per-phase wall_clock64 stamps of workgroup 0 / max end stamp
 };
-#define SWEEP_STAMP(i) do { if (prm.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) prm.dbg[i] = wall_clock64(); } while (0)
+// Phase stamps (wall_clock64) are a tuning aid: compiled in only with -DDSOPP_HIP_STAMPS (scripts/dbg_*.py); the release
+// kernels carry none of it.
+#ifdef DSOPP_HIP_STAMPS
+constexpr bool kStamps = true;
+#else
+constexpr bool kStamps = false;
+#endif
+#define SWEEP_STAMP(i) do { if (kStamps && prm.dbg && threadIdx.x == 0 && blockIdx.x == gridDim.x / 2) prm.dbg[i] = wall_clock64(); } while (0)
 
 
 /** Workgroup barrier that only orders LDS traffic: unlike __syncthreads() it does not drain outstanding global stores
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
   }
   SWEEP_STAMP(1);
-  if (prm.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kStamps && prm.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   SWEEP_STAMP(2);
   const S idepth = static_cast<S>(idepth_d + idepth_step_d);
   const S Wr = S(be.width_r), Hr = S(be.height_r), Wt = S(be.width_t), Ht = S(be.height_t);
@@ -585,7 +592,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   }
   SWEEP_STAMP(5);
   SWEEP_STAMP(6);
-  if (prm.dbg && threadIdx.x == 0) {
+  if (kStamps && prm.dbg && threadIdx.x == 0) {
     atomicMin(reinterpret_cast<unsigned long long *>(prm.dbg + 8), static_cast<unsigned long long>(wall_clock64()));
     atomicMax(reinterpret_cast<unsigned long long *>(prm.dbg + 9), static_cast<unsigned long long>(wall_clock64()));
   }

@@ -105,7 +105,7 @@ struct ReduceSchurArgs {
   LmParams prm;
   long long *dbg;  // nullable tuning aid
 };
-#define RS_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[i] = wall_clock64(); } while (0)
+#define RS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[i] = wall_clock64(); } while (0)
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -227,7 +227,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
 #pragma unroll
   for (int e = 0; e < 6; ++e) lds[e * RS + tid] = v[e];
   ldsBarrier();
-  if (a.dbg && tid == 0) s_dbg[0] = wall_clock64();
+  if (kStamps && a.dbg && tid == 0) s_dbg[0] = wall_clock64();
   // three-level tree (8-way per level), fixed order => deterministic
   static_assert(kSchurThreads == 512, "reduction tree below assumes 512 threads");
   double *l2 = lds + 6 * RS;  // [6][64]
@@ -310,8 +310,8 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
     s_out = c;
   }
   ldsBarrier();
-  if (a.dbg && tid == 0) s_dbg[1] = wall_clock64();
-  if (a.dbg && tid == 0) { dbg_out[0] = s_dbg[0]; dbg_out[1] = s_dbg[1]; }
+  if (kStamps && a.dbg && tid == 0) s_dbg[1] = wall_clock64();
+  if (kStamps && a.dbg && tid == 0) { dbg_out[0] = s_dbg[0]; dbg_out[1] = s_dbg[1]; }
   ar.accept = s_accept;
   ar.pending = cin.pending;
   ar.publish = 1;
@@ -343,7 +343,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
  */
 __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const long long rs_t0 = a.dbg ? wall_clock64() : 0;
+  const long long rs_t0 = (kStamps && a.dbg) ? wall_clock64() : 0;
   long long rs_dbg[2] = {0, 0};
   ApplyRegs ar;
   ar.pending = 0;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   const SchurBlock &be = a.schur_table[blockIdx.x];
   const int r = be.r;
   const bool bd_in_pad = K < Kp;  // H_schur^T W b_d as one more column of the SYRK when the tiles have a spare column
-  if (a.dbg && threadIdx.x == 0 && blockIdx.x == 1) { a.dbg[0] = rs_t0; a.dbg[6] = rs_dbg[0]; a.dbg[7] = rs_dbg[1]; }
+  if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) { a.dbg[0] = rs_t0; a.dbg[6] = rs_dbg[0]; a.dbg[7] = rs_dbg[1]; }
   RS_STAMP(1);
   // phase 1: 8 threads per landmark, thread `sub` owns the targets t = sub, sub + 8, ...; the loads of its first target,
   // of the landmark flags and of this thread's share of the per-target constants T = blockdiag(Adj, 1, s0) are issued
@@ -638,7 +638,7 @@ struct SolveArgs {
   int use_marginal;  // the marginal prior is non-zero
   long long *dbg_stamps;  // nullable: wall_clock64() stamps of the phases (tuning aid)
 };
-#define DSOPP_STAMP(i) do { if (a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
+#define DSOPP_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
 /** prior + marginal energy terms of calculateEnergy (problem.hpp:293-312) for state x = eps (+ step); whole workgroup */
 __device__ inline double priorEnergyBlock(const SolveArgs &a, bool with_step, double *lds /* K + 8 */, int tid) {

@@ -187,6 +187,25 @@ int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, i
 typedef int (*dsopp_hip_allreduce_fn)(void *user, void *device_buffer, size_t count, void *stream);
 int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn fn, void *user, int rank, int world_size);
 
+/* The same exchange as native code: a communicator of one rank per GPU (one process per GPU) whose all-reduce the library
+ * enqueues itself — ncclAllReduce(sum, double) over RCCL / xGMI on the window's stream, no callback into the host language.
+ * Replaces the mutex reduction of the per-thread partial systems (PBA_INT/hessian_block_evaluation.hpp:101-145,178-235) across
+ * GPUs.  Rank 0 obtains an id (dsopp_hip_comm_unique_id), hands it to the other ranks by any means (MPI, a file, a socket),
+ * then EVERY rank calls dsopp_hip_comm_create (collective).  dsopp_hip_comm_adopt wraps an ncclComm_t the host program
+ * already owns (not destroyed with the wrapper).  librccl is loaded on first use only. */
+#define DSOPP_HIP_COMM_ID_BYTES 128
+typedef struct dsopp_hip_comm dsopp_hip_comm;
+int dsopp_hip_comm_unique_id(uint8_t id[DSOPP_HIP_COMM_ID_BYTES]);
+int dsopp_hip_comm_create(const uint8_t id[DSOPP_HIP_COMM_ID_BYTES], int rank, int world_size, int device, dsopp_hip_comm **out);
+int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out);
+void dsopp_hip_comm_destroy(dsopp_hip_comm *c);
+int dsopp_hip_comm_rank(const dsopp_hip_comm *c, int *rank, int *world_size);
+/* in-place sum of `count` doubles in device memory across the ranks, ordered on `stream` (a hipStream_t) */
+int dsopp_hip_comm_allreduce(dsopp_hip_comm *c, void *device_buffer, size_t count, void *stream);
+/* attach (NULL: detach) a communicator: the window sums its partial systems / energy scalars through it.  The communicator
+ * must outlive its use by the window; landmarks are sharded by the caller exactly as with dsopp_hip_window_set_allreduce. */
+int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm);
+
 /* the Levenberg-Marquardt loop of solve() alone (firstEstimateJacobians + levenberg_marquardt_algorithm::solve,
  * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:83-86) without the post-processing (relinearise, covariance, statuses).
  * One loop body = one Gauss-Newton iteration = linearize + calculateStep + calculateEnergy + accept/reject. */
@@ -230,6 +249,8 @@ enum {
   DSOPP_HIP_KERNEL_BACKSUB,
   DSOPP_HIP_KERNEL_ENERGY_REDUCE,
   DSOPP_HIP_KERNEL_ACCEPT,
+  DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP, /* the linearisation sweep as the fused LM loop runs it: back-substitution of the pending step
+                                          * (calculateIdepths) + linearisation at the candidate state in one pass */
   DSOPP_HIP_NUM_KERNEL_CLASSES
 };
 /* when enabled every kernel launch is bracketed by HIP events on the window's stream; get_profile returns the summed
@@ -239,7 +260,8 @@ int dsopp_hip_window_get_profile(dsopp_hip_window *w, int kernel_class, double *
 const char *dsopp_hip_kernel_class_name(int kernel_class);
 /* average duration (microseconds) of `repeats` back-to-back launches of one kernel class at the window's current state,
  * bracketed by ONE pair of HIP events on the window's stream (amortises the ~5 us an event pair costs around a single
- * short kernel).  Supported: SWEEP_LINEARIZE, SWEEP_ENERGY, SCHUR, ASSEMBLE_SOLVE.  The window state is left unchanged. */
+ * short kernel).  Supported: SWEEP_LINEARIZE, SWEEP_LINEARIZE_LOOP, SWEEP_ENERGY, SCHUR, ASSEMBLE_SOLVE.  The window state is
+ * left unchanged. */
 int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repeats, double *avg_us);
 
 /* ---- reference depth maps of the newest keyframe (row a21) ----

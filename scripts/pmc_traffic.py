@@ -1,7 +1,8 @@
 """HBM traffic of the hot kernels from the TCC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in
-SEPARATE rocprofv3 --pmc passes (they do not fit one pass), no trace domains besides --kernel-trace, and a calibration on
-a known byte count (512 MiB elementwise copy) in the same pass.  Writes gpurun_out/pmc_traffic.json.
-Run on the GPU box:  python scripts/pmc_traffic.py"""
+SEPARATE rocprofv3 --pmc passes (they do not fit one pass), no trace domains besides --kernel-trace, and calibrations on
+known byte counts in the same pass: a 512 MiB streaming copy AND texel gathers with the access shape of the sweeps
+(scripts/pmc_target.py).  Writes gpurun_out/pmc_traffic.json (+ the raw counter csv files under gpurun_out/pmc/).
+Run on the GPU box:  python scripts/pmc_traffic.py [c1|large]"""
 import csv
 import glob
 import json
@@ -10,7 +11,18 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "gpurun_out", "pmc")
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "c1"
+OUT = os.path.join(ROOT, "gpurun_out", "pmc_" + WHICH)
+
+N_LANES = 2 * 1024 * 1024
+# known byte counts of the gather calibrations (scripts/pmc_target.py): useful = bytes the lanes consume, seg64 / line128 =
+# bytes of the distinct 64-byte segments / 128-byte lines they touch
+GATHER = {
+    "isolated": {"useful": N_LANES * 32, "seg64": N_LANES * 64, "line128": N_LANES * 128},
+    "pair": {"useful": N_LANES * 64, "seg64": N_LANES * 64, "line128": N_LANES * 128},
+    # 2 rows x {texels c, c+1}, c uniform in {0, 1, 2} of a 4-texel line: c = 1 straddles two 64-byte segments of one line
+    "footprint": {"useful": N_LANES * 128, "seg64": int(N_LANES * 2 * (1 + 1 / 3) * 64), "line128": N_LANES * 2 * 128},
+}
 
 
 def run_pass(counter):
@@ -18,58 +30,78 @@ def run_pass(counter):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-           sys.executable, os.path.join(ROOT, "scripts", "pmc_target.py")]
-    subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+           sys.executable, os.path.join(ROOT, "scripts", "pmc_target.py"), WHICH]
+    subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1200)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-    per_kernel = {}
+    rows = []
     for f in files:
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") != counter:
-                continue
-            per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
-    return per_kernel
-
-
-def pick(per_kernel, needle):
-    for name, vals in per_kernel.items():
-        if needle in name:
-            return name, vals
-    return None, []
+            if row.get("Counter_Name") == counter:
+                rows.append((int(row.get("Dispatch_Id", 0)), row["Kernel_Name"], float(row["Counter_Value"])))
+    rows.sort()
+    return rows
 
 
 def main():
     res = {}
-    calib_bytes = 128 * 1024 * 1024 * 4
+    copy_bytes = 128 * 1024 * 1024 * 4
+    labels = (("sweep_linearize", "sweepKernel<double, true, true, true, false"),
+              ("sweep_linearize_loop", "sweepKernel<double, true, true, true, true"),
+              ("sweep_energy", "sweepKernel<double, false, true, true, false"),
+              ("schur", "reduceSchurKernel"), ("assemble_solve", "assembleSolveKernel"))
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        pk = run_pass(counter)
-        # calibration kernel: the torch elementwise copy (largest counter value in the pass)
-        cal_name, cal_vals = max(pk.items(), key=lambda kv: max(kv[1]))
+        rows = run_pass(counter)
+        by_kernel = {}
+        for _, name, v in rows:
+            by_kernel.setdefault(name, []).append(v)
+        # calibration 1: the largest counter value of the pass is the 512 MiB copy
+        cal_name, cal_vals = max(by_kernel.items(), key=lambda kv: max(kv[1]))
         cal = max(cal_vals)
-        entry = {"calibration_kernel": cal_name[:80], "calibration_counter_value": cal, "calibration_bytes": calib_bytes,
-                 "bytes_per_count": calib_bytes / cal, "kernels": {}}
-        for label, needle in (("sweep_linearize", "sweepKernel<double, true, true, true, false>"),
-                              ("sweep_linearize_backsub", "sweepKernel<double, true, true, true, true>"),
-                              ("sweep_energy", "sweepKernel<double, false, true, true, false>"),
-                              ("schur", "reduceSchurKernel"), ("assemble_solve", "assembleSolveKernel")):
-            name, vals = pick(pk, needle)
+        entry = {"copy_kernel": cal_name[:80], "copy_counter_value": cal, "copy_bytes": copy_bytes, "bytes_per_count": copy_bytes / cal,
+                 "kernels": {}, "gather": {}}
+        # calibration 2: the gather kernel's launches come in pairs per pattern, in the order isolated, pair, footprint
+        gvals = [v for _, name, v in rows if "gatherCalibrationKernel" in name]
+        for k, pat in enumerate(("isolated", "pair", "footprint")):
+            if len(gvals) >= 2 * k + 2:
+                c = gvals[2 * k + 1]
+                known = GATHER[pat]
+                entry["gather"][pat] = {"counter_value": c, **known,
+                                        "bytes_per_count_if_seg64": known["seg64"] / c if c else None,
+                                        "bytes_per_count_if_line128": known["line128"] / c if c else None,
+                                        "bytes_per_count_if_useful": known["useful"] / c if c else None}
+        for label, needle in labels:
+            vals = next((v for name, v in by_kernel.items() if needle in name), [])
             if vals:
                 tail = vals[-20:]  # the back-to-back launches of time_kernel
-                avg = sum(tail) / len(tail)
-                entry["kernels"][label] = {"launches": len(tail), "counter_avg": avg, "bytes_avg": avg * entry["bytes_per_count"]}
+                entry["kernels"][label] = {"launches": len(tail), "counter_avg": sum(tail) / len(tail)}
         res[counter] = entry
-    out = {"source": "rocprofv3 --kernel-trace --pmc <C> -- python scripts/pmc_target.py (one pass per counter)",
-           "note": "bytes = counter x bytes_per_count, bytes_per_count calibrated on a 512 MiB elementwise copy in the same pass "
-                   "(MI355X_MICROARCH.md: FETCH_SIZE under-reports wide streaming reads 2x on gfx950; WRITE_SIZE uncalibrated)",
-           "passes": res, "per_launch_bytes": {}}
+    # conversion: reads of the sweeps are texel gathers -> the footprint calibration at 64-byte-segment granularity (the
+    # counter's unit is 1 KiB of 64-byte fabric requests: bytes_per_count ~ 1024 there if gathers are counted exactly);
+    # writes and the small dense kernels use the streaming calibration
+    fp = res["FETCH_SIZE"]["gather"].get("footprint", {})
+    gather_bpc = fp.get("bytes_per_count_if_seg64") or res["FETCH_SIZE"]["bytes_per_count"]
+    out = {"source": f"rocprofv3 --kernel-trace --pmc <C> -- python scripts/pmc_target.py {WHICH} (one pass per counter)",
+           "workload": "C1: 7 KF / 2000 points / 640x480" if WHICH == "c1" else "12 KF / 50 000 points / 640x480",
+           "note": "bytes = counter x bytes_per_count.  Streaming calibration: 512 MiB elementwise copy (MI355X_MICROARCH.md: FETCH_SIZE "
+                   "under-reports wide streaming reads 2x on gfx950).  Gather calibration: texel gathers of known geometry in the same pass; "
+                   "the sweeps' fetches are converted with the 2x2-footprint pattern at 64-byte-segment granularity.",
+           "passes": res, "calibration": {"fetch_streaming_bytes_per_count": res["FETCH_SIZE"]["bytes_per_count"],
+                                          "fetch_gather_bytes_per_count": gather_bpc,
+                                          "write_bytes_per_count": res["WRITE_SIZE"]["bytes_per_count"]},
+           "per_launch_bytes": {}}
     for label in res["FETCH_SIZE"]["kernels"]:
-        f = res["FETCH_SIZE"]["kernels"][label]["bytes_avg"]
-        w = res["WRITE_SIZE"]["kernels"].get(label, {}).get("bytes_avg", 0.0)
-        out["per_launch_bytes"][label] = {"fetch": f, "write": w, "total": f + w}
+        is_sweep = label.startswith("sweep")
+        f = res["FETCH_SIZE"]["kernels"][label]["counter_avg"] * (gather_bpc if is_sweep else res["FETCH_SIZE"]["bytes_per_count"])
+        w = res["WRITE_SIZE"]["kernels"].get(label, {}).get("counter_avg", 0.0) * res["WRITE_SIZE"]["bytes_per_count"]
+        out["per_launch_bytes"][label] = {"fetch": f, "write": w, "total": f + w,
+                                          "fetch_if_streaming_calibration": res["FETCH_SIZE"]["kernels"][label]["counter_avg"] * res["FETCH_SIZE"]["bytes_per_count"]}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w") as fh:
+    name = "pmc_traffic.json" if WHICH == "c1" else "pmc_traffic_large.json"
+    with open(os.path.join(ROOT, "gpurun_out", name), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out["per_launch_bytes"], indent=1))
-    print({c: (res[c]["calibration_kernel"], res[c]["bytes_per_count"]) for c in res})
+    print(json.dumps(out["calibration"], indent=1))
+    print(json.dumps(res["FETCH_SIZE"]["gather"], indent=1))
 
 
 if __name__ == "__main__":

@@ -73,21 +73,84 @@ def test_sharded_solve_matches_single_window(lm_mode):
     assert res[0] is True, res
 
 
-def test_bench_script_runs_with_two_ranks():
-    """bench.py's own N > 1 path (sharding, collective callback, MAX-over-ranks timing, rank-0 JSON line) end to end: two
-    ranks on this one GPU over gloo (DSOPP_BENCH_SINGLE_DEVICE=1); the driver runs the same script over RCCL with one GPU per rank"""
-    import json
+def _run_bench(extra, env_extra=None, timeout=900):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DSOPP_BENCH_SINGLE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "28", "--warmup", "7"]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, **(env_extra or {}))
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_script_runs_with_two_ranks():
+    """bench.py's own N > 1 path end to end, started the way the driver starts it when no launcher is involved
+    (`python bench.py --gpus 2`: the script spawns its ranks through torch.distributed.run): sharding, collective, MAX-over-ranks
+    block timing, rank-0 JSON line.  Two ranks share this one GPU over gloo (DSOPP_BENCH_SINGLE_DEVICE=1); on a multi-GPU node the
+    same script runs one rank per GPU with the library's native ncclAllReduce."""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "28", "--warmup", "7", "--no-extras", "--no-cpu"], {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 28 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["total_points"] == 4000 and "roofline" in d
+    assert d["config"]["total_points"] == 4000 and "roofline" in d and d["config"]["ranks"] == 2
+    assert d["timing"]["blocks"] >= 1 and abs(d["value"] - 2 * 28 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_strong_scaling_workload_two_ranks():
+    """--workload c3: the TOTAL landmark count (20 000) is fixed and sharded; value counts whole-window iterations"""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "14", "--warmup", "7", "--workload", "c3", "--no-extras", "--no-cpu"],
+                     {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["total_points"] == 20000 and d["config"]["points_per_gpu"] == 10000
+    assert abs(d["value"] - 14 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a node with fewer GPUs must fail loudly — never print a line for a smaller job"""
+    import torch
+    n = torch.cuda.device_count()
+    out = _run_bench(["--gpus", str(n + 1), "--steps", "7", "--no-extras", "--no-cpu"], timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "GPU" in (out.stderr + out.stdout)
+
+
+def test_native_communicator_single_rank():
+    """dsopp_hip_comm (lazy dlopen of librccl, ncclCommInitRank, ncclAllReduce on the window's stream) with one rank: the
+    sharded code path (accumulate -> one collective -> decide -> solve) must reproduce the plain solve.  Multi-rank RCCL
+    needs one GPU per rank and is exercised by the driver's scaling run."""
+    import torch
+    from dsopp_amd import capi, synthetic as syn
+    win = syn.make_window(num_frames=4, num_points=400, width=320, height=240, seed=5)
+    g0 = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g0, win)
+    ref = (g0.solve(), [g0.get_pose(f.frame_id) for f in win.frames])
+    g0.close()
+    comm = capi.Comm(0, 1, 0, lambda raw: raw)
+    # the collective itself: sum over one rank leaves the buffer unchanged, and is ordered on the given stream
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    comm.allreduce(t.data_ptr(), t.numel(), st.cuda_stream)
+    st.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    for lm_mode in (0, 1):
+        g = capi.HipWindow(capi.default_pba_options())
+        syn.load_window(g, win)
+        g.set_comm(comm)
+        g.set_lm_mode(lm_mode)
+        e, it, nv = g.solve()
+        (e0, it0, nv0), poses0 = ref
+        assert (it, nv) == (it0, nv0) and abs(e - e0) <= 1e-7 * abs(e0)
+        for f, (T0, ab0) in zip(win.frames, poses0):
+            T, ab = g.get_pose(f.frame_id)
+            assert np.abs(T - T0).max() <= 1e-7 and np.abs(ab - ab0).max() <= 1e-7
+        g.set_comm(None)
+        g.close()
+    comm.close()
