@@ -12,6 +12,7 @@
 
 #include "host_linalg.hpp"
 #include "pba_solve_kernels.hpp"
+#include "pba_solve_combined.hpp"
 #include "depth_map_kernels.hpp"
 #include "point_status_kernels.hpp"
 #include "depth_maps.hpp"
@@ -90,6 +91,8 @@ struct dsopp_hip_window {
     HIP_CHECK(hipMemcpyAsync(host, dbsc() + off, n * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   size_t reduceCount() const { return 2 * (static_cast<size_t>(K()) * K() + K()); }
+  /** fused LM loop: the combined block-packed system [blocks | rhs] at the head of d_reduce (pba_solve_kernels.hpp: ReduceSchurArgs::comb) */
+  size_t combCount() const { return static_cast<size_t>(combBlockCount(F())) * 64 + static_cast<size_t>(K()); }
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
   bool state_dirty = true;   // host mirror newer than device
@@ -557,6 +560,7 @@ struct SweepExtras {
   bool gate_on_pending = false;  // fused loop: BACKSUB only when a candidate step is pending (LmControl::pending)
   const int *run_flag = nullptr;
   bool fused_lin_backsub = false;
+  bool combined = false;  // the following reduction builds the combined system: only that much has to be zeroed
 };
 
 template <typename S>
@@ -571,7 +575,7 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.use_fej_flag = w.fej() ? 1 : 0;
   prm.ctrl = ctrl;
   prm.clear_buf = lin ? w.d_reduce.ptr : nullptr;
-  prm.clear_count = static_cast<int>(w.reduceCount());
+  prm.clear_count = static_cast<int>(ex.combined ? w.combCount() + 4 : w.reduceCount());
   prm.step = w.d_step.ptr;
   prm.lambda = lambda;
   prm.F = w.F();
@@ -650,6 +654,8 @@ struct FusedReduce {
   int ublk_parity;
   LmControl *ctrl_out;
   LmParams prm;
+  bool combined = false;   // emit the combined block-packed system instead of H_pp / H_schur (fused loop)
+  double comb_lambda = 0;  // its damping when no control block is given
 };
 
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
@@ -677,10 +683,14 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.ublk_parity = fused ? fused->ublk_parity : 0;
   a.ctrl_out = (fused && mode != ReduceMode::kAccumulateOnly) ? fused->ctrl_out : nullptr;
   a.st = w.d_state.ptr;
-  a.scalars = mode == ReduceMode::kDecideOnly ? w.d_reduce.ptr + w.reduceCount() : w.d_scalars.ptr;
+  const bool combined = fused && fused->combined;
+  const size_t reduce_count = combined ? w.combCount() : w.reduceCount();
+  a.comb = combined ? w.d_reduce.ptr : nullptr;
+  a.comb_lambda = fused ? fused->comb_lambda : 0.0;
+  a.scalars = mode == ReduceMode::kDecideOnly ? w.d_reduce.ptr + reduce_count : w.d_scalars.ptr;
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
-  a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + w.reduceCount() : nullptr;
+  a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + reduce_count : nullptr;
   if (fused) a.prm = fused->prm;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
   const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
@@ -697,7 +707,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
   // (in the fused loop the 4 energy scalars of the sweep sit right behind the systems and travel with them)
-  allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount() + (mode == ReduceMode::kAccumulateOnly ? 4 : 0));
+  allreduceIfNeeded(w, w.d_reduce.ptr, reduce_count + (mode == ReduceMode::kAccumulateOnly ? 4 : 0));
   (void)K;
 }
 
@@ -748,6 +758,35 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
   timedLaunch(w, do_solve ? DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE : DSOPP_HIP_KERNEL_ASSEMBLE,
               [&] { assembleSolveKernel<<<1, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
   if (do_solve && !w.fej()) {
+    // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
+    pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+/** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
+void launchSolveCombined(W &w, double lambda, LmControl *ctrl) {
+  ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel), w.sr.device, 150 * 1024);
+  SolveCombArgs a;
+  a.frames = w.d_frames.ptr;
+  a.st = w.d_state.ptr;
+  a.pc = w.d_pc.ptr;
+  a.comb = w.d_reduce.ptr;
+  a.Hm = w.d_Hm.ptr;
+  a.bm = w.d_bm.ptr;
+  a.step = w.d_step.ptr;
+  a.ctrl = ctrl;
+  a.lambda = lambda;
+  a.affine_reg[0] = w.opt.affine_brightness_regularizer[0];
+  a.affine_reg[1] = w.opt.affine_brightness_regularizer[1];
+  a.fixed_reg = w.opt.fixed_state_regularizer;
+  a.energy_marginalized = w.energy_marginalized;
+  a.F = w.F();
+  a.fej = w.fej() ? 1 : 0;
+  a.use_marginal = w.marg_nonzero ? 1 : 0;
+  a.dbg_stamps = w.dbg_stamps;
+  timedLaunch(w, DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE, [&] { solveCombinedKernel<<<1, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
+  if (!w.fej()) {
     // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
     pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);
   }
@@ -991,12 +1030,14 @@ void lmSolveFusedEnqueue(W &w) {
     ex.ublk_write = r & 1;
     ex.gate_on_pending = true;
     ex.fused_lin_backsub = true;
+    ex.combined = true;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
     launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
     fr.prm = prm;
+    fr.combined = true;  // (the sharded accumulate pass reads lambda from the incoming control block: constant, decrease = increase = 1)
     if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
@@ -1004,7 +1045,7 @@ void lmSolveFusedEnqueue(W &w) {
     } else {
       launchReduceSchur(w, false, cin, &fr);
     }
-    if (r + 1 < rounds) launchAssemble(w, 0.0, true, true, false, cout);
+    if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout);
   }
   LmControl *cfin = ctrl + (rounds & 1);
   HIP_CHECK(hipGetLastError());
@@ -2351,15 +2392,32 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
           launchSweep(*w, true, true, false, nullptr, true, 1e-5, ex);
           break;
         }
-        case DSOPP_HIP_KERNEL_SCHUR: launchReduceSchur(*w, false, nullptr); break;
-        case DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE: launchAssemble(*w, 1e-5, true, true, false, nullptr); break;
+        case DSOPP_HIP_KERNEL_SCHUR: {  // as the fused loop launches it (combined system), without the decision prologue
+          FusedReduce fr;
+          fr.ublk_parity = 0;
+          fr.ctrl_out = nullptr;
+          fr.combined = true;
+          fr.comb_lambda = 1e-5;
+          HIP_CHECK(hipMemsetAsync(w->d_reduce.ptr, 0, (w->combCount() + 4) * sizeof(double), w->sr.stream));
+          launchReduceSchur(*w, false, nullptr, &fr, ReduceMode::kAccumulateOnly);
+          break;
+        }
+        case DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE: launchSolveCombined(*w, 1e-5, nullptr); break;
         default: fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "kernel class %d cannot be timed in isolation", kernel_class);
       }
     };
     const bool needs_step = kernel_class == DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE || kernel_class == DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP;
     if (kernel_class == DSOPP_HIP_KERNEL_SCHUR || needs_step) launchSweep(*w, true, true, false);
-    if (needs_step) launchReduceSchur(*w, false, nullptr);
-    if (kernel_class == DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP) launchAssemble(*w, 1e-5, true, true, false, nullptr);  // a pose step to back-substitute
+    if (needs_step) {
+      FusedReduce fr;
+      fr.ublk_parity = 0;
+      fr.ctrl_out = nullptr;
+      fr.combined = true;
+      fr.comb_lambda = 1e-5;
+      HIP_CHECK(hipMemsetAsync(w->d_reduce.ptr, 0, (w->combCount() + 4) * sizeof(double), w->sr.stream));
+      launchReduceSchur(*w, false, nullptr, &fr, ReduceMode::kAccumulateOnly);
+    }
+    if (kernel_class == DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP) launchSolveCombined(*w, 1e-5, nullptr);  // a pose step to back-substitute
     once();  // warm
     HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
     for (int i = 0; i < repeats; ++i) once();

@@ -1,0 +1,441 @@
+// K3 of the fused Levenberg-Marquardt loop: priors + dense solve of the combined system the reduction kernel emits
+// (pba_solve_kernels.hpp: ReduceSchurArgs::comb), candidate pair constants, prior energy of the candidate — one workgroup.
+//
+// Replaces, like assembleSolveKernel (which stays for the stage API / marginalisation / covariance paths that need the four
+// systems separately): evaluateLinearSystemPrior (problem.hpp:37-77), calculateStep (:342-361), NormalLinearSystem::solve
+// (normal_linear_system.cpp:10-16,52-59).  What is different from assembleSolveKernel:
+//   * input is ONE block-packed lower triangle (14 KB at 7 frames) instead of H_pp and H_schur as K x K matrices (2 x 25 KB) plus
+//     their right-hand sides: the load phase is a single coalesced sweep, 7 loads per thread;
+//   * one workgroup barrier per 8 x 8 block step instead of two: the panel wave applies the previous panel to its own block
+//     column itself (LDS broadcast reads) and no longer waits for the other waves before factoring;
+//   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own.
+// The arithmetic of the factorisation (blocked Cholesky over the frame blocks, right-hand side as an extra row, f32 rsqrt
+// seed + two Newton steps, pivots below 1e-30 of the Jacobi-scaled diagonal treated as zero) is unchanged.
+#pragma once
+#include "pba_solve_kernels.hpp"
+
+namespace dsopp_hip {
+
+struct SolveCombArgs {
+  const FrameDev *frames;
+  WindowState *st;
+  PairConst *pc;
+  const double *comb;  // combBlockCount(F) * 64 block entries, then K right-hand-side entries
+  const double *Hm, *bm;  // marginal prior
+  double *step;        // out: K
+  LmControl *ctrl;     // nullable (isolated timing launches pass lambda explicitly)
+  double lambda;
+  double affine_reg[2];
+  double fixed_reg;
+  double energy_marginalized;
+  int F;
+  int fej;
+  int use_marginal;
+  long long *dbg_stamps;  // compiled in with -DDSOPP_HIP_STAMPS only
+};
+#define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
+
+/** block index b of the packed lower triangle -> (bi, bj), bj <= bi */
+__device__ __forceinline__ void combBlockDecode(int b, int &bi, int &bj) {
+  int r = static_cast<int>((__fsqrt_rn(8.0f * static_cast<float>(b) + 1.0f) - 1.0f) * 0.5f);
+  if ((r + 1) * (r + 2) / 2 <= b) ++r;
+  if (r * (r + 1) / 2 > b) --r;
+  bi = r;
+  bj = b - r * (r + 1) / 2;
+}
+
+__global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCombArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int F = a.F, K = kBlk * F;
+  const int N = K + 1;   // augmented with the right-hand side row
+  const int ld = N + 1;
+  double *A = reinterpret_cast<double *>(smem_raw);  // N x ld (lower triangle used)
+  double *pv = A + N * ld;                           // K pivot guards
+  double *xs = pv + K;                               // K + 16 scratch
+  double *Linv = xs + K + 16;                        // F x 36: reciprocals of the factor's diagonal
+  double *epsl = Linv + 36 * kMaxFrames;             // K: state increment eps of every frame
+  double *stpl = epsl + K;                           // K: the new step (-x), kept in LDS for the pair refresh / prior energy
+  double *ab0l = stpl + K;                           // 2 F: affine brightness at the linearisation point
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+
+  // ---- everything is requested before anything waits: the kernel start costs one memory round trip
+  int c_active = 1, c_relin = 0;
+  double lam = a.lambda;
+  if (a.ctrl) {
+    c_active = a.ctrl->active;
+    c_relin = a.ctrl->relin;
+    lam = a.ctrl->lambda;
+  }
+  SC_STAMP(0);
+  struct {
+    int valid;
+    Rigid T0;
+    double fxr, fyr, cxr, cyr, fxt, fyt, cxt, cyt, exposure_r, exposure_t;
+  } pp;
+  pp.valid = 0;
+  const bool fast_refresh = a.fej != 0;
+  if (fast_refresh && tid < F * F) {
+    const int r = tid / F, t = tid - F * (tid / F);
+    const PairConst &P = a.pc[r * kMaxFrames + t];
+    pp.valid = P.valid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
+      pp.T0.t[i] = P.T0rel[4 * i + 3];
+    }
+    const FrameDev &fr = a.frames[r];
+    const FrameDev &ft = a.frames[t];
+    pp.fxr = fr.fx;
+    pp.fyr = fr.fy;
+    pp.cxr = fr.cx;
+    pp.cyr = fr.cy;
+    pp.fxt = ft.fx;
+    pp.fyt = ft.fy;
+    pp.cxt = ft.cx;
+    pp.cyt = ft.cy;
+    pp.exposure_r = fr.exposure;
+    pp.exposure_t = ft.exposure;
+  }
+  double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < kSolveThreads)
+  int fixed_c = 0, tomarg_c = 0;
+  if (tid < K) {
+    const int f = tid >> 3, i = tid & 7;
+    eps_c = a.st->eps[f][i];
+    fixed_c = a.frames[f].fixed;
+    tomarg_c = a.frames[f].to_marginalize;
+    ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];
+    rhs_c = a.comb[combBlockCount(F) * 64 + tid];
+    if (a.use_marginal) bm_c = a.bm[tid];
+  }
+  // the block-packed lower triangle: entry e = tid + 256 u, coalesced.  kBatch loads are in flight per thread.
+  const int n_entries = combBlockCount(F) * 64;
+  constexpr int kBatch = 8;
+  double hv[kBatch], hm[kBatch];
+  auto loadBatch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int e = base + tid + kSolveThreads * u;
+      hv[u] = a.comb[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
+      hm[u] = 0;
+    }
+    if (a.use_marginal) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int e = min(base + tid + kSolveThreads * u, n_entries - 1);
+        int bi, bj;
+        combBlockDecode(e >> 6, bi, bj);
+        hm[u] = a.Hm[(8 * bi + ((e >> 3) & 7)) * K + 8 * bj + (e & 7)];
+      }
+    }
+  };
+  loadBatch(0);
+  // opaque to the optimiser: stops it from testing these loaded flags (and waiting for them) above the loads
+  asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(pp.valid), "+v"(c_active), "+v"(c_relin));
+  int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness (evaluateLinearSystemPrior, problem.hpp:39-62)
+  double pd_c = 0;
+  if (tid < K) {
+    if (!tomarg_c) prior_kind = fixed_c ? 1 : ((tid & 7) >= 6 ? 2 : 0);
+    pd_c = prior_kind == 1 ? a.fixed_reg : (prior_kind == 2 ? a.affine_reg[(tid & 7) - 6] : 0.0);
+    xs[tid] = eps_c;
+    epsl[tid] = eps_c;
+    Linv[tid] = pd_c;  // prior diagonal, parked in the Linv area until the factorisation starts
+    if ((tid & 7) >= 6) ab0l[2 * (tid >> 3) + (tid & 7) - 6] = ab0_c;
+  }
+  __syncthreads();  // keeps every load above; prior diagonal / eps visible
+  if (!c_active || c_relin) return;
+  const double *prior_diag = Linv;
+  auto storeBatch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int e = base + tid + kSolveThreads * u;
+      if (e >= n_entries) continue;
+      int bi, bj;
+      combBlockDecode(e >> 6, bi, bj);
+      const int row = 8 * bi + ((e >> 3) & 7), col = 8 * bj + (e & 7);
+      if (col > row) continue;  // upper half of a diagonal block
+      double v = hv[u] + hm[u];
+      if (row == col) {
+        v += prior_diag[row] * (1.0 + lam);  // the prior's diagonal takes the damping too (problem.hpp:347-349)
+        // The reference solves the Jacobi-scaled system p H p, p = 1/sqrt(diag + 10) (normal_linear_system.cpp:10-16,52-59).  A
+        // Cholesky factorisation is invariant under symmetric diagonal scaling, so only the zero-pivot guard refers to it
+        pv[row] = v + 10.0;
+      }
+      A[row * ld + col] = v;
+    }
+  };
+  storeBatch(0);
+  for (int base = kBatch * kSolveThreads; base < n_entries; base += kBatch * kSolveThreads) {
+    loadBatch(base);
+    storeBatch(base);
+  }
+  if (tid < K) {
+    double v = rhs_c;
+    if (prior_kind == 1)
+      v += a.fixed_reg * eps_c;
+    else if (prior_kind == 2)
+      v += a.affine_reg[(tid & 7) - 6] * (ab0_c + eps_c);
+    if (a.use_marginal) {
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += a.Hm[tid * K + k] * xs[k];
+      v += bm_c + s;
+    }
+    A[K * ld + tid] = v;
+  }
+  if (tid == 0) A[K * ld + K] = 0;
+  __syncthreads();
+  SC_STAMP(1);
+
+  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T.
+  // One barrier per block step: wave 0 ("panel wave") owns block column kb+1 — it applies panel kb to it, factors its diagonal
+  // block in registers and solves the panel below — WHILE waves 1..3 apply panel kb to the columns >= kb+2.  Panel kb was written
+  // by wave 0 itself one step earlier, column kb+1 last by waves 1..3 one step earlier: one barrier orders both.
+  auto readLane = [](double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+  };
+  auto factorAndPanel = [&](int kb) {
+    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below it): one
+    // elimination loop does the Cholesky of the diagonal block and the triangular solve of the panel together.
+    const int k0 = kb * kBlk, kp0 = k0 - kBlk;
+    const int row = k0 + lane;
+    const bool valid = row < N;
+    double c[kBlk], invd[kBlk], lj[28];
+    {
+      const double *src = A + (valid ? row : k0) * ld + k0;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) c[j] = src[j];
+    }
+    if (kb > 0) {
+      // block column kb -= panel (kb-1) contribution: c_j -= sum_c L[row][kp0 + c] * L[k0 + j][kp0 + c].  The second factor is the
+      // same for every lane (LDS broadcast read).
+      double lic[kBlk];
+      const double *li = A + (valid ? row : k0) * ld + kp0;
+#pragma unroll
+      for (int cc = 0; cc < kBlk; ++cc) lic[cc] = li[cc];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) {
+        const double *ljp = A + (k0 + j) * ld + kp0;
+        double sacc = 0;
+#pragma unroll
+        for (int cc = 0; cc < kBlk; ++cc) sacc += lic[cc] * ljp[cc];
+        c[j] -= sacc;
+      }
+    }
+    double guard[kBlk];
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
+    int e = 0;
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      const double d = readLane(c[k], k);
+      const bool okp = d > guard[k];
+      double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = okp ? inv : 0.0;
+      invd[k] = inv;
+      const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik
+      c[k] = l;
+#pragma unroll
+      for (int j = k + 1; j < kBlk; ++j) {
+        const double ljk = readLane(l, j);
+        lj[e++] = ljk;
+        c[j] -= l * ljk;
+      }
+    }
+    if (valid) {
+      double *dst = A + row * ld + k0;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j)
+        if (lane >= kBlk || j <= lane) dst[j] = c[j];  // the diagonal block keeps its lower triangle only
+    }
+    // rows beyond the first 64 of this block column (windows of more than 7 frames)
+    for (int r2 = row + 64; r2 < N; r2 += 64) {
+      double v[kBlk];
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) v[j] = A[r2 * ld + k0 + j];
+      if (kb > 0) {
+        double lic[kBlk];
+#pragma unroll
+        for (int cc = 0; cc < kBlk; ++cc) lic[cc] = A[r2 * ld + kp0 + cc];
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) {
+          const double *ljp = A + (k0 + j) * ld + kp0;
+          double sacc = 0;
+#pragma unroll
+          for (int cc = 0; cc < kBlk; ++cc) sacc += lic[cc] * ljp[cc];
+          v[j] -= sacc;
+        }
+      }
+      int e2 = 0;
+#pragma unroll
+      for (int k = 0; k < kBlk; ++k) {
+        v[k] *= invd[k];
+#pragma unroll
+        for (int j = k + 1; j < kBlk; ++j) v[j] -= v[k] * lj[e2++];
+      }
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) A[r2 * ld + k0 + j] = v[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];
+    }
+  };
+  // (the prior diagonal parked in Linv has been consumed: every thread passed the barrier after storeBatch)
+  if (wave == 0) factorAndPanel(0);
+  __syncthreads();
+  for (int kb = 0; kb + 1 < F; ++kb) {
+    const int k0 = kb * kBlk, k2 = k0 + 2 * kBlk;
+    if (wave == 0) {
+      factorAndPanel(kb + 1);
+    } else {
+      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
+      const int t = tid - 64, tr = t >> 4, tc = t & 15;
+      for (int row = k2 + tr; row < N; row += 12) {
+        const double *li = A + row * ld + k0;
+        double lic[kBlk];
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) lic[c] = li[c];
+        for (int col = k2 + tc; col <= row; col += 16) {
+          const double *ljp = A + col * ld + k0;
+          double sacc = 0;
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) sacc += lic[c] * ljp[c];
+          A[row * ld + col] -= sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  SC_STAMP(2);
+  // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
+  // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
+  if (wave == 0) {
+    auto run = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+      const int j0 = lane, j1 = lane + 64;
+      double y0 = j0 < K ? A[K * ld + j0] : 0.0, y1 = (TWO && j1 < K) ? A[K * ld + j1] : 0.0;
+      const double gi0 = j0 < K ? Linv[(j0 >> 3) * 36 + lowIdx(j0 & 7, j0 & 7)] : 0.0;
+      const double gi1 = (TWO && j1 < K) ? Linv[(j1 >> 3) * 36 + lowIdx(j1 & 7, j1 & 7)] : 0.0;
+      double g0[kBlk], g1[kBlk], n0[kBlk], n1[kBlk];
+      auto loadBlock = [&](int kb, double *o0, double *o1) {
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          o0[c] = A[(kb * kBlk + c) * ld + j0];  // lanes beyond the row read into the next row: in bounds, never used
+          if (TWO) o1[c] = j1 < K ? A[(kb * kBlk + c) * ld + j1] : 0.0;
+        }
+      };
+      loadBlock(F - 1, g0, g1);
+      for (int kb = F - 1; kb >= 0; --kb) {
+        if (kb > 0) loadBlock(kb - 1, n0, n1);
+        double xo[kBlk];
+#pragma unroll
+        for (int c = kBlk - 1; c >= 0; --c) {
+          const int k = kb * kBlk + c;
+          const double xk = (!TWO || k < 64) ? readLane(y0 * gi0, k & 63) : readLane(y1 * gi1, k & 63);
+          xo[c] = xk;
+          y0 -= g0[c] * xk;
+          if (TWO) y1 -= g1[c] * xk;
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) xs[kb * kBlk + c] = xo[c];
+        }
+#pragma unroll
+        for (int c = 0; c < kBlk; ++c) {
+          g0[c] = n0[c];
+          if (TWO) g1[c] = n1[c];
+        }
+      }
+    };
+    if (K > 64)
+      run(std::true_type{});
+    else
+      run(std::false_type{});
+  }
+  __syncthreads();
+  if (tid < K) {
+    const double x = xs[tid];
+    stpl[tid] = -x;
+    a.step[tid] = x;
+    a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
+  }
+  SC_STAMP(3);
+  if (fast_refresh) {
+    // FEJ: only the current reprojection / brightness constants move with the state; all inputs are in registers / LDS
+    ldsBarrier();
+    Rigid *E = reinterpret_cast<Rigid *>(A);  // [2][F]: exp(+xi_f), exp(-xi_f); A is free now
+    if (tid < 2 * F) {
+      const int f = tid < F ? tid : tid - F;
+      const double sign = tid < F ? 1.0 : -1.0;
+      double xi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xi[i] = sign * (epsl[kBlk * f + i] + stpl[kBlk * f + i]);
+      E[tid] = rigidExp(xi);
+    }
+    ldsBarrier();
+    if (tid < F * F && pp.valid) {
+      const int r = tid / F, t = tid - F * (tid / F);
+      PairConst &P = a.pc[r * kMaxFrames + t];
+      const Rigid T_tr = rigidMul(E[F + t], rigidMul(pp.T0, E[r]));
+      // ArrayReprojector ctor — camera_reproject.hpp:235-260 (as buildProjectionMatrices)
+      const double ifx = 1.0 / pp.fxr, ify = 1.0 / pp.fyr;
+      const double k02 = -pp.cxr * ifx, k12 = -pp.cyr * ify;
+      double U[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        U[4 * i + 0] = T_tr.R[3 * i + 0] * ifx;
+        U[4 * i + 1] = T_tr.R[3 * i + 1] * ify;
+        U[4 * i + 2] = T_tr.R[3 * i + 0] * k02 + T_tr.R[3 * i + 1] * k12 + T_tr.R[3 * i + 2];
+        U[4 * i + 3] = T_tr.t[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        P.M[0 + j] = pp.fxt * U[0 + j] + pp.cxt * U[8 + j];
+        P.M[4 + j] = pp.fyt * U[4 + j] + pp.cyt * U[8 + j];
+        P.M[8 + j] = U[8 + j];
+      }
+      const double a_r = ab0l[2 * r] + epsl[kBlk * r + 6] + stpl[kBlk * r + 6];
+      const double a_t = ab0l[2 * t] + epsl[kBlk * t + 6] + stpl[kBlk * t + 6];
+      P.s = (pp.exposure_t / pp.exposure_r) * exp(a_t - a_r);
+      P.b_t = ab0l[2 * t + 1] + epsl[kBlk * t + 7] + stpl[kBlk * t + 7];
+      P.b_r = ab0l[2 * r + 1] + epsl[kBlk * r + 7] + stpl[kBlk * r + 7];
+    }
+  }
+  // (without first-estimate Jacobians every pair constant moves with the state: the host launches pairSetupKernel behind this
+  // kernel, as it does behind assembleSolveKernel)
+  SC_STAMP(4);
+  if (a.ctrl) {
+    // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312)
+    double part = 0;
+    if (tid < K) {
+      const double xc = epsl[tid] + stpl[tid];
+      if (a.use_marginal) {
+        double sacc = 0;
+        for (int k = 0; k < K; ++k) sacc += a.Hm[tid * K + k] * (epsl[k] + stpl[k]);
+        part += bm_c * xc + 0.5 * xc * sacc;
+      }
+      if ((tid & 7) >= 6) {
+        const double ab = ab0_c + xc;
+        part += 0.5 * ab * a.affine_reg[(tid & 7) - 6] * ab;
+      }
+    }
+    part = waveSum(part);
+    ldsBarrier();  // E (in A) fully consumed before the scratch below is written; stpl visible
+    if ((tid & 63) == 0) pv[tid >> 6] = part;
+    ldsBarrier();
+    if (tid == 0) {
+      double total = a.energy_marginalized;
+      for (int w = 0; w < kSolveThreads / 64; ++w) total += pv[w];
+      a.ctrl->cand_prior = total;
+      a.ctrl->pending = 1;
+    }
+  }
+  SC_STAMP(5);
+}
+
+}  // namespace dsopp_hip

@@ -81,6 +81,12 @@ __device__ inline void derivePairBlocks(const double *__restrict__ G /* [48] */,
   }
 }
 
+/** combined system layout (fused LM loop): 8 x 8 block (bi, bj), bj <= bi, at combBlockIndex * 64, row-major inside */
+__host__ __device__ constexpr int combBlockIndex(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+__host__ __device__ constexpr int combBlockCount(int F) { return F * (F + 1) / 2; }
+/** address of entry (row, col), row >= col or same diagonal block, in the combined system */
+__device__ __forceinline__ int combIndex(int row, int col) { return combBlockIndex(row >> 3, col >> 3) * 64 + ((row & 7) << 3) + (col & 7); }
+
 struct ReduceSchurArgs {
   const FrameDev *frames;
   const PairConst *pc;
@@ -102,6 +108,12 @@ struct ReduceSchurArgs {
   int n_sweep_blocks;
   int total_blocks;
   double *scalars_out;  // nullable: accumulate-only launches of sharded windows write {energy, n_valid, |step|^2, idepth.step} here
+  // fused LM loop: ONE combined system instead of the four above (nullable = off).  Block-packed lower triangle of
+  //   A = H_pp (1 + lambda on the diagonal) - H_schur / (1 + lambda)        (calculateStep, problem.hpp:347-351, without priors)
+  // as combBlockCount(F) 8 x 8 blocks (bi >= bj) of 64 doubles, followed by b = b_pp - b_schur / (1 + lambda) (K doubles): the solve
+  // kernel then loads 14 KB instead of two K x K matrices, and a sharded window all-reduces 14 KB instead of 51 KB
+  double *comb;
+  double comb_lambda;  // lambda when neither control block is given (isolated timing launches)
   LmParams prm;
   long long *dbg;  // nullable tuning aid
 };
@@ -357,6 +369,9 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     return;
   }
   const int F = a.F, K = kBlk * F;
+  // damping of the system being built: the decision just taken (fused), the incoming control block (sharded accumulate
+  // pass: the PBA's LM keeps lambda constant, eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
+  const double comb_lam = a.ctrl_out ? ar.out->lambda : (a.ctrl ? a.ctrl->lambda : a.comb_lambda);
   if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {
     // ---- landmark-sharded windows: one extra workgroup sums the sweep's 4 energy scalars (fixed order) into the tail of
     // the reduction buffer, so that they travel in the same collective as the systems (no separate kernel for it)
@@ -417,6 +432,23 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const int i = lane >> 3, j = lane & 7;
+    if (a.comb) {
+      // combined system: diagonal entries carry the (1 + lambda) of calculateStep; of the two off-diagonal blocks
+      // H_rt = -(G T)^T and H_tr = -G T only the one below the diagonal is kept
+      const double dl = i == j ? 1.0 + comb_lam : 1.0;
+      atomicAdd(&a.comb[combBlockIndex(r, r) * 64 + lane], dl * drv[lane]);
+      atomicAdd(&a.comb[combBlockIndex(t, t) * 64 + lane], dl * lds[symIdx(i, j)]);
+      if (r > t)
+        atomicAdd(&a.comb[combBlockIndex(r, t) * 64 + lane], -drv[64 + 8 * j + i]);
+      else
+        atomicAdd(&a.comb[combBlockIndex(t, r) * 64 + lane], -drv[64 + lane]);
+      if (lane < 8) {
+        double *rhs = a.comb + combBlockCount(F) * 64;
+        atomicAdd(&rhs[kBlk * r + lane], drv[128 + lane]);
+        atomicAdd(&rhs[kBlk * t + lane], -lds[36 + lane]);
+      }
+      return;
+    }
     atomicAdd(&a.Hpp[(kBlk * r + i) * K + kBlk * r + j], drv[lane]);
     atomicAdd(&a.Hpp[(kBlk * t + i) * K + kBlk * t + j], lds[symIdx(i, j)]);
     atomicAdd(&a.Hpp[(kBlk * r + i) * K + kBlk * t + j], -drv[64 + 8 * j + i]);
@@ -428,6 +460,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     return;
   }
   // ---- Schur block
+  const double comb_sc = -1.0 / (1.0 + comb_lam);
   const int Kp = (K + 15) & ~15;
   const int stride = schurRowStride(Kp);
   double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
@@ -574,6 +607,13 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       for (int reg = 0; reg < 4; ++reg) {
         const int row = 16 * ti + lk + 4 * reg, col = 16 * tj + li;
         const double v = acc[reg];
+        if (a.comb) {
+          // symmetric: the upper-triangular tile entry (row, col) lands at (col, row) of the lower-packed combined system
+          const double sv = v * comb_sc;
+          if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.comb[combIndex(col, row)], sv);
+          if (bd_in_pad && row < K && col == K && v != 0) atomicAdd(&a.comb[combBlockCount(F) * 64 + row], sv);
+          continue;
+        }
         if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.Hsc[row * K + col], v);
         if (bd_in_pad && row < K && col == K && v != 0) atomicAdd(&a.bsc[row], v);  // b_schur rides in the pad column
       }
@@ -583,7 +623,12 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       double s = 0;
 #pragma unroll 1
       for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + c];
-      if (s != 0) atomicAdd(&a.bsc[c], s);
+      if (s != 0) {
+        if (a.comb)
+          atomicAdd(&a.comb[combBlockCount(F) * 64 + c], s * comb_sc);
+        else
+          atomicAdd(&a.bsc[c], s);
+      }
     }
     RS_STAMP(5);
   }

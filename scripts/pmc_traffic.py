@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WHICH = sys.argv[1] if len(sys.argv) > 1 else "c1"
+WHICH = next((a for a in sys.argv[1:] if not a.startswith("--")), "c1")
 OUT = os.path.join(ROOT, "gpurun_out", "pmc_" + WHICH)
 
 N_LANES = 2 * 1024 * 1024
@@ -25,13 +25,17 @@ GATHER = {
 }
 
 
+PARSE_ONLY = "--parse-only" in sys.argv  # re-derive the json from csv files of an earlier run
+
+
 def run_pass(counter):
     d = os.path.join(OUT, counter)
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
            sys.executable, os.path.join(ROOT, "scripts", "pmc_target.py"), WHICH]
-    subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1200)
+    if not PARSE_ONLY:
+        subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1200)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     rows = []
     for f in files:
@@ -54,8 +58,10 @@ def main():
         by_kernel = {}
         for _, name, v in rows:
             by_kernel.setdefault(name, []).append(v)
-        # calibration 1: the largest counter value of the pass is the 512 MiB copy
-        cal_name, cal_vals = max(by_kernel.items(), key=lambda kv: max(kv[1]))
+        # calibration 1: the 512 MiB device-to-device copy (torch's copy_ of a contiguous tensor: __amd_rocclr_copyBuffer, or an
+        # elementwise copy kernel, depending on the torch build) — the first launches of the pass
+        cal_name, cal_vals = next(((n, v) for n, v in by_kernel.items() if "copyBuffer" in n or "direct_copy" in n or "CopyFunctor" in n),
+                                  max(((n, v) for n, v in by_kernel.items() if "gatherCalibration" not in n), key=lambda kv: max(kv[1])))
         cal = max(cal_vals)
         entry = {"copy_kernel": cal_name[:80], "copy_counter_value": cal, "copy_bytes": copy_bytes, "bytes_per_count": copy_bytes / cal,
                  "kernels": {}, "gather": {}}
@@ -75,11 +81,15 @@ def main():
                 tail = vals[-20:]  # the back-to-back launches of time_kernel
                 entry["kernels"][label] = {"launches": len(tail), "counter_avg": sum(tail) / len(tail)}
         res[counter] = entry
-    # conversion: reads of the sweeps are texel gathers -> the footprint calibration at 64-byte-segment granularity (the
-    # counter's unit is 1 KiB of 64-byte fabric requests: bytes_per_count ~ 1024 there if gathers are counted exactly);
-    # writes and the small dense kernels use the streaming calibration
-    fp = res["FETCH_SIZE"]["gather"].get("footprint", {})
-    gather_bpc = fp.get("bytes_per_count_if_seg64") or res["FETCH_SIZE"]["bytes_per_count"]
+    # Conversion.  The counter's unit is 1 KiB of 64-byte fabric requests.  The ISOLATED gather (one 32-byte texel per lane, each
+    # in its own 128-byte line) pins the unit for gathers: counter x 1024 = lanes x 64 B within a few per cent, i.e. a texel
+    # access fetches its 64-byte half line and the counter tallies it exactly (a wide stream is tallied at HALF its bytes, the
+    # copy calibration).  The pair / footprint patterns read MORE than their distinct segments (x1.2 / x1.5: the several 16-byte
+    # loads of a lane touch a segment at different times and part of them miss again) — that excess is real traffic and the
+    # kernel times confirm it (all three patterns run at the same ~3.3 TB/s of counted bytes).  So: sweeps (texel gathers) are
+    # converted with the isolated-gather unit, the small dense kernels with the streaming unit, writes with the copy's write unit.
+    iso = res["FETCH_SIZE"]["gather"].get("isolated", {})
+    gather_bpc = iso.get("bytes_per_count_if_seg64") or 1024.0
     out = {"source": f"rocprofv3 --kernel-trace --pmc <C> -- python scripts/pmc_target.py {WHICH} (one pass per counter)",
            "workload": "C1: 7 KF / 2000 points / 640x480" if WHICH == "c1" else "12 KF / 50 000 points / 640x480",
            "note": "bytes = counter x bytes_per_count.  Streaming calibration: 512 MiB elementwise copy (MI355X_MICROARCH.md: FETCH_SIZE "
