@@ -692,7 +692,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.total_blocks = a.n_schur_blocks + F * F;
   a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + reduce_count : nullptr;
   if (fused) a.prm = fused->prm;
-  a.dbg = w.dbg_stamps ? w.dbg_stamps + 8 : nullptr;
+  a.dbg = w.dbg_stamps ? w.dbg_stamps + 24 : nullptr;
   const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
   if (mode == ReduceMode::kDecideOnly) {
     timedLaunch(w, DSOPP_HIP_KERNEL_ACCEPT,
@@ -2398,8 +2398,7 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
           fr.ctrl_out = nullptr;
           fr.combined = true;
           fr.comb_lambda = 1e-5;
-          HIP_CHECK(hipMemsetAsync(w->d_reduce.ptr, 0, (w->combCount() + 4) * sizeof(double), w->sr.stream));
-          launchReduceSchur(*w, false, nullptr, &fr, ReduceMode::kAccumulateOnly);
+          launchReduceSchur(*w, false, nullptr, &fr, ReduceMode::kAccumulateOnly);  // (accumulates on top of the previous repeat: timing only)
           break;
         }
         case DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE: launchSolveCombined(*w, 1e-5, nullptr); break;

@@ -8,9 +8,11 @@
 //     their right-hand sides: the load phase is a single coalesced sweep, 7 loads per thread;
 //   * one workgroup barrier per 8 x 8 block step instead of two: the panel wave applies the previous panel to its own block
 //     column itself (LDS broadcast reads) and no longer waits for the other waves before factoring;
-//   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own.
-// The arithmetic of the factorisation (blocked Cholesky over the frame blocks, right-hand side as an extra row, f32 rsqrt
-// seed + two Newton steps, pivots below 1e-30 of the Jacobi-scaled diagonal treated as zero) is unchanged.
+//   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own;
+//   * the factorisation is L D L^T instead of Cholesky (same blocking over the frame blocks, right-hand side as an extra row,
+//     pivots below 1e-30 of the Jacobi-scaled diagonal dropped): 9 instead of 15 dependent operations per pivot, and a
+//     back-substitution without divisions.  Both are backward-stable factorisations of the same matrix; the reference itself
+//     uses Eigen's LDLT (normal_linear_system.cpp:57).
 #pragma once
 #include "pba_solve_kernels.hpp"
 
@@ -52,7 +54,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   double *A = reinterpret_cast<double *>(smem_raw);  // N x ld (lower triangle used)
   double *pv = A + N * ld;                           // K pivot guards
   double *xs = pv + K;                               // K + 16 scratch
-  double *Linv = xs + K + 16;                        // F x 36: reciprocals of the factor's diagonal
+  double *Linv = xs + K + 16;                        // 36 x kMaxFrames doubles: prior diagonal during assembly, then pivots | reciprocals
   double *epsl = Linv + 36 * kMaxFrames;             // K: state increment eps of every frame
   double *stpl = epsl + K;                           // K: the new step (-x), kept in LDS for the pair refresh / prior energy
   double *ab0l = stpl + K;                           // 2 F: affine brightness at the linearisation point
@@ -187,70 +189,93 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   __syncthreads();
   SC_STAMP(1);
 
-  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T.
-  // One barrier per block step: wave 0 ("panel wave") owns block column kb+1 — it applies panel kb to it, factors its diagonal
-  // block in registers and solves the panel below — WHILE waves 1..3 apply panel kb to the columns >= kb+2.  Panel kb was written
-  // by wave 0 itself one step earlier, column kb+1 last by waves 1..3 one step earlier: one barrier orders both.
+  // ---- blocked L D L^T on the augmented (K+1) x (K+1) matrix (unit lower L, diagonal D): the last row of L becomes
+  // z^T = (D^-1 L^-1 b)^T, and L^T x = z needs no division.  On this part a DEPENDENT f64 operation costs 10-15 ns on the one
+  // wave that walks the pivots (measured: 8 pivots of the Cholesky form = 1.0 us), so what counts is the number of dependent
+  // operations per pivot: reciprocal (v_rcp_f64 + two Newton steps) -> multiplier -> update of the next diagonal = 9, against 15
+  // for the reciprocal square root of the Cholesky form; the row-k factors every lane needs are the UNSCALED entries u_jk =
+  // l_jk d_k, broadcast with v_readlane before the reciprocal is ready.
+  // One barrier per block step: wave 0 ("panel wave") owns block column kb+1 — it applies panel kb to it, eliminates its diagonal
+  // block in registers together with the panel below — WHILE waves 1..3 apply panel kb to the columns >= kb+2.  Panel kb was
+  // written by wave 0 itself one step earlier, column kb+1 last by waves 1..3 one step earlier: one barrier orders both.
+  double *dvec = Linv;             // K: pivots d_k            (the prior diagonal parked here has been consumed)
+  double *wvec = Linv + kMaxFrames * kBlk;  // K: their reciprocals (0 for a dropped pivot)
   auto readLane = [](double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
   };
   auto factorAndPanel = [&](int kb) {
-    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below it): one
-    // elimination loop does the Cholesky of the diagonal block and the triangular solve of the panel together.
+    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below it).
     const int k0 = kb * kBlk, kp0 = k0 - kBlk;
     const int row = k0 + lane;
     const bool valid = row < N;
-    double c[kBlk], invd[kBlk], lj[28];
+    double c[kBlk], w[kBlk], uj[28];
     {
       const double *src = A + (valid ? row : k0) * ld + k0;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) c[j] = src[j];
     }
+    double dprev[kBlk];
     if (kb > 0) {
-      // block column kb -= panel (kb-1) contribution: c_j -= sum_c L[row][kp0 + c] * L[k0 + j][kp0 + c].  The second factor is the
-      // same for every lane (LDS broadcast read).
+      // block column kb -= panel (kb-1) contribution: c_j -= sum_c L[row][kp0 + c] d_c L[k0 + j][kp0 + c].  The last factor is
+      // the same for every lane (LDS broadcast read); two partial sums halve the dependent chain.
       double lic[kBlk];
       const double *li = A + (valid ? row : k0) * ld + kp0;
 #pragma unroll
-      for (int cc = 0; cc < kBlk; ++cc) lic[cc] = li[cc];
+      for (int cc = 0; cc < kBlk; ++cc) {
+        dprev[cc] = dvec[kp0 + cc];
+        lic[cc] = li[cc];
+      }
+#pragma unroll
+      for (int cc = 0; cc < kBlk; ++cc) lic[cc] *= dprev[cc];
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) {
         const double *ljp = A + (k0 + j) * ld + kp0;
-        double sacc = 0;
+        double s0 = 0, s1 = 0;
 #pragma unroll
-        for (int cc = 0; cc < kBlk; ++cc) sacc += lic[cc] * ljp[cc];
-        c[j] -= sacc;
+        for (int cc = 0; cc < kBlk; cc += 2) {
+          s0 += lic[cc] * ljp[cc];
+          s1 += lic[cc + 1] * ljp[cc + 1];
+        }
+        c[j] -= s0 + s1;
       }
     }
     double guard[kBlk];
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
+    double dk[kBlk];
     int e = 0;
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
-      const double d = readLane(c[k], k);
+      const double uk = c[k];            // lane k: the pivot d_k; lanes i > k: u_ik = l_ik d_k
+      const double d = readLane(uk, k);
+      // the row-k factors of the remaining columns do not depend on the reciprocal: they are broadcast first
+      double ujk[kBlk];
+#pragma unroll
+      for (int j = k + 1; j < kBlk; ++j) ujk[j] = readLane(uk, j);
+      // pivots whose Jacobi-scaled value d / (diag + 10) is below 1e-30 are dropped, as a rank-revealing factorisation would
       const bool okp = d > guard[k];
-      double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
-      inv = okp ? inv : 0.0;
-      invd[k] = inv;
-      const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik
+      const double dd = okp ? d : 1.0;
+      double x = __builtin_amdgcn_rcp(dd);
+      x = fma(fma(-dd, x, 1.0), x, x);
+      x = fma(fma(-dd, x, 1.0), x, x);
+      x = okp ? x : 0.0;
+      w[k] = x;
+      dk[k] = d;
+      const double l = uk * x;  // l_ik
       c[k] = l;
 #pragma unroll
       for (int j = k + 1; j < kBlk; ++j) {
-        const double ljk = readLane(l, j);
-        lj[e++] = ljk;
-        c[j] -= l * ljk;
+        uj[e++] = ujk[j];
+        c[j] -= l * ujk[j];
       }
     }
     if (valid) {
       double *dst = A + row * ld + k0;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j)
-        if (lane >= kBlk || j <= lane) dst[j] = c[j];  // the diagonal block keeps its lower triangle only
+        if (lane >= kBlk || j < lane) dst[j] = c[j];  // the diagonal block keeps its strictly lower triangle (unit diagonal implied)
     }
     // rows beyond the first 64 of this block column (windows of more than 7 frames)
     for (int r2 = row + 64; r2 < N; r2 += 64) {
@@ -260,67 +285,80 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
       if (kb > 0) {
         double lic[kBlk];
 #pragma unroll
-        for (int cc = 0; cc < kBlk; ++cc) lic[cc] = A[r2 * ld + kp0 + cc];
+        for (int cc = 0; cc < kBlk; ++cc) lic[cc] = A[r2 * ld + kp0 + cc] * dprev[cc];
 #pragma unroll
         for (int j = 0; j < kBlk; ++j) {
           const double *ljp = A + (k0 + j) * ld + kp0;
-          double sacc = 0;
+          double s0 = 0, s1 = 0;
 #pragma unroll
-          for (int cc = 0; cc < kBlk; ++cc) sacc += lic[cc] * ljp[cc];
-          v[j] -= sacc;
+          for (int cc = 0; cc < kBlk; cc += 2) {
+            s0 += lic[cc] * ljp[cc];
+            s1 += lic[cc + 1] * ljp[cc + 1];
+          }
+          v[j] -= s0 + s1;
         }
       }
       int e2 = 0;
 #pragma unroll
       for (int k = 0; k < kBlk; ++k) {
-        v[k] *= invd[k];
+        const double l = v[k] * w[k];
+        v[k] = l;
 #pragma unroll
-        for (int j = k + 1; j < kBlk; ++j) v[j] -= v[k] * lj[e2++];
+        for (int j = k + 1; j < kBlk; ++j) v[j] -= l * uj[e2++];
       }
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) A[r2 * ld + k0 + j] = v[j];
     }
     if (lane == 0) {
 #pragma unroll
-      for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];
+      for (int k = 0; k < kBlk; ++k) {
+        dvec[k0 + k] = dk[k];
+        wvec[k0 + k] = w[k];
+      }
     }
   };
-  // (the prior diagonal parked in Linv has been consumed: every thread passed the barrier after storeBatch)
   if (wave == 0) factorAndPanel(0);
   __syncthreads();
+  SC_STAMP(8);
   for (int kb = 0; kb + 1 < F; ++kb) {
     const int k0 = kb * kBlk, k2 = k0 + 2 * kBlk;
     if (wave == 0) {
       factorAndPanel(kb + 1);
     } else {
-      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
+      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic d_c L_jc  (192 threads as a 12 x 16 tile)
       const int t = tid - 64, tr = t >> 4, tc = t & 15;
+      double dk[kBlk];
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) dk[c] = dvec[k0 + c];
       for (int row = k2 + tr; row < N; row += 12) {
         const double *li = A + row * ld + k0;
         double lic[kBlk];
 #pragma unroll
-        for (int c = 0; c < kBlk; ++c) lic[c] = li[c];
+        for (int c = 0; c < kBlk; ++c) lic[c] = li[c] * dk[c];
         for (int col = k2 + tc; col <= row; col += 16) {
           const double *ljp = A + col * ld + k0;
-          double sacc = 0;
+          double s0 = 0, s1 = 0;
 #pragma unroll
-          for (int c = 0; c < kBlk; ++c) sacc += lic[c] * ljp[c];
-          A[row * ld + col] -= sacc;
+          for (int c = 0; c < kBlk; c += 2) {
+            s0 += lic[c] * ljp[c];
+            s1 += lic[c + 1] * ljp[c + 1];
+          }
+          A[row * ld + col] -= s0 + s1;
         }
       }
     }
     __syncthreads();
+    SC_STAMP(9 + kb);
   }
   SC_STAMP(2);
-  // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
-  // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
+  // ---- back substitution L^T x = z (z = row K of L), column-oriented on one wave: lane j carries z_j (and z_{j+64});
+  // going down from k = K-1, x_k = z_k is broadcast with v_readlane and every lane j < k takes z_j -= L_kj x_k: two dependent
+  // operations per unknown.  (Lanes >= k pick up garbage from entries on / above the diagonal; they are never read again.)
   if (wave == 0) {
     auto run = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
       const int j0 = lane, j1 = lane + 64;
       double y0 = j0 < K ? A[K * ld + j0] : 0.0, y1 = (TWO && j1 < K) ? A[K * ld + j1] : 0.0;
-      const double gi0 = j0 < K ? Linv[(j0 >> 3) * 36 + lowIdx(j0 & 7, j0 & 7)] : 0.0;
-      const double gi1 = (TWO && j1 < K) ? Linv[(j1 >> 3) * 36 + lowIdx(j1 & 7, j1 & 7)] : 0.0;
       double g0[kBlk], g1[kBlk], n0[kBlk], n1[kBlk];
       auto loadBlock = [&](int kb, double *o0, double *o1) {
 #pragma unroll
@@ -336,7 +374,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
 #pragma unroll
         for (int c = kBlk - 1; c >= 0; --c) {
           const int k = kb * kBlk + c;
-          const double xk = (!TWO || k < 64) ? readLane(y0 * gi0, k & 63) : readLane(y1 * gi1, k & 63);
+          const double xk = (!TWO || k < 64) ? readLane(y0, k & 63) : readLane(y1, k & 63);
           xo[c] = xk;
           y0 -= g0[c] * xk;
           if (TWO) y1 -= g1[c] * xk;
@@ -357,6 +395,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     else
       run(std::false_type{});
   }
+  SC_STAMP(6);
   __syncthreads();
   if (tid < K) {
     const double x = xs[tid];

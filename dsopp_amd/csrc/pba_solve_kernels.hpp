@@ -596,12 +596,18 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       f64x4 acc = {0, 0, 0, 0};
       const double *pa = hrow + lk * stride + 16 * ti + li;
       const double *pb = hrow + lk * stride + 16 * tj + li;
-#pragma unroll 4
-      for (int l0 = 0; l0 < kSchurLandmarks; l0 += 4) {
-        const double av = wgt[l0 + lk] * pa[l0 * stride];
-        const double bv = pb[l0 * stride];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      // all 48 operand words of the tile are requested before the first matrix instruction: one LDS latency per tile instead
+      // of one per instruction (the loop was LDS-latency-bound: 3.3 us for two tiles per wave)
+      constexpr int kSteps = kSchurLandmarks / 4;
+      double av[kSteps], bv[kSteps], wv[kSteps];
+#pragma unroll
+      for (int q = 0; q < kSteps; ++q) {
+        wv[q] = wgt[4 * q + lk];
+        av[q] = pa[4 * q * stride];
+        bv[q] = pb[4 * q * stride];
       }
+#pragma unroll
+      for (int q = 0; q < kSteps; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[q] * av[q], bv[q], acc, 0, 0, 0);
       // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {

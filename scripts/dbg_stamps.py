@@ -1,19 +1,21 @@
+"""Phase stamps of the fused loop's solve kernel (solveCombinedKernel) and reduction kernel on the C1 window.
+Needs a library built with -DDSOPP_HIP_STAMPS:  DSOPP_HIP_EXTRA_FLAGS=-DDSOPP_HIP_STAMPS bash dsopp_amd/csrc/build.sh"""
 import sys, ctypes as C, numpy as np
-sys.path.insert(0,'.')
+sys.path.insert(0, '.')
 from dsopp_amd import capi, synthetic as syn
-win = syn.make_window(7, 2000, 640, 480, seed=0)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+win = syn.make_window(F, P, 640, 480, seed=0)
 g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
-out = (C.c_longlong*48)()
-capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
+out = (C.c_longlong * 48)()
+assert capi.lib().dsopp_hip_debug_solve_stamps(g._h, out) == 0, capi.lib().dsopp_hip_last_error()
 g.snapshot()
 for _ in range(3):
     g.restore(); g.optimize()
 capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
-st = np.array(list(out), dtype=np.int64)
-print("solve phase us:", np.diff(st[:7]) / 100.0, "total", (st[6]-st[0])/100.0)
-print("reduceSchur (wg 1) phase us:", np.diff(st[8:14]) / 100.0, "total", (st[13]-st[8])/100.0)
-print("prologue: loads+lds", (st[14]-st[8])/100.0, "tree+decide", (st[15]-st[14])/100.0, "apply", (st[9]-st[15])/100.0)
-ch = st[16:16+3*7+1]
-print("chol: factor0", (st[16]-st[2])/100.0)
-for kb in range(7):
-    print(f"  kb={kb}: colupdate+bar {(ch[1+3*kb]-ch[3*kb])/100.0:5.2f}  factor+panel(w0) {(ch[2+3*kb]-ch[1+3*kb])/100.0:5.2f}  wait-bar {(ch[3+3*kb]-ch[2+3*kb])/100.0:5.2f}")
+st = np.array(list(out), dtype=np.int64) / 100.0   # wall_clock64 ticks at 100 MHz -> us
+print(f"solve: loads+assemble {st[1]-st[0]:.2f}  cholesky {st[2]-st[1]:.2f}  backsub(w0) {st[6]-st[2]:.2f}  barrier+step {st[3]-st[6]:.2f}  "
+      f"pair refresh {st[4]-st[3]:.2f}  prior energy {st[5]-st[4]:.2f}  total {st[5]-st[0]:.2f}")
+print(f"  factor(0) {st[8]-st[1]:.2f}; steps:", " ".join(f"{st[9+k]-st[8+k]:.2f}" for k in range(F - 1)))
+rs = st[24:]
+print("reduceSchur (wg 1) stamps us:", np.round(rs[:8] - rs[0], 2))
