@@ -6,13 +6,10 @@
 // (normal_linear_system.cpp:10-16,52-59).  What is different from assembleSolveKernel:
 //   * input is ONE block-packed lower triangle (14 KB at 7 frames) instead of H_pp and H_schur as K x K matrices (2 x 25 KB) plus
 //     their right-hand sides: the load phase is a single coalesced sweep, 7 loads per thread;
-//   * one workgroup barrier per 8 x 8 block step instead of two: the panel wave applies the previous panel to its own block
-//     column itself (LDS broadcast reads) and no longer waits for the other waves before factoring;
-//   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own;
-//   * the factorisation is L D L^T instead of Cholesky (same blocking over the frame blocks, right-hand side as an extra row,
-//     pivots below 1e-30 of the Jacobi-scaled diagonal dropped): 9 instead of 15 dependent operations per pivot, and a
-//     back-substitution without divisions.  Both are backward-stable factorisations of the same matrix; the reference itself
-//     uses Eigen's LDLT (normal_linear_system.cpp:57).
+//   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own.
+// The factorisation itself (blocked Cholesky over the frame blocks with a look-ahead panel wave, right-hand side as an extra row,
+// f32 rsqrt seed + two Newton steps, pivots below 1e-30 of the Jacobi-scaled diagonal treated as zero) and the back-substitution
+// are those of assembleSolveKernel.
 #pragma once
 #include "pba_solve_kernels.hpp"
 
@@ -189,176 +186,138 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   __syncthreads();
   SC_STAMP(1);
 
-  // ---- blocked L D L^T on the augmented (K+1) x (K+1) matrix (unit lower L, diagonal D): the last row of L becomes
-  // z^T = (D^-1 L^-1 b)^T, and L^T x = z needs no division.  On this part a DEPENDENT f64 operation costs 10-15 ns on the one
-  // wave that walks the pivots (measured: 8 pivots of the Cholesky form = 1.0 us), so what counts is the number of dependent
-  // operations per pivot: reciprocal (v_rcp_f64 + two Newton steps) -> multiplier -> update of the next diagonal = 9, against 15
-  // for the reciprocal square root of the Cholesky form; the row-k factors every lane needs are the UNSCALED entries u_jk =
-  // l_jk d_k, broadcast with v_readlane before the reciprocal is ready.
-  // One barrier per block step: wave 0 ("panel wave") owns block column kb+1 — it applies panel kb to it, eliminates its diagonal
-  // block in registers together with the panel below — WHILE waves 1..3 apply panel kb to the columns >= kb+2.  Panel kb was
-  // written by wave 0 itself one step earlier, column kb+1 last by waves 1..3 one step earlier: one barrier orders both.
-  double *dvec = Linv;             // K: pivots d_k            (the prior diagonal parked here has been consumed)
-  double *wvec = Linv + kMaxFrames * kBlk;  // K: their reciprocals (0 for a dropped pivot)
+  // (Measured alternatives, all slower on this part — scripts/probes/bcast_probe.hip, dbg_stamps.py: a single barrier per block
+  // step with the panel wave applying the previous panel to its own column: 10.2 us against 9.2 us for the 7-frame window; L D L^T
+  // with v_rcp_f64 pivots: 11.0 us; the diagonal block eliminated redundantly per lane from LDS broadcast reads: 11.5 us.  The
+  // panel wave is bound by its instruction count (~4.7 cycles per instruction, v_readlane ~8) and by the LDS instructions a lone
+  // wave can issue, not by dependent latency.)
+  // ---- blocked Cholesky A = L L^T on the augmented (K+1) x (K+1) matrix: the last row of L becomes y^T = (L^-1 b)^T.
+  // Look-ahead schedule, one barrier per 8x8 frame block: wave 0 ("panel wave") brings block column kb+1 up to date with
+  // panel kb, factors its diagonal block in registers and solves the panel below it, WHILE waves 1..3 apply panel kb to
+  // the rest of the trailing matrix (columns >= kb+2).  The sequential factor chain is thus off the other waves' path.
   auto readLane = [](double v, int src_lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
   };
   auto factorAndPanel = [&](int kb) {
-    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below it).
-    const int k0 = kb * kBlk, kp0 = k0 - kBlk;
+    // wave 0 only.  Lane i owns row k0 + i of block column kb (the 8 rows of the diagonal block AND the panel rows below
+    // it): one elimination loop does the Cholesky of the diagonal block and the triangular solve of the panel together.
+    // Per pivot k: d = C[k][k] (v_readlane from lane k), l_ik = c_ik / sqrt(d) in every lane, then for the remaining columns
+    // j the row-k factor l_jk is broadcast by v_readlane and every lane updates its own c_ij.  A wave issues one
+    // instruction per ~4.7 cycles whether or not it depends on the previous one (measured), so what matters is the
+    // instruction count: ~200 here against ~430 for a per-lane redundant 8x8 factorisation + per-row substitution.
+    const int k0 = kb * kBlk;
     const int row = k0 + lane;
     const bool valid = row < N;
-    double c[kBlk], w[kBlk], uj[28];
+    double c[kBlk], invd[kBlk], lj[28];  // lj: strictly-lower factor entries l_jk of the diagonal block (uniform), for rows beyond 64
     {
       const double *src = A + (valid ? row : k0) * ld + k0;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) c[j] = src[j];
     }
-    double dprev[kBlk];
-    if (kb > 0) {
-      // block column kb -= panel (kb-1) contribution: c_j -= sum_c L[row][kp0 + c] d_c L[k0 + j][kp0 + c].  The last factor is
-      // the same for every lane (LDS broadcast read); two partial sums halve the dependent chain.
-      double lic[kBlk];
-      const double *li = A + (valid ? row : k0) * ld + kp0;
-#pragma unroll
-      for (int cc = 0; cc < kBlk; ++cc) {
-        dprev[cc] = dvec[kp0 + cc];
-        lic[cc] = li[cc];
-      }
-#pragma unroll
-      for (int cc = 0; cc < kBlk; ++cc) lic[cc] *= dprev[cc];
-#pragma unroll
-      for (int j = 0; j < kBlk; ++j) {
-        const double *ljp = A + (k0 + j) * ld + kp0;
-        double s0 = 0, s1 = 0;
-#pragma unroll
-        for (int cc = 0; cc < kBlk; cc += 2) {
-          s0 += lic[cc] * ljp[cc];
-          s1 += lic[cc + 1] * ljp[cc + 1];
-        }
-        c[j] -= s0 + s1;
-      }
-    }
-    double guard[kBlk];
+    double guard[kBlk];  // zero-pivot thresholds, fetched before the pivot chain starts
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
-    double dk[kBlk];
     int e = 0;
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
-      const double uk = c[k];            // lane k: the pivot d_k; lanes i > k: u_ik = l_ik d_k
-      const double d = readLane(uk, k);
-      // the row-k factors of the remaining columns do not depend on the reciprocal: they are broadcast first
-      double ujk[kBlk];
-#pragma unroll
-      for (int j = k + 1; j < kBlk; ++j) ujk[j] = readLane(uk, j);
-      // pivots whose Jacobi-scaled value d / (diag + 10) is below 1e-30 are dropped, as a rank-revealing factorisation would
+      const double d = readLane(c[k], k);
+      // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64; pivots whose Jacobi-scaled value d / (diag + 10) is
+      // below 1e-30 are treated as zero, as a rank-revealing factorisation would
       const bool okp = d > guard[k];
-      const double dd = okp ? d : 1.0;
-      double x = __builtin_amdgcn_rcp(dd);
-      x = fma(fma(-dd, x, 1.0), x, x);
-      x = fma(fma(-dd, x, 1.0), x, x);
-      x = okp ? x : 0.0;
-      w[k] = x;
-      dk[k] = d;
-      const double l = uk * x;  // l_ik
+      double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      inv = okp ? inv : 0.0;
+      invd[k] = inv;
+      const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik
       c[k] = l;
 #pragma unroll
       for (int j = k + 1; j < kBlk; ++j) {
-        uj[e++] = ujk[j];
-        c[j] -= l * ujk[j];
+        const double ljk = readLane(l, j);
+        lj[e++] = ljk;
+        c[j] -= l * ljk;
       }
     }
     if (valid) {
       double *dst = A + row * ld + k0;
 #pragma unroll
       for (int j = 0; j < kBlk; ++j)
-        if (lane >= kBlk || j < lane) dst[j] = c[j];  // the diagonal block keeps its strictly lower triangle (unit diagonal implied)
+        if (lane >= kBlk || j <= lane) dst[j] = c[j];  // the diagonal block keeps its lower triangle only
     }
-    // rows beyond the first 64 of this block column (windows of more than 7 frames)
+    // rows beyond the first 64 of this block column (windows of more than 7 frames): substitution with the broadcast factors
     for (int r2 = row + 64; r2 < N; r2 += 64) {
       double v[kBlk];
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) v[j] = A[r2 * ld + k0 + j];
-      if (kb > 0) {
-        double lic[kBlk];
-#pragma unroll
-        for (int cc = 0; cc < kBlk; ++cc) lic[cc] = A[r2 * ld + kp0 + cc] * dprev[cc];
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-          const double *ljp = A + (k0 + j) * ld + kp0;
-          double s0 = 0, s1 = 0;
-#pragma unroll
-          for (int cc = 0; cc < kBlk; cc += 2) {
-            s0 += lic[cc] * ljp[cc];
-            s1 += lic[cc + 1] * ljp[cc + 1];
-          }
-          v[j] -= s0 + s1;
-        }
-      }
       int e2 = 0;
 #pragma unroll
       for (int k = 0; k < kBlk; ++k) {
-        const double l = v[k] * w[k];
-        v[k] = l;
+        v[k] *= invd[k];
 #pragma unroll
-        for (int j = k + 1; j < kBlk; ++j) v[j] -= l * uj[e2++];
+        for (int j = k + 1; j < kBlk; ++j) v[j] -= v[k] * lj[e2++];
       }
 #pragma unroll
       for (int j = 0; j < kBlk; ++j) A[r2 * ld + k0 + j] = v[j];
     }
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < kBlk; ++k) {
-        dvec[k0 + k] = dk[k];
-        wvec[k0 + k] = w[k];
-      }
+      for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];  // diagonal of the inverse; completed below
     }
   };
   if (wave == 0) factorAndPanel(0);
   __syncthreads();
-  SC_STAMP(8);
-  for (int kb = 0; kb + 1 < F; ++kb) {
-    const int k0 = kb * kBlk, k2 = k0 + 2 * kBlk;
-    if (wave == 0) {
-      factorAndPanel(kb + 1);
-    } else {
-      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic d_c L_jc  (192 threads as a 12 x 16 tile)
-      const int t = tid - 64, tr = t >> 4, tc = t & 15;
-      double dk[kBlk];
+  for (int kb = 0; kb < F; ++kb) {
+    const int k0 = kb * kBlk, k1 = k0 + kBlk, k2 = k1 + kBlk;
+    if (kb + 1 < F) {
+      // all waves: block column kb+1 (rows k1 .. N-1, columns k1 .. k1+7) -= panel kb contribution (one element per thread)
+      const int n_el = (N - k1) * kBlk;
+      for (int e = tid; e < n_el; e += kSolveThreads) {
+        const int row = k1 + (e >> 3), col = k1 + (e & 7);
+        if (col > row) continue;
+        const double *li = A + row * ld + k0, *lj = A + col * ld + k0;
+        double sacc = 0;
 #pragma unroll
-      for (int c = 0; c < kBlk; ++c) dk[c] = dvec[k0 + c];
+        for (int c = 0; c < kBlk; ++c) sacc += li[c] * lj[c];
+        A[row * ld + col] -= sacc;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      if (kb + 1 < F) factorAndPanel(kb + 1);
+    } else {
+      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
+      const int t = tid - 64, tr = t >> 4, tc = t & 15;
       for (int row = k2 + tr; row < N; row += 12) {
         const double *li = A + row * ld + k0;
         double lic[kBlk];
 #pragma unroll
-        for (int c = 0; c < kBlk; ++c) lic[c] = li[c] * dk[c];
+        for (int c = 0; c < kBlk; ++c) lic[c] = li[c];
         for (int col = k2 + tc; col <= row; col += 16) {
-          const double *ljp = A + col * ld + k0;
-          double s0 = 0, s1 = 0;
+          const double *lj = A + col * ld + k0;
+          double sacc = 0;
 #pragma unroll
-          for (int c = 0; c < kBlk; c += 2) {
-            s0 += lic[c] * ljp[c];
-            s1 += lic[c + 1] * ljp[c + 1];
-          }
-          A[row * ld + col] -= s0 + s1;
+          for (int c = 0; c < kBlk; ++c) sacc += lic[c] * lj[c];
+          A[row * ld + col] -= sacc;
         }
       }
     }
     __syncthreads();
-    SC_STAMP(9 + kb);
   }
-  SC_STAMP(2);
-  // ---- back substitution L^T x = z (z = row K of L), column-oriented on one wave: lane j carries z_j (and z_{j+64});
-  // going down from k = K-1, x_k = z_k is broadcast with v_readlane and every lane j < k takes z_j -= L_kj x_k: two dependent
-  // operations per unknown.  (Lanes >= k pick up garbage from entries on / above the diagonal; they are never read again.)
+  // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
+  // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
+  // 4-7 instructions per unknown, no LDS round trip or barrier inside the chain (L_kj is prefetched a frame block ahead).
   if (wave == 0) {
+    // No masking anywhere: lane j is consumed at step k = j (x_j = y_j / L_jj); whatever the later steps k < j add to it
+    // (entries on / above the diagonal, uninitialised LDS) is never read again.  x_k leaves the chain as a wave-uniform
+    // value and is written to LDS by lane 0, eight at a time.
     auto run = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
       const int j0 = lane, j1 = lane + 64;
       double y0 = j0 < K ? A[K * ld + j0] : 0.0, y1 = (TWO && j1 < K) ? A[K * ld + j1] : 0.0;
+      const double gi0 = j0 < K ? Linv[(j0 >> 3) * 36 + lowIdx(j0 & 7, j0 & 7)] : 0.0;
+      const double gi1 = (TWO && j1 < K) ? Linv[(j1 >> 3) * 36 + lowIdx(j1 & 7, j1 & 7)] : 0.0;
       double g0[kBlk], g1[kBlk], n0[kBlk], n1[kBlk];
       auto loadBlock = [&](int kb, double *o0, double *o1) {
 #pragma unroll
@@ -374,7 +333,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
 #pragma unroll
         for (int c = kBlk - 1; c >= 0; --c) {
           const int k = kb * kBlk + c;
-          const double xk = (!TWO || k < 64) ? readLane(y0, k & 63) : readLane(y1, k & 63);
+          const double xk = (!TWO || k < 64) ? readLane(y0 * gi0, k & 63) : readLane(y1 * gi1, k & 63);
           xo[c] = xk;
           y0 -= g0[c] * xk;
           if (TWO) y1 -= g1[c] * xk;
@@ -395,7 +354,6 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     else
       run(std::false_type{});
   }
-  SC_STAMP(6);
   __syncthreads();
   if (tid < K) {
     const double x = xs[tid];
