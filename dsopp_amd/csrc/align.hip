@@ -539,6 +539,246 @@ __global__ void __launch_bounds__(kLoopThreads) alignLoopKernel(AlignFrameDev re
   if (tid < kCtrlWords) reinterpret_cast<double *>(ctrl_io + 1)[tid] = reinterpret_cast<const double *>(&sc)[tid];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// estimatePose's coarse-to-fine loop of ONE initialisation as ONE launch (monocular_tracker.cpp:202-226): all pyramid levels,
+// every Levenberg-Marquardt iteration of each.  The launch-per-iteration path spends 8.5 us + a ~2.5 us kernel boundary per
+// iteration, of which the sweep itself is a fraction: the rest is the start-up of a kernel (control block and point words from
+// memory, again every iteration).  Here a few dozen workgroups stay resident, keep the LM state in LDS and meet once per
+// iteration at a device-scope arrival counter:
+//     sweep own points at the candidate -> workgroup sums (LDS) -> 48 partial sums written write-through (sc1) -> arrive ->
+//     every workgroup reads all partial sums back (sc1 loads, fixed order: deterministic and identical in every workgroup) ->
+//     every workgroup takes the same LM decision (alignDecide) -> next sweep.
+// Hand-off per cdna_hip_programming.md, guideline 16 (R1: sc1 payload stores, every storing wave drains vmcnt, ONE relaxed
+// agent-scope arrival, relaxed polls with s_sleep, sc1 loads on the consumer side — no fences).  The partial sums are double
+// buffered by pass parity: a workgroup can only be one barrier ahead of the slowest one.  Every spin is bounded; a time-out
+// sets `failed` and the host repeats the frame on the launch-per-iteration path.
+// Level transitions (reset; push the keyframe's points of the next finer level; push the target with the current estimate;
+// accept the level when rmse < 2.5 * rmse_last[level]) run on the device as well: identical in every workgroup.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPyramidMaxWorkgroups = 64;
+
+struct AlignLevelDev {
+  AlignFrameDev ref, tgt;
+  const double *pu, *pv, *pid, *pint;
+  int n_points;
+  int pad;
+  double rmse_limit;  // kEnergyRatioThreshold * rmse_last_pose_estimation[level]
+};
+
+struct AlignPyramidResult {
+  int levels_done;   // levels whose solve ran (counted from the coarsest)
+  int success;       // every level passed its energy test
+  int failed;        // a bounded spin timed out: nothing in here is valid
+  int lm_iterations; // sum over the levels
+  double rmse[DSOPP_HIP_MAX_LEVELS];
+  int iterations[DSOPP_HIP_MAX_LEVELS];
+  int n_valid[DSOPP_HIP_MAX_LEVELS];
+  double T_tr[12];   // T_target_reference after the last accepted level ([R | t] rows)
+  double ab[2];      // target affine brightness after the last accepted level
+};
+
+struct AlignPyramidArgs {
+  AlignLevelDev level[DSOPP_HIP_MAX_LEVELS];
+  int n_levels;
+  int max_iterations;
+  double sigma_huber, affine_reg[2], function_tolerance, parameter_tolerance, decrease_on_accept, increase_on_reject, lambda0;
+  double T_tr0[12];
+  double ab0[2];
+  double *partials;        // [2][gridDim.x][kAlignPartial]
+  unsigned *counter;       // zeroed by the host before the launch
+  unsigned *failed;        // zeroed by the host before the launch
+  AlignPyramidResult *out;
+};
+
+using gu32 = __attribute__((address_space(1))) unsigned;
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+
+template <typename S>
+__global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramidArgs a) {
+  __shared__ __attribute__((aligned(16))) double red[kAlignPartial * (kAlignThreads + 2)];
+  __shared__ AlignControl sc;
+  __shared__ double tot[kAlignPartial];
+  __shared__ int s_failed;
+  const int tid = threadIdx.x;
+  const int G = gridDim.x;
+  unsigned pass_global = 0;  // barriers passed so far (identical in every workgroup)
+  double T_cur[12], ab_cur[2] = {a.ab0[0], a.ab0[1]};
+#pragma unroll
+  for (int i = 0; i < 12; ++i) T_cur[i] = a.T_tr0[i];
+  if (tid == 0) s_failed = 0;
+  int levels_done = 0, success = 1, lm_iterations = 0;
+  for (int lvl = a.n_levels - 1; lvl >= 0; --lvl) {
+    const AlignLevelDev &L = a.level[lvl];
+    AlignFrameDev tgt = L.tgt;
+    tgt.ab0[0] = ab_cur[0];
+    tgt.ab0[1] = ab_cur[1];
+    AlignParams prm;
+    prm.sigma_huber = a.sigma_huber;
+    prm.affine_reg[0] = a.affine_reg[0];
+    prm.affine_reg[1] = a.affine_reg[1];
+    prm.function_tolerance = a.function_tolerance;
+    prm.parameter_tolerance = a.parameter_tolerance;
+    prm.decrease_on_accept = a.decrease_on_accept;
+    prm.increase_on_reject = a.increase_on_reject;
+    prm.max_iterations = a.max_iterations;
+    prm.n_points = L.n_points;
+    prm.n_blocks = G;
+    __syncthreads();  // previous level's reads of sc are done
+    if (tid == 0) {
+      // reset(); pushFrame(reference); pushFrame(target, current estimate): the control block dsopp_hip_aligner_solve prepares
+      AlignControl c;
+      for (int i = 0; i < 12; ++i) c.T_tr[i] = c.cand_T[i] = T_cur[i];
+      c.ab_eps[0] = c.ab_eps[1] = c.cand_ab[0] = c.cand_ab[1] = 0;
+      for (int i = 0; i < 64; ++i) c.H[i] = c.H_used[i] = 0;
+      for (int i = 0; i < 8; ++i) c.b[i] = c.step[i] = 0;
+      c.lambda = a.lambda0;
+      c.energy = 0;
+      c.n_valid = 0;
+      c.converged = 0;
+      c.active = 1;
+      c.iteration = 0;
+      c.have_candidate = 0;
+      c.linear_system_valid = 0;
+      c.pad0 = c.pad1 = 0;
+      sc = c;
+    }
+    __syncthreads();
+    const int total_passes = a.max_iterations + 2;  // initial evaluation + one per iteration + the closing control step
+    for (int pass = 0; pass < total_passes; ++pass) {
+      if (pass > 0) {
+        if (tid == 0) alignDecide(sc, tot, tgt, prm);
+        __syncthreads();
+        if (!sc.active) break;
+      }
+      // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
+      const int first = blockIdx.x * kAlignThreads + tid;
+      double *dst = a.partials + (static_cast<size_t>(pass_global & 1u) * G + blockIdx.x) * kAlignPartial;
+      if (static_cast<int>(blockIdx.x) * kAlignThreads < L.n_points) {
+        double acc[kAlignPartial];
+        alignSweep<S>(L.ref, tgt, L.pu, L.pv, L.pid, L.pint, sc, prm, first, G * kAlignThreads, acc);
+        constexpr int RS = kAlignThreads + 2;
+#pragma unroll
+        for (int e = 0; e < kAlignPartial; ++e) red[e * RS + tid] = acc[e];
+        __syncthreads();
+        const int row_idx = tid >> 2, quarter = tid & 3;
+        double s = 0;
+        if (row_idx < kAlignPartial) {
+          const double2 *row = reinterpret_cast<const double2 *>(red + row_idx * RS) + quarter * (kAlignThreads / 8);
+          double s0 = 0, s1 = 0;
+#pragma unroll 8
+          for (int j = 0; j < kAlignThreads / 8; ++j) {
+            const double2 q = row[j];
+            s0 += q.x;
+            s1 += q.y;
+          }
+          s = s0 + s1;
+        }
+        s += alignDpp<0xB1>(s);
+        s += alignDpp<0x4E>(s);
+        if (row_idx < kAlignPartial && quarter == 0)
+          __hip_atomic_store((gu64 *)(dst + row_idx), static_cast<unsigned long long>(__double_as_longlong(s)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (tid < kAlignPartial) {
+        // no points on this level for this workgroup: it still takes part in the exchange
+        __hip_atomic_store((gu64 *)(dst + tid), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- publish / arrive / wait (R1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+      __syncthreads();
+      if (tid == 0) {
+        gu32 *cnt = (gu32 *)a.counter;
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = static_cast<unsigned>(G) * (pass_global + 1u);
+        unsigned spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1u << 22) || __hip_atomic_load((gu32 *)a.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store((gu32 *)a.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_failed = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (s_failed) {
+        if (blockIdx.x == 0 && tid == 0) a.out->failed = 1;
+        return;
+      }
+      // ---- every workgroup sums all partial sums in the same fixed order (thread e < 48 x 5 groups, as alignIterationKernel)
+      {
+        constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
+        const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
+        const double *src = a.partials + static_cast<size_t>(pass_global & 1u) * G * kAlignPartial + e;
+        if (grp < kGroups) {
+          double p0 = 0, p1 = 0;
+          int b = grp;
+          for (; b + kGroups < G; b += 2 * kGroups) {
+            const unsigned long long w0 = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b) * kAlignPartial),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long w1 = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b + kGroups) * kAlignPartial),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p0 += __longlong_as_double(static_cast<long long>(w0));
+            p1 += __longlong_as_double(static_cast<long long>(w1));
+          }
+          if (b < G)
+            p0 += __longlong_as_double(static_cast<long long>(
+                __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+          red[grp * kAlignPartial + e] = p0 + p1;
+        }
+        __syncthreads();
+        if (tid < kAlignPartial) {
+          double t = 0;
+#pragma unroll
+          for (int g2 = 0; g2 < kGroups; ++g2) t += red[g2 * kAlignPartial + tid];
+          tot[tid] = t;
+        }
+        __syncthreads();
+      }
+      ++pass_global;
+    }
+    // ---- the level's verdict (identical in every workgroup) — monocular_tracker.cpp:218-226, eigen_pose_alignment.cpp:320-328
+    ++levels_done;
+    const double rmse = sqrt(sc.energy / static_cast<double>(sc.n_valid));  // NaN without a valid residual: fails the test below
+    lm_iterations += sc.iteration;
+    if (blockIdx.x == 0 && tid == 0) {
+      a.out->rmse[lvl] = rmse;
+      a.out->iterations[lvl] = sc.iteration;
+      a.out->n_valid[lvl] = sc.n_valid;
+    }
+    if (!(rmse < L.rmse_limit)) {
+      success = 0;
+      break;
+    }
+    // accepted: the next finer level starts from this estimate
+    Rigid Tfin;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = sc.T_tr[4 * i + j];
+      Tfin.t[i] = sc.T_tr[4 * i + 3];
+    }
+    rigidNormalize(Tfin);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) T_cur[4 * i + j] = Tfin.R[3 * i + j];
+      T_cur[4 * i + 3] = Tfin.t[i];
+    }
+    ab_cur[0] += sc.ab_eps[0];
+    ab_cur[1] += sc.ab_eps[1];
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.out->levels_done = levels_done;
+    a.out->success = success;
+    a.out->failed = 0;
+    a.out->lm_iterations = lm_iterations;
+    for (int i = 0; i < 12; ++i) a.out->T_tr[i] = T_cur[i];
+    a.out->ab[0] = ab_cur[0];
+    a.out->ab[1] = ab_cur[1];
+  }
+}
+
 }  // namespace
 }  // namespace dsopp_hip
 
@@ -560,6 +800,12 @@ struct dsopp_hip_aligner {
   int lm_path = 0;                 // 0: automatic (single-workgroup loop for small point sets), 1: always one launch per iteration
   bool skip_covariance = false;    // estimate_pose: the per-level covariance is not read by the tracker loop
   bool pyramids_ordered = false;   // estimate_pose already ordered this stream behind both pyramids' builds (one wait per frame, not per level)
+  // estimate_pose as one persistent launch over all levels (alignPyramidKernel)
+  DeviceBuffer<double> d_pyr_partials;
+  DeviceBuffer<unsigned> d_pyr_sync;           // [0] arrival counter, [1] failed flag
+  DeviceBuffer<AlignPyramidResult> d_pyr_out;
+  AlignPyramidResult *h_pyr_out = nullptr;     // pinned
+  bool pyramid_kernel_disabled = false;        // a bounded spin timed out once (GPU shared with other work): stay on the launch-per-iteration path
   bool have_rotation_prior = false;  // setRotationPrior, cleared by reset() (eigen_pose_alignment.cpp:254-263)
   double rotation_prior[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   // launches the previous solve on a target level of this width needed: consecutive frames of a sequence need nearly the same
@@ -688,6 +934,37 @@ __global__ void compactDepthMapRowsKernel(const double *__restrict__ idsum, cons
 }
 
 
+/** reference points of one level of device-resident depth maps (LocalFrame depth-map constructor, PBA_INT/local_frame.hpp:367-392),
+ *  extracted on first use and cached with the maps: scan / compaction on the device in the reference's row-major order,
+ *  intensities sampled from the keyframe's own pyramid */
+dsopp_hip_depth_maps::LevelPoints &ensureLevelPoints(dsopp_hip_aligner *a, const dsopp_hip_depth_maps *maps, const dsopp_hip_pyramid *pyramid, int level) {
+  hipStream_t st = a->sr.stream;
+  const int W = pyramid->w(level), H = pyramid->h(level);
+  dsopp_hip_depth_maps::LevelPoints &pts = maps->points[static_cast<size_t>(level)];
+  if (pts.n < 0 || pts.pyramid != pyramid) {
+    const double *idsum = maps->idepth_sum[static_cast<size_t>(level)].ptr, *wgt = maps->weight[static_cast<size_t>(level)].ptr;
+    a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
+    int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
+    countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
+    scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
+    int total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
+    a->sr.sync();
+    const size_t n = static_cast<size_t>(total);
+    pts.u.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.v.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.idepth.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.intensity.reserve(std::max<size_t>(n, 1), 0, st);
+    if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
+    HIP_CHECK(hipGetLastError());
+    sampleReferenceIntensitiesImpl(st, pyramid, level, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
+    a->sr.sync();
+    pts.n = total;
+    pts.pyramid = pyramid;
+  }
+  return pts;
+}
+
 void checkPyramid(dsopp_hip_aligner *a, const dsopp_hip_pyramid *p, int level) {
   if (!p) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null pyramid");
   if (level < 0 || level >= p->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
@@ -721,6 +998,7 @@ void dsopp_hip_aligner_destroy(dsopp_hip_aligner *a) {
   (void)hipSetDevice(a->sr.device);
   if (a->sr.stream) (void)hipStreamSynchronize(a->sr.stream);
   if (a->h_ctrl) (void)hipHostFree(a->h_ctrl);
+  if (a->h_pyr_out) (void)hipHostFree(a->h_pyr_out);
   StreamRef sr = a->sr;
   delete a;
   sr.destroy();
@@ -815,28 +1093,7 @@ int dsopp_hip_aligner_push_reference_depth_maps(dsopp_hip_aligner *a, int64_t ti
     a->sr.use();
     hipStream_t st = a->sr.stream;
     if (maps->sr.stream != st) HIP_CHECK(hipStreamSynchronize(maps->sr.stream));  // producer finished (it synchronises at creation anyway)
-    dsopp_hip_depth_maps::LevelPoints &pts = maps->points[static_cast<size_t>(level)];
-    if (pts.n < 0 || pts.pyramid != pyramid) {
-      const double *idsum = maps->idepth_sum[static_cast<size_t>(level)].ptr, *wgt = maps->weight[static_cast<size_t>(level)].ptr;
-      a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
-      int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
-      countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
-      scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
-      int total = 0;
-      HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
-      a->sr.sync();
-      const size_t n = static_cast<size_t>(total);
-      pts.u.reserve(std::max<size_t>(n, 1), 0, st);
-      pts.v.reserve(std::max<size_t>(n, 1), 0, st);
-      pts.idepth.reserve(std::max<size_t>(n, 1), 0, st);
-      pts.intensity.reserve(std::max<size_t>(n, 1), 0, st);
-      if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
-      HIP_CHECK(hipGetLastError());
-      sampleReferenceIntensitiesImpl(st, pyramid, level, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
-      a->sr.sync();
-      pts.n = total;
-      pts.pyramid = pyramid;
-    }
+    dsopp_hip_depth_maps::LevelPoints &pts = ensureLevelPoints(a, maps, pyramid, level);
     setFrame(a->ref, pyramid, level, intrinsics, exposure_time, affine_brightness);
     a->T_w_ref = rigidFromParams(T_world_agent);
     a->ref_time = timestamp;
@@ -1088,6 +1345,107 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
     ab[0] = affine_init[0];
     ab[1] = affine_init[1];
     std::copy(rmse_last_pose_estimation, rmse_last_pose_estimation + levels, local_rmse.begin());
+    // ---- one persistent launch over all levels (alignPyramidKernel); the launch-per-iteration loop below is the fallback
+    // (lm_path 1, a known pose for this frame, or a spin time-out on a GPU shared with other work)
+    if (a->lm_path == 0 && !a->pyramid_kernel_disabled && a->known_poses.find(target_time) == a->known_poses.end()) {
+      int fast = 0;  // 1: the try was decided by the persistent launch
+      const int rc = guarded([&] {
+        a->sr.use();
+        hipStream_t st = a->sr.stream;
+        AlignPyramidArgs args;
+        std::memset(&args, 0, sizeof(args));
+        int max_blocks = 1;
+        const double zero_ab[2] = {0, 0};
+        for (int lvl = 0; lvl < levels; ++lvl) {
+          checkPyramid(a, reference_pyramid, lvl);
+          checkPyramid(a, target_pyramid, lvl);
+          if (reference_depth_maps->sr.device != a->sr.device) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "depth maps live on another device");
+          if (reference_pyramid->w(lvl) != reference_depth_maps->width[static_cast<size_t>(lvl)] ||
+              reference_pyramid->h(lvl) != reference_depth_maps->height[static_cast<size_t>(lvl)])
+            fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "depth map level %d does not match the pyramid level", lvl);
+          if (reference_depth_maps->sr.stream != st) HIP_CHECK(hipStreamSynchronize(reference_depth_maps->sr.stream));
+          const dsopp_hip_depth_maps::LevelPoints &pts = ensureLevelPoints(a, reference_depth_maps, reference_pyramid, lvl);
+          const double sl = static_cast<double>(1 << lvl);  // CameraCalibration::cameraModel(level), camera_calibration.cpp:66-70
+          const double intr[4] = {intrinsics[0] / sl, intrinsics[1] / sl, intrinsics[2] / sl, intrinsics[3] / sl};
+          AlignLevelDev &L = args.level[lvl];
+          setFrame(L.ref, reference_pyramid, lvl, intr, reference_exposure, reference_affine);
+          setFrame(L.tgt, target_pyramid, lvl, intr, target_exposure, zero_ab);
+          L.pu = pts.u.ptr;
+          L.pv = pts.v.ptr;
+          L.pid = pts.idepth.ptr;
+          L.pint = pts.intensity.ptr;
+          L.n_points = pts.n;
+          L.rmse_limit = kEnergyRatioThreshold * local_rmse[static_cast<size_t>(lvl)];
+          max_blocks = std::max(max_blocks, (pts.n + kAlignThreads - 1) / kAlignThreads);
+        }
+        const int G = std::min(kPyramidMaxWorkgroups, max_blocks);
+        args.n_levels = levels;
+        args.max_iterations = a->opt.max_iterations;
+        args.sigma_huber = a->opt.sigma_huber_loss;
+        args.affine_reg[0] = a->opt.affine_brightness_regularizer[0];
+        args.affine_reg[1] = a->opt.affine_brightness_regularizer[1];
+        args.function_tolerance = a->opt.function_tolerance;
+        args.parameter_tolerance = a->opt.parameter_tolerance;
+        args.decrease_on_accept = 2.0;  // eigen_pose_alignment.cpp:304-305
+        args.increase_on_reject = 2.0;
+        args.lambda0 = 1.0 / a->opt.initial_trust_region_radius;
+        const Rigid T_tr = rigidMul(rigidInverse(rigidFromParams(T)), rigidFromParams(T_world_reference));  // eigen_pose_alignment.cpp:307-308
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) args.T_tr0[4 * i + j] = T_tr.R[3 * i + j];
+          args.T_tr0[4 * i + 3] = T_tr.t[i];
+        }
+        args.ab0[0] = ab[0];
+        args.ab0[1] = ab[1];
+        a->d_pyr_partials.reserve(2 * static_cast<size_t>(kPyramidMaxWorkgroups) * kAlignPartial, 0, st);
+        a->d_pyr_sync.reserve(2, 0, st);
+        a->d_pyr_out.reserve(1, 0, st);
+        if (!a->h_pyr_out) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_pyr_out), sizeof(AlignPyramidResult), hipHostMallocDefault));
+        args.partials = a->d_pyr_partials.ptr;
+        args.counter = a->d_pyr_sync.ptr;
+        args.failed = a->d_pyr_sync.ptr + 1;
+        args.out = a->d_pyr_out.ptr;
+        HIP_CHECK(hipMemsetAsync(a->d_pyr_sync.ptr, 0, 2 * sizeof(unsigned), st));  // arrival counter + failed flag: re-initialised every call
+        if (a->opt.dtype == DSOPP_HIP_F64)
+          alignPyramidKernel<double><<<G, kAlignThreads, 0, st>>>(args);
+        else
+          alignPyramidKernel<float><<<G, kAlignThreads, 0, st>>>(args);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(a->h_pyr_out, a->d_pyr_out.ptr, sizeof(AlignPyramidResult), hipMemcpyDeviceToHost, st));
+        a->sr.sync();
+        const AlignPyramidResult &o = *a->h_pyr_out;
+        if (o.failed) {
+          a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
+          return;
+        }
+        fast = 1;
+        lm_iterations += o.lm_iterations;
+        success = o.success != 0;
+        const int accepted = o.success ? o.levels_done : o.levels_done - 1;  // the last level run failed its energy test
+        for (int k = 0; k < accepted; ++k) {
+          const int lvl = levels - 1 - k;
+          local_rmse[static_cast<size_t>(lvl)] = o.rmse[lvl];
+        }
+        Rigid Tfin;
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = o.T_tr[4 * i + j];
+          Tfin.t[i] = o.T_tr[4 * i + 3];
+        }
+        if (accepted > 0) {  // (no level accepted: the initialisation itself is what the reference keeps)
+          rigidToParams(rigidMul(rigidFromParams(T_world_reference), rigidInverse(Tfin)), T);
+          ab[0] = o.ab[0];
+          ab[1] = o.ab[1];
+        }
+      });
+      if (rc != DSOPP_HIP_OK) return rc;
+      if (fast) {
+        if (try_number == 0) {
+          std::memcpy(T_const, T, sizeof(T));
+          ab_const[0] = ab[0];
+          ab_const[1] = ab[1];
+        }
+        continue;
+      }
+    }
     for (int lvl = levels - 1; success && lvl >= 0; --lvl) {
       const double s = static_cast<double>(1 << lvl);  // CameraCalibration::cameraModel(level), camera_calibration.cpp:66-70
       const double intr[4] = {intrinsics[0] / s, intrinsics[1] / s, intrinsics[2] / s, intrinsics[3] / s};

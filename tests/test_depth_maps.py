@@ -320,3 +320,50 @@ def test_tracker_full_size_identity_property():
     assert rmse_last[0] < 1.0   # grey levels: the level-0 residual of a frame against itself
     for obj in (a, maps, pyr, g):
         obj.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(320, 240, 4), (1280, 1024, 5)])
+def test_estimate_pose_persistent_launch_equals_launch_per_iteration(size):
+    """estimatePose as ONE persistent launch over all pyramid levels (lm_path 0: resident workgroups meet at a device-scope
+    counter once per LM iteration) against the launch-per-iteration path (lm_path 1): same state machine and arithmetic, so the
+    iteration counts and per-level rmse must be identical and the pose equal to rounding — at the tracker's full C2 size too.
+    Several hypotheses: the first one is hopeless (fails a level on the device), the second succeeds."""
+    from dsopp_amd import capi
+    W, H, L = size
+    win = syn.make_window(num_frames=4, num_points=1200, width=W, height=H, seed=29)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    g.solve()
+    maps = g.create_reference_depth_maps(L)
+    newest, target = win.frames[-1], win.frames[-2]
+    pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
+    pr.build(newest.image_u8)
+    pt.build(target.image_u8)
+    T_ref, ab_ref = g.get_pose(newest.frame_id)
+    T_good = syn.mat_to_params(target.T_w_c_init)
+    T_bad = syn.mat_to_params(target.T_w_c_gt @ syn.se3_exp(np.array([1.5, -1.0, 0.8, 0.3, -0.4, 0.25])))
+    out = []
+    for path in (0, 1):
+        a = capi.HipAligner(capi.default_align_options())
+        a.set_lm_path(path)
+        frames = []
+        rmse_last = np.full(L, 1e10)
+        # frame 1 sets the per-level energy bounds, frame 2 runs against them: [bad, good] -> the bad hypothesis must be rejected
+        frames.append(a.estimate_pose(newest.timestamp, T_ref, pr, maps, 1.0, ab_ref, newest.timestamp + 1, pt, 1.0, win.scene.intrinsics,
+                                      T_good[None, :], np.zeros(2), rmse_last))
+        frames.append(dict(rmse=rmse_last.copy()))
+        frames.append(a.estimate_pose(newest.timestamp, T_ref, pr, maps, 1.0, ab_ref, newest.timestamp + 2, pt, 1.0, win.scene.intrinsics,
+                                      np.stack([T_bad, T_good]), np.zeros(2), rmse_last))
+        frames.append(dict(rmse=rmse_last.copy()))
+        out.append(frames)
+        a.close()
+    (f0, r0, f1, r1), (h0, s0, h1, s1) = out
+    assert f0["success"] and h0["success"] and f0["tries"] == h0["tries"] == 1
+    assert f1["success"] and h1["success"] and f1["tries"] == h1["tries"] == 2, (f1["tries"], h1["tries"])
+    for fa, fb in ((f0, h0), (f1, h1)):
+        assert fa["lm_iterations"] == fb["lm_iterations"], (fa["lm_iterations"], fb["lm_iterations"])
+        assert np.abs(fa["T_w_target"] - fb["T_w_target"]).max() <= 1e-12
+        assert np.abs(fa["affine_brightness"] - fb["affine_brightness"]).max() <= 1e-10
+    assert np.allclose(r0["rmse"], s0["rmse"], rtol=1e-12) and np.allclose(r1["rmse"], s1["rmse"], rtol=1e-12)
+    for obj in (maps, pr, pt, g):
+        obj.close()
