@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -71,6 +72,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                                "dsopp_amd has no CPU fallback")
+        # PyTorch ships its own HIP runtime; if it is imported but its CUDA state is not up yet, bring it up BEFORE this library
+        # touches the device: initialised second, torch reports "No HIP GPUs are available" (the other order works)
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available() and not torch.cuda.is_initialized():
+                    torch.cuda.init()
+            except Exception:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.dsopp_hip_last_error.restype = C.c_char_p
         _lib.dsopp_hip_version.restype = C.c_char_p

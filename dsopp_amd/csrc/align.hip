@@ -222,135 +222,250 @@ __device__ inline void alignDecide(AlignControl &c, const double *red, const Ali
     }
 }
 
+/**
+ * alignDecide executed by ONE WAVE (all 64 lanes of wave 0, uniform control flow) on register copies.  The single-lane form
+ * above works in place on the LDS control block: every access is an LDS instruction whose address the compiler cannot prove
+ * distinct from the previous store, so the ~300 loads and stores of a control step serialise at one LDS latency each
+ * (measured: 4.7 us per step, more than the sweep, the workgroup reduction and the cross-workgroup exchange together).
+ * Here everything is loaded first (one LDS latency), the 8 x 8 system is expanded / copied one entry per lane, the decision
+ * and the solve run in registers (redundantly in every lane: no cross-lane traffic), and the results leave in one batch of
+ * stores.  Same arithmetic, operation for operation, as alignDecide.
+ */
+__device__ inline void alignDecideWave(AlignControl &c, const double *red, const AlignFrameDev &tgt, const AlignParams &prm) {
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, hj = lane & 7;
+  // ---- loads
+  const double cand_ab0 = c.cand_ab[0], cand_ab1 = c.cand_ab[1];
+  double ab_eps0 = c.ab_eps[0], ab_eps1 = c.ab_eps[1];
+  double energy = c.energy, lambda = c.lambda;
+  int n_valid = c.n_valid, converged = c.converged, active = c.active, iteration = c.iteration;
+  const int have_candidate = c.have_candidate;
+  double stepv[8], Ttr[12], candT[12];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) stepv[a] = c.step[a];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    Ttr[a] = c.T_tr[a];
+    candT[a] = c.cand_T[a];
+  }
+  const double red_energy = red[44], red_n = red[45];
+  const int lo8 = hi < hj ? hi : hj, hi8 = hi < hj ? hj : hi;
+  const double h_new = red[lo8 * 8 - lo8 * (lo8 - 1) / 2 + (hi8 - lo8)], h_old = c.H[lane];  // packed upper triangle, as alignDecide expands it
+  const double b_new = red[36 + hj], b_old = c.b[hj];
+  // ---- decision (uniform)
+  const double tab0 = tgt.ab0[0] + cand_ab0, tab1 = tgt.ab0[1] + cand_ab1;
+  const double e_eval = red_energy + 0.5 * (tab0 * prm.affine_reg[0] * tab0 + tab1 * prm.affine_reg[1] * tab1);
+  const int n_eval = static_cast<int>(red_n + 0.5);
+  bool take_system = false;
+  if (!have_candidate) {
+    energy = e_eval;
+    n_valid = n_eval;
+    active = (prm.max_iterations > 0 && n_eval > 0) ? 1 : 0;
+    take_system = true;
+  } else {
+    iteration += 1;
+    if (n_eval == 0) {
+      active = 0;
+    } else {
+      if (fabs(energy - e_eval) / energy < prm.function_tolerance) converged = 1;
+      if (e_eval < energy) {
+        const double a0 = tgt.ab0[0] + ab_eps0, a1 = tgt.ab0[1] + ab_eps1;
+        double step_sq = 0;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) step_sq += stepv[a] * stepv[a];
+        if (step_sq < prm.parameter_tolerance * ((a0 * a0 + a1 * a1) + prm.parameter_tolerance)) converged = 1;
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Ttr[a] = candT[a];
+        ab_eps0 = cand_ab0;
+        ab_eps1 = cand_ab1;
+        energy = e_eval;
+        n_valid = n_eval;
+        lambda /= prm.decrease_on_accept;
+        take_system = true;
+      } else {
+        lambda *= prm.increase_on_reject;
+      }
+      if (converged || iteration >= prm.max_iterations) active = 0;
+    }
+  }
+  // ---- system of the accepted state: one entry per lane
+  double h = h_old, b = b_old;
+  if (take_system) {
+    h = h_new;
+    b = b_new;
+    if (lane == 8 * 6 + 6) h += prm.affine_reg[0];
+    if (lane == 8 * 7 + 7) h += prm.affine_reg[1];
+    if (hj == 6) b += prm.affine_reg[0] * tab0;
+    if (hj == 7) b += prm.affine_reg[1] * tab1;
+    c.H[lane] = h;
+    if (lane < 8) c.b[lane] = b;
+  }
+  double stepn[8], candTn[12], cand_abn0 = cand_ab0, cand_abn1 = cand_ab1;
+  int have_candidate_n = have_candidate;
+  if (active) {
+    c.H_used[lane] = h;
+    // the stores above are this wave's own and LDS executes a wave's instructions in order: the solve's reads see them
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    solve8(c.H, lambda, c.b, stepn);
+    const Rigid E = rigidExp(stepn);
+    double Em[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Em[4 * i + j] = E.R[3 * i + j];
+      Em[4 * i + 3] = E.t[i];
+    }
+    mat34Compose(Em, Ttr, candTn);
+    cand_abn0 = ab_eps0 - stepn[6];
+    cand_abn1 = ab_eps1 - stepn[7];
+    have_candidate_n = 1;
+  } else {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) stepn[a] = stepv[a];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) candTn[a] = candT[a];
+  }
+  // ---- one batch of stores (lane 0)
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      c.T_tr[a] = Ttr[a];
+      c.cand_T[a] = candTn[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) c.step[a] = stepn[a];
+    c.ab_eps[0] = ab_eps0;
+    c.ab_eps[1] = ab_eps1;
+    c.cand_ab[0] = cand_abn0;
+    c.cand_ab[1] = cand_abn1;
+    c.lambda = lambda;
+    c.energy = energy;
+    c.n_valid = n_valid;
+    c.converged = converged;
+    c.active = active;
+    c.iteration = iteration;
+    c.have_candidate = have_candidate_n;
+  }
+}
+
+/** per-pass constants of the sweep: reprojection matrices of the candidate pose, photometric parameters */
+template <typename S>
+struct AlignSweepCtx {
+  S U[12], M[12];
+  S s_scale, b_t, b_r, Wr, Hr, Wt, Ht, fxt, fyt;
+  const Texel<S> *img;
+  int W;
+  double sigma;
+};
+
+template <typename S>
+__device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const AlignFrameDev &ref, const AlignFrameDev &tgt, const AlignControl &sc,
+                                                const AlignParams &prm) {
+  const double *T = sc.cand_T;
+  // ArrayReprojector ctor — camera_reproject.hpp:235-260
+  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
+  double Ud[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Ud[4 * i] = T[4 * i] * ifx;
+    Ud[4 * i + 1] = T[4 * i + 1] * ify;
+    Ud[4 * i + 2] = T[4 * i] * k02 + T[4 * i + 1] * k12 + T[4 * i + 2];
+    Ud[4 * i + 3] = T[4 * i + 3];
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x.U[i] = S(Ud[i]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x.M[j] = S(tgt.fx * Ud[j] + tgt.cx * Ud[8 + j]);
+    x.M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
+    x.M[8 + j] = S(Ud[8 + j]);
+  }
+  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
+  x.s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
+  x.b_t = S(tab1);
+  x.b_r = S(ref.ab0[1]);
+  x.Wr = S(ref.width);
+  x.Hr = S(ref.height);
+  x.Wt = S(tgt.width);
+  x.Ht = S(tgt.height);
+  x.fxt = S(tgt.fx);
+  x.fyt = S(tgt.fy);
+  x.img = static_cast<const Texel<S> *>(tgt.texels);
+  x.W = tgt.width;
+  x.sigma = prm.sigma_huber;
+}
+
+/** one reference point: residual, Huber weight, Jacobian row and its contribution to H (36 upper) | b (8) | energy | n_valid.
+ *  Everything is predicated instead of branching: an invalid point reads a safe texel and contributes with weight zero. */
+template <typename S>
+__device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, S idepth, S iref, bool present, double (&acc)[kAlignPartial]) {
+  const S *M = x.M, *U = x.U;
+  // reproject (checked) — camera_reproject.hpp:270-293
+  bool good = present && validIdepth(idepth) && insideROI(u, v, x.Wr, x.Hr);
+  const S px = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
+  const S py = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
+  const S pz = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
+  const S ta = px / pz, tb = py / pz;
+  good = good && (pz > S(0)) && insideROI(ta, tb, x.Wt, x.Ht);
+  const S tu = good ? ta : S(4), tv = good ? tb : S(4);
+  const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
+  const Texel<S> *p = x.img + static_cast<size_t>(iy) * x.W + ix;
+  const Texel<S> t00 = p[0], t10 = p[1], t01 = p[x.W], t11 = p[x.W + 1];
+  const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy), dxdy = dx * dy;
+  const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
+  const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
+  const bool valid = good && (m != S(0));  // mask_.valid(target_pattern) — eigen_pose_alignment.cpp:78
+  const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+  const S sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
+  const S sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
+  const S sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
+  const S right = x.s_scale * (iref - x.b_r);
+  const double r = static_cast<double>((sI - x.b_t) - right);
+  const double r2 = r * r, sig = x.sigma;
+  const bool lin = r2 > sig * sig;
+  const double nrm = fabs(r);
+  const double wgt = valid ? (lin ? sig / nrm : 1.0) : 0.0;
+  acc[44] += valid ? (lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2) : 0.0;
+  acc[45] += valid ? 1.0 : 0.0;
+  // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
+  const S X = U[0] * u + U[1] * v + (U[2] + U[3] * idepth);
+  const S Y = U[4] * u + U[5] * v + (U[6] + U[7] * idepth);
+  const S Z = U[8] * u + U[9] * v + (U[10] + U[11] * idepth);
+  const S rho = valid ? S(1) / Z : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
+  const S fxt = x.fxt, fyt = x.fyt, b0b1 = b0 * b1;
+  double d[8];
+  d[0] = -static_cast<double>(sIx * (fxt * nid));
+  d[1] = -static_cast<double>(sIy * (fyt * nid));
+  d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
+  d[3] = -static_cast<double>(sIx * (fxt * (-b0b1)) + sIy * (fyt * (-(b1 * b1 + S(1)))));
+  d[4] = -static_cast<double>(sIx * (fxt * (b0 * b0 + S(1))) + sIy * (fyt * b0b1));
+  d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
+  d[6] = -static_cast<double>(right);
+  d[7] = -1.0;
+  int e = 0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const double wa = wgt * d[a];
+#pragma unroll
+    for (int b2 = a; b2 < 8; ++b2) acc[e++] += wa * d[b2];
+    acc[36 + a] += wa * r;
+  }
+}
+
 /** PoseAlignerProblem::calculateEnergy + linearize (eigen_pose_alignment.cpp:55-192) at the candidate state of `sc` for the
  *  points first, first + stride, ...: fills acc with this thread's share of H (36 upper) | b (8) | energy | n_valid */
 template <typename S>
 __device__ __forceinline__ void alignSweep(const AlignFrameDev &ref, const AlignFrameDev &tgt, const double *__restrict__ pu, const double *__restrict__ pv,
                                            const double *__restrict__ pid, const double *__restrict__ pint, const AlignControl &sc,
                                            const AlignParams &prm, int first, int stride, double (&acc)[kAlignPartial]) {
-  // ---------------- sweep at the candidate state ----------------
 #pragma unroll
   for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
-  const double *T = sc.cand_T;
-  // ArrayReprojector ctor — camera_reproject.hpp:235-260
-  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
-  S U[12], M[12];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double u0 = T[4 * i] * ifx, u1 = T[4 * i + 1] * ify, u2 = T[4 * i] * k02 + T[4 * i + 1] * k12 + T[4 * i + 2], u3 = T[4 * i + 3];
-    U[4 * i] = S(u0);
-    U[4 * i + 1] = S(u1);
-    U[4 * i + 2] = S(u2);
-    U[4 * i + 3] = S(u3);
-  }
-  {
-    const double *Tt = T;
-    double Ud[12];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      Ud[4 * i] = Tt[4 * i] * ifx;
-      Ud[4 * i + 1] = Tt[4 * i + 1] * ify;
-      Ud[4 * i + 2] = Tt[4 * i] * k02 + Tt[4 * i + 1] * k12 + Tt[4 * i + 2];
-      Ud[4 * i + 3] = Tt[4 * i + 3];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      M[j] = S(tgt.fx * Ud[j] + tgt.cx * Ud[8 + j]);
-      M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
-      M[8 + j] = S(Ud[8 + j]);
-    }
-  }
-  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
-  const S s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
-  const S b_t = S(tab1), b_r = S(ref.ab0[1]);
-  const S Wr = S(ref.width), Hr_ = S(ref.height), Wt = S(tgt.width), Ht = S(tgt.height);
-  const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(tgt.texels);
-  const int W = tgt.width;
-  // kBatch points of this thread are in flight together: all point words first, then all texel footprints, then the
-  // arithmetic.  Everything is predicated instead of branching (an early `continue` would serialise the memory round trips
-  // of consecutive points): an invalid point reads a safe texel and contributes with weight zero.
-  constexpr int kBatch = 1;  // (4 in flight was tried: the 48 f64 accumulators + 16 texels per lane spill)
-  for (int i0 = first; i0 < prm.n_points; i0 += kBatch * stride) {
-    S u[kBatch], v[kBatch], idepth[kBatch], iref[kBatch];
-    bool ok[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int i = i0 + k * stride;
-      ok[k] = i < prm.n_points;
-      const int ii = ok[k] ? i : prm.n_points - 1;  // (in bounds: the loop runs only when n_points > first >= 0)
-      u[k] = static_cast<S>(pu[ii]);
-      v[k] = static_cast<S>(pv[ii]);
-      idepth[k] = static_cast<S>(pid[ii]);
-      iref[k] = static_cast<S>(pint[ii]);
-    }
-    S tu[kBatch], tv[kBatch];
-    const Texel<S> *p[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      // reproject (checked) — camera_reproject.hpp:270-293
-      bool good = ok[k] && validIdepth(idepth[k]) && insideROI(u[k], v[k], Wr, Hr_);
-      const S x = M[0] * u[k] + M[1] * v[k] + (M[2] + M[3] * idepth[k]);
-      const S y = M[4] * u[k] + M[5] * v[k] + (M[6] + M[7] * idepth[k]);
-      const S z = M[8] * u[k] + M[9] * v[k] + (M[10] + M[11] * idepth[k]);
-      S a = x / z, b = y / z;
-      good = good && (z > S(0)) && insideROI(a, b, Wt, Ht);
-      ok[k] = good;
-      tu[k] = good ? a : S(4);
-      tv[k] = good ? b : S(4);
-      p[k] = img + static_cast<size_t>(static_cast<int>(tv[k])) * W + static_cast<int>(tu[k]);
-    }
-    Texel<S> t00[kBatch], t10[kBatch], t01[kBatch], t11[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      t00[k] = p[k][0];
-      t10[k] = p[k][1];
-      t01[k] = p[k][W];
-      t11[k] = p[k][W + 1];
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int ix = static_cast<int>(tu[k]), iy = static_cast<int>(tv[k]);
-      const S dx = tu[k] - static_cast<S>(ix), dy = tv[k] - static_cast<S>(iy), dxdy = dx * dy;
-      const int rx = static_cast<int>(floor(tu[k] + S(0.5))) - ix, ry = static_cast<int>(floor(tv[k] + S(0.5))) - iy;
-      const S m = ry ? (rx ? t11[k].mask : t01[k].mask) : (rx ? t10[k].mask : t00[k].mask);
-      const bool valid = ok[k] && (m != S(0));  // mask_.valid(target_pattern) — eigen_pose_alignment.cpp:78
-      const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
-      const S sI = w11 * t11[k].I + w01 * t01[k].I + w10 * t10[k].I + w00 * t00[k].I;
-      const S sIx = w11 * t11[k].Ix + w01 * t01[k].Ix + w10 * t10[k].Ix + w00 * t00[k].Ix;
-      const S sIy = w11 * t11[k].Iy + w01 * t01[k].Iy + w10 * t10[k].Iy + w00 * t00[k].Iy;
-      const S right = s_scale * (iref[k] - b_r);
-      const double r = static_cast<double>((sI - b_t) - right);
-      const double r2 = r * r, sig = prm.sigma_huber;
-      const bool lin = r2 > sig * sig;
-      const double nrm = fabs(r);
-      const double wgt = valid ? (lin ? sig / nrm : 1.0) : 0.0;
-      acc[44] += valid ? (lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2) : 0.0;
-      acc[45] += valid ? 1.0 : 0.0;
-      // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
-      const S X = U[0] * u[k] + U[1] * v[k] + (U[2] + U[3] * idepth[k]);
-      const S Y = U[4] * u[k] + U[5] * v[k] + (U[6] + U[7] * idepth[k]);
-      const S Z = U[8] * u[k] + U[9] * v[k] + (U[10] + U[11] * idepth[k]);
-      const S rho = valid ? S(1) / Z : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth[k] * rho;
-      const S fxt = S(tgt.fx), fyt = S(tgt.fy), b0b1 = b0 * b1;
-      double d[8];
-      d[0] = -static_cast<double>(sIx * (fxt * nid));
-      d[1] = -static_cast<double>(sIy * (fyt * nid));
-      d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
-      d[3] = -static_cast<double>(sIx * (fxt * (-b0b1)) + sIy * (fyt * (-(b1 * b1 + S(1)))));
-      d[4] = -static_cast<double>(sIx * (fxt * (b0 * b0 + S(1))) + sIy * (fyt * b0b1));
-      d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
-      d[6] = -static_cast<double>(right);
-      d[7] = -1.0;
-      int e = 0;
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const double wa = wgt * d[a];
-#pragma unroll
-        for (int b2 = a; b2 < 8; ++b2) acc[e++] += wa * d[b2];
-        acc[36 + a] += wa * r;
-      }
-    }
-  }
+  AlignSweepCtx<S> x;
+  alignSweepSetup<S>(x, ref, tgt, sc, prm);
+  // (4 points in flight per thread was tried: the 48 f64 accumulators + 16 texels per lane spill)
+  for (int i = first; i < prm.n_points; i += stride)
+    alignPoint<S>(x, static_cast<S>(pu[i]), static_cast<S>(pv[i]), static_cast<S>(pid[i]), static_cast<S>(pint[i]), true, acc);
 }
 
 /**
@@ -419,7 +534,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignIterationKernel(AlignFrame
       if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = ctrl_word;
       return;
     }
-    if (tid == 0) alignDecide(sc, red, tgt, prm);  // in place on the LDS copy: no private 1.4 KB struct (= scratch memory)
+    if (tid < 64) alignDecideWave(sc, red, tgt, prm);  // wave 0, register copies (see alignDecideWave)
     __syncthreads();
     if (blockIdx.x == 0 && tid < kCtrlWords) reinterpret_cast<double *>(cout)[tid] = reinterpret_cast<const double *>(&sc)[tid];
     if (!sc.active) return;
@@ -498,7 +613,7 @@ __global__ void __launch_bounds__(kLoopThreads) alignLoopKernel(AlignFrameDev re
   const int total_passes = prm.max_iterations + 2;  // initial evaluation + one per iteration + the closing control step
   for (int pass = 0; pass < total_passes; ++pass) {
     if (pass > 0) {
-      if (tid == 0) alignDecide(sc, tot, tgt, prm);
+      if (tid < 64) alignDecideWave(sc, tot, tgt, prm);
       __syncthreads();
       if (!sc.active) break;
     }
@@ -576,7 +691,13 @@ struct AlignPyramidResult {
   int n_valid[DSOPP_HIP_MAX_LEVELS];
   double T_tr[12];   // T_target_reference after the last accepted level ([R | t] rows)
   double ab[2];      // target affine brightness after the last accepted level
+  long long stamps[8];  // -DDSOPP_HIP_STAMPS: wall_clock64 at the phase boundaries of one pass (level 0, third pass) of workgroup 0
 };
+#ifdef DSOPP_HIP_STAMPS
+#define AP_STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && lvl == 0 && pass == 2) a.out->stamps[i] = wall_clock64(); } while (0)
+#else
+#define AP_STAMP(i) do { } while (0)
+#endif
 
 struct AlignPyramidArgs {
   AlignLevelDev level[DSOPP_HIP_MAX_LEVELS];
@@ -644,23 +765,52 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       sc = c;
     }
     __syncthreads();
+    // up to kPreload points per thread are read once per level (all of them when the level has <= kPreload * G * 256 points)
+    constexpr int kPreload = 2;
+    const bool preloaded = L.n_points <= kPreload * G * kAlignThreads;
+    S ru[kPreload], rv[kPreload], rid[kPreload], rint[kPreload];
+    if (preloaded) {
+#pragma unroll
+      for (int q = 0; q < kPreload; ++q) {
+        const int i = blockIdx.x * kAlignThreads + tid + q * G * kAlignThreads;
+        const int ic = i < L.n_points ? i : (L.n_points > 0 ? L.n_points - 1 : 0);
+        const bool have = L.n_points > 0;
+        ru[q] = have ? static_cast<S>(L.pu[ic]) : S(0);
+        rv[q] = have ? static_cast<S>(L.pv[ic]) : S(0);
+        rid[q] = have ? static_cast<S>(L.pid[ic]) : S(0);
+        rint[q] = have ? static_cast<S>(L.pint[ic]) : S(0);
+      }
+    }
     const int total_passes = a.max_iterations + 2;  // initial evaluation + one per iteration + the closing control step
     for (int pass = 0; pass < total_passes; ++pass) {
+      AP_STAMP(0);
       if (pass > 0) {
-        if (tid == 0) alignDecide(sc, tot, tgt, prm);
+        if (tid < 64) alignDecideWave(sc, tot, tgt, prm);
         __syncthreads();
         if (!sc.active) break;
       }
+      AP_STAMP(1);
       // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
       const int first = blockIdx.x * kAlignThreads + tid;
       double *dst = a.partials + (static_cast<size_t>(pass_global & 1u) * G + blockIdx.x) * kAlignPartial;
       if (static_cast<int>(blockIdx.x) * kAlignThreads < L.n_points) {
         double acc[kAlignPartial];
-        alignSweep<S>(L.ref, tgt, L.pu, L.pv, L.pid, L.pint, sc, prm, first, G * kAlignThreads, acc);
+        if (preloaded) {
+          // this thread's points live in registers for the whole level: a pass starts with the texel gather
+#pragma unroll
+          for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
+          AlignSweepCtx<S> x;
+          alignSweepSetup<S>(x, L.ref, tgt, sc, prm);
+#pragma unroll
+          for (int q = 0; q < kPreload; ++q) alignPoint<S>(x, ru[q], rv[q], rid[q], rint[q], first + q * G * kAlignThreads < L.n_points, acc);
+        } else {
+          alignSweep<S>(L.ref, tgt, L.pu, L.pv, L.pid, L.pint, sc, prm, first, G * kAlignThreads, acc);
+        }
         constexpr int RS = kAlignThreads + 2;
 #pragma unroll
         for (int e = 0; e < kAlignPartial; ++e) red[e * RS + tid] = acc[e];
         __syncthreads();
+        AP_STAMP(2);
         const int row_idx = tid >> 2, quarter = tid & 3;
         double s = 0;
         if (row_idx < kAlignPartial) {
@@ -686,6 +836,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       // ---- publish / arrive / wait (R1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
       __syncthreads();
+      AP_STAMP(3);
       if (tid == 0) {
         gu32 *cnt = (gu32 *)a.counter;
         __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -701,6 +852,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         }
       }
       __syncthreads();
+      AP_STAMP(4);
       if (s_failed) {
         if (blockIdx.x == 0 && tid == 0) a.out->failed = 1;
         return;
@@ -711,19 +863,25 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
         const double *src = a.partials + static_cast<size_t>(pass_global & 1u) * G * kAlignPartial + e;
         if (grp < kGroups) {
-          double p0 = 0, p1 = 0;
-          int b = grp;
-          for (; b + kGroups < G; b += 2 * kGroups) {
-            const unsigned long long w0 = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b) * kAlignPartial),
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long w1 = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b + kGroups) * kAlignPartial),
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            p0 += __longlong_as_double(static_cast<long long>(w0));
-            p1 += __longlong_as_double(static_cast<long long>(w1));
+          // all loads of this thread are issued before the first add: clamped indices + a 0 / 1 factor instead of predicated
+          // loads (G <= 64: at most 13 per thread, one L2 round trip)
+          constexpr int kMaxPer = (kPyramidMaxWorkgroups + kGroups - 1) / kGroups;
+          unsigned long long w[kMaxPer];
+#pragma unroll
+          for (int j = 0; j < kMaxPer; ++j) {
+            const int b = grp + j * kGroups;
+            const int bc = b < G ? b : G - 1;
+            w[j] = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(bc) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          if (b < G)
-            p0 += __longlong_as_double(static_cast<long long>(
-                __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(b) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+          double p0 = 0, p1 = 0;
+#pragma unroll
+          for (int j = 0; j < kMaxPer; ++j) {
+            const double v = (grp + j * kGroups < G) ? __longlong_as_double(static_cast<long long>(w[j])) : 0.0;
+            if (j & 1)
+              p1 += v;
+            else
+              p0 += v;
+          }
           red[grp * kAlignPartial + e] = p0 + p1;
         }
         __syncthreads();
@@ -735,6 +893,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         }
         __syncthreads();
       }
+      AP_STAMP(5);
       ++pass_global;
     }
     // ---- the level's verdict (identical in every workgroup) — monocular_tracker.cpp:218-226, eigen_pose_alignment.cpp:320-328
@@ -1413,6 +1572,12 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         HIP_CHECK(hipMemcpyAsync(a->h_pyr_out, a->d_pyr_out.ptr, sizeof(AlignPyramidResult), hipMemcpyDeviceToHost, st));
         a->sr.sync();
         const AlignPyramidResult &o = *a->h_pyr_out;
+#ifdef DSOPP_HIP_STAMPS
+        if (std::getenv("DSOPP_HIP_TRACE"))
+          std::fprintf(stderr, "alignPyramid pass (level 0): decide %.2f  sweep %.2f  wg-reduce+store %.2f  arrive+wait %.2f  global sum %.2f us (G = %d)\n",
+                       (o.stamps[1] - o.stamps[0]) / 100.0, (o.stamps[2] - o.stamps[1]) / 100.0, (o.stamps[3] - o.stamps[2]) / 100.0,
+                       (o.stamps[4] - o.stamps[3]) / 100.0, (o.stamps[5] - o.stamps[4]) / 100.0, G);
+#endif
         if (o.failed) {
           a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
           return;
