@@ -37,7 +37,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "dsopp_hip_window_frame_ids",
+    "dsopp_hip_window_frame_ids", "dsopp_hip_window_set_deterministic",
     "dsopp_hip_comm_unique_id", "dsopp_hip_comm_create", "dsopp_hip_comm_adopt", "dsopp_hip_comm_destroy", "dsopp_hip_comm_rank",
     "dsopp_hip_comm_allreduce", "dsopp_hip_window_set_comm",
     "dsopp_hip_window_optimize_async", "dsopp_hip_window_optimize_wait",
@@ -430,6 +430,10 @@ class HipWindow:
         us = C.c_double()
         _chk(lib().dsopp_hip_window_time_kernel(self._h, self.KERNEL_CLASSES[name], int(repeats), C.byref(us)))
         return us.value
+
+    def set_deterministic(self, enable: bool):
+        """two-stage (atomic-free, bit-reproducible) build of the reduced normal equations at every window size"""
+        _chk(lib().dsopp_hip_window_set_deterministic(self._h, int(bool(enable))))
 
     def set_lm_mode(self, mode: int):
         """0 fused device loop (default), 1 host-driven stages, 2 unfused device loop"""

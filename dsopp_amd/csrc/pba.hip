@@ -13,6 +13,7 @@
 #include "host_linalg.hpp"
 #include "pba_solve_kernels.hpp"
 #include "pba_solve_combined.hpp"
+#include "pba_schur_two_stage.hpp"
 #include "depth_map_kernels.hpp"
 #include "point_status_kernels.hpp"
 #include "depth_maps.hpp"
@@ -73,6 +74,10 @@ struct dsopp_hip_window {
   // d_reduce = [Hpp K*K | bpp K | Hsc K*K | bsc K] (no priors): everything a multi-GPU run must sum across ranks, contiguous
   DeviceBuffer<double> d_partials, d_reduce, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
   bool marg_nonzero = false;
+  // two-stage (atomic-free, order-deterministic) build of the combined system: pba_schur_two_stage.hpp
+  DeviceBuffer<double> d_schur_partials, d_pair_out;
+  bool deterministic = false;  // dsopp_hip_window_set_deterministic: the two-stage build at every window size
+  bool twoStage() const { return deterministic || n_schur_blocks > kTwoStageMinChunks; }
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
@@ -764,6 +769,51 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
   HIP_CHECK(hipGetLastError());
 }
 
+/** two-stage build of the combined system (large windows / deterministic mode): partial systems without atomics, then one
+ *  ordered sum per entry.  `ctrl` (nullable) is the control block whose `active` gates both launches and whose lambda damps the
+ *  system; the LM decision is NOT taken here (decideApplyKernel runs in front of / behind it). */
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda) {
+  const int F = w.F(), K = w.K();
+  hipStream_t st = w.sr.stream;
+  ensureDynamicLds(reinterpret_cast<const void *>(schurTwoStageKernel), w.sr.device, 96 * 1024);
+  const int n_chunks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
+  // as many workgroups as the chip has compute units (one fits per unit: 90 KB of LDS), each taking its share of the chunks
+  const int chunks_per_wg = std::max(1, (n_chunks + 255) / 256);
+  const int n_wgs = (n_chunks + chunks_per_wg - 1) / chunks_per_wg;
+  w.d_schur_partials.reserve(std::max<size_t>(1, static_cast<size_t>(n_wgs)) * w.combCount(), 0, st);
+  w.d_pair_out.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * kPairOut, 0, st);
+  TwoStageArgs a;
+  a.frames = w.d_frames.ptr;
+  a.pc = w.d_pc.ptr;
+  a.schur_table = w.d_schur_table.ptr;
+  a.partials = w.d_partials.ptr;
+  a.pair_first_block = w.d_pair_first.ptr;
+  a.pair_num_blocks = w.d_pair_count.ptr;
+  a.ctrl = ctrl;
+  a.schur_partials = w.d_schur_partials.ptr;
+  a.pair_out = w.d_pair_out.ptr;
+  a.F = F;
+  a.n_chunks = n_chunks;
+  a.chunks_per_wg = chunks_per_wg;
+  a.n_schur_wgs = n_wgs;
+  a.ublk_parity = ublk_parity;
+  CombineArgs c;
+  c.pc = w.d_pc.ptr;
+  c.schur_partials = w.d_schur_partials.ptr;
+  c.pair_out = w.d_pair_out.ptr;
+  c.ctrl = ctrl;
+  c.lambda = lambda;
+  c.comb = w.d_reduce.ptr;
+  c.F = F;
+  c.n_schur_wgs = n_wgs;
+  const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);
+  timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
+    schurTwoStageKernel<<<n_wgs + F * F, kSchurThreads, std::max(schurSmemBytes(K), pair_smem), st>>>(a);
+    combineSystemKernel<<<static_cast<unsigned>((w.combCount() + 255) / 256), 256, 0, st>>>(c);
+  });
+  HIP_CHECK(hipGetLastError());
+}
+
 /** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
 void launchSolveCombined(W &w, double lambda, LmControl *ctrl) {
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel), w.sr.device, 150 * 1024);
@@ -1038,7 +1088,20 @@ void lmSolveFusedEnqueue(W &w) {
     fr.ctrl_out = cout;
     fr.prm = prm;
     fr.combined = true;  // (the sharded accumulate pass reads lambda from the incoming control block: constant, decrease = increase = 1)
-    if (w.allreduce) {
+    if (w.twoStage() && r + 1 < rounds) {
+      // large windows / deterministic mode: the combined system without atomics (pba_schur_two_stage.hpp)
+      if (w.allreduce) {
+        // landmark shards: local partial systems -> ordered sum -> ONE collective over [system | energy scalars] -> decision
+        launchTwoStage(w, cin, fr.ublk_parity, 0.0);
+        sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.combCount(), cin);
+        HIP_CHECK(hipGetLastError());
+        allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4);
+        launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
+      } else {
+        launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);  // decision + accept / reject from the sweep's energy
+        launchTwoStage(w, cout, fr.ublk_parity, 0.0);                    // system at the accepted state, damped with the new lambda
+      }
+    } else if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
@@ -2332,6 +2395,13 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
   });
 }
 
+int dsopp_hip_window_set_deterministic(dsopp_hip_window *w, int enable) {
+  return guarded([&] {
+    if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
+    w->deterministic = enable != 0;
+  });
+}
+
 int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm) {
   int rank = 0, world = 1;
   if (comm) {
@@ -2393,6 +2463,10 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
           break;
         }
         case DSOPP_HIP_KERNEL_SCHUR: {  // as the fused loop launches it (combined system), without the decision prologue
+          if (w->twoStage()) {
+            launchTwoStage(*w, nullptr, 0, 1e-5);
+            break;
+          }
           FusedReduce fr;
           fr.ublk_parity = 0;
           fr.ctrl_out = nullptr;

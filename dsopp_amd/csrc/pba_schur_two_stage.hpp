@@ -1,0 +1,306 @@
+// Two-stage, order-deterministic build of the combined system (pba_solve_kernels.hpp: ReduceSchurArgs::comb) for large windows.
+//
+// reduceSchurKernel accumulates H_schur with fp64 atomics: every 64-landmark workgroup adds its K x K contribution to the same
+// ~K^2/2 addresses.  At 7 frames / 2000 landmarks that is 35 workgroups and the cheapest way to sum; at 12 frames / 50 000
+// landmarks it is 782 workgroups x 4.7 k atomics onto 4.7 k addresses (114 us per iteration, the second largest kernel of that
+// window) and the result depends on the arrival order.  Here:
+//   stage 1  schurTwoStageKernel: a workgroup takes SEVERAL 64-landmark chunks, keeps its MFMA tiles in registers across them and
+//            writes ONE partial system, without atomics; the frame-pair workgroups write their derived blocks to per-pair slots;
+//   stage 2  combineSystemKernel: one thread per entry of the combined system sums the partial systems and the pair blocks in a
+//            fixed order, applies the damping and writes the entry once.
+// Same arithmetic per landmark as reduceSchurKernel (hessian_block_evaluation.hpp:96-164,169-236); the LM decision runs in
+// decideApplyKernel in front (the kernel sequence of the landmark-sharded windows).  Selected when a window has more 64-landmark
+// chunks than kTwoStageMinChunks, or always with dsopp_hip_window_set_deterministic.
+#pragma once
+#include "pba_solve_kernels.hpp"
+
+namespace dsopp_hip {
+
+constexpr int kPairOut = 208;  // per ordered frame pair: T^T G T [64] | G T [64] | T^T q [8] | G [64] | q [8]
+constexpr int kTwoStageMinChunks = 96;
+constexpr int kMaxTilesPerWave = 5;  // K <= 128: 36 upper-triangular 16 x 16 tiles over 8 waves
+
+struct TwoStageArgs {
+  const FrameDev *frames;
+  const PairConst *pc;
+  const SchurBlock *schur_table;  // one entry per 64-landmark chunk
+  const double *partials;         // the sweep's per-workgroup sums (G, q per pair block)
+  const int *pair_first_block, *pair_num_blocks;
+  const LmControl *ctrl;          // nullable; the launch is a no-op when the loop has ended
+  double *schur_partials;         // [n_schur_wgs][combCount]: lower-packed blocks | b
+  double *pair_out;               // [kMaxFrames * kMaxFrames][kPairOut]
+  int F;
+  int n_chunks, chunks_per_wg, n_schur_wgs;
+  int ublk_parity;
+};
+
+__global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (a.ctrl && !a.ctrl->active) return;
+  const int F = a.F, K = kBlk * F;
+  if (static_cast<int>(blockIdx.x) >= a.n_schur_wgs) {
+    // ---- frame pair: deterministic sum of the sweep's partials, derived blocks, one slot per pair (no atomics)
+    const int p = blockIdx.x - a.n_schur_wgs;
+    const int r = p / F, t = p % F, pi = r * kMaxFrames + t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const PairConst &P = a.pc[pi];
+    const int valid = P.valid;
+    double *lds = reinterpret_cast<double *>(smem_raw);  // [48] G/q + [64] scratch + [kPairBlk] derived + [8][48] wave sums
+    double *wsum = lds + 48 + 64 + kPairBlk;
+    {
+      double sw = 0;
+      if (valid && lane < 44) {
+        const int first = a.pair_first_block[pi], cnt = a.pair_num_blocks[pi];
+        const double *src = a.partials + static_cast<size_t>(first) * kPartial + lane;
+        int b = wave;
+        for (; b + 8 < cnt; b += 16) sw += src[static_cast<size_t>(b) * kPartial] + src[static_cast<size_t>(b + 8) * kPartial];
+        if (b < cnt) sw += src[static_cast<size_t>(b) * kPartial];
+      }
+      if (lane < 48) wsum[wave * 48 + lane] = sw;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64 || !valid) return;
+    double s = 0;
+    if (lane < 44) {
+#pragma unroll
+      for (int w = 0; w < kSchurThreads / 64; ++w) s += wsum[w * 48 + lane];
+    }
+    if (lane < 48) lds[lane] = s;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    double *drv = lds + 48 + 64;
+    derivePairBlocks(lds, P, drv, lds + 48, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    double *out = a.pair_out + static_cast<size_t>(pi) * kPairOut;
+    out[lane] = drv[lane];
+    out[64 + lane] = drv[64 + lane];
+    out[136 + lane] = lds[symIdx(lane >> 3, lane & 7)];
+    if (lane < 8) {
+      out[128 + lane] = drv[128 + lane];
+      out[200 + lane] = lds[36 + lane];
+    }
+    return;
+  }
+  // ---- Schur workgroup: chunks [first, last) of 64 landmarks each, tiles kept in registers across them
+  const int Kp = (K + 15) & ~15;
+  const int stride = schurRowStride(Kp);
+  double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
+  double *wgt = hrow + kSchurLandmarks * stride;        // inv per landmark (0 = excluded)
+  double *wbd = wgt + kSchurLandmarks;                  // inv * bd
+  double *Tm = wbd + kSchurLandmarks;                   // [F][40]: Adj (36), s0 of the chunk's frame towards every target
+  const bool bd_in_pad = K < Kp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = Kp >> 4, n_tiles = nt * (nt + 1) / 2;
+  const int li = lane & 15, lk = lane >> 4;
+  f64x4 acc[kMaxTilesPerWave];
+#pragma unroll
+  for (int q = 0; q < kMaxTilesPerWave; ++q) acc[q] = f64x4{0, 0, 0, 0};
+  double bs_acc = 0;  // b_schur entry threadIdx.x when the tiles have no spare column
+  const int first_chunk = blockIdx.x * a.chunks_per_wg, last_chunk = min(first_chunk + a.chunks_per_wg, a.n_chunks);
+  int staged_r = -1;
+  for (int chunk = first_chunk; chunk < last_chunk; ++chunk) {
+    const SchurBlock &be = a.schur_table[chunk];
+    const int r = be.r;
+    const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int i = be.offset + l;
+    const unsigned conn = be.conn_mask & ~(1u << r);
+    const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+    const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
+    __syncthreads();  // the previous chunk's tiles have been read
+    for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;  // pad columns must be 0
+    if (r != staged_r) {
+      for (int e = threadIdx.x; e < F * 37; e += kSchurThreads) {
+        const int t = e / 37, c = e - 37 * t;
+        const PairConst &P = a.pc[r * kMaxFrames + t];
+        Tm[t * 40 + c] = c < 36 ? P.Adj[c] : P.s0;
+      }
+      staged_r = r;
+    }
+    bool take = false;
+    uint8_t flg = 0;
+    if (i < be.n) {
+      flg = be.flags[i];
+      take = (flg & kFlagMarginalized) == 0;
+    }
+    __syncthreads();
+    {
+      // phase 1 (as reduceSchurKernel): 8 threads per landmark, thread `sub` owns the targets t = sub, sub + 8, ...
+      double hr[kBlk];
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) hr[c] = 0;
+      double hdd = 0, bd = 0;
+      double *row = hrow + l * stride;
+      if (take) {
+        for (int t = sub; t < F; t += 8) {
+          if (!((conn >> t) & 1u)) continue;
+          double ht[kUblk];
+          const double *src = ubase + t * plane;
+#pragma unroll
+          for (int c = 0; c < kUblk; ++c) ht[c] = src[c];
+          const double *Tt = Tm + t * 40;
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) row[kBlk * t + c] = ht[c];
+          hdd += ht[8];
+          bd += ht[9];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += Tt[6 * k + c] * ht[k];
+            hr[c] -= s;
+          }
+          hr[6] -= ht[6];
+          hr[7] -= Tt[36] * ht[7];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kBlk; ++c) hr[c] = sum8(hr[c]);
+      hdd = sum8(hdd);
+      bd = sum8(bd);
+      if (sub == 0) {
+        double inv = 0, ibd = 0;
+        if (take) {
+          double *dst = const_cast<double *>(ubase) + r * plane;
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) {
+            row[kBlk * r + c] = hr[c];
+            dst[c] = hr[c];
+          }
+          be.b_d[i] = bd;
+          const double kIdepthNullSpaceThreshold = 1e-15;
+          if (hdd > kIdepthNullSpaceThreshold) {
+            inv = 1.0 / hdd;
+            be.inv_hdd[i] = inv;
+            flg &= static_cast<uint8_t>(~kFlagIllConditioned);
+            ibd = inv * bd;
+          } else {
+            flg |= kFlagIllConditioned;
+          }
+          be.flags[i] = flg;
+        }
+        wgt[l] = inv;
+        wbd[l] = ibd;
+        if (bd_in_pad && take) row[K] = bd;
+      }
+    }
+    __syncthreads();
+    // phase 2: this wave's tiles += A^T W A over the chunk (v_mfma_f64_16x16x4_f64), operands of a tile requested up front
+    int q = 0;
+    for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
+      int ti = 0, rem = tile;
+      while (rem >= nt - ti) {
+        rem -= nt - ti;
+        ++ti;
+      }
+      const int tj = ti + rem;
+      const double *pa = hrow + lk * stride + 16 * ti + li;
+      const double *pb = hrow + lk * stride + 16 * tj + li;
+      constexpr int kSteps = kSchurLandmarks / 4;
+      double av[kSteps], bv[kSteps], wv[kSteps];
+#pragma unroll
+      for (int s4 = 0; s4 < kSteps; ++s4) {
+        wv[s4] = wgt[4 * s4 + lk];
+        av[s4] = pa[4 * s4 * stride];
+        bv[s4] = pb[4 * s4 * stride];
+      }
+      f64x4 c4 = acc[0];
+#pragma unroll
+      for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
+#pragma unroll
+      for (int s4 = 0; s4 < kSteps; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[s4] * av[s4], bv[s4], c4, 0, 0, 0);
+#pragma unroll
+      for (int qq = 0; qq < kMaxTilesPerWave; ++qq) acc[qq] = (qq == q) ? c4 : acc[qq];
+    }
+    if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) {
+      double s = 0;
+#pragma unroll 1
+      for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + threadIdx.x];
+      bs_acc += s;
+    }
+  }
+  // ---- this workgroup's partial system, written once: lower-packed blocks (entry (col, row) of every upper-triangular tile entry)
+  double *out = a.schur_partials + static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(combBlockCount(F)) * 64 + K);
+  double *out_b = out + combBlockCount(F) * 64;
+  int q = 0;
+  for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
+    int ti = 0, rem = tile;
+    while (rem >= nt - ti) {
+      rem -= nt - ti;
+      ++ti;
+    }
+    const int tj = ti + rem;
+    f64x4 c4 = acc[0];
+#pragma unroll
+    for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
+    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 16 * ti + lk + 4 * reg, col = 16 * tj + li;
+      if (row < K && col < K && col >= row) out[combIndex(col, row)] = c4[reg];
+      if (bd_in_pad && row < K && col == K) out_b[row] = c4[reg];
+    }
+  }
+  if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) out_b[threadIdx.x] = bs_acc;
+}
+
+struct CombineArgs {
+  const PairConst *pc;
+  const double *schur_partials, *pair_out;
+  const LmControl *ctrl;  // nullable
+  double lambda;          // when ctrl is null
+  double *comb;
+  int F, n_schur_wgs;
+};
+
+/** stage 2: entry e of the combined system = (pair blocks, fixed order)(1 + lambda on the diagonal) - (sum of the partial Schur
+ *  systems, workgroup order) / (1 + lambda).  One thread per entry; every entry is written exactly once. */
+__global__ void __launch_bounds__(256) combineSystemKernel(CombineArgs a) {
+  if (a.ctrl && !a.ctrl->active) return;
+  const int F = a.F, K = kBlk * F;
+  const int n_block_entries = combBlockCount(F) * 64, count = n_block_entries + K;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= count) return;
+  const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
+  const double sc = -1.0 / (1.0 + lam);
+  double pair = 0;
+  bool has_schur = true;
+  if (e < n_block_entries) {
+    int bi = 0, b = e >> 6;
+    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+    const int bj = b - bi * (bi + 1) / 2;
+    const int i = (e >> 3) & 7, j = e & 7;
+    if (bi == bj) {
+      const int f = bi;
+      for (int t = 0; t < F; ++t)  // f as reference: T^T G T
+        if (t != f && a.pc[f * kMaxFrames + t].valid) pair += a.pair_out[static_cast<size_t>(f * kMaxFrames + t) * kPairOut + 8 * i + j];
+      for (int r = 0; r < F; ++r)  // f as target: G
+        if (r != f && a.pc[r * kMaxFrames + f].valid) pair += a.pair_out[static_cast<size_t>(r * kMaxFrames + f) * kPairOut + 136 + 8 * i + j];
+      if (i == j) pair *= 1.0 + lam;
+      has_schur = j <= i;  // the partial systems hold the lower triangle only
+    } else {
+      // block (a, b), a > b: H_rt = -(G T)^T of the pair (r = a, t = b), H_tr = -G T of the pair (r = b, t = a)
+      if (a.pc[bi * kMaxFrames + bj].valid) pair -= a.pair_out[static_cast<size_t>(bi * kMaxFrames + bj) * kPairOut + 64 + 8 * j + i];
+      if (a.pc[bj * kMaxFrames + bi].valid) pair -= a.pair_out[static_cast<size_t>(bj * kMaxFrames + bi) * kPairOut + 64 + 8 * i + j];
+    }
+  } else {
+    const int c = e - n_block_entries, f = c >> 3, i = c & 7;
+    for (int t = 0; t < F; ++t)
+      if (t != f && a.pc[f * kMaxFrames + t].valid) pair += a.pair_out[static_cast<size_t>(f * kMaxFrames + t) * kPairOut + 128 + i];
+    for (int r = 0; r < F; ++r)
+      if (r != f && a.pc[r * kMaxFrames + f].valid) pair -= a.pair_out[static_cast<size_t>(r * kMaxFrames + f) * kPairOut + 200 + i];
+  }
+  double s0 = 0, s1 = 0;
+  if (has_schur) {
+    const double *src = a.schur_partials + e;
+    int w = 0;
+    for (; w + 1 < a.n_schur_wgs; w += 2) {
+      s0 += src[static_cast<size_t>(w) * count];
+      s1 += src[static_cast<size_t>(w + 1) * count];
+    }
+    if (w < a.n_schur_wgs) s0 += src[static_cast<size_t>(w) * count];
+  }
+  a.comb[e] = pair + sc * (s0 + s1);
+}
+
+}  // namespace dsopp_hip

@@ -140,11 +140,12 @@ def test_native_communicator_single_rank():
     comm.allreduce(t.data_ptr(), t.numel(), st.cuda_stream)
     st.synchronize()
     assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
-    for lm_mode in (0, 1):
+    for lm_mode, deterministic in ((0, False), (1, False), (0, True)):   # (deterministic: the two-stage build under the collective)
         g = capi.HipWindow(capi.default_pba_options())
         syn.load_window(g, win)
         g.set_comm(comm)
         g.set_lm_mode(lm_mode)
+        g.set_deterministic(deterministic)
         e, it, nv = g.solve()
         (e0, it0, nv0), poses0 = ref
         assert (it, nv) == (it0, nv0) and abs(e - e0) <= 1e-7 * abs(e0)
