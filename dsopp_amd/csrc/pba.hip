@@ -250,7 +250,7 @@ void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   f.relative_baseline.reserve(cap, keep, st);
   f.n_inliers.reserve(cap, keep, st);
   f.dflags.reserve(cap, keep, st);
-  f.ublk.reserve(2 * static_cast<size_t>(kMaxFrames) * cap * kUblk, 0, st);  // double-buffered (fused LM loop)
+  f.ublk.reserve(2 * static_cast<size_t>(kMaxFrames) * ublkPlane(cap), 0, st);  // double-buffered (fused LM loop)
   for (auto &kv : f.residuals) {
     ResidualTable &rt = *kv.second;
     const size_t k = static_cast<size_t>(rt.n);
@@ -477,7 +477,7 @@ void syncTopology(W &w) {
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
-  w.d_scalars.reserve(16, 0, st);
+  w.d_scalars.reserve(16 + 4 * kScalarGroups, 0, st);
   w.sr.sync();  // host staging vectors go out of scope
   w.topology_dirty = false;
   w.pair_valid = false;
@@ -566,6 +566,7 @@ struct SweepExtras {
   const int *run_flag = nullptr;
   bool fused_lin_backsub = false;
   bool combined = false;  // the following reduction builds the combined system: only that much has to be zeroed
+  bool external_backsub = false;  // calculateIdepths ran in backsubKernel in front of this sweep (large windows)
 };
 
 template <typename S>
@@ -588,6 +589,7 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.ublk_write = ex.ublk_write;
   prm.gate_on_pending = ex.gate_on_pending ? 1 : 0;
   prm.run_flag = ex.run_flag;
+  prm.external_backsub = ex.external_backsub ? 1 : 0;
   prm.dbg = (w.dbg_sweep && lin == w.dbg_sweep_lin) ? w.dbg_sweep : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
@@ -661,6 +663,7 @@ struct FusedReduce {
   LmParams prm;
   bool combined = false;   // emit the combined block-packed system instead of H_pp / H_schur (fused loop)
   double comb_lambda = 0;  // its damping when no control block is given
+  const double *scalars = nullptr;  // decide-only launches: where the (group) sums of the sweep's scalars are
 };
 
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
@@ -697,6 +700,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.total_blocks = a.n_schur_blocks + F * F;
   a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + reduce_count : nullptr;
   if (fused) a.prm = fused->prm;
+  if (fused && fused->scalars) a.scalars = fused->scalars;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 24 : nullptr;
   const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
   if (mode == ReduceMode::kDecideOnly) {
@@ -777,10 +781,12 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda)
   hipStream_t st = w.sr.stream;
   ensureDynamicLds(reinterpret_cast<const void *>(schurTwoStageKernel), w.sr.device, 96 * 1024);
   const int n_chunks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
-  // as many workgroups as the chip has compute units (one fits per unit: 90 KB of LDS), each taking its share of the chunks
-  const int chunks_per_wg = std::max(1, (n_chunks + 255) / 256);
+  // two workgroups fit per compute unit (64 landmarks x K doubles of LDS each): twice as many workgroups as the chip has units,
+  // each taking its share of the chunks
+  static const int chunks_override = std::getenv("DSOPP_HIP_SCHUR_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_SCHUR_CHUNKS")) : 0;  // tuning aid
+  const int chunks_per_wg = chunks_override > 0 ? chunks_override : std::max(1, (n_chunks + 511) / 512);
   const int n_wgs = (n_chunks + chunks_per_wg - 1) / chunks_per_wg;
-  w.d_schur_partials.reserve(std::max<size_t>(1, static_cast<size_t>(n_wgs)) * w.combCount(), 0, st);
+  w.d_schur_partials.reserve(std::max<size_t>(1, static_cast<size_t>(n_wgs)) * static_cast<size_t>(twoStagePartialCount(F)), 0, st);
   w.d_pair_out.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames * kPairOut, 0, st);
   TwoStageArgs a;
   a.frames = w.d_frames.ptr;
@@ -809,7 +815,7 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda)
   const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     schurTwoStageKernel<<<n_wgs + F * F, kSchurThreads, std::max(schurSmemBytes(K), pair_smem), st>>>(a);
-    combineSystemKernel<<<static_cast<unsigned>((w.combCount() + 255) / 256), 256, 0, st>>>(c);
+    combineSystemKernel<<<static_cast<unsigned>((twoStagePartialCount(F) + kCombineEntries - 1) / kCombineEntries), kCombineEntries * kCombineSlices, 0, st>>>(c);
   });
   HIP_CHECK(hipGetLastError());
 }
@@ -843,10 +849,11 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl) {
   HIP_CHECK(hipGetLastError());
 }
 
-void launchBacksub(W &w, double lambda, const LmControl *ctrl) {
+void launchBacksub(W &w, double lambda, const LmControl *ctrl, int ublk_parity = 0, bool gate_on_pending = false) {
   if (!w.opt.optimize_idepths || !w.n_schur_blocks) return;
   timedLaunch(w, DSOPP_HIP_KERNEL_BACKSUB, [&] {
-    backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F(), ctrl);
+    backsubKernel<<<w.n_schur_blocks, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.d_step.ptr, lambda, w.F(), ctrl,
+                                                                         ublk_parity, gate_on_pending ? 1 : 0);
   });
   HIP_CHECK(hipGetLastError());
 }
@@ -1082,7 +1089,17 @@ void lmSolveFusedEnqueue(W &w) {
     ex.fused_lin_backsub = true;
     ex.combined = true;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
-    launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
+    if (w.n_schur_blocks > kTwoStageMinChunks && r + 1 < rounds) {
+      // large windows: the back-substitution fused into the sweep re-reads a landmark's whole Schur row for every one of its
+      // (landmark, target) items — (F - 1) x the traffic (12 frames / 50 000 landmarks: 196 against 131 us).  One kernel per
+      // landmark in front of the sweep instead.
+      launchBacksub(w, 0.0, cin, ex.ublk_read, /*gate_on_pending=*/true);
+      ex.fused_lin_backsub = false;
+      ex.external_backsub = true;
+      launchSweep(w, true, true, false, cin, false, 0.0, ex);
+    } else {
+      launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
+    }
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
@@ -1090,14 +1107,20 @@ void lmSolveFusedEnqueue(W &w) {
     fr.combined = true;  // (the sharded accumulate pass reads lambda from the incoming control block: constant, decrease = increase = 1)
     if (w.twoStage() && r + 1 < rounds) {
       // large windows / deterministic mode: the combined system without atomics (pba_schur_two_stage.hpp)
+      // the sweep's energy scalars in 64 fixed groups first: with tens of thousands of sweep blocks no workgroup of the
+      // decision kernel should walk them all by itself
+      sweepScalarGroupsKernel<<<kScalarGroups, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr + 16, cin);
+      HIP_CHECK(hipGetLastError());
       if (w.allreduce) {
         // landmark shards: local partial systems -> ordered sum -> ONE collective over [system | energy scalars] -> decision
         launchTwoStage(w, cin, fr.ublk_parity, 0.0);
-        sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.combCount(), cin);
+        sweepScalarGroupsFinalKernel<<<1, 64, 0, st>>>(w.d_scalars.ptr + 16, w.d_reduce.ptr + w.combCount());
         HIP_CHECK(hipGetLastError());
         allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4);
         launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
       } else {
+        fr.prm.use_reduced_scalars = 2;
+        fr.scalars = w.d_scalars.ptr + 16;
         launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);  // decision + accept / reject from the sweep's energy
         launchTwoStage(w, cout, fr.ublk_parity, 0.0);                    // system at the accepted state, damped with the new lambda
       }
@@ -2104,7 +2127,7 @@ int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double
       const int F = w->F(), K = w->K();
       std::vector<double> blk(static_cast<size_t>(f.cap) * kUblk);
       for (int t = 0; t < F; ++t) {
-        f.ublk.download(blk.data(), n * kUblk, static_cast<size_t>(t) * f.cap * kUblk, st);
+        f.ublk.download(blk.data(), n * kUblk, static_cast<size_t>(t) * ublkPlane(f.cap), st);
         w->sr.sync();
         for (size_t i = 0; i < n; ++i)
           for (int a = 0; a < kBlk; ++a) hpib[i * K + static_cast<size_t>(kBlk * t + a)] = blk[i * kUblk + static_cast<size_t>(a)];

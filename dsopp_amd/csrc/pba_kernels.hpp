@@ -237,6 +237,8 @@ struct SweepParams {
   int ublk_read, ublk_write;  // parity of the double-buffered Schur rows read by BACKSUB / written by LIN (0, 0 outside the fused loop)
   int gate_on_pending;        // fused loop: BACKSUB only when a candidate step is pending (LmControl::pending)
   const int *run_flag;        // nullable: launch is a no-op unless *run_flag != 0 (closing evaluation after a rejected step)
+  int external_backsub;       // large windows: calculateIdepths ran as its own kernel (once per landmark instead of once per
+                              // (landmark, target) item); this sweep still records the step norms
   long long *dbg;  // nullable tuning aid: per-phase wall_clock64 stamps of workgroup 0 / max end stamp
 };
 // Phase stamps (wall_clock64) are a tuning aid: compiled in only with -DDSOPP_HIP_STAMPS (scripts/dbg_*.py); the release
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   double hrow[kBlk], srow[kBlk];  // BACKSUB: Schur row block / pose step block of this lane's frame slot tt = k
 #pragma unroll
   for (int c = 0; c < kBlk; ++c) hrow[c] = srow[c] = 0;
-  const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+  const size_t plane = ublkPlane(be.cap);
   if (inb) {
     flg = be.flags[i];
     u = static_cast<S>(be.uv[2 * i]);
@@ -572,7 +574,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       acc[44] = energy;
       acc[45] = energy > 0 ? 1.0 : 0.0;
     }
-    if ((!LIN || BACKSUB) && be.owns_landmark_sums) {
+    if ((!LIN || BACKSUB || prm.external_backsub) && be.owns_landmark_sums) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
       // (the opening round of the fused loop has no step yet: slot 46 carries sum idepth^2, the initial state norm)
       acc[46] = (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;

@@ -20,6 +20,12 @@ constexpr int kPairOut = 208;  // per ordered frame pair: T^T G T [64] | G T [64
 constexpr int kTwoStageMinChunks = 96;
 constexpr int kMaxTilesPerWave = 5;  // K <= 128: 36 upper-triangular 16 x 16 tiles over 8 waves
 
+/** doubles of one partial Schur system: the upper-triangular 16 x 16 tiles in MFMA layout + b_schur */
+__host__ __device__ inline int twoStagePartialCount(int F) {
+  const int K = kBlk * F, nt = ((K + 15) & ~15) >> 4;
+  return nt * (nt + 1) / 2 * 256 + K;
+}
+
 struct TwoStageArgs {
   const FrameDev *frames;
   const PairConst *pc;
@@ -27,14 +33,14 @@ struct TwoStageArgs {
   const double *partials;         // the sweep's per-workgroup sums (G, q per pair block)
   const int *pair_first_block, *pair_num_blocks;
   const LmControl *ctrl;          // nullable; the launch is a no-op when the loop has ended
-  double *schur_partials;         // [n_schur_wgs][combCount]: lower-packed blocks | b
+  double *schur_partials;         // [n_schur_wgs][twoStagePartialCount(F)]: tiles in MFMA layout | b
   double *pair_out;               // [kMaxFrames * kMaxFrames][kPairOut]
   int F;
   int n_chunks, chunks_per_wg, n_schur_wgs;
   int ublk_parity;
 };
 
-__global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArgs a) {
+__global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStageArgs a) {  // 2 workgroups of 8 waves per compute unit
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (a.ctrl && !a.ctrl->active) return;
   const int F = a.F, K = kBlk * F;
@@ -59,7 +65,15 @@ __global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArg
       if (lane < 48) wsum[wave * 48 + lane] = sw;
     }
     __syncthreads();
-    if (threadIdx.x >= 64 || !valid) return;
+    if (threadIdx.x >= 64) return;
+    if (!valid) {
+      // no connection r -> t: the slot is zeroed, so that the ordered sums of stage 2 can add every slot unconditionally
+      if (r != t) {
+        double *out = a.pair_out + static_cast<size_t>(pi) * kPairOut;
+        for (int k = lane; k < kPairOut; k += 64) out[k] = 0;
+      }
+      return;
+    }
     double s = 0;
     if (lane < 44) {
 #pragma unroll
@@ -105,7 +119,7 @@ __global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArg
     const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const int i = be.offset + l;
     const unsigned conn = be.conn_mask & ~(1u << r);
-    const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+    const size_t plane = ublkPlane(be.cap);
     const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
     __syncthreads();  // the previous chunk's tiles have been read
     for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;  // pad columns must be 0
@@ -196,19 +210,25 @@ __global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArg
       const int tj = ti + rem;
       const double *pa = hrow + lk * stride + 16 * ti + li;
       const double *pb = hrow + lk * stride + 16 * tj + li;
-      constexpr int kSteps = kSchurLandmarks / 4;
-      double av[kSteps], bv[kSteps], wv[kSteps];
-#pragma unroll
-      for (int s4 = 0; s4 < kSteps; ++s4) {
-        wv[s4] = wgt[4 * s4 + lk];
-        av[s4] = pa[4 * s4 * stride];
-        bv[s4] = pb[4 * s4 * stride];
-      }
+      // operands in two batches of 8 steps (24 words in flight): with all 16 steps preloaded the kernel needs 168 registers and
+      // only ONE workgroup fits per compute unit; at <= 128 two fit, and the second hides the first one's memory round trips
+      constexpr int kHalf = kSchurLandmarks / 8;
       f64x4 c4 = acc[0];
 #pragma unroll
       for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
 #pragma unroll
-      for (int s4 = 0; s4 < kSteps; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[s4] * av[s4], bv[s4], c4, 0, 0, 0);
+      for (int half = 0; half < 2; ++half) {
+        double av[kHalf], bv[kHalf], wv[kHalf];
+#pragma unroll
+        for (int s4 = 0; s4 < kHalf; ++s4) {
+          const int st4 = 4 * (half * kHalf + s4);
+          wv[s4] = wgt[st4 + lk];
+          av[s4] = pa[st4 * stride];
+          bv[s4] = pb[st4 * stride];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < kHalf; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[s4] * av[s4], bv[s4], c4, 0, 0, 0);
+      }
 #pragma unroll
       for (int qq = 0; qq < kMaxTilesPerWave; ++qq) acc[qq] = (qq == q) ? c4 : acc[qq];
     }
@@ -219,29 +239,18 @@ __global__ void __launch_bounds__(kSchurThreads) schurTwoStageKernel(TwoStageArg
       bs_acc += s;
     }
   }
-  // ---- this workgroup's partial system, written once: lower-packed blocks (entry (col, row) of every upper-triangular tile entry)
-  double *out = a.schur_partials + static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(combBlockCount(F)) * 64 + K);
-  double *out_b = out + combBlockCount(F) * 64;
+  // ---- this workgroup's partial system, written once, in the MFMA's own layout: [tile][reg][lane] (coalesced 512-byte stores
+  // per wave), then K entries of b_schur when the tiles have no spare column
+  double *out = a.schur_partials + static_cast<size_t>(blockIdx.x) * twoStagePartialCount(F);
   int q = 0;
   for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
-    int ti = 0, rem = tile;
-    while (rem >= nt - ti) {
-      rem -= nt - ti;
-      ++ti;
-    }
-    const int tj = ti + rem;
     f64x4 c4 = acc[0];
 #pragma unroll
     for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
-    // C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = 16 * ti + lk + 4 * reg, col = 16 * tj + li;
-      if (row < K && col < K && col >= row) out[combIndex(col, row)] = c4[reg];
-      if (bd_in_pad && row < K && col == K) out_b[row] = c4[reg];
-    }
+    for (int reg = 0; reg < 4; ++reg) out[static_cast<size_t>(tile) * 256 + reg * 64 + lane] = c4[reg];
   }
-  if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) out_b[threadIdx.x] = bs_acc;
+  if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) out[static_cast<size_t>(n_tiles) * 256 + threadIdx.x] = bs_acc;
 }
 
 struct CombineArgs {
@@ -253,54 +262,110 @@ struct CombineArgs {
   int F, n_schur_wgs;
 };
 
-/** stage 2: entry e of the combined system = (pair blocks, fixed order)(1 + lambda on the diagonal) - (sum of the partial Schur
- *  systems, workgroup order) / (1 + lambda).  One thread per entry; every entry is written exactly once. */
-__global__ void __launch_bounds__(256) combineSystemKernel(CombineArgs a) {
+constexpr int kCombineEntries = 32, kCombineSlices = 8;  // a workgroup of 256 threads: 32 entries x 8 slices of the partial systems
+
+/** pair-block part of entry (row R, col C), R >= C, of the combined system (without the damping of the diagonal).  Slots of
+ *  unconnected pairs hold zeros (stage 1), so every slot is added, in frame order, with all loads in flight together. */
+__device__ inline double pairEntry(const CombineArgs &a, int R, int C) {
+  const int F = a.F, bi = R >> 3, bj = C >> 3, i = R & 7, j = C & 7;
+  if (bi == bj) {
+    const int f = bi;
+    double v[2 * kMaxFrames];
+#pragma unroll
+    for (int t = 0; t < kMaxFrames; ++t) {
+      const int tc = t < F ? t : 0;
+      v[t] = a.pair_out[static_cast<size_t>(f * kMaxFrames + tc) * kPairOut + 8 * i + j];                     // f as reference: T^T G T
+      v[kMaxFrames + t] = a.pair_out[static_cast<size_t>(tc * kMaxFrames + f) * kPairOut + 136 + 8 * i + j];  // f as target: G
+    }
+    double pair = 0;
+#pragma unroll
+    for (int t = 0; t < kMaxFrames; ++t) pair += (t < F && t != f) ? v[t] : 0.0;
+#pragma unroll
+    for (int t = 0; t < kMaxFrames; ++t) pair += (t < F && t != f) ? v[kMaxFrames + t] : 0.0;
+    return pair;
+  }
+  // block (a, b), a > b: H_rt = -(G T)^T of the pair (r = a, t = b), H_tr = -G T of the pair (r = b, t = a)
+  const double p0 = a.pair_out[static_cast<size_t>(bi * kMaxFrames + bj) * kPairOut + 64 + 8 * j + i];
+  const double p1 = a.pair_out[static_cast<size_t>(bj * kMaxFrames + bi) * kPairOut + 64 + 8 * i + j];
+  return -p0 - p1;
+}
+__device__ inline double pairRhs(const CombineArgs &a, int c) {
+  const int F = a.F, f = c >> 3, i = c & 7;
+  double v[2 * kMaxFrames];
+#pragma unroll
+  for (int t = 0; t < kMaxFrames; ++t) {
+    const int tc = t < F ? t : 0;
+    v[t] = a.pair_out[static_cast<size_t>(f * kMaxFrames + tc) * kPairOut + 128 + i];
+    v[kMaxFrames + t] = a.pair_out[static_cast<size_t>(tc * kMaxFrames + f) * kPairOut + 200 + i];
+  }
+  double pair = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxFrames; ++t) pair += (t < F && t != f) ? v[t] : 0.0;
+#pragma unroll
+  for (int t = 0; t < kMaxFrames; ++t) pair -= (t < F && t != f) ? v[kMaxFrames + t] : 0.0;
+  return pair;
+}
+
+/** stage 2: one thread group per word of the partial systems (coalesced reads in the MFMA tile layout): 32 words per workgroup,
+ *  8 threads per word — thread `slice` adds the partial systems slice, slice + 8, ... with eight loads in flight (one thread
+ *  walking all partial systems of a word is a chain of L2 round trips), the eight slice sums are then added in slice order: a
+ *  fixed order for a given window, hence bit-reproducible.  The word's owner maps it to its entry (row >= col) of the combined
+ *  system, adds the pair blocks in fixed order and the damping, and writes the entry — every entry exactly once. */
+__global__ void __launch_bounds__(kCombineEntries * kCombineSlices) combineSystemKernel(CombineArgs a) {
+  __shared__ double part[kCombineSlices][kCombineEntries];
   if (a.ctrl && !a.ctrl->active) return;
-  const int F = a.F, K = kBlk * F;
-  const int n_block_entries = combBlockCount(F) * 64, count = n_block_entries + K;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= count) return;
+  const int F = a.F, K = kBlk * F, Kp = (K + 15) & ~15, nt = Kp >> 4, n_tiles = nt * (nt + 1) / 2;
+  const bool bd_in_pad = K < Kp;
+  const int count = twoStagePartialCount(F);
+  const int le = threadIdx.x & (kCombineEntries - 1), slice = threadIdx.x / kCombineEntries;
+  const int e = blockIdx.x * kCombineEntries + le;
+  // which entry of the system is word e?  tile words: row = 16 ti + (lane >> 4) + 4 reg, col = 16 tj + (lane & 15), kept for col >= row
+  int row = -1, col = -1;  // (row <= col: the symmetric entry (col, row) of the lower-packed system); col == K: b_schur[row]
+  if (e < n_tiles * 256) {
+    int ti = 0, rem = e >> 8;
+    while (rem >= nt - ti) {
+      rem -= nt - ti;
+      ++ti;
+    }
+    const int tj = ti + rem, reg = (e >> 6) & 3, lane = e & 63;
+    const int r0 = 16 * ti + (lane >> 4) + 4 * reg, c0 = 16 * tj + (lane & 15);
+    if (r0 < K && ((c0 < K && c0 >= r0) || (bd_in_pad && c0 == K))) {
+      row = r0;
+      col = c0;
+    }
+  } else if (e < count && !bd_in_pad) {
+    row = e - n_tiles * 256;
+    col = K;
+  }
+  double s = 0;
+  if (row >= 0) {
+    const double *src = a.schur_partials + e;
+    constexpr int kDepth = 8;
+    int w = slice;
+    for (; w + (kDepth - 1) * kCombineSlices < a.n_schur_wgs; w += kDepth * kCombineSlices) {
+      double v[kDepth];
+#pragma unroll
+      for (int q = 0; q < kDepth; ++q) v[q] = src[static_cast<size_t>(w + q * kCombineSlices) * count];
+#pragma unroll
+      for (int q = 0; q < kDepth; ++q) s += v[q];
+    }
+    for (; w < a.n_schur_wgs; w += kCombineSlices) s += src[static_cast<size_t>(w) * count];
+  }
+  part[slice][le] = s;
+  __syncthreads();
+  if (slice != 0 || row < 0) return;
+  double schur = 0;
+#pragma unroll
+  for (int q = 0; q < kCombineSlices; ++q) schur += part[q][le];
   const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
   const double sc = -1.0 / (1.0 + lam);
-  double pair = 0;
-  bool has_schur = true;
-  if (e < n_block_entries) {
-    int bi = 0, b = e >> 6;
-    while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-    const int bj = b - bi * (bi + 1) / 2;
-    const int i = (e >> 3) & 7, j = e & 7;
-    if (bi == bj) {
-      const int f = bi;
-      for (int t = 0; t < F; ++t)  // f as reference: T^T G T
-        if (t != f && a.pc[f * kMaxFrames + t].valid) pair += a.pair_out[static_cast<size_t>(f * kMaxFrames + t) * kPairOut + 8 * i + j];
-      for (int r = 0; r < F; ++r)  // f as target: G
-        if (r != f && a.pc[r * kMaxFrames + f].valid) pair += a.pair_out[static_cast<size_t>(r * kMaxFrames + f) * kPairOut + 136 + 8 * i + j];
-      if (i == j) pair *= 1.0 + lam;
-      has_schur = j <= i;  // the partial systems hold the lower triangle only
-    } else {
-      // block (a, b), a > b: H_rt = -(G T)^T of the pair (r = a, t = b), H_tr = -G T of the pair (r = b, t = a)
-      if (a.pc[bi * kMaxFrames + bj].valid) pair -= a.pair_out[static_cast<size_t>(bi * kMaxFrames + bj) * kPairOut + 64 + 8 * j + i];
-      if (a.pc[bj * kMaxFrames + bi].valid) pair -= a.pair_out[static_cast<size_t>(bj * kMaxFrames + bi) * kPairOut + 64 + 8 * i + j];
-    }
+  if (col == K) {
+    a.comb[combBlockCount(F) * 64 + row] = pairRhs(a, row) + sc * schur;
   } else {
-    const int c = e - n_block_entries, f = c >> 3, i = c & 7;
-    for (int t = 0; t < F; ++t)
-      if (t != f && a.pc[f * kMaxFrames + t].valid) pair += a.pair_out[static_cast<size_t>(f * kMaxFrames + t) * kPairOut + 128 + i];
-    for (int r = 0; r < F; ++r)
-      if (r != f && a.pc[r * kMaxFrames + f].valid) pair -= a.pair_out[static_cast<size_t>(r * kMaxFrames + f) * kPairOut + 200 + i];
+    double pair = pairEntry(a, col, row);
+    if (row == col) pair *= 1.0 + lam;
+    a.comb[combIndex(col, row)] = pair + sc * schur;
   }
-  double s0 = 0, s1 = 0;
-  if (has_schur) {
-    const double *src = a.schur_partials + e;
-    int w = 0;
-    for (; w + 1 < a.n_schur_wgs; w += 2) {
-      s0 += src[static_cast<size_t>(w) * count];
-      s1 += src[static_cast<size_t>(w + 1) * count];
-    }
-    if (w < a.n_schur_wgs) s0 += src[static_cast<size_t>(w) * count];
-  }
-  a.comb[e] = pair + sc * (s0 + s1);
 }
 
 }  // namespace dsopp_hip

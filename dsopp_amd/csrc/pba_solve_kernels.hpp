@@ -19,7 +19,8 @@ struct LmParams {
   double lambda0;
   int max_iterations, min_iterations;
   int force_accept;
-  int use_reduced_scalars;  // multi-GPU: (energy, n_valid, step^2, idepth.step) were summed across ranks into `scalars`
+  int use_reduced_scalars;  // 1: (energy, n_valid, step^2, idepth.step) were summed (across ranks) into `scalars`;
+                            // 2: `scalars` holds kScalarGroups group sums of them (sweepScalarGroupsKernel: large windows)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -127,6 +128,8 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
  * workgroup's landmark chunk (acceptStep / rejectStep, problem.hpp:366-402), workgroup 0 also moves the frame states and
  * publishes the outgoing control block.  Returns true when a linear system has to be built from the sweep's output.
  */
+constexpr int kScalarGroups = 64;
+
 struct ApplyRegs {
   uint8_t *p_status[2], *p_cand[2];
   uint8_t v_status[2], v_cand[2];
@@ -213,7 +216,15 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
   }
   // deterministic sums: energy, n_valid, |idepth step|^2, idepth . step (sweep partials) and the frame norms
   double v[6] = {0, 0, 0, 0, 0, 0};
-  if (a.prm.use_reduced_scalars) {
+  if (a.prm.use_reduced_scalars == 2) {
+    if (tid < kScalarGroups) {
+      const double *p = a.scalars + 4 * tid;
+      v[0] = p[0];
+      v[1] = p[1];
+      v[2] = p[2];
+      v[3] = p[3];
+    }
+  } else if (a.prm.use_reduced_scalars) {
     if (tid == 0) {
       v[0] = a.scalars[0];
       v[1] = a.scalars[1];
@@ -477,7 +488,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
   const int i = be.offset + l;
   const unsigned conn = be.conn_mask & ~(1u << r);
-  const size_t plane = static_cast<size_t>(be.cap) * kUblk;
+  const size_t plane = ublkPlane(be.cap);
   const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
   bool take = false;
   uint8_t flg = 0;
@@ -1158,9 +1169,9 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
 // ---------------------------------------------------------------------------------------------------------------
 /** calculateIdepths — hessian_block_evaluation.hpp:238-263 */
 __global__ void backsubKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, const double *__restrict__ step,
-                              double lambda, int F, const LmControl *ctrl) {
+                              double lambda, int F, const LmControl *ctrl, int ublk_parity, int gate_on_pending) {
   if (ctrl) {
-    if (!ctrl->active) return;
+    if (!ctrl->active || (gate_on_pending && !ctrl->pending)) return;
     lambda = ctrl->lambda;
   }
   const SchurBlock be = table[blockIdx.x];
@@ -1173,7 +1184,7 @@ __global__ void backsubKernel(const FrameDev *__restrict__ frames, const SchurBl
   double d = 0;
   for (int t = 0; t < F; ++t) {
     if (t != be.r && fr.status[t] == nullptr) continue;
-    const double *src = fr.ublk + (static_cast<size_t>(t) * fr.cap + i) * kUblk;
+    const double *src = fr.ublk + (static_cast<size_t>(ublk_parity) * kMaxFrames + t) * ublkPlane(fr.cap) + static_cast<size_t>(i) * kUblk;
 #pragma unroll
     for (int c = 0; c < kBlk; ++c) d += src[c] * step[kBlk * t + c];
   }
@@ -1476,6 +1487,41 @@ __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
     c.relin = 0;
     a.ctrl[0] = c;
     a.ctrl[1] = c;
+  }
+}
+
+/** large windows: the four per-block scalars of a sweep summed in kScalarGroups fixed groups (out[g][4]) — every workgroup of
+ *  the decision kernel then adds 64 x 4 numbers instead of walking tens of thousands of sweep blocks itself */
+__global__ void __launch_bounds__(256) sweepScalarGroupsKernel(const double *__restrict__ partials, int n_blocks, double *out, const LmControl *ctrl) {
+  __shared__ double lds[(256 / 64) * 4];
+  double v[4] = {0, 0, 0, 0};
+  const bool live = !ctrl || ctrl->active;
+  const int per = (n_blocks + kScalarGroups - 1) / kScalarGroups;
+  const int b0 = blockIdx.x * per, b1 = min(b0 + per, n_blocks);
+  if (live)
+    for (int b = b0 + threadIdx.x; b < b1; b += 256) {
+      const double *p = partials + static_cast<size_t>(b) * kPartial;
+      v[0] += p[44];
+      v[1] += p[45];
+      v[2] += p[46];
+      v[3] += p[47];
+    }
+  blockSum<4, 256>(v, lds);
+  if (threadIdx.x == 0) {
+    out[4 * blockIdx.x + 0] = v[0];
+    out[4 * blockIdx.x + 1] = v[1];
+    out[4 * blockIdx.x + 2] = v[2];
+    out[4 * blockIdx.x + 3] = v[3];
+  }
+}
+
+/** the group sums added up (fixed order) into out[0..3]: the sharded large-window path needs the four scalars contiguous for its
+ *  collective */
+__global__ void sweepScalarGroupsFinalKernel(const double *__restrict__ groups, double *out) {
+  if (threadIdx.x < 4) {
+    double s = 0;
+    for (int g = 0; g < kScalarGroups; ++g) s += groups[4 * g + threadIdx.x];
+    out[threadIdx.x] = s;
   }
 }
 

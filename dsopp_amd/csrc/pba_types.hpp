@@ -11,6 +11,11 @@ constexpr int kMaxFrames = DSOPP_HIP_MAX_FRAMES;
 constexpr int kBlk = DSOPP_HIP_BLOCK_SIZE;  // 8 = 6 pose + 2 affine
 constexpr int kPat = DSOPP_HIP_PATTERN_SIZE;
 constexpr int kUblk = 10;                   // per (landmark, slot): u[8], hdd, bd
+constexpr int kUblkPad = 272;               // doubles between two slot planes of the Schur rows (see ublkPlane)
+/** Plane stride (in doubles) of the Schur rows ublk[parity][slot][landmark][kUblk].  The landmark capacity is a power of two, so
+ *  un-padded planes start at multiples of cap x 80 bytes (655 360 B at 8192 landmarks): the 8..12 slot planes a landmark's lanes
+ *  touch together then fall onto the same memory channels.  2 176 bytes of padding per plane spreads them. */
+__host__ __device__ inline size_t ublkPlane(int cap) { return static_cast<size_t>(cap) * kUblk + kUblkPad; }
 constexpr int kPartial = 48;                // per sweep block: G (36 upper) + q (8) + energy + n_valid + pad
 constexpr int kSweepThreads = 128;        // 16 (landmark, target) items x 8 pattern pixels
 
