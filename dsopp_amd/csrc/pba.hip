@@ -68,7 +68,10 @@ struct dsopp_hip_window {
   DeviceBuffer<FrameDev> d_frames;
   DeviceBuffer<WindowState> d_state, d_state_snap;
   DeviceBuffer<PairConst> d_pc;
-  DeviceBuffer<SweepBlock> d_sweep_table;
+  DeviceBuffer<SweepBlock> d_sweep_table;   // the sweeps' table: one entry (= one workgroup, one row of d_partials) per n_groups x 16 items
+  DeviceBuffer<SweepBlock> d_fine_table;    // one entry per 16 items (first-estimate and point-status kernels); the same when n_groups == 1
+  int n_fine_blocks = 0;
+  const SweepBlock *fineTable() const { return d_fine_table.ptr ? d_fine_table.ptr : d_sweep_table.ptr; }
   DeviceBuffer<SchurBlock> d_schur_table;
   DeviceBuffer<int> d_pair_first, d_pair_count;
   // d_reduce = [Hpp K*K | bpp K | Hsc K*K | bsc K] (no priors): everything a multi-GPU run must sum across ranks, contiguous
@@ -346,8 +349,14 @@ void syncTopology(W &w) {
   const int F = w.F();
   std::vector<FrameDev> fd(static_cast<size_t>(kMaxFrames));
   std::memset(fd.data(), 0, fd.size() * sizeof(FrameDev));
-  std::vector<SweepBlock> sweep;
+  std::vector<SweepBlock> sweep, fine;
   std::vector<SchurBlock> schur;
+  // large windows: a sweep workgroup takes 4 groups of 16 items (pba_kernels.hpp: SweepBlock::n_groups)
+  size_t total_items = 0;
+  for (int r = 0; r < F; ++r)
+    for (const auto &kv : w.frames[static_cast<size_t>(r)]->residuals) total_items += static_cast<size_t>(kv.second->n);
+  static const int groups_override = std::getenv("DSOPP_HIP_SWEEP_GROUPS") ? std::atoi(std::getenv("DSOPP_HIP_SWEEP_GROUPS")) : 0;  // tuning aid
+  const int groups = groups_override > 0 ? groups_override : (total_items >= 30000 ? 4 : 1);
   std::vector<int> pair_first(kMaxFrames * kMaxFrames, -1), pair_count(kMaxFrames * kMaxFrames, 0);
   for (int r = 0; r < F; ++r) {
     HostFrame &f = *w.frames[static_cast<size_t>(r)];
@@ -395,6 +404,7 @@ void syncTopology(W &w) {
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
       for (int off = 0; off < rt.n; off += kItemsPerBlock) {
+        const bool coarse_entry = (off / kItemsPerBlock) % groups == 0;
         SweepBlock sb;
         std::memset(&sb, 0, sizeof(sb));
         sb.r = r;
@@ -418,8 +428,13 @@ void syncTopology(W &w) {
         sb.status = rt.status.ptr;
         sb.fej_valid = rt.fej_valid.ptr;
         sb.cand = rt.cand.ptr;
-        sweep.push_back(sb);
-        ++cnt;
+        sb.n_groups = 1;
+        if (groups > 1) fine.push_back(sb);
+        if (coarse_entry) {
+          sb.n_groups = std::min(groups, (rt.n - off + kItemsPerBlock - 1) / kItemsPerBlock);
+          sweep.push_back(sb);
+          ++cnt;
+        }
       }
       pair_count[static_cast<size_t>(r * kMaxFrames + t)] = cnt;
     }
@@ -447,20 +462,29 @@ void syncTopology(W &w) {
       schur.push_back(sb);
     }
   }
-  for (SweepBlock &sb : sweep) {
-    const FrameDev &dr = fd[static_cast<size_t>(sb.r)], &dt = fd[static_cast<size_t>(sb.t)];
-    sb.width_t = dt.width;
-    sb.height_t = dt.height;
-    sb.texels_t = dt.texels;
-    for (int k = 0; k < F; ++k)
-      if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
-  }
+  for (std::vector<SweepBlock> *tbl : {&sweep, &fine})
+    for (SweepBlock &sb : *tbl) {
+      const FrameDev &dr = fd[static_cast<size_t>(sb.r)], &dt = fd[static_cast<size_t>(sb.t)];
+      sb.width_t = dt.width;
+      sb.height_t = dt.height;
+      sb.texels_t = dt.texels;
+      for (int k = 0; k < F; ++k)
+        if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
+    }
   w.d_frames.reserve(kMaxFrames, 0, st);
   w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
   w.n_sweep_blocks = static_cast<int>(sweep.size());
   w.n_schur_blocks = static_cast<int>(schur.size());
   w.d_sweep_table.reserve(std::max<size_t>(1, sweep.size()), 0, st);
   w.d_sweep_table.upload(sweep.data(), sweep.size(), 0, st);
+  if (groups > 1) {
+    w.d_fine_table.reserve(std::max<size_t>(1, fine.size()), 0, st);
+    w.d_fine_table.upload(fine.data(), fine.size(), 0, st);
+    w.n_fine_blocks = static_cast<int>(fine.size());
+  } else {
+    w.d_fine_table.release();
+    w.n_fine_blocks = static_cast<int>(sweep.size());
+  }
   w.d_schur_table.reserve(std::max<size_t>(1, schur.size()), 0, st);
   w.d_schur_table.upload(schur.data(), schur.size(), 0, st);
   w.d_pair_first.reserve(kMaxFrames * kMaxFrames, 0, st);
@@ -544,8 +568,8 @@ void launchFej(W &w) {
   timedLaunch(w, DSOPP_HIP_KERNEL_FEJ,
               [&] {
                 const int per_wave = 64 / kItemsPerBlock;
-                fejKernel<S><<<(w.n_sweep_blocks + per_wave - 1) / per_wave, 64, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.d_sweep_table.ptr,
-                                                                                                   w.n_sweep_blocks);
+                fejKernel<S><<<(w.n_fine_blocks + per_wave - 1) / per_wave, 64, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_pc.ptr, w.fineTable(),
+                                                                                                  w.n_fine_blocks);
               });
   HIP_CHECK(hipGetLastError());
 }
@@ -1206,9 +1230,9 @@ void updatePointStatusesDevice(W &w) {
   const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
   if (w.n_sweep_blocks) {
     const int per_group = kSelectThreads / kItemsPerBlock;
-    const int grid = (w.n_sweep_blocks + per_group - 1) / per_group;
+    const int grid = (w.n_fine_blocks + per_group - 1) / per_group;
     for (int pass = 7; pass >= 0; --pass)  // each pass advances the select state from the previous pass's histogram itself
-      selectHistKernel<<<grid, kSelectThreads, 0, st>>>(w.d_frames.ptr, w.d_sweep_table.ptr, w.n_sweep_blocks, w.d_select.ptr, pass);
+      selectHistKernel<<<grid, kSelectThreads, 0, st>>>(w.d_frames.ptr, w.fineTable(), w.n_fine_blocks, w.d_select.ptr, pass);
   }
   pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr, w.n_sweep_blocks ? w.d_select.ptr : nullptr, half_sigma_sq);
   if (w.n_schur_blocks)

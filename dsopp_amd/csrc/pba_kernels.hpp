@@ -358,7 +358,6 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   SWEEP_STAMP(0);
   const PairConst &P = pc[be.r * kMaxFrames + be.t];
   const int k = threadIdx.x & 7;                  // pattern pixel of this lane
-  const int i = be.offset + (threadIdx.x >> 3);   // landmark
   // pattern offsets (x_i, y_i) — src/common/pattern/include/common/pattern/pattern.hpp:21-32, +2 packed in nibbles
   const int ox = static_cast<int>((0x21420312u >> (4 * k)) & 0xFu) - 2;
   const int oy = static_cast<int>((0x01222334u >> (4 * k)) & 0xFu) - 2;
@@ -366,6 +365,12 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   double acc[kPartial];
 #pragma unroll
   for (int e = 0; e < kPartial; ++e) acc[e] = 0;
+
+  // Large windows (hundreds of thousands of items) give a workgroup several groups of 16 items of its frame pair
+  // (SweepBlock::n_groups, chosen by the host): the 48 workgroup sums are reduced once per workgroup instead of once per 16
+  // items, and the chip dispatches a quarter of the workgroups.  Small windows keep one group per workgroup (parallelism).
+  for (int grp = 0; grp < be.n_groups; ++grp) {
+  const int i = be.offset + grp * kItemsPerBlock + (threadIdx.x >> 3);   // landmark
 
   // ---- round trip 2: per-item words (identical addresses within the 8 lanes of an item: one request).  Every load is
   // gated by the index bound only, never by a loaded value, so they all go out together.
@@ -544,8 +549,8 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
         const double wga = wgt * static_cast<double>(g[a]);
         if (accumulate) {
 #pragma unroll
-          for (int b = a; b < kBlk; ++b) acc[e + (b - a)] = wga * static_cast<double>(g[b]);
-          acc[36 + a] = wga * rk;
+          for (int b = a; b < kBlk; ++b) acc[e + (b - a)] += wga * static_cast<double>(g[b]);
+          acc[36 + a] += wga * rk;
         }
         e += kBlk - a;
         gj[a] = wga * jdd;
@@ -571,16 +576,17 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     be.energy[i] = energy;
     be.cand[i] = cand;
     if (accumulate) {
-      acc[44] = energy;
-      acc[45] = energy > 0 ? 1.0 : 0.0;
+      acc[44] += energy;
+      acc[45] += energy > 0 ? 1.0 : 0.0;
     }
     if ((!LIN || BACKSUB || prm.external_backsub) && be.owns_landmark_sums) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
       // (the opening round of the fused loop has no step yet: slot 46 carries sum idepth^2, the initial state norm)
-      acc[46] = (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;
-      acc[47] = idepth_d * idepth_step_d;
+      acc[46] += (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;
+      acc[47] += idepth_d * idepth_step_d;
     }
   }
+  }  // groups
   SWEEP_STAMP(4);
   double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
   if (LIN && SMALL_LDS) {

@@ -102,7 +102,7 @@ struct SweepBlock {
   int owns_landmark_sums;  // t is the first connected target of r: its items own the per-landmark sums / writes
   int width_r, height_r, width_t, height_t;
   unsigned conn_mask;  // bit k: frame r has residuals in target slot k
-  int pad;
+  int n_groups;        // groups of 16 items this workgroup sweeps (1 except in the coarse table of large windows)
   const double *uv, *idepth, *patch, *idepth_fej, *b_d, *inv_hdd;
   double *idepth_step, *ublk, *energy;
   const uint8_t *flags, *status, *fej_valid;
