@@ -376,11 +376,13 @@ def load_pmc_traffic(F, P, args):
             k = per.get("sweep_linearize_loop") or per["sweep_linearize"]
             detail = {"fetch_bytes": k["fetch"], "write_bytes": k["write"], "source": f"profiles/{name}",
                       "kernel": "sweep_linearize_loop" if "sweep_linearize_loop" in per else "sweep_linearize",
-                      "fetch_bytes_per_count": pmc["passes"]["FETCH_SIZE"]["bytes_per_count"],
+                      "fetch_bytes_per_count": (pmc.get("calibration") or {}).get("fetch_gather_bytes_per_count",
+                                                                                  pmc["passes"]["FETCH_SIZE"]["bytes_per_count"]),
                       "write_bytes_per_count": pmc["passes"]["WRITE_SIZE"]["bytes_per_count"],
                       "calibration": pmc.get("calibration"),
-                      "note": "per launch of the same kernel on the same window; counters are per XCD-L2 fabric requests, "
-                              "Infinity-Cache hits included"}
+                      "note": "per launch of the same kernel on the same window (scripts/pmc_traffic.py); TCC_EA0 counters = "
+                              "XCD-L2 fabric requests, Infinity-Cache hits included; fetch counts converted with the unit a texel "
+                              "gather of known geometry measured in the same pass (a wide stream is tallied at half that)"}
             return k["total"], detail
         except (OSError, KeyError, ValueError):
             continue

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdsopp_hip.so")
 
 F64, F32 = 0, 1
-NUM_KERNEL_CLASSES = 10
+NUM_KERNEL_CLASSES = 11
 
 
 class Options(C.Structure):

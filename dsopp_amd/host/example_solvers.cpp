@@ -30,6 +30,81 @@ std::vector<uint8_t> render(double tx) {  // camera at (tx, 0, 0), identity rota
     }
   return img;
 }
+
+/** The back end exactly as MonocularTracker::tick drives it for every new keyframe (monocular_tracker.cpp:497-507):
+ *    pushFrame(new keyframe) -> updateSolver [updateLocalFrame of every active frame] -> refinePoses [solve, then updateFrame of
+ *    every active frame] -> marginalize [the strategy flags a keyframe and landmarks] -> updateSolver again,
+ *  over six keyframes through a four-frame window: the same call order the reference-side adapter
+ *  (dsopp_amd/host/reference_adapter/hip_photometric_bundle_adjustment.cpp) forwards, including the fold-in of the
+ *  marginalised frame by the next pushFrame. */
+bool trackerCallOrder() {
+  const int kFrames = 6, kWindow = 4, kLandmarks = 80;
+  TrustRegionOptions opt{7, 1e5, 1e-8, 1e-8, {1e12, 1e8}, 1e16, 20};
+  HipPhotometricBundleAdjustment pba(opt, true, true);
+  const PinholeModel model{fx, fy, cx, cy};
+  std::mt19937 rng(7);
+  std::uniform_int_distribution<int> ux(20, W - 21), uy(20, H - 21);
+  std::vector<std::unique_ptr<DevicePyramid>> pyramids;
+  std::vector<std::vector<uint8_t>> images;
+  std::vector<KeyframeView> track(kFrames);
+  std::vector<int> active;  // indices into `track`, oldest first
+  bool ok = true;
+  for (int i = 0; i < kFrames; ++i) {
+    const double tx_gt = 0.08 * i, tx_init = tx_gt + (i ? 0.012 * ((i % 2) ? 1 : -1) : 0.0);
+    images.push_back(render(tx_gt));
+    pyramids.push_back(std::make_unique<DevicePyramid>(W, H, 1));
+    pyramids.back()->build(images.back().data());
+    KeyframeView &f = track[static_cast<size_t>(i)];
+    f.keyframe_id = i;
+    f.timestamp = 1000 * (i + 1);
+    f.t_world_agent = {0, 0, 0, 1, tx_init, 0, 0};
+    f.exposure_time = 1;
+    f.affine_brightness = {0, 0};
+    f.is_marginalized = false;
+    f.pyramids = pyramids.back().get();
+    for (int k = 0; k < kLandmarks; ++k) {
+      LandmarkView lm;
+      const int u = ux(rng), v = uy(rng);
+      lm.projection = {static_cast<double>(u), static_cast<double>(v)};
+      lm.idepth = 1.0 / Z * (1 + 0.002 * ((k % 5) - 2));
+      static const int px[8] = {0, -1, 1, -2, 0, 2, -1, 0}, py[8] = {2, 1, 1, 0, 0, 0, -1, -2};
+      for (int p = 0; p < 8; ++p) lm.patch[static_cast<size_t>(p)] = images.back()[static_cast<size_t>(v + py[p]) * W + u + px[p]];
+      lm.is_marginalized = lm.is_outlier = false;
+      f.active_landmarks.push_back(lm);
+    }
+    // pushNewKeyframe: connections between the new keyframe and every active one (both directions)
+    for (int j : active) {
+      f.reprojection_statuses[j] = std::vector<uint8_t>(f.active_landmarks.size(), DSOPP_HIP_STATUS_OK);
+      track[static_cast<size_t>(j)].reprojection_statuses[i] = std::vector<uint8_t>(track[static_cast<size_t>(j)].active_landmarks.size(), DSOPP_HIP_STATUS_OK);
+    }
+    active.push_back(i);
+    pba.pushFrame(f, 0, model, i == 0 ? FrameParameterization::kFixed : FrameParameterization::kFree);  // :497
+    for (int j : active) pba.updateLocalFrame(track[static_cast<size_t>(j)]);                           // updateSolver, :499
+    if (active.size() < 2) continue;
+    const double energy = pba.solve(1);                                                                  // refinePoses, :501
+    for (int j : active) pba.updateFrame(track[static_cast<size_t>(j)]);
+    ok = ok && std::isfinite(energy);
+    const double err = std::abs(f.t_world_agent[4] - tx_gt);
+    std::printf("keyframe %d: window of %zu, energy %.2f, |tx error| of the new keyframe %.5f\n", i, active.size(), energy, err);
+    ok = ok && err < 0.012 * 0.6 + 2e-3;
+    // marginalize (:503): once the window is full the strategy retires the oldest free keyframe and a few landmarks elsewhere
+    if (static_cast<int>(active.size()) == kWindow) {
+      const int victim = active[1];
+      KeyframeView &v = track[static_cast<size_t>(victim)];
+      v.is_marginalized = true;
+      for (auto &lm : v.active_landmarks) lm.is_marginalized = true;
+      for (int j : active)
+        if (j != victim)
+          for (size_t k = 0; k < track[static_cast<size_t>(j)].active_landmarks.size(); k += 9) track[static_cast<size_t>(j)].active_landmarks[k].is_marginalized = true;
+      for (int j : active) pba.updateLocalFrame(track[static_cast<size_t>(j)]);                         // updateSolver, :505
+      active.erase(active.begin() + 1);  // the next pushFrame folds it into the prior and drops it from the window
+    }
+  }
+  int32_t in_window = 0;
+  ok = ok && dsopp_hip_window_num_frames(pba.handle(), &in_window) == DSOPP_HIP_OK && in_window == static_cast<int32_t>(active.size()) + 1;
+  std::printf("tracker call order: %d frames in the solver's window (one of them awaiting its fold-in)\n", in_window);
+  return ok;
+}
 }  // namespace
 
 int main() {
@@ -183,5 +258,6 @@ int main() {
   std::printf("activation: %d of %zu immature landmarks activated (%d skipped, %d deleted), worst relative idepth error %.4f, distance %.3f\n", n_act,
               act[0].size(), activator.lastResult().n_skipped, activator.lastResult().n_deleted, worst, activator.minDistanceToNeighbor());
   ok = ok && n_act > 20 && worst < 0.05;
+  ok = trackerCallOrder() && ok;
   return ok ? 0 : 1;
 }
