@@ -110,8 +110,23 @@ class Job:
                     box = [raw]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
-                self.comm = capi.Comm(self.rank, self.world, self.local_rank, exchange)
-                self.transport = "native ncclAllReduce (dsopp_hip_comm, RCCL)"
+                # multi-rank RCCL cannot be exercised on the builder's single-GPU boxes: if the native communicator fails to come
+                # up on ANY rank, every rank falls back to the torch.distributed callback (still RCCL) and the line says so
+                try:
+                    self.comm = capi.Comm(self.rank, self.world, self.local_rank, exchange)
+                    ok = 1.0
+                except Exception as exc:  # noqa: BLE001
+                    print(f"[bench] rank {self.rank}: native communicator failed ({exc}); using the torch.distributed callback", file=sys.stderr)
+                    self.comm, ok = None, 0.0
+                flag = torch.tensor([ok], device="cuda", dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) < 1.0:
+                    if self.comm is not None:
+                        self.comm.close()
+                        self.comm = None
+                    self.transport = "torch.distributed callback (nccl = RCCL; native communicator unavailable)"
+                else:
+                    self.transport = "native ncclAllReduce (dsopp_hip_comm, RCCL)"
             else:
                 self.transport = "torch.distributed callback (gloo)" if self.single_device else "torch.distributed callback (nccl = RCCL)"
 

@@ -36,12 +36,12 @@ constexpr double kActMinCell = 4.0;  // grid cell edge = max(distance, kActMinCe
 struct ActKeyframe {
   double M[12];  // reproject_ = K1 [R|t] K1^-1 of T_newest^-1 T_keyframe at the sparsity level (camera_reproject.hpp:256)
   int n_active, n_immature, immature_offset, frame_slot;
-  const double *active_uv, *active_idepth;
-  const uint8_t *active_flags;
-  const double *projection, *patch, *uniqueness, *search_pixel_interval;
-  double *idepth_min, *idepth_max;
-  uint8_t *status;
-  const uint8_t *traced;
+  const hbm_f64 *active_uv, *active_idepth;
+  const hbm_u8 *active_flags;
+  const hbm_f64 *projection, *patch, *uniqueness, *search_pixel_interval;
+  hbm_f64 *idepth_min, *idepth_max;
+  hbm_u8 *status;
+  const hbm_u8 *traced;
 };
 
 /** reference keyframe r -> target keyframe t at level 0 (the refinement) */
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64) activationRefineKernel(ActArgs a) {
       bool ok = false;
       double tu = 0, tv = 0;
       const ActPair *pc = a.pairs + static_cast<size_t>(r) * F + (has ? t : 0);
-      const Texel<S> *img = static_cast<const Texel<S> *>(a.texels0[has ? t : 0]);
+      const Texel<S> DSOPP_HBM *img = (const Texel<S> DSOPP_HBM *)a.texels0[has ? t : 0];
       if (has) {
         const double *M = pc->M;
         const double x = M[0] * ru + M[1] * rv + (M[2] + M[3] * idepth);
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(64) activationRefineKernel(ActArgs a) {
       if (gok) {
         const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
         const double dx = tu - ix, dy = tv - iy, dxdy = dx * dy;
-        const Texel<S> *q = img + static_cast<size_t>(iy) * a.width + ix;
+        const Texel<S> DSOPP_HBM *q = img + static_cast<size_t>(iy) * a.width + ix;
         const double sI = dxdy * static_cast<double>(q[a.width + 1].I) + (dy - dxdy) * static_cast<double>(q[a.width].I) +
                           (dx - dxdy) * static_cast<double>(q[1].I) + (1 - dx - dy + dxdy) * static_cast<double>(q[0].I);
         rr = (sI - pc->b_t) - pc->scale * (patch - pc->b_r);
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64) activationRefineKernel(ActArgs a) {
       bool ok = false;
       double tu = 0, tv = 0, dui = 0, dvi = 0;
       const ActPair *pc = a.pairs + static_cast<size_t>(r) * F + (has ? t : 0);
-      const Texel<S> *img = static_cast<const Texel<S> *>(a.texels0[has ? t : 0]);
+      const Texel<S> DSOPP_HBM *img = (const Texel<S> DSOPP_HBM *)a.texels0[has ? t : 0];
       if (has) {  // reproject with Jacobians — camera_reproject.hpp:305-367
         const double *U = pc->U;
         const double X = U[0] * ru + U[1] * rv + (U[2] + U[3] * idepth);
@@ -467,9 +467,9 @@ __global__ void __launch_bounds__(64) activationRefineKernel(ActArgs a) {
       if (gok) {
         const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
         const double dx = tu - ix, dy = tv - iy, dxdy = dx * dy;
-        const Texel<S> *q = img + static_cast<size_t>(iy) * a.width + ix;
+        const Texel<S> DSOPP_HBM *q = img + static_cast<size_t>(iy) * a.width + ix;
         const double w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-        const Texel<S> t00 = q[0], t10 = q[1], t01 = q[a.width], t11 = q[a.width + 1];
+        const Texel<S> t00 = loadTexel(q), t10 = loadTexel(q + 1), t01 = loadTexel(q + a.width), t11 = loadTexel(q + a.width + 1);
         const double sI = w11 * static_cast<double>(t11.I) + w01 * static_cast<double>(t01.I) + w10 * static_cast<double>(t10.I) + w00 * static_cast<double>(t00.I);
         const double sIx = w11 * static_cast<double>(t11.Ix) + w01 * static_cast<double>(t01.Ix) + w10 * static_cast<double>(t10.Ix) + w00 * static_cast<double>(t00.Ix);
         const double sIy = w11 * static_cast<double>(t11.Iy) + w01 * static_cast<double>(t01.Iy) + w10 * static_cast<double>(t10.Iy) + w00 * static_cast<double>(t00.Iy);

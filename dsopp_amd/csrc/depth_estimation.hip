@@ -36,7 +36,7 @@ inline int depthMaxLine(int W, int H) { return ((static_cast<int>(std::ceil(std:
 enum : uint8_t { kImGood = 0, kImOutOfBoundary = 1, kImOutlier = 2, kImSkipped = 3, kImIllConditioned = 4, kImUninitialized = 5, kImDelete = 6 };
 
 struct DepthFrame {
-  const void *texels;
+  const hbm_void *texels;
   int width, height;
   double fx, fy, cx, cy;
   double R[9], t[3];          // T_target_reference
@@ -50,9 +50,9 @@ struct DepthFrame {
 };
 
 struct DepthLandmarks {
-  const double *projection, *direction, *patch, *gradient;
-  double *idepth_min, *idepth_max, *uniqueness, *search_pixel_interval;
-  uint8_t *status, *traced;
+  const hbm_f64 *projection, *direction, *patch, *gradient;
+  hbm_f64 *idepth_min, *idepth_max, *uniqueness, *search_pixel_interval;
+  hbm_u8 *status, *traced;
 };
 
 template <int CTRL>
@@ -602,7 +602,7 @@ DepthFrame makeDepthFrame(const dsopp_hip_pyramid *target_pyramid, int level, co
                           double sigma_huber_loss, int n) {
   const LevelView lv = target_pyramid->view(level);
   DepthFrame f;
-  f.texels = lv.texels;
+  f.texels = hbm(lv.texels);
   f.width = lv.width;
   f.height = lv.height;
   f.max_line = depthMaxLine(lv.width, lv.height);
@@ -647,16 +647,16 @@ DepthFrame makeDepthFrame(const dsopp_hip_pyramid *target_pyramid, int level, co
 DepthLandmarks landmarkPointers(dsopp_hip_immature_set *s) {
   const size_t N = static_cast<size_t>(s->n);
   DepthLandmarks L;
-  L.projection = s->d_in.ptr;
-  L.direction = s->d_in.ptr + 2 * N;
-  L.patch = s->d_in.ptr + 5 * N;
-  L.gradient = s->d_in.ptr + 13 * N;
-  L.idepth_min = s->d_io.ptr;
-  L.idepth_max = s->d_io.ptr + N;
-  L.uniqueness = s->d_io.ptr + 2 * N;
-  L.search_pixel_interval = s->d_io.ptr + 3 * N;
-  L.status = s->d_flags.ptr;
-  L.traced = s->d_flags.ptr + N;
+  L.projection = hbm(s->d_in.ptr);
+  L.direction = hbm(s->d_in.ptr + 2 * N);
+  L.patch = hbm(s->d_in.ptr + 5 * N);
+  L.gradient = hbm(s->d_in.ptr + 13 * N);
+  L.idepth_min = hbm(s->d_io.ptr);
+  L.idepth_max = hbm(s->d_io.ptr + N);
+  L.uniqueness = hbm(s->d_io.ptr + 2 * N);
+  L.search_pixel_interval = hbm(s->d_io.ptr + 3 * N);
+  L.status = hbm(s->d_flags.ptr);
+  L.traced = hbm(s->d_flags.ptr + N);
   return L;
 }
 

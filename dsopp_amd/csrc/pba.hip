@@ -362,7 +362,7 @@ void syncTopology(W &w) {
     HostFrame &f = *w.frames[static_cast<size_t>(r)];
     FrameDev &d = fd[static_cast<size_t>(r)];
     const LevelView lv = f.pyramid->view(f.level);
-    d.texels = lv.texels;
+    d.texels = hbm(lv.texels);
     d.width = lv.width;
     d.height = lv.height;
     d.fx = f.intr[0];
@@ -375,31 +375,31 @@ void syncTopology(W &w) {
     d.to_marginalize = f.to_marginalize;
     d.n = f.n;
     d.cap = f.cap;
-    d.uv = f.uv.ptr;
-    d.idepth = f.idepth.ptr;
-    d.idepth_step = f.idepth_step.ptr;
-    d.idepth_fej = f.idepth_fej.ptr;
-    d.patch = f.patch.ptr;
-    d.inv_hdd = f.inv_hdd.ptr;
-    d.b_d = f.b_d.ptr;
-    d.relative_baseline = f.relative_baseline.ptr;
-    d.n_inliers = f.n_inliers.ptr;
-    d.flags = f.dflags.ptr;
-    d.ublk = f.ublk.ptr;
-    d.snap_idepth = f.snap_idepth.ptr;
-    d.snap_flags = f.snap_flags.ptr;
+    d.uv = hbm(f.uv.ptr);
+    d.idepth = hbm(f.idepth.ptr);
+    d.idepth_step = hbm(f.idepth_step.ptr);
+    d.idepth_fej = hbm(f.idepth_fej.ptr);
+    d.patch = hbm(f.patch.ptr);
+    d.inv_hdd = hbm(f.inv_hdd.ptr);
+    d.b_d = hbm(f.b_d.ptr);
+    d.relative_baseline = hbm(f.relative_baseline.ptr);
+    d.n_inliers = hbm(f.n_inliers.ptr);
+    d.flags = hbm(f.dflags.ptr);
+    d.ublk = hbm(f.ublk.ptr);
+    d.snap_idepth = hbm(f.snap_idepth.ptr);
+    d.snap_flags = hbm(f.snap_flags.ptr);
     d.first_conn = -1;
     for (int t = 0; t < F; ++t) {
       if (t == r) continue;
       auto it = f.residuals.find(w.frames[static_cast<size_t>(t)]->id);
       if (it == f.residuals.end() || it->second->n == 0) continue;
       ResidualTable &rt = *it->second;
-      d.status[t] = rt.status.ptr;
-      d.cand[t] = rt.cand.ptr;
-      d.fej_valid[t] = rt.fej_valid.ptr;
-      d.energy[t] = rt.energy.ptr;
+      d.status[t] = hbm(rt.status.ptr);
+      d.cand[t] = hbm(rt.cand.ptr);
+      d.fej_valid[t] = hbm(rt.fej_valid.ptr);
+      d.energy[t] = hbm(rt.energy.ptr);
       d.n_res[t] = rt.n;
-      d.snap_status[t] = rt.snap_status.ptr;
+      d.snap_status[t] = hbm(rt.snap_status.ptr);
       if (d.first_conn < 0) d.first_conn = t;
       pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
       int cnt = 0;
@@ -423,11 +423,11 @@ void syncTopology(W &w) {
         sb.inv_hdd = d.inv_hdd;
         sb.idepth_step = d.idepth_step;
         sb.ublk = d.ublk;
-        sb.energy = rt.energy.ptr;
+        sb.energy = hbm(rt.energy.ptr);
         sb.flags = d.flags;
-        sb.status = rt.status.ptr;
-        sb.fej_valid = rt.fej_valid.ptr;
-        sb.cand = rt.cand.ptr;
+        sb.status = hbm(rt.status.ptr);
+        sb.fej_valid = hbm(rt.fej_valid.ptr);
+        sb.cand = hbm(rt.cand.ptr);
         sb.n_groups = 1;
         if (groups > 1) fine.push_back(sb);
         if (coarse_entry) {
@@ -2823,22 +2823,22 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
       std::memset(&a, 0, sizeof(a));
       reprojectors(rigidMul(T_newest_inv, T[static_cast<size_t>(k)]), intr[0] / 2, intr[1] / 2, intr[2] / 2, intr[3] / 2, a.M, nullptr);  // cameraModel(1)
       a.n_active = fr.n;
-      a.active_uv = fr.uv.ptr;
-      a.active_idepth = fr.idepth.ptr;
-      a.active_flags = fr.dflags.ptr;
+      a.active_uv = hbm(fr.uv.ptr);
+      a.active_idepth = hbm(fr.idepth.ptr);
+      a.active_flags = hbm(fr.dflags.ptr);
       a.frame_slot = k;
       a.immature_offset = n_immature;
       if (const dsopp_hip_immature_set *s = immature[k]) {
         const size_t N = static_cast<size_t>(s->n);
         a.n_immature = s->n;
-        a.projection = s->d_in.ptr;
-        a.patch = s->d_in.ptr + 5 * N;
-        a.idepth_min = s->d_io.ptr;
-        a.idepth_max = s->d_io.ptr + N;
-        a.uniqueness = s->d_io.ptr + 2 * N;
-        a.search_pixel_interval = s->d_io.ptr + 3 * N;
-        a.status = s->d_flags.ptr;
-        a.traced = s->d_flags.ptr + N;
+        a.projection = hbm(s->d_in.ptr);
+        a.patch = hbm(s->d_in.ptr + 5 * N);
+        a.idepth_min = hbm(s->d_io.ptr);
+        a.idepth_max = hbm(s->d_io.ptr + N);
+        a.uniqueness = hbm(s->d_io.ptr + 2 * N);
+        a.search_pixel_interval = hbm(s->d_io.ptr + 3 * N);
+        a.status = hbm(s->d_flags.ptr);
+        a.traced = hbm(s->d_flags.ptr + N);
       }
       n_immature += a.n_immature;
       n_active_cap += a.n_active;

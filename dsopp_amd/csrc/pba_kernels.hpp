@@ -274,6 +274,25 @@ __device__ __forceinline__ double sum8(double v) {
   return v;
 }
 
+/** 1 / x for the projective divisions: v_rcp_f64 (2^-23 relative) + two Newton steps, ~1 ulp; 5 instructions instead of the
+ *  ~13 of an IEEE division.  x = 0 gives inf -> NaN, which every caller rejects through its ROI / z > 0 test. */
+__device__ __forceinline__ double fastRcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fastRcp(float x) { return 1.0f / x; }
+
+/** 1 / sqrt(x), x > 0: v_rsq_f64 + two Newton steps (~1 ulp) */
+__device__ __forceinline__ double fastRsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  y = fma(y, fma(-h * y, y, 0.5), y);
+  return y;
+}
+
 constexpr int kRedStride = kSweepThreads + 2;  // even (16-byte aligned rows), 4-bank skew between rows for ds_read_b128
 
 /**
@@ -356,6 +375,13 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     for (int k = blockIdx.x * kSweepThreads + threadIdx.x; k < prm.clear_count; k += gridDim.x * kSweepThreads) prm.clear_buf[k] = 0;
   }
   SWEEP_STAMP(0);
+  // every pointer of the descriptor addresses HBM (see glb())
+  const auto g_flags = glb(be.flags), g_status = glb(be.status), g_fej_valid = glb(be.fej_valid);
+  const auto g_cand = glb(be.cand);
+  const auto g_uv = glb(be.uv), g_idepth = glb(be.idepth), g_patch = glb(be.patch), g_idepth_fej = glb(be.idepth_fej);
+  const auto g_b_d = glb(be.b_d), g_inv_hdd = glb(be.inv_hdd);
+  const auto g_idepth_step = glb(be.idepth_step), g_ublk = glb(be.ublk), g_energy = glb(be.energy);
+  const auto g_step = glb(prm.step);
   const PairConst &P = pc[be.r * kMaxFrames + be.t];
   const int k = threadIdx.x & 7;                  // pattern pixel of this lane
   // pattern offsets (x_i, y_i) — src/common/pattern/include/common/pattern/pattern.hpp:21-32, +2 packed in nibbles
@@ -386,27 +412,27 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   for (int c = 0; c < kBlk; ++c) hrow[c] = srow[c] = 0;
   const size_t plane = ublkPlane(be.cap);
   if (inb) {
-    flg = be.flags[i];
-    u = static_cast<S>(be.uv[2 * i]);
-    v = static_cast<S>(be.uv[2 * i + 1]);
-    idepth_d = be.idepth[i];
-    idepth_step_d = be.idepth_step[i];
-    status = be.status[i];
-    cand = be.cand[i];
-    patch_k = static_cast<S>(be.patch[kPat * i + k]);
+    flg = g_flags[i];
+    u = static_cast<S>(g_uv[2 * i]);
+    v = static_cast<S>(g_uv[2 * i + 1]);
+    idepth_d = g_idepth[i];
+    idepth_step_d = g_idepth_step[i];
+    status = g_status[i];
+    cand = g_cand[i];
+    patch_k = static_cast<S>(g_patch[kPat * i + k]);
     if (FEJ) {
-      if (prm.use_fej_flag) fej_bit = be.fej_valid[i];  // evaluate_jacobians.hpp:94
-      if (LIN) idepth_fej_d = be.idepth_fej[i];
+      if (prm.use_fej_flag) fej_bit = g_fej_valid[i];  // evaluate_jacobians.hpp:94
+      if (LIN) idepth_fej_d = g_idepth_fej[i];
     }
     if (BACKSUB) {
-      bd_d = be.b_d[i];
-      inv_hdd_d = be.inv_hdd[i];
+      bd_d = g_b_d[i];
+      inv_hdd_d = g_inv_hdd[i];
       if (k < prm.F && (k == be.r || ((be.conn_mask >> k) & 1u))) {
-        const double *src = be.ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + k) * plane + static_cast<size_t>(i) * kUblk;
+        const auto src = g_ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + k) * plane + static_cast<size_t>(i) * kUblk;
 #pragma unroll
         for (int c = 0; c < kBlk; ++c) {
           hrow[c] = src[c];
-          srow[c] = prm.step[kBlk * k + c];
+          srow[c] = g_step[kBlk * k + c];
         }
       }
     }
@@ -428,15 +454,15 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     if (upd) {
       for (int tt = k + kPat; tt < prm.F; tt += kPat) {  // windows of more than 8 frames
         if (tt != be.r && !((be.conn_mask >> tt) & 1u)) continue;
-        const double *src = be.ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + tt) * plane + static_cast<size_t>(i) * kUblk;
+        const auto src = g_ublk + (static_cast<size_t>(prm.ublk_read) * kMaxFrames + tt) * plane + static_cast<size_t>(i) * kUblk;
 #pragma unroll
-        for (int c = 0; c < kBlk; ++c) d += src[c] * prm.step[kBlk * tt + c];
+        for (int c = 0; c < kBlk; ++c) d += src[c] * g_step[kBlk * tt + c];
       }
     }
     d = sum8(d);
     if (upd) {
       idepth_step_d = -((bd_d - d) * (1.0 / (1.0 + lam)) * inv_hdd_d);
-      if (k == 0 && be.owns_landmark_sums) be.idepth_step[i] = idepth_step_d;
+      if (k == 0 && be.owns_landmark_sums) g_idepth_step[i] = idepth_step_d;
     }
   }
   SWEEP_STAMP(1);
@@ -454,8 +480,9 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     const S x = S(P.M[0]) * pu + S(P.M[1]) * pv + (S(P.M[2]) + S(P.M[3]) * idepth);
     const S y = S(P.M[4]) * pu + S(P.M[5]) * pv + (S(P.M[6]) + S(P.M[7]) * idepth);
     const S z = S(P.M[8]) * pu + S(P.M[9]) * pv + (S(P.M[10]) + S(P.M[11]) * idepth);
-    tu = x / z;
-    tv = y / z;
+    const S iz = fastRcp(z);
+    tu = x * iz;
+    tv = y * iz;
     ok = ok && (z > S(0));
   } else {
     // non-FEJ linearisation: positions come from the Jacobian path — camera_reproject.hpp:323-333
@@ -480,7 +507,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
     const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
     const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
-    const Texel<S> t00 = p[0], t10 = p[1], t01 = p[W], t11 = p[W + 1];
+    const Texel<S> t00 = loadTexel(p), t10 = loadTexel(p + 1), t01 = loadTexel(p + W), t11 = loadTexel(p + W + 1);
     const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
     ok = (m != S(0));
     sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
@@ -506,8 +533,9 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   if (HUBER) {
     const double sig = prm.sigma_huber;
     if (r2 > sig * sig) {
-      const double nrm = sqrt(r2);
-      wgt = sig / nrm;
+      const double inv_nrm = fastRsqrt(r2);
+      const double nrm = r2 * inv_nrm;
+      wgt = sig * inv_nrm;
       energy = sig * nrm - 0.5 * sig * sig;
     }
   }
@@ -524,7 +552,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idj);
       const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idj);
       const S fxt = S(P.fxt), fyt = S(P.fyt);
-      const S rho = S(1) / Z;
+      const S rho = fastRcp(Z);
       const S b0 = X * rho, b1 = Y * rho;
       const S du_id = fxt * (S(P.tl[0]) * rho - S(P.tl[2]) * (rho * b0));
       const S dv_id = fyt * (S(P.tl[1]) * rho - S(P.tl[2]) * (rho * b1));
@@ -559,22 +587,39 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       gj[9] = wgt * jdd * rk;
     }
     // per-item Schur quantities: sum over the 8 pixels; h_p block of target t is w * J_t^T J_d = -u
-    // (hessian_block_evaluation.hpp:207-208), zero for invalid residuals (:190-192)
+    // (hessian_block_evaluation.hpp:207-208), zero for invalid residuals (:190-192).  Transposed butterfly: in every step a lane
+    // keeps one value of a pair and hands the other to its partner, so the 8 totals end up one per lane (lane k holds entry
+    // 4 b1 + 2 b0 + b2 of u, k = b2 b1 b0) after 7 exchanges instead of 24, and the 8 lanes store the row without a select chain.
+    {
+      const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0, b2 = (k & 4) != 0;
+      double ra[4];
 #pragma unroll
-    for (int a = 0; a < kBlk + 2; ++a) gj[a] = sum8(gj[a]);
-    if (active) {
-      double mine = gj[0];
+      for (int j = 0; j < 4; ++j) {  // partner 7 - k (row_half_mirror)
+        const double keep = b2 ? gj[2 * j + 1] : gj[2 * j], send = b2 ? gj[2 * j] : gj[2 * j + 1];
+        ra[j] = keep + dppMove<0x141>(send);
+      }
+      double rb[2];
 #pragma unroll
-      for (int a = 1; a < kBlk; ++a) mine = (k == a) ? gj[a] : mine;
-      double *dst = be.ublk + (static_cast<size_t>(prm.ublk_write) * kMaxFrames + be.t) * plane + static_cast<size_t>(i) * kUblk;
-      dst[k] = -mine;
-      if (k < 2) dst[8 + k] = k == 0 ? gj[8] : gj[9];
+      for (int m = 0; m < 2; ++m) {  // partner k ^ 1
+        const double keep = b0 ? ra[2 * m + 1] : ra[2 * m], send = b0 ? ra[2 * m] : ra[2 * m + 1];
+        rb[m] = keep + dppMove<0xB1>(send);
+      }
+      const double u_tot = (b1 ? rb[1] : rb[0]) + dppMove<0x4E>(b1 ? rb[0] : rb[1]);  // partner k ^ 2
+      // (H_dd, b_d) partials: lanes 0..3 end with the first, lanes 4..7 with the second
+      double hb = (b2 ? gj[9] : gj[8]) + dppMove<0x141>(b2 ? gj[8] : gj[9]);
+      hb += dppMove<0xB1>(hb);
+      hb += dppMove<0x4E>(hb);
+      if (active) {
+        const auto dst = g_ublk + (static_cast<size_t>(prm.ublk_write) * kMaxFrames + be.t) * plane + static_cast<size_t>(i) * kUblk;
+        dst[((k & 3) << 1) | (k >> 2)] = -u_tot;
+        if ((k & 3) == 0) dst[8 + (k >> 2)] = hb;
+      }
     }
   }
   // NEW_EVALUATION_POINT bookkeeping (lane 0 of the item)
   if (active && k == 0) {
-    be.energy[i] = energy;
-    be.cand[i] = cand;
+    g_energy[i] = energy;
+    g_cand[i] = cand;
     if (accumulate) {
       acc[44] += energy;
       acc[45] += energy > 0 ? 1.0 : 0.0;

@@ -26,7 +26,7 @@ constexpr uint8_t kFlagMarginalized = 1, kFlagOutlier = 2, kFlagToMarginalize = 
  *  Replaces LocalFrame (PBA_INT/local_frame.hpp:232-584) minus the materialised ResidualPoint Jacobians:
  *  of ResidualPoint's 259 scalars only status, candidate status, energy and the FEJ validity bit are kept. */
 struct FrameDev {
-  const void *texels;  // Texel<S>* of the level this frame was pushed with
+  const hbm_void *texels;  // Texel<S>* of the level this frame was pushed with
   int width, height;
   double fx, fy, cx, cy;
   double exposure;
@@ -35,18 +35,18 @@ struct FrameDev {
   int cap;  // landmark capacity (stride of the per-slot planes of ublk)
   int first_conn;  // first connected target slot (-1 = none): the thread of that pair owns per-landmark sums
   int pad;
-  double *uv, *idepth, *idepth_step, *idepth_fej, *patch;
-  double *inv_hdd, *b_d, *relative_baseline;
-  int32_t *n_inliers;
-  uint8_t *flags;
-  double *ublk;  // [kMaxFrames][cap][kUblk]: slot t != r: {-u_pt (= h_p block t), hdd_pt, bd_pt}; slot r: {h_p block r, -, -}
-  uint8_t *status[kMaxFrames], *cand[kMaxFrames], *fej_valid[kMaxFrames];  // by target slot; nullptr = no connection
-  double *energy[kMaxFrames];
+  hbm_f64 *uv, *idepth, *idepth_step, *idepth_fej, *patch;
+  hbm_f64 *inv_hdd, *b_d, *relative_baseline;
+  hbm_i32 *n_inliers;
+  hbm_u8 *flags;
+  hbm_f64 *ublk;  // [kMaxFrames][cap][kUblk]: slot t != r: {-u_pt (= h_p block t), hdd_pt, bd_pt}; slot r: {h_p block r, -, -}
+  hbm_u8 *status[kMaxFrames], *cand[kMaxFrames], *fej_valid[kMaxFrames];  // by target slot; nullptr = no connection
+  hbm_f64 *energy[kMaxFrames];
   int n_res[kMaxFrames];
   // device-side snapshot (dsopp_hip_window_snapshot / _restore)
-  double *snap_idepth;
-  uint8_t *snap_flags;
-  uint8_t *snap_status[kMaxFrames];
+  hbm_f64 *snap_idepth;
+  hbm_u8 *snap_flags;
+  hbm_u8 *snap_status[kMaxFrames];
 };
 
 /** dynamic state of the window, lives in HBM and is advanced by the kernels */
@@ -103,11 +103,11 @@ struct SweepBlock {
   int width_r, height_r, width_t, height_t;
   unsigned conn_mask;  // bit k: frame r has residuals in target slot k
   int n_groups;        // groups of 16 items this workgroup sweeps (1 except in the coarse table of large windows)
-  const double *uv, *idepth, *patch, *idepth_fej, *b_d, *inv_hdd;
-  double *idepth_step, *ublk, *energy;
-  const uint8_t *flags, *status, *fej_valid;
-  uint8_t *cand;
-  const void *texels_t;  // Texel<S>* of the target frame's level
+  const hbm_f64 *uv, *idepth, *patch, *idepth_fej, *b_d, *inv_hdd;
+  hbm_f64 *idepth_step, *ublk, *energy;
+  const hbm_u8 *flags, *status, *fej_valid;
+  hbm_u8 *cand;
+  const hbm_void *texels_t;  // Texel<S>* of the target frame's level
 };
 
 /** one thread block of the Schur kernel = a chunk of landmarks of one frame.  The descriptor repeats the frame's
@@ -118,9 +118,9 @@ struct SchurBlock {
   int n, cap;  // landmarks / landmark capacity of frame r
   int fixed;
   unsigned conn_mask;  // bit t: frame r has residuals in target slot t
-  double *idepth, *idepth_step, *inv_hdd, *b_d, *ublk;
-  uint8_t *flags;
-  uint8_t *status[kMaxFrames], *cand[kMaxFrames];
+  hbm_f64 *idepth, *idepth_step, *inv_hdd, *b_d, *ublk;
+  hbm_u8 *flags;
+  hbm_u8 *status[kMaxFrames], *cand[kMaxFrames];
   int n_res[kMaxFrames];
 };
 

@@ -11,12 +11,59 @@
 #pragma once
 #include "common.hpp"
 
+// Pointer members of descriptors that live in device memory: in the device pass they are typed as address_space(1) pointers, so
+// every access through them is a global_load / global_store instead of a FLAT access (the compiler cannot know where a pointer
+// it read from memory points to); in the host pass they are ordinary pointers of the same size.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSOPP_HBM __attribute__((address_space(1)))
+#else
+#define DSOPP_HBM
+#endif
+typedef double DSOPP_HBM hbm_f64;
+typedef unsigned char DSOPP_HBM hbm_u8;
+typedef int DSOPP_HBM hbm_i32;
+typedef void DSOPP_HBM hbm_void;
+/** host side: a device allocation's address as the descriptor member type (identity outside the device pass) */
+template <typename T>
+inline T DSOPP_HBM *hbm(T *p) {
+  return (T DSOPP_HBM *)p;
+}
+
 namespace dsopp_hip {
 
 template <typename S>
 struct alignas(sizeof(S) * 4) Texel {
   S I, mask, Ix, Iy;
 };
+
+/** Pointers read out of a descriptor in memory are generic to the compiler, which then emits FLAT loads / stores (both
+ *  counters, LDS aperture check).  Everything the sweeps touch lives in HBM: glb() re-types such a pointer as
+ *  address_space(1) so that the accesses become global_load / global_store. */
+template <typename T>
+using GlobalPtr = T __attribute__((address_space(1))) *;
+template <typename T>
+__device__ __forceinline__ GlobalPtr<T> glb(T *p) {
+  return (GlobalPtr<T>)p;
+}
+
+/** one texel {I, mask, Ix, Iy} as a single aligned vector load from HBM */
+template <typename S>
+__device__ __forceinline__ Texel<S> loadTexel(const Texel<S> DSOPP_HBM *p) {
+  typedef S Vec4 __attribute__((ext_vector_type(4)));
+  const Vec4 q = *(GlobalPtr<const Vec4>)p;
+  Texel<S> t;
+  t.I = q.x;
+  t.mask = q.y;
+  t.Ix = q.z;
+  t.Iy = q.w;
+  return t;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename S>
+__device__ __forceinline__ Texel<S> loadTexel(const Texel<S> *p) {  // a generic pointer that is known to address HBM
+  return loadTexel((const Texel<S> DSOPP_HBM *)p);
+}
+#endif
 
 struct LevelView {
   const void *texels;  // Texel<S>*
