@@ -76,12 +76,13 @@ __device__ inline void mat34Compose(const double *A, const double *B, double *C)
   }
 }
 
-/** 1/sqrt(x) for x > 0: f32 estimate + two Newton steps in f64 (~1 ulp); a libm sqrt + division pair costs ~180 cycles on
+/** 1/sqrt(x) for x > 0: hardware estimate + two Newton steps (~1 ulp); a libm sqrt + division pair costs ~180 cycles on
  *  the single thread that runs the LM control, this a dozen instructions */
 __device__ inline double rsqrtNewton(double x) {
-  double r = static_cast<double>(__frsqrt_rn(static_cast<float>(x)));
-  r = r * (1.5 - 0.5 * x * r * r);
-  r = r * (1.5 - 0.5 * x * r * r);
+  const double h = 0.5 * x;
+  double r = __builtin_amdgcn_rsq(x);  // v_rsq_f64, 2^-23 relative: no f32 round trip on the dependent chain
+  r = fma(r, fma(-h * r, r, 0.5), r);
+  r = fma(r, fma(-h * r, r, 0.5), r);
   return r;
 }
 

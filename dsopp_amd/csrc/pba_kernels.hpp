@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   const auto g_b_d = glb(be.b_d), g_inv_hdd = glb(be.inv_hdd);
   const auto g_idepth_step = glb(be.idepth_step), g_ublk = glb(be.ublk), g_energy = glb(be.energy);
   const auto g_step = glb(prm.step);
-  const PairConst &P = pc[be.r * kMaxFrames + be.t];
+  const PairConst DSOPP_CONSTANT &P = *(const PairConst DSOPP_CONSTANT *)(pc + (be.r * kMaxFrames + be.t));
   const int k = threadIdx.x & 7;                  // pattern pixel of this lane
   // pattern offsets (x_i, y_i) — src/common/pattern/include/common/pattern/pattern.hpp:21-32, +2 packed in nibbles
   const int ox = static_cast<int>((0x21420312u >> (4 * k)) & 0xFu) - 2;
@@ -397,6 +397,11 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   // items, and the chip dispatches a quarter of the workgroups.  Small windows keep one group per workgroup (parallelism).
   for (int grp = 0; grp < be.n_groups; ++grp) {
   const int i = be.offset + grp * kItemsPerBlock + (threadIdx.x >> 3);   // landmark
+  // The pair constants are read through pointers that are opaque to the compiler at two points of every group (here, and
+  // after the reprojection): each group re-fetches the ~20 doubles it needs with scalar loads next to the vector loads it has
+  // to wait for anyway, instead of holding 50+ scalar registers across the loop (they were spilled into vector lanes).
+  const PairConst DSOPP_CONSTANT *Pm = &P;
+  asm volatile("" : "+s"(Pm) : "v"(i));
 
   // ---- round trip 2: per-item words (identical addresses within the 8 lanes of an item: one request).  Every load is
   // gated by the index bound only, never by a loaded value, so they all go out together.
@@ -477,20 +482,20 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   bool ok = active && validIdepth(idepth) && insideROI(pu, pv, Wr, Hr);
   if (!LIN || FEJ) {
     // reproject without Jacobians — camera_reproject.hpp:270-293
-    const S x = S(P.M[0]) * pu + S(P.M[1]) * pv + (S(P.M[2]) + S(P.M[3]) * idepth);
-    const S y = S(P.M[4]) * pu + S(P.M[5]) * pv + (S(P.M[6]) + S(P.M[7]) * idepth);
-    const S z = S(P.M[8]) * pu + S(P.M[9]) * pv + (S(P.M[10]) + S(P.M[11]) * idepth);
+    const S x = S(Pm->M[0]) * pu + S(Pm->M[1]) * pv + (S(Pm->M[2]) + S(Pm->M[3]) * idepth);
+    const S y = S(Pm->M[4]) * pu + S(Pm->M[5]) * pv + (S(Pm->M[6]) + S(Pm->M[7]) * idepth);
+    const S z = S(Pm->M[8]) * pu + S(Pm->M[9]) * pv + (S(Pm->M[10]) + S(Pm->M[11]) * idepth);
     const S iz = fastRcp(z);
     tu = x * iz;
     tv = y * iz;
     ok = ok && (z > S(0));
   } else {
     // non-FEJ linearisation: positions come from the Jacobian path — camera_reproject.hpp:323-333
-    const S X = S(P.U[0]) * pu + S(P.U[1]) * pv + (S(P.U[2]) + S(P.U[3]) * idepth);
-    const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idepth);
-    const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idepth);
-    tu = (S(P.fxt) * X + S(P.cxt) * Z) / Z;
-    tv = (S(P.fyt) * Y + S(P.cyt) * Z) / Z;
+    const S X = S(Pm->U[0]) * pu + S(Pm->U[1]) * pv + (S(Pm->U[2]) + S(Pm->U[3]) * idepth);
+    const S Y = S(Pm->U[4]) * pu + S(Pm->U[5]) * pv + (S(Pm->U[6]) + S(Pm->U[7]) * idepth);
+    const S Z = S(Pm->U[8]) * pu + S(Pm->U[9]) * pv + (S(Pm->U[10]) + S(Pm->U[11]) * idepth);
+    tu = (S(Pm->fxt) * X + S(Pm->cxt) * Z) / Z;
+    tv = (S(Pm->fyt) * Y + S(Pm->cyt) * Z) / Z;
     ok = ok && (Z > S(0));
   }
   ok = ok && insideROI(tu, tv, Wt, Ht);
@@ -517,6 +522,8 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
   }
   SWEEP_STAMP(3);
+  const PairConst DSOPP_CONSTANT *Pj = &P;  // constants of the residual and of the Jacobian path: fetched from here on
+  asm volatile("" : "+s"(Pj) : "v"(tu));
   // success of the item = all 8 pixels fine (and the FEJ validity bit)
   const unsigned long long okmask = __ballot(ok);
   const int shift = (threadIdx.x & 63) & ~7;
@@ -527,7 +534,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   if (evaluate) cand = DSOPP_HIP_STATUS_OK;
 
   // ---- residual, Huber on the norm of the 8-vector — evaluate_jacobians.hpp:124-146
-  const S res = evaluate ? (sI - S(P.b_t)) - S(P.s) * (patch_k - S(P.b_r)) : S(0);
+  const S res = evaluate ? (sI - S(Pj->b_t)) - S(Pj->s) * (patch_k - S(Pj->b_r)) : S(0);
   const double r2 = sum8(static_cast<double>(res * res));
   double wgt = 1.0, energy = 0.5 * r2;
   if (HUBER) {
@@ -548,14 +555,14 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     if (evaluate) {
       // geometric Jacobians at the linearisation point (FEJ: idepth snapshot) — camera_reproject.hpp:339-365
       const S idj = FEJ ? static_cast<S>(idepth_fej_d) : idepth;
-      const S X = S(P.U[0]) * pu + S(P.U[1]) * pv + (S(P.U[2]) + S(P.U[3]) * idj);
-      const S Y = S(P.U[4]) * pu + S(P.U[5]) * pv + (S(P.U[6]) + S(P.U[7]) * idj);
-      const S Z = S(P.U[8]) * pu + S(P.U[9]) * pv + (S(P.U[10]) + S(P.U[11]) * idj);
-      const S fxt = S(P.fxt), fyt = S(P.fyt);
+      const S X = S(Pj->U[0]) * pu + S(Pj->U[1]) * pv + (S(Pj->U[2]) + S(Pj->U[3]) * idj);
+      const S Y = S(Pj->U[4]) * pu + S(Pj->U[5]) * pv + (S(Pj->U[6]) + S(Pj->U[7]) * idj);
+      const S Z = S(Pj->U[8]) * pu + S(Pj->U[9]) * pv + (S(Pj->U[10]) + S(Pj->U[11]) * idj);
+      const S fxt = S(Pj->fxt), fyt = S(Pj->fyt);
       const S rho = fastRcp(Z);
       const S b0 = X * rho, b1 = Y * rho;
-      const S du_id = fxt * (S(P.tl[0]) * rho - S(P.tl[2]) * (rho * b0));
-      const S dv_id = fyt * (S(P.tl[1]) * rho - S(P.tl[2]) * (rho * b1));
+      const S du_id = fxt * (S(Pj->tl[0]) * rho - S(Pj->tl[2]) * (rho * b0));
+      const S dv_id = fyt * (S(Pj->tl[1]) * rho - S(Pj->tl[2]) * (rho * b1));
       const S nid = idj * rho;
       const S Iu = sIx, Iv = sIy;
       // g = [ Iv * d_v_T + Iu * d_u_T (6) , c , 1 ] — evaluate_jacobians.hpp:149-157,176-182
@@ -567,7 +574,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       g[3] = Iv * (fyt * (-(b1 * b1 + S(1)))) + Iu * (fxt * (-b0b1));
       g[4] = Iv * (fyt * b0b1) + Iu * (fxt * (b0 * b0 + S(1)));
       g[5] = Iv * (fyt * b0) + Iu * (fxt * (-b1));
-      g[6] = S(P.sigma_r) * (patch_k - S(P.b_r0));
+      g[6] = S(Pj->sigma_r) * (patch_k - S(Pj->b_r0));
       g[7] = S(1);
       const double jdd = static_cast<double>(Iu * du_id + Iv * dv_id);  // evaluate_jacobians.hpp:165-174
       const double rk = static_cast<double>(res);

@@ -8,7 +8,7 @@
 //     their right-hand sides: the load phase is a single coalesced sweep, 7 loads per thread;
 //   * the Jacobi guard (pivot threshold) is taken while the diagonal is written, not in a pass of its own.
 // The factorisation itself (blocked Cholesky over the frame blocks with a look-ahead panel wave, right-hand side as an extra row,
-// f32 rsqrt seed + two Newton steps, pivots below 1e-30 of the Jacobi-scaled diagonal treated as zero) and the back-substitution
+// v_rsq_f64 seed + two Newton steps, pivots below 1e-30 of the Jacobi-scaled diagonal treated as zero) and the back-substitution
 // are those of assembleSolveKernel.
 #pragma once
 #include "pba_solve_kernels.hpp"
@@ -223,12 +223,14 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
       const double d = readLane(c[k], k);
-      // inv = 1/sqrt(d) from the f32 estimate + two Newton steps in f64; pivots whose Jacobi-scaled value d / (diag + 10) is
+      // inv = 1/sqrt(d) from the hardware estimate + two Newton steps; pivots whose Jacobi-scaled value d / (diag + 10) is
       // below 1e-30 are treated as zero, as a rank-revealing factorisation would
       const bool okp = d > guard[k];
-      double inv = static_cast<double>(__frsqrt_rn(static_cast<float>(okp ? d : 1.0)));
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
-      inv = inv * (1.5 - 0.5 * d * inv * inv);
+      // (v_rsq_f64 seed, 2^-23 relative, straight on the f64 pivot: the f32 seed cost two conversions on the dependent chain)
+      const double hd = 0.5 * d;
+      double inv = __builtin_amdgcn_rsq(d);
+      inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
+      inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
       inv = okp ? inv : 0.0;
       invd[k] = inv;
       const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik

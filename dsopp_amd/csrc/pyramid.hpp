@@ -19,6 +19,14 @@
 #else
 #define DSOPP_HBM
 #endif
+// Data a kernel only reads and that an earlier kernel wrote (pair constants, control blocks): typed as constant-address-space
+// so that uniform loads stay scalar loads even after the kernel's own stores (which "may alias" any generic or global pointer
+// and otherwise force the compiler to re-load such values with vector loads inside loops).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DSOPP_CONSTANT __attribute__((address_space(4)))
+#else
+#define DSOPP_CONSTANT
+#endif
 typedef double DSOPP_HBM hbm_f64;
 typedef unsigned char DSOPP_HBM hbm_u8;
 typedef int DSOPP_HBM hbm_i32;
