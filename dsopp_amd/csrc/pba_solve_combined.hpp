@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     }
     __syncthreads();
   }
+  SC_STAMP(2);
   // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
   // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
   // 4-7 instructions per unknown, no LDS round trip or barrier inside the chain (L_kj is prefetched a frame block ahead).
@@ -351,10 +352,14 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
         }
       }
     };
+    // (Measured and dropped: back-substitution by frame blocks with inverted diagonal blocks, x_blk = W^T y_blk then y -= L_blk^T x_blk,
+    // which halves the dependent chain but doubles the broadcasts: 3.2 us against 2.6 us.  A v_readlane pair costs as much as three
+    // dependent f64 FMAs here (scripts/probes/bcast_probe.hip), so the count of broadcasts decides, not the chain length.)
     if (K > 64)
       run(std::true_type{});
     else
       run(std::false_type{});
+    SC_STAMP(6);
   }
   __syncthreads();
   if (tid < K) {
