@@ -673,6 +673,14 @@ __global__ void __launch_bounds__(kLoopThreads) alignLoopKernel(AlignFrameDev re
 // accept the level when rmse < 2.5 * rmse_last[level]) run on the device as well: identical in every workgroup.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kPyramidMaxWorkgroups = 64;
+// Cross-workgroup exchange of the persistent kernel: every partial sum is its own ready flag.  The host fills the three rotating
+// partial buffers with a NaN bit pattern no sum can take (both 32-bit halves equal, so one 32-bit fill does it); a workgroup
+// re-arms its slots of the buffer after next before it publishes into the current one; consumers poll the values themselves.
+// One memory round trip per pass (store -> load) instead of three (arrive atomic, counter poll, partial loads).
+constexpr unsigned kPyramidSentinelWord = 0x7FF85A5Au;
+constexpr unsigned long long kPyramidSentinel = (static_cast<unsigned long long>(kPyramidSentinelWord) << 32) | kPyramidSentinelWord;
+constexpr int kPyramidBuffers = 3;
+constexpr unsigned kPyramidFailed = 1u;
 
 struct AlignLevelDev {
   AlignFrameDev ref, tgt;
@@ -708,8 +716,7 @@ struct AlignPyramidArgs {
   double T_tr0[12];
   double ab0[2];
   double *partials;        // [2][gridDim.x][kAlignPartial]
-  unsigned *counter;       // zeroed by the host before the launch
-  unsigned *failed;        // zeroed by the host before the launch
+  unsigned *failed;        // == kPyramidFailed once a workgroup gave up waiting (anything else: running); behind the partial buffers
   AlignPyramidResult *out;
 };
 
@@ -791,9 +798,14 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         if (!sc.active) break;
       }
       AP_STAMP(1);
+      // re-arm this workgroup's slots of the buffer the NEXT pass publishes into (its last readers finished two passes ago);
+      // the stores complete behind the sweep and are waited for before this pass's sums go out
+      if (tid < kAlignPartial)
+        __hip_atomic_store((gu64 *)(a.partials + (static_cast<size_t>((pass_global + 1u) % kPyramidBuffers) * G + blockIdx.x) * kAlignPartial + tid),
+                           kPyramidSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
       const int first = blockIdx.x * kAlignThreads + tid;
-      double *dst = a.partials + (static_cast<size_t>(pass_global & 1u) * G + blockIdx.x) * kAlignPartial;
+      double *dst = a.partials + (static_cast<size_t>(pass_global % kPyramidBuffers) * G + blockIdx.x) * kAlignPartial;
       if (static_cast<int>(blockIdx.x) * kAlignThreads < L.n_points) {
         double acc[kAlignPartial];
         if (preloaded) {
@@ -827,6 +839,8 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         }
         s += alignDpp<0xB1>(s);
         s += alignDpp<0x4E>(s);
+        // (the re-arming stores of the previous pass target these addresses from other lanes: they were drained by the
+        // s_waitcnt below in that pass, ahead of the barriers in between)
         if (row_idx < kAlignPartial && quarter == 0)
           __hip_atomic_store((gu64 *)(dst + row_idx), static_cast<unsigned long long>(__double_as_longlong(s)),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -834,46 +848,40 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         // no points on this level for this workgroup: it still takes part in the exchange
         __hip_atomic_store((gu64 *)(dst + tid), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // ---- publish / arrive / wait (R1)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (sums and re-arming)
+      __syncthreads();                                   // ... and red[] is free for the sums below
       AP_STAMP(3);
-      if (tid == 0) {
-        gu32 *cnt = (gu32 *)a.counter;
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned target = static_cast<unsigned>(G) * (pass_global + 1u);
-        unsigned spins = 0;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1u << 22) || __hip_atomic_load((gu32 *)a.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            __hip_atomic_store((gu32 *)a.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_failed = 1;
-            break;
-          }
-        }
-      }
-      __syncthreads();
-      AP_STAMP(4);
-      if (s_failed) {
-        if (blockIdx.x == 0 && tid == 0) a.out->failed = 1;
-        return;
-      }
-      // ---- every workgroup sums all partial sums in the same fixed order (thread e < 48 x 5 groups, as alignIterationKernel)
+      // ---- every workgroup polls and sums all partial sums in the same fixed order (thread e < 48 x 5 groups, as
+      // alignIterationKernel): a value that is not the sentinel IS the published sum
       {
         constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
         const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
-        const double *src = a.partials + static_cast<size_t>(pass_global & 1u) * G * kAlignPartial + e;
+        const double *src = a.partials + static_cast<size_t>(pass_global % kPyramidBuffers) * G * kAlignPartial + e;
         if (grp < kGroups) {
-          // all loads of this thread are issued before the first add: clamped indices + a 0 / 1 factor instead of predicated
-          // loads (G <= 64: at most 13 per thread, one L2 round trip)
+          // all loads of this thread are issued before the first test: clamped indices + a 0 / 1 factor instead of predicated
+          // loads (G <= 64: at most 13 per thread, one round trip per poll)
           constexpr int kMaxPer = (kPyramidMaxWorkgroups + kGroups - 1) / kGroups;
           unsigned long long w[kMaxPer];
+          unsigned spins = 0;
+          for (;;) {
+            bool ready = true;
 #pragma unroll
-          for (int j = 0; j < kMaxPer; ++j) {
-            const int b = grp + j * kGroups;
-            const int bc = b < G ? b : G - 1;
-            w[j] = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(bc) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < kMaxPer; ++j) {
+              const int b = grp + j * kGroups;
+              const int bc = b < G ? b : G - 1;
+              w[j] = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(bc) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxPer; ++j) ready = ready && (w[j] != kPyramidSentinel);
+            if (ready) break;
+            if (++spins > (1u << 20) || __hip_atomic_load((gu32 *)a.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPyramidFailed) {
+              __hip_atomic_store((gu32 *)a.failed, kPyramidFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              s_failed = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
+          AP_STAMP(4);
           double p0 = 0, p1 = 0;
 #pragma unroll
           for (int j = 0; j < kMaxPer; ++j) {
@@ -886,6 +894,10 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
           red[grp * kAlignPartial + e] = p0 + p1;
         }
         __syncthreads();
+        if (s_failed) {  // a workgroup never showed up (GPU shared with other work): the host falls back to launch-per-iteration
+          if (blockIdx.x == 0 && tid == 0) a.out->failed = 1;
+          return;
+        }
         if (tid < kAlignPartial) {
           double t = 0;
 #pragma unroll
@@ -962,7 +974,7 @@ struct dsopp_hip_aligner {
   bool pyramids_ordered = false;   // estimate_pose already ordered this stream behind both pyramids' builds (one wait per frame, not per level)
   // estimate_pose as one persistent launch over all levels (alignPyramidKernel)
   DeviceBuffer<double> d_pyr_partials;
-  DeviceBuffer<unsigned> d_pyr_sync;           // [0] arrival counter, [1] failed flag
+
   DeviceBuffer<AlignPyramidResult> d_pyr_out;
   AlignPyramidResult *h_pyr_out = nullptr;     // pinned
   bool pyramid_kernel_disabled = false;        // a bounded spin timed out once (GPU shared with other work): stay on the launch-per-iteration path
@@ -1556,15 +1568,15 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         }
         args.ab0[0] = ab[0];
         args.ab0[1] = ab[1];
-        a->d_pyr_partials.reserve(2 * static_cast<size_t>(kPyramidMaxWorkgroups) * kAlignPartial, 0, st);
-        a->d_pyr_sync.reserve(2, 0, st);
+        const size_t n_partial = static_cast<size_t>(kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial;
+        a->d_pyr_partials.reserve(n_partial + 1, 0, st);  // + one word pair for the failed flag
         a->d_pyr_out.reserve(1, 0, st);
         if (!a->h_pyr_out) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_pyr_out), sizeof(AlignPyramidResult), hipHostMallocDefault));
         args.partials = a->d_pyr_partials.ptr;
-        args.counter = a->d_pyr_sync.ptr;
-        args.failed = a->d_pyr_sync.ptr + 1;
+        args.failed = reinterpret_cast<unsigned *>(a->d_pyr_partials.ptr + n_partial);
         args.out = a->d_pyr_out.ptr;
-        HIP_CHECK(hipMemsetAsync(a->d_pyr_sync.ptr, 0, 2 * sizeof(unsigned), st));  // arrival counter + failed flag: re-initialised every call
+        // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill per call
+        HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
         if (a->opt.dtype == DSOPP_HIP_F64)
           alignPyramidKernel<double><<<G, kAlignThreads, 0, st>>>(args);
         else
