@@ -817,6 +817,7 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda)
   a.pc = w.d_pc.ptr;
   a.schur_table = w.d_schur_table.ptr;
   a.partials = w.d_partials.ptr;
+  a.dbg = w.dbg_stamps ? w.dbg_stamps + 32 : nullptr;
   a.pair_first_block = w.d_pair_first.ptr;
   a.pair_num_blocks = w.d_pair_count.ptr;
   a.ctrl = ctrl;

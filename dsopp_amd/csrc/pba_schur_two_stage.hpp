@@ -38,7 +38,9 @@ struct TwoStageArgs {
   int F;
   int n_chunks, chunks_per_wg, n_schur_wgs;
   int ublk_parity;
+  long long *dbg;  // nullable tuning aid (-DDSOPP_HIP_STAMPS): phase stamps of workgroup 1, first chunk
 };
+#define TS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1 && chunk == first_chunk) a.dbg[i] = wall_clock64(); } while (0)
 
 __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStageArgs a) {  // 2 workgroups of 8 waves per compute unit
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -121,6 +123,7 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     const unsigned conn = be.conn_mask & ~(1u << r);
     const size_t plane = ublkPlane(be.cap);
     const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
+    TS_STAMP(0);
     __syncthreads();  // the previous chunk's tiles have been read
     for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;  // pad columns must be 0
     if (r != staged_r) {
@@ -138,8 +141,12 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       take = (flg & kFlagMarginalized) == 0;
     }
     __syncthreads();
+    TS_STAMP(1);
     {
       // phase 1 (as reduceSchurKernel): 8 threads per landmark, thread `sub` owns the targets t = sub, sub + 8, ...
+      // (Measured and dropped: staging every slot's 64 rows as one contiguous 5 KB run with 16-byte loads by consecutive lanes,
+      // finalisation from LDS — 16-26 us for the staging alone against 10 us for this whole phase; the register file cannot hold
+      // the staged words next to the resident MFMA tiles at two workgroups per compute unit.)
       double hr[kBlk];
 #pragma unroll
       for (int c = 0; c < kBlk; ++c) hr[c] = 0;
@@ -198,7 +205,9 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
         if (bd_in_pad && take) row[K] = bd;
       }
     }
+    TS_STAMP(2);
     __syncthreads();
+    TS_STAMP(3);
     // phase 2: this wave's tiles += A^T W A over the chunk (v_mfma_f64_16x16x4_f64), operands of a tile requested up front
     int q = 0;
     for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
@@ -232,13 +241,21 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
 #pragma unroll
       for (int qq = 0; qq < kMaxTilesPerWave; ++qq) acc[qq] = (qq == q) ? c4 : acc[qq];
     }
+    TS_STAMP(4);
     if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) {
-      double s = 0;
-#pragma unroll 1
-      for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + threadIdx.x];
-      bs_acc += s;
+      double s = 0, s1 = 0, s2 = 0, s3 = 0;  // four partial sums, 16 LDS reads in flight per batch
+#pragma unroll 4
+      for (int ll = 0; ll < kSchurLandmarks; ll += 4) {
+        s += wbd[ll] * hrow[ll * stride + threadIdx.x];
+        s1 += wbd[ll + 1] * hrow[(ll + 1) * stride + threadIdx.x];
+        s2 += wbd[ll + 2] * hrow[(ll + 2) * stride + threadIdx.x];
+        s3 += wbd[ll + 3] * hrow[(ll + 3) * stride + threadIdx.x];
+      }
+      bs_acc += (s + s1) + (s2 + s3);
     }
+    TS_STAMP(5);
   }
+  if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[6] = wall_clock64();
   // ---- this workgroup's partial system, written once, in the MFMA's own layout: [tile][reg][lane] (coalesced 512-byte stores
   // per wave), then K entries of b_schur when the tiles have no spare column
   double *out = a.schur_partials + static_cast<size_t>(blockIdx.x) * twoStagePartialCount(F);
@@ -251,6 +268,7 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     for (int reg = 0; reg < 4; ++reg) out[static_cast<size_t>(tile) * 256 + reg * 64 + lane] = c4[reg];
   }
   if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) out[static_cast<size_t>(n_tiles) * 256 + threadIdx.x] = bs_acc;
+  if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[7] = wall_clock64();
 }
 
 struct CombineArgs {

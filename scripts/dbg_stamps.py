@@ -18,3 +18,5 @@ print(f"solve: loads+assemble {st[1]-st[0]:.2f}  cholesky {st[2]-st[1]:.2f}  bac
       f"total {st[5]-st[0]:.2f}")
 rs = st[24:]
 print("reduceSchur (wg 1) stamps us:", np.round(rs[:8] - rs[0], 2))
+ts = st[32:40]
+print("schurTwoStage (wg 1, first chunk) stamps us:", np.round(ts - ts[0], 2), "(0 chunk start, 1 rows cleared + flags, 2 phase 1 done, 3 barrier, 4 MFMA done, 5 b_schur done, 6 all chunks done, 7 partial written)")
