@@ -693,9 +693,16 @@ struct FusedReduce {
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
  *  in the fused loop it starts with the LM decision for the pending candidate */
 enum class ReduceMode { kFused, kAccumulateOnly, kDecideOnly };
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense);
 void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr, ReduceMode mode = ReduceMode::kFused) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
+  if (!fused && !for_marg && !ctrl && w.deterministic) {
+    // stage API / host-driven loop under dsopp_hip_window_set_deterministic: the four dense arrays without atomics
+    launchTwoStage(w, nullptr, 0, 0.0, true);
+    allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
+    return;
+  }
   ensureDynamicLds(reinterpret_cast<const void *>(reduceSchurKernel), w.sr.device, 96 * 1024);
   ReduceSchurArgs a;
   a.frames = w.d_frames.ptr;
@@ -800,7 +807,7 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
 /** two-stage build of the combined system (large windows / deterministic mode): partial systems without atomics, then one
  *  ordered sum per entry.  `ctrl` (nullable) is the control block whose `active` gates both launches and whose lambda damps the
  *  system; the LM decision is NOT taken here (decideApplyKernel runs in front of / behind it). */
-void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda) {
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false) {
   const int F = w.F(), K = w.K();
   hipStream_t st = w.sr.stream;
   ensureDynamicLds(reinterpret_cast<const void *>(schurTwoStageKernel), w.sr.device, 96 * 1024);
@@ -835,6 +842,7 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda)
   c.ctrl = ctrl;
   c.lambda = lambda;
   c.comb = w.d_reduce.ptr;
+  c.dense = dense ? w.d_reduce.ptr : nullptr;
   c.F = F;
   c.n_schur_wgs = n_wgs;
   const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);

@@ -277,6 +277,9 @@ struct CombineArgs {
   const LmControl *ctrl;  // nullable
   double lambda;          // when ctrl is null
   double *comb;
+  // nullable: write the four dense arrays of the stage API instead (H_pp K x K | b_pp K | H_schur K x K | b_schur K, undamped,
+  // both triangles) — the deterministic build of dsopp_hip_window_linearize under dsopp_hip_window_set_deterministic
+  double *dense;
   int F, n_schur_wgs;
 };
 
@@ -375,6 +378,20 @@ __global__ void __launch_bounds__(kCombineEntries * kCombineSlices) combineSyste
   double schur = 0;
 #pragma unroll
   for (int q = 0; q < kCombineSlices; ++q) schur += part[q][le];
+  if (a.dense) {
+    double *Hpp = a.dense, *bpp = Hpp + static_cast<size_t>(K) * K, *Hs = bpp + K, *bs = Hs + static_cast<size_t>(K) * K;
+    if (col == K) {
+      bpp[row] = pairRhs(a, row);
+      bs[row] = schur;
+    } else {
+      const double pair = pairEntry(a, col, row);
+      Hpp[static_cast<size_t>(col) * K + row] = pair;
+      Hpp[static_cast<size_t>(row) * K + col] = pair;
+      Hs[static_cast<size_t>(col) * K + row] = schur;
+      Hs[static_cast<size_t>(row) * K + col] = schur;
+    }
+    return;
+  }
   const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
   const double sc = -1.0 / (1.0 + lam);
   if (col == K) {

@@ -334,6 +334,39 @@ def test_deterministic_mode_is_bit_reproducible_and_matches_oracle():
     g.close()
 
 
+def test_deterministic_stage_api_systems_are_bit_reproducible():
+    """under set_deterministic the stage API builds H_pp / b_pp / H_schur / b_schur through the same atomic-free two-stage path:
+    two linearisations of the same state give identical arrays bit for bit, equal to the oracle's and to the atomics build
+    within the usual tolerance"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=5, num_points=1500, width=320, height=240, seed=43)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
+    o.begin()
+    o.calculate_energy()
+    o.linearize()
+    ref = o.get_system()
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    got = []
+    for det in (True, True, False):
+        g.set_deterministic(det)
+        g.begin()
+        g.calculate_energy()
+        g.linearize()
+        got.append(g.get_system())
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    for sysm in got:
+        for name, a, r in zip(["H_pp", "b_pp", "H_schur", "b_schur"], sysm, ref):
+            scale = max(1.0, np.abs(r).max())
+            assert np.abs(a - r).max() <= 1e-9 * scale, name
+            if name == "H_pp":   # the fixed frame's 1e16 prior dominates the max: the free part against its own scale too
+                assert np.abs(a[8:, 8:] - r[8:, 8:]).max() <= 1e-9 * np.abs(r[8:, 8:]).max()
+    for a in (got[0][0], got[0][2]):
+        assert np.array_equal(a, a.T)   # written as symmetric pairs
+    g.close()
+
+
 def test_large_window_two_stage_is_bit_reproducible():
     """windows above 96 landmark chunks take the two-stage build by themselves (C3 size: 7 frames / 20 000 points): reproducible"""
     from dsopp_amd import capi
