@@ -356,7 +356,8 @@ void syncTopology(W &w) {
   for (int r = 0; r < F; ++r)
     for (const auto &kv : w.frames[static_cast<size_t>(r)]->residuals) total_items += static_cast<size_t>(kv.second->n);
   static const int groups_override = std::getenv("DSOPP_HIP_SWEEP_GROUPS") ? std::atoi(std::getenv("DSOPP_HIP_SWEEP_GROUPS")) : 0;  // tuning aid
-  const int groups = groups_override > 0 ? groups_override : (total_items >= 30000 ? 4 : 1);
+  // measured: 7 KF / 20k points (120k items) 36.8 / 33.1 / 38.8 us at 2 / 4 / 6 groups; 12 KF / 50k points (550k items) 143 / 125 / 119 us
+  const int groups = groups_override > 0 ? groups_override : (total_items >= 300000 ? 6 : (total_items >= 30000 ? 4 : 1));
   std::vector<int> pair_first(kMaxFrames * kMaxFrames, -1), pair_count(kMaxFrames * kMaxFrames, 0);
   for (int r = 0; r < F; ++r) {
     HostFrame &f = *w.frames[static_cast<size_t>(r)];
