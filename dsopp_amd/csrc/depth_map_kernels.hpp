@@ -103,13 +103,18 @@ struct FlowArgs {
   double cx, cy, ifx, ify;
   int width, height, n_transforms;
 };
+constexpr int kFlowRows = 16;
 __global__ void __launch_bounds__(256) opticalFlowPartialsKernel(const double *__restrict__ idsum, const double *__restrict__ wgt, FlowArgs a,
                                                                  double *__restrict__ partials) {
   __shared__ double lds[4 * 2 * kMaxFlowTransforms];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
   double sum[kMaxFlowTransforms], cnt[kMaxFlowTransforms];
 #pragma unroll
   for (int t = 0; t < kMaxFlowTransforms; ++t) sum[t] = cnt[t] = 0;
+  // a workgroup takes kFlowRows rows of its 256-column strip (rows in order, one running sum per thread): 16 x fewer partial
+  // blocks for the closing kernel to add up
+  for (int ry = 0; ry < kFlowRows; ++ry) {
+  const int y = blockIdx.y * kFlowRows + ry;
   if (x >= 4 && x < a.width - 4 && y >= 4 && y < a.height - 4) {
     const size_t c = static_cast<size_t>(y) * a.width + x;
     const double w = wgt[c];
@@ -128,12 +133,13 @@ __global__ void __launch_bounds__(256) opticalFlowPartialsKernel(const double *_
           const double tu = px / pz, tv = py / pz;
           if (validIdepth(idepth) && insideROI(u, v, W, H) && (pz > 0) && insideROI(tu, tv, W, H)) {  // camera_reproject.hpp:270-293
             const double bx = (tu - a.cx) * a.ifx, by = (tv - a.cy) * a.ify;
-            sum[t] = (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
-            cnt[t] = 1;
+            sum[t] += (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+            cnt[t] += 1;
           }
         }
       }
     }
+  }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -155,19 +161,42 @@ __global__ void __launch_bounds__(256) opticalFlowPartialsKernel(const double *_
     partials[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 2 * kMaxFlowTransforms + threadIdx.x] = s;
   }
 }
-__global__ void __launch_bounds__(64) opticalFlowFinishKernel(const double *__restrict__ partials, int n_blocks, int n_transforms, double *__restrict__ out) {
-  const int lane = threadIdx.x;
-  for (int t = 0; t < n_transforms; ++t) {
-    double s = 0, n = 0;
-    for (int b = lane; b < n_blocks; b += 64) {
-      s += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2];
-      n += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2 + 1];
+/** closing sum over the partial blocks, fixed order: thread j adds the blocks j, j + 256, ... (all loads of a thread in flight
+ *  together), then wave sums by shuffles and the four wave sums in wave order.  (One wave walking 5 120 single-row blocks
+ *  with a load per step made this the longest part of the call: 0.2 ms for a 1280 x 1024 map.) */
+__global__ void __launch_bounds__(256) opticalFlowFinishKernel(const double *__restrict__ partials, int n_blocks, int n_transforms, double *__restrict__ out) {
+  __shared__ double lds[4][2 * kMaxFlowTransforms];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s[kMaxFlowTransforms], n[kMaxFlowTransforms];
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) s[t] = n[t] = 0;
+  for (int b = tid; b < n_blocks; b += 256) {
+#pragma unroll
+    for (int t = 0; t < kMaxFlowTransforms; ++t) {
+      s[t] += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2];
+      n[t] += partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2 + 1];
     }
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) {
+    double ss = s[t], nn = n[t];
     for (int off = 32; off > 0; off >>= 1) {
-      s += __shfl_down(s, off);
-      n += __shfl_down(n, off);
+      ss += __shfl_down(ss, off);
+      nn += __shfl_down(nn, off);
     }
-    if (lane == 0) out[t] = sqrt(s / n);  // 0 / 0 = NaN for an empty map, as in the reference
+    if (lane == 0) {
+      lds[wave][2 * t] = ss;
+      lds[wave][2 * t + 1] = nn;
+    }
+  }
+  __syncthreads();
+  if (tid < n_transforms) {
+    double ss = 0, nn = 0;
+    for (int w = 0; w < 4; ++w) {
+      ss += lds[w][2 * tid];
+      nn += lds[w][2 * tid + 1];
+    }
+    out[tid] = sqrt(ss / nn);  // 0 / 0 = NaN for an empty map, as in the reference
   }
 }
 

@@ -2739,12 +2739,12 @@ int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m,
     a.width = m->width[static_cast<size_t>(level)];
     a.height = m->height[static_cast<size_t>(level)];
     a.n_transforms = n_transforms;
-    const dim3 grid(static_cast<unsigned>((a.width + 255) / 256), static_cast<unsigned>(a.height));
+    const dim3 grid(static_cast<unsigned>((a.width + 255) / 256), static_cast<unsigned>((a.height + kFlowRows - 1) / kFlowRows));
     const size_t n_blocks = static_cast<size_t>(grid.x) * grid.y;
     m->flow_scratch.reserve(n_blocks * 2 * kMaxFlowTransforms + kMaxFlowTransforms, 0, st);
     double *out = m->flow_scratch.ptr + n_blocks * 2 * kMaxFlowTransforms;
     opticalFlowPartialsKernel<<<grid, 256, 0, st>>>(m->idepth_sum[static_cast<size_t>(level)].ptr, m->weight[static_cast<size_t>(level)].ptr, a, m->flow_scratch.ptr);
-    opticalFlowFinishKernel<<<1, 64, 0, st>>>(m->flow_scratch.ptr, static_cast<int>(n_blocks), n_transforms, out);
+    opticalFlowFinishKernel<<<1, 256, 0, st>>>(m->flow_scratch.ptr, static_cast<int>(n_blocks), n_transforms, out);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(flow, out, sizeof(double) * static_cast<size_t>(n_transforms), hipMemcpyDeviceToHost, st));
     m->sr.sync();
