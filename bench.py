@@ -618,6 +618,8 @@ def run_depth_estimation_timing(capi, syn, args, repeats=10):
     good = 0
     for rep in range(repeats + 1):
         dsets = [capi.ImmatureSet(l) for l in sets]   # device-resident: the landmarks persist over frames, only their state moves
+        for ds in dsets:
+            ds.sync()                                 # (their uploads are not part of the per-frame call)
         t0 = time.perf_counter()
         capi.estimate_depths_batched(dsets, pyr, 0, intr, np.stack(Ts), np.ones(KF), np.zeros((KF, 2)))   # one launch over all keyframes
         dsets[0].sync()
@@ -687,6 +689,8 @@ def run_landmark_activation_timing(capi, syn, args, repeats=10):
     for rep in range(repeats + 1):
         for ds, s0 in zip(dsets, states):
             ds.upload(s0)
+        for ds in dsets:
+            ds.sync()   # (restoring the pre-activation state is not part of the per-keyframe call)
         t0 = time.perf_counter()
         st, _, res = g.activate_landmarks(ids, dsets, pyramids[KF], syn.mat_to_params(new.T_w_c_gt), 1.0, (0, 0), KF * NA, 2.0, True)
         if rep:
