@@ -694,13 +694,34 @@ struct FusedReduce {
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
  *  in the fused loop it starts with the LM decision for the pending candidate */
 enum class ReduceMode { kFused, kAccumulateOnly, kDecideOnly };
-void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense);
+constexpr size_t kDecideSmemBytes = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
+
+/** arguments of the LM decision (fusedDecideApply + applyDecision) when it runs as the prologue of another kernel */
+ReduceSchurArgs makeDecideArgs(W &w, const LmControl *cin, const FusedReduce &fr) {
+  ReduceSchurArgs a{};
+  a.frames = w.d_frames.ptr;
+  a.pc = w.d_pc.ptr;
+  a.schur_table = w.d_schur_table.ptr;
+  a.partials = w.d_partials.ptr;
+  a.ctrl = cin;
+  a.ctrl_out = fr.ctrl_out;
+  a.st = w.d_state.ptr;
+  a.F = w.F();
+  a.n_schur_blocks = 0;
+  a.n_sweep_blocks = w.n_sweep_blocks;
+  a.scalars = fr.scalars ? fr.scalars : w.d_scalars.ptr;
+  a.prm = fr.prm;
+  a.dbg = nullptr;
+  return a;
+}
+
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense, const ReduceSchurArgs *decide);
 void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr, ReduceMode mode = ReduceMode::kFused) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
   if (!fused && !for_marg && !ctrl && w.deterministic) {
     // stage API / host-driven loop under dsopp_hip_window_set_deterministic: the four dense arrays without atomics
-    launchTwoStage(w, nullptr, 0, 0.0, true);
+    launchTwoStage(w, nullptr, 0, 0.0, true, nullptr);
     allreduceIfNeeded(w, w.d_reduce.ptr, w.reduceCount());
     return;
   }
@@ -734,7 +755,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   if (fused) a.prm = fused->prm;
   if (fused && fused->scalars) a.scalars = fused->scalars;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 24 : nullptr;
-  const size_t decide_smem = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
+  const size_t decide_smem = kDecideSmemBytes;
   if (mode == ReduceMode::kDecideOnly) {
     timedLaunch(w, DSOPP_HIP_KERNEL_ACCEPT,
                 [&] { decideApplyKernel<<<std::max(1, a.n_schur_blocks), kSchurThreads, decide_smem, st>>>(a); });
@@ -808,7 +829,7 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
 /** two-stage build of the combined system (large windows / deterministic mode): partial systems without atomics, then one
  *  ordered sum per entry.  `ctrl` (nullable) is the control block whose `active` gates both launches and whose lambda damps the
  *  system; the LM decision is NOT taken here (decideApplyKernel runs in front of / behind it). */
-void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false) {
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false, const ReduceSchurArgs *decide = nullptr) {
   const int F = w.F(), K = w.K();
   hipStream_t st = w.sr.stream;
   ensureDynamicLds(reinterpret_cast<const void *>(schurTwoStageKernel), w.sr.device, 96 * 1024);
@@ -836,6 +857,8 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
   a.chunks_per_wg = chunks_per_wg;
   a.n_schur_wgs = n_wgs;
   a.ublk_parity = ublk_parity;
+  a.fused_decide = decide ? 1 : 0;
+  if (decide) a.dec = *decide;
   CombineArgs c;
   c.pc = w.d_pc.ptr;
   c.schur_partials = w.d_schur_partials.ptr;
@@ -848,7 +871,7 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
   c.n_schur_wgs = n_wgs;
   const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
-    schurTwoStageKernel<<<n_wgs + F * F, kSchurThreads, std::max(schurSmemBytes(K), pair_smem), st>>>(a);
+    schurTwoStageKernel<<<n_wgs + F * F, kSchurThreads, std::max(std::max(schurSmemBytes(K), pair_smem), decide ? kDecideSmemBytes : size_t(0)), st>>>(a);
     combineSystemKernel<<<static_cast<unsigned>((twoStagePartialCount(F) + kCombineEntries - 1) / kCombineEntries), kCombineEntries * kCombineSlices, 0, st>>>(c);
   });
   HIP_CHECK(hipGetLastError());
@@ -1155,8 +1178,10 @@ void lmSolveFusedEnqueue(W &w) {
       } else {
         fr.prm.use_reduced_scalars = 2;
         fr.scalars = w.d_scalars.ptr + 16;
-        launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);  // decision + accept / reject from the sweep's energy
-        launchTwoStage(w, cout, fr.ublk_parity, 0.0);                    // system at the accepted state, damped with the new lambda
+        // decision + accept / reject from the sweep's energy as the prologue of the partial-system kernel; the ordered sum then
+        // damps with the lambda of the published control block
+        const ReduceSchurArgs dec = makeDecideArgs(w, cin, fr);
+        launchTwoStage(w, cout, fr.ublk_parity, 0.0, false, &dec);
       }
     } else if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide

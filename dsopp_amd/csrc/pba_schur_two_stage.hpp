@@ -39,12 +39,53 @@ struct TwoStageArgs {
   int n_chunks, chunks_per_wg, n_schur_wgs;
   int ublk_parity;
   long long *dbg;  // nullable tuning aid (-DDSOPP_HIP_STAMPS): phase stamps of workgroup 1, first chunk
+  // unsharded fused loop: the LM decision for the pending candidate and its accept / reject stores run as this kernel's prologue
+  // (every workgroup decides from the 64 group sums of the sweep's scalars, applies it to the landmarks of ITS chunks; workgroup 0
+  // also to the frames, and publishes the outgoing control block) instead of as a kernel of their own in front
+  int fused_decide;
+  ReduceSchurArgs dec;  // ctrl (incoming), ctrl_out, prm, scalars, st, F of that decision
 };
 #define TS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1 && chunk == first_chunk) a.dbg[i] = wall_clock64(); } while (0)
 
 __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStageArgs a) {  // 2 workgroups of 8 waves per compute unit
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (a.ctrl && !a.ctrl->active) return;
+  if (a.fused_decide) {
+    ReduceSchurArgs d = a.dec;
+    d.n_schur_blocks = 0;  // (no per-block preloads in the decision: this workgroup owns several chunks, handled below)
+    ApplyRegs ar;
+    ar.pending = 0;
+    ar.publish = 0;
+    long long dbg2[2] = {0, 0};
+    const bool proceed = fusedDecideApply(d, reinterpret_cast<double *>(smem_raw), dbg2, ar);
+    applyDecision(d, ar);  // frames + control block (workgroup 0)
+    if (ar.pending && static_cast<int>(blockIdx.x) < a.n_schur_wgs) {
+      // acceptStep / rejectStep of the landmarks of this workgroup's chunks (problem.hpp:364-402): 8 threads per landmark, thread
+      // `sub` owns the targets sub and sub + 8
+      const int c0 = blockIdx.x * a.chunks_per_wg, c1 = min(c0 + a.chunks_per_wg, a.n_chunks);
+      for (int chunk = c0; chunk < c1; ++chunk) {
+        const SchurBlock &be = a.schur_table[chunk];
+        const int l = threadIdx.x >> 3, sub = threadIdx.x & 7, i = be.offset + l;
+        if (i >= be.n) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t = sub + 8 * h;
+          if (t < a.F && be.status[t] != nullptr && i < be.n_res[t]) {
+            if (ar.accept)
+              be.status[t][i] = be.cand[t][i];
+            else
+              be.cand[t][i] = be.status[t][i];
+          }
+        }
+        if (sub == 0) {
+          if (ar.accept) be.idepth[i] += be.idepth_step[i];
+          be.idepth_step[i] = 0;
+        }
+      }
+    }
+    if (!proceed) return;
+  } else if (a.ctrl && !a.ctrl->active) {
+    return;
+  }
   const int F = a.F, K = kBlk * F;
   if (static_cast<int>(blockIdx.x) >= a.n_schur_wgs) {
     // ---- frame pair: deterministic sum of the sweep's partials, derived blocks, one slot per pair (no atomics)
