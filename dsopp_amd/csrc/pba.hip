@@ -87,6 +87,7 @@ struct dsopp_hip_window {
   DeviceBuffer<LmControl> d_ctrl;
   const LmControl *fused_final_ctrl = nullptr;  // control block the enqueued fused loop ends in
   bool async_pending = false;                   // dsopp_hip_window_optimize_async enqueued, _wait not called yet
+  bool begun_with_first_estimate = true;        // the solve in progress started with firstEstimate() (stageBegin) rather than fusedBegin
   int lm_mode = 0;  // 0: fused device loop (3 launches / iteration), 1: host-driven stages, 2: unfused device loop (5 launches)
   double *dHppRaw() const { return d_reduce.ptr; }
   double *dbppRaw() const { return d_reduce.ptr + static_cast<size_t>(K()) * K(); }
@@ -106,6 +107,8 @@ struct dsopp_hip_window {
   bool state_dirty = true;   // host mirror newer than device
   bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
+  LmControl *h_ctrl_pool[2] = {nullptr, nullptr};  // optimize_repeated keeps two solves in flight: one result slot + event each
+  hipEvent_t ctrl_ready[2] = {nullptr, nullptr};
   DeviceBuffer<SelectState> d_select;   // radix-select state of updatePointStatuses
   DeviceBuffer<double> d_pair_dist;     // camera-centre distances of all frame pairs
   DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
@@ -592,6 +595,7 @@ struct SweepExtras {
   bool fused_lin_backsub = false;
   bool combined = false;  // the following reduction builds the combined system: only that much has to be zeroed
   bool external_backsub = false;  // calculateIdepths ran in backsubKernel in front of this sweep (large windows)
+  bool write_fej = false;         // opening linearisation of a fused solve: the sweep takes the first-estimate snapshot itself
 };
 
 template <typename S>
@@ -625,8 +629,16 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   const PairConst *pc = w.d_pc.ptr;
   const SweepBlock *tb = w.d_sweep_table.ptr;
   double *pa = w.d_partials.ptr;
+  const bool opening = lin && huber && ex.write_fej && w.fej();
+  if (opening) prm.external_backsub = 1;  // (nothing is pending in the opening round: only the state norms are recorded)
   timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
-    if (lin && ex.fused_lin_backsub) {
+    if (opening) {
+      // opening linearisation of a fused solve: first-estimate snapshot taken by the sweep itself, no back-substitution
+      if (small_lds)
+        sweepKernel<S, true, true, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      else
+        sweepKernel<S, true, true, true, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+    } else if (lin && ex.fused_lin_backsub) {
       // fused LM loop: linearisation at the candidate state = its energy evaluation + calculateIdepths in one pass
       if (w.fej() && small_lds)
         sweepKernel<S, true, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
@@ -689,6 +701,7 @@ struct FusedReduce {
   bool combined = false;   // emit the combined block-packed system instead of H_pp / H_schur (fused loop)
   double comb_lambda = 0;  // its damping when no control block is given
   const double *scalars = nullptr;  // decide-only launches: where the (group) sums of the sweep's scalars are
+  LmControl *ctrl_host = nullptr;   // closing round: pinned host destination of the final control block
 };
 
 /** K2: per-pair reduction + Schur complement (+ the cross-rank sum of everything that is a sum over landmarks);
@@ -754,6 +767,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + reduce_count : nullptr;
   if (fused) a.prm = fused->prm;
   if (fused && fused->scalars) a.scalars = fused->scalars;
+  a.ctrl_host = fused ? fused->ctrl_host : nullptr;
   a.dbg = w.dbg_stamps ? w.dbg_stamps + 24 : nullptr;
   const size_t decide_smem = kDecideSmemBytes;
   if (mode == ReduceMode::kDecideOnly) {
@@ -947,6 +961,21 @@ void stageBegin(W &w) {
   if (w.F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
   prepare(w);
   if (w.fej()) firstEstimate(w);
+  w.begun_with_first_estimate = true;
+  w.begun = true;
+  w.linearized = false;
+}
+
+/** begin of a fused solve (lm_mode 0): firstEstimateJacobians is folded into the solve's own first kernels (lmSolveFusedEnqueue)
+ *  whenever there is a linearisation to fold it into */
+void fusedBegin(W &w) {
+  if (w.F() == 0) fail(DSOPP_HIP_ERR_STATE, "window is empty");
+  if (!(w.fej() && w.opt.max_iterations > 0)) {
+    stageBegin(w);
+    return;
+  }
+  prepare(w);
+  w.begun_with_first_estimate = false;
   w.begun = true;
   w.linearized = false;
 }
@@ -1120,9 +1149,17 @@ void lmSolveFusedEnqueue(W &w) {
   prm.force_accept = w.opt.force_accept;
   prm.use_reduced_scalars = w.allreduce ? 1 : 0;
   LmControl *ctrl = w.d_ctrl.ptr;
-  ensurePairConstants(w);
+  // With first-estimate Jacobians the opening linearisation takes the snapshot (idepth, reprojection validity) for its own items
+  // and the pair constants are set up by lmBeginKernel: a solve starts with ONE small kernel instead of three (pair set-up,
+  // first-estimate kernel, LM initialisation).  fusedBegin() skipped firstEstimate() when this holds.
+  const bool sweep_takes_fej = w.fej() && w.opt.max_iterations > 0 && !w.begun_with_first_estimate;
+  const bool begin_sets_pairs = !w.pair_valid;
   {
     LmInitArgs ia;
+    ia.pair_frames = begin_sets_pairs ? w.d_frames.ptr : nullptr;
+    ia.pair_pc = w.d_pc.ptr;
+    ia.pair_fej = w.fej() ? 1 : 0;
+    w.pair_valid = true;
     ia.sa = makeSolveArgs(w);
     ia.partials = w.d_partials.ptr;
     ia.scalars = nullptr;
@@ -1137,6 +1174,7 @@ void lmSolveFusedEnqueue(W &w) {
   // one round per iteration + the opening evaluation; without force_accept a rejected step costs one more round (the
   // re-linearisation at the reverted state), so the budget doubles — rounds after the loop has ended are no-op launches
   const int rounds = (w.opt.force_accept ? w.opt.max_iterations : 2 * w.opt.max_iterations) + 1;
+  bool result_written_by_kernel = false;
   for (int r = 0; r < rounds; ++r) {
     LmControl *cin = ctrl + (r & 1), *cout = ctrl + ((r + 1) & 1);
     SweepExtras ex;
@@ -1145,6 +1183,7 @@ void lmSolveFusedEnqueue(W &w) {
     ex.gate_on_pending = true;
     ex.fused_lin_backsub = true;
     ex.combined = true;
+    ex.write_fej = r == 0 && sweep_takes_fej;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
     if (w.n_schur_blocks > kTwoStageMinChunks && r + 1 < rounds) {
       // large windows: the back-substitution fused into the sweep re-reads a landmark's whole Schur row for every one of its
@@ -1187,6 +1226,13 @@ void lmSolveFusedEnqueue(W &w) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
+    } else if (r + 1 == rounds) {
+      // the closing round only takes the decision for the last candidate (its sweep was residual-only: no system to build) and
+      // leaves the solve's result in pinned host memory itself (a copy kernel behind it cost 4 us per solve)
+      if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
+      fr.ctrl_host = w.h_ctrl;
+      result_written_by_kernel = true;
+      launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else {
       launchReduceSchur(w, false, cin, &fr);
     }
@@ -1198,7 +1244,7 @@ void lmSolveFusedEnqueue(W &w) {
   // one small read-back into pinned memory (a pageable destination makes the copy synchronous and staged); the host
   // mirror of the frame states is refreshed lazily, by the first reader (downloadState)
   if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
-  HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  if (!result_written_by_kernel) HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
   w.host_stale = true;
   w.fused_final_ctrl = cfin;
 }
@@ -1720,7 +1766,11 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->sr.stream) (void)hipStreamSynchronize(w->sr.stream);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
-  if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
+  if (w->h_ctrl && w->h_ctrl != w->h_ctrl_pool[0] && w->h_ctrl != w->h_ctrl_pool[1]) (void)hipHostFree(w->h_ctrl);
+  for (int k = 0; k < 2; ++k) {
+    if (w->h_ctrl_pool[k]) (void)hipHostFree(w->h_ctrl_pool[k]);
+    if (w->ctrl_ready[k]) (void)hipEventDestroy(w->ctrl_ready[k]);
+  }
   if (w->h_export) (void)hipHostFree(w->h_export);
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
@@ -1991,7 +2041,10 @@ static void runOptimize(dsopp_hip_window *w, double &e, int &it, int &nv) {
   w->sr.use();
   prepare(*w);
   HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
-  stageBegin(*w);
+  if (w->lm_mode == 0)
+    fusedBegin(*w);
+  else
+    stageBegin(*w);
   if (w->lm_mode == 1)
     lmSolve(*w, e, it, nv);
   else if (w->lm_mode == 2)
@@ -2076,7 +2129,7 @@ int dsopp_hip_window_optimize_async(dsopp_hip_window *w) {
     if (w->async_pending) fail(DSOPP_HIP_ERR_STATE, "an asynchronous solve is already pending: call dsopp_hip_window_optimize_wait first");
     w->sr.use();
     prepare(*w);
-    stageBegin(*w);
+    fusedBegin(*w);
     lmSolveFusedEnqueue(*w);
     w->async_pending = true;
   });
@@ -2599,8 +2652,88 @@ int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
   });
 }
 
+namespace {
+/** optimize_repeated with the host running ahead: up to two solves of the window are enqueued (restore -> begin -> the fused LM
+ *  rounds -> 64-byte result into its own pinned slot + event) before the older one's result is awaited, so the stream never
+ *  drains between solves.  Sequentially every solve ends with a host synchronisation and the next one starts with ~25 us of
+ *  enqueue latency in front of its first kernels: ~60 us of an idle GPU per 7 iterations (rocprofv3 kernel trace), which belongs to
+ *  this helper's bookkeeping, not to a Gauss-Newton iteration.  A solve never runs more iterations than its budget, so the total
+ *  cannot overshoot; solves that stop early are made up for by further ones, exactly as in the sequential loop. */
+void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, double &energy) {
+  w.sr.use();
+  const int configured = w.opt.max_iterations;
+  LmControl *const saved = w.h_ctrl;
+  for (int k = 0; k < 2; ++k) {
+    if (!w.h_ctrl_pool[k]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl_pool[k]), sizeof(LmControl), hipHostMallocDefault));
+    if (!w.ctrl_ready[k]) HIP_CHECK(hipEventCreateWithFlags(&w.ctrl_ready[k], hipEventDisableTiming));
+  }
+  struct InFlight {
+    int slot, budget;
+  };
+  InFlight q[2];
+  int head = 0, count = 0, next_slot = 0, budgeted = 0;
+  done = 0;
+  bool stalled = false, last_needs_closing = false;
+  auto restoreBudget = [&] { w.opt.max_iterations = configured; w.h_ctrl = saved ? saved : w.h_ctrl_pool[0]; };
+  try {
+    for (;;) {
+      while (!stalled && count < 2 && done + budgeted < target) {
+        const int budget = std::min(configured, target - done - budgeted);
+        if (dsopp_hip_window_restore(&w) != DSOPP_HIP_OK) fail(DSOPP_HIP_ERR_STATE, "%s", lastError().c_str());
+        w.opt.max_iterations = budget;
+        prepare(w);
+        fusedBegin(w);
+        w.h_ctrl = w.h_ctrl_pool[next_slot];   // where this solve's result lands
+        lmSolveFusedEnqueue(w);
+        HIP_CHECK(hipEventRecord(w.ctrl_ready[next_slot], w.sr.stream));
+        q[(head + count) & 1] = InFlight{next_slot, budget};
+        ++count;
+        budgeted += budget;
+        next_slot ^= 1;
+      }
+      if (count == 0) break;
+      const InFlight f = q[head];
+      head ^= 1;
+      --count;
+      HIP_CHECK(hipEventSynchronize(w.ctrl_ready[f.slot]));
+      const LmControl &r = *w.h_ctrl_pool[f.slot];
+      budgeted -= f.budget;
+      energy = r.energy;
+      if (r.iteration <= 0) stalled = true;  // no progress: drain what is in flight and leave (iterations_done < target)
+      done += r.iteration;
+      last_needs_closing = r.need_final_setup != 0;
+    }
+    if (last_needs_closing) {
+      // the last solve ended on a rejected step: closing evaluation at the reverted state, as lmSolveFusedFinish does
+      ensurePairConstants(w);
+      launchSweep(w, false, true, false);
+      HIP_CHECK(hipGetLastError());
+    }
+  } catch (...) {
+    (void)hipStreamSynchronize(w.sr.stream);
+    restoreBudget();
+    throw;
+  }
+  restoreBudget();
+  w.sr.sync();
+  w.begun = false;
+}
+}  // namespace
+
 int dsopp_hip_window_optimize_repeated(dsopp_hip_window *w, int32_t iterations_target, int32_t *iterations_done, double *last_energy) {
   if (!w || iterations_target < 0) return dsopp_hip_window_restore(nullptr);  // reports the invalid argument
+  static const bool no_pipeline = std::getenv("DSOPP_HIP_NO_PIPELINE") != nullptr;  // tuning aid: one solve at a time
+  if (!no_pipeline && w->lm_mode == 0 && w->opt.force_accept && !(w->allreduce && w->world > 1) && w->F() > 0 && !w->async_pending) {
+    int done = 0;
+    double e = 0;
+    const int rc = guarded([&] {
+      w->export_valid = false;
+      optimizeRepeatedPipelined(*w, iterations_target, done, e);
+    });
+    if (iterations_done) *iterations_done = done;
+    if (last_energy) *last_energy = e;
+    return rc;
+  }
   const int configured = w->opt.max_iterations;
   int done = 0, rc = DSOPP_HIP_OK;
   double e = 0;

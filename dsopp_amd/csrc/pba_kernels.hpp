@@ -344,12 +344,14 @@ __device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], 
  * (PBA_INT/evaluate_jacobians.hpp:20-202, hessian_block_evaluation.hpp:38-90,198-212).
  *   LIN = false: residual-only sweep (calculateEnergy), optionally with calculateIdepths fused in (BACKSUB).
  *   LIN = true : linearisation sweep.
+ *   WFEJ = true: the opening linearisation of a fused solve — the sweep IS firstEstimateJacobians_ for its items: it takes the
+ *                inverse-depth snapshot and the reprojection validity itself (and uses them) instead of a kernel in front.
  * Thread mapping: one lane per pattern pixel, 8 adjacent lanes per (landmark, target) item, a workgroup = 16 items of one
  * ordered frame pair.  The dependent chain of a lane is: landmark words (coalesced, broadcast within the item) ->
  * 1 reprojection -> 4 texel loads (2 x 64 B segments) -> 1 Jacobian row -> reductions, so a C1-sized sweep is one
  * memory round trip deep per stage instead of eight.
  */
-template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool SMALL_LDS = false>
+template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool SMALL_LDS = false, bool WFEJ = false>
 __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
@@ -426,8 +428,9 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     cand = g_cand[i];
     patch_k = static_cast<S>(g_patch[kPat * i + k]);
     if (FEJ) {
-      if (prm.use_fej_flag) fej_bit = g_fej_valid[i];  // evaluate_jacobians.hpp:94
-      if (LIN) idepth_fej_d = g_idepth_fej[i];
+      constexpr bool fresh_fej = LIN && WFEJ;
+      if (prm.use_fej_flag && !fresh_fej) fej_bit = g_fej_valid[i];  // evaluate_jacobians.hpp:94
+      if (LIN) idepth_fej_d = fresh_fej ? idepth_d : g_idepth_fej[i];
     }
     if (BACKSUB) {
       bd_d = g_b_d[i];
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   }
   bool active = inb && !((flg & kFlagMarginalized) && !(flg & kFlagToMarginalize));  // evaluate_jacobians.hpp:83-85
   const bool accumulate = active && (prm.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0);
-  const bool fej_ok = fej_bit != 0;
+  bool fej_ok = fej_bit != 0;
   if (!active) {
     status = DSOPP_HIP_STATUS_OOB;
     cand = DSOPP_HIP_STATUS_OOB;
@@ -524,9 +527,27 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   SWEEP_STAMP(3);
   const PairConst DSOPP_CONSTANT *Pj = &P;  // constants of the residual and of the Jacobian path: fetched from here on
   asm volatile("" : "+s"(Pj) : "v"(tu));
+  const int shift = (threadIdx.x & 63) & ~7;
+  if (FEJ && LIN && WFEJ) {
+    // firstEstimateJacobians_ for this item (first_estimate_jacobians.hpp:30-62, as fejKernel): all 8 pattern pixels reproject
+    // with valid Jacobians at the snapshot inverse depth, the pattern's extent lies inside the reference image
+    const S idf = static_cast<S>(idepth_d);
+    const S X = S(Pj->U[0]) * pu + S(Pj->U[1]) * pv + (S(Pj->U[2]) + S(Pj->U[3]) * idf);
+    const S Y = S(Pj->U[4]) * pu + S(Pj->U[5]) * pv + (S(Pj->U[6]) + S(Pj->U[7]) * idf);
+    const S Z = S(Pj->U[8]) * pu + S(Pj->U[9]) * pv + (S(Pj->U[10]) + S(Pj->U[11]) * idf);
+    const S tuf = (S(Pj->fxt) * X + S(Pj->cxt) * Z) / Z, tvf = (S(Pj->fyt) * Y + S(Pj->cyt) * Z) / Z;
+    const bool okf = (Z > S(0)) && insideROI(tuf, tvf, Wt, Ht);
+    const unsigned long long fmask = __ballot(okf);
+    const bool item_ok = (((fmask >> shift) & 0xFFull) == 0xFFull) && validIdepth(idf) && insideROI(u - S(2), v - S(2), Wr, Hr) &&
+                         insideROI(u + S(2), v + S(2), Wr, Hr);
+    if (prm.use_fej_flag) fej_ok = item_ok;
+    if (active && k == 0) {
+      glb(const_cast<uint8_t *>(static_cast<const uint8_t *>(be.fej_valid)))[i] = item_ok ? 1 : 0;
+      glb(const_cast<double *>(static_cast<const double *>(be.idepth_fej)))[i] = idepth_d;  // every connected target writes the same value
+    }
+  }
   // success of the item = all 8 pixels fine (and the FEJ validity bit)
   const unsigned long long okmask = __ballot(ok);
-  const int shift = (threadIdx.x & 63) & ~7;
   const bool success = active && fej_ok && (((okmask >> shift) & 0xFFull) == 0xFFull);
 
   if (active && !success) cand = DSOPP_HIP_STATUS_OOB;  // evaluate_jacobians.hpp:111-113

@@ -117,6 +117,7 @@ struct ReduceSchurArgs {
   double comb_lambda;  // lambda when neither control block is given (isolated timing launches)
   LmParams prm;
   long long *dbg;  // nullable tuning aid
+  LmControl *ctrl_host = nullptr;  // nullable: pinned host copy of the published control block (closing round of a solve)
 };
 #define RS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[i] = wall_clock64(); } while (0)
 
@@ -163,7 +164,10 @@ __device__ inline void applyDecision(const ReduceSchurArgs &a, const ApplyRegs &
       a.st->step[f][c] = 0;
     }
   }
-  if (ar.publish && blockIdx.x == 0 && tid == 0) *a.ctrl_out = *ar.out;
+  if (ar.publish && blockIdx.x == 0 && tid == 0) {
+    *a.ctrl_out = *ar.out;
+    if (a.ctrl_host) *a.ctrl_host = *ar.out;  // closing round: the solve's result goes straight into pinned host memory
+  }
 }
 
 __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, long long *dbg_out, ApplyRegs &ar) {
@@ -241,7 +245,10 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
     }
   }
   if (!cin.active) {  // (the loads above are speculative: they overlap the control block's round trip)
-    if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
+    if (blockIdx.x == 0 && tid == 0) {
+      *a.ctrl_out = cin;
+      if (a.ctrl_host) *a.ctrl_host = cin;
+    }
     return false;
   }
   v[4] = st_eps * st_eps + st_ab0 * st_ab0;
@@ -1272,6 +1279,11 @@ struct LmInitArgs {
   int n_sweep_blocks, n_schur_blocks;
   LmControl *ctrl;  // [2]
   LmParams prm;
+  // nullable: the pair constants of every ordered frame pair are set up here too (a solve that starts from a state whose constants
+  // are not current: restore, new keyframe, accepted steps of the previous solve) — one launch less at the head of the solve
+  const FrameDev *pair_frames = nullptr;
+  PairConst *pair_pc = nullptr;
+  int pair_fej = 0;
 };
 
 /** sum of idepth^2 over this rank's landmarks (state norm of acceptStep, problem.hpp:379); grid = schur blocks */
@@ -1470,6 +1482,8 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
 __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const double idepth_sq = 0;  // set by the decide step of the opening round (sum idepth^2 rides in the sweep's partials)
+  if (a.pair_frames && static_cast<int>(threadIdx.x) < a.sa.F * a.sa.F)
+    computePairConst(a.pair_frames, a.sa.st, a.pair_pc, threadIdx.x / a.sa.F, threadIdx.x % a.sa.F, a.sa.F, a.pair_fej != 0);
   const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
   if (threadIdx.x == 0) {
     LmControl c;
