@@ -1482,8 +1482,15 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
 __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const double idepth_sq = 0;  // set by the decide step of the opening round (sum idepth^2 rides in the sweep's partials)
-  if (a.pair_frames && static_cast<int>(threadIdx.x) < a.sa.F * a.sa.F)
-    computePairConst(a.pair_frames, a.sa.st, a.pair_pc, threadIdx.x / a.sa.F, threadIdx.x % a.sa.F, a.sa.F, a.pair_fej != 0);
+  if (a.pair_frames) {
+    // the 2 F frame increments exp(+-(eps + step)) once per frame, shared through LDS, instead of twice per ordered pair
+    __shared__ Rigid s_inc[2 * kMaxFrames];
+    const int F = a.sa.F, tid = threadIdx.x;
+    if (tid < 2 * F) s_inc[tid] = frameIncrement(a.sa.st, tid < F ? tid : tid - F, tid < F ? 1.0 : -1.0);
+    __syncthreads();
+    if (tid < F * F) computePairConst(a.pair_frames, a.sa.st, a.pair_pc, tid / F, tid % F, F, a.pair_fej != 0, &s_inc[tid / F], &s_inc[F + tid % F]);
+    __syncthreads();  // (priorEnergyBlock below has its own scratch; keep the phases apart)
+  }
   const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
   if (threadIdx.x == 0) {
     LmControl c;
