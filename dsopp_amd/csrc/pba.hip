@@ -107,8 +107,9 @@ struct dsopp_hip_window {
   bool state_dirty = true;   // host mirror newer than device
   bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
-  LmControl *h_ctrl_pool[2] = {nullptr, nullptr};  // optimize_repeated keeps two solves in flight: one result slot + event each
-  hipEvent_t ctrl_ready[2] = {nullptr, nullptr};
+  DeviceBuffer<LmControl> d_results;  // optimize_repeated: one result slot per solve of a batch ...
+  LmControl *h_results = nullptr;     // ... fetched together into pinned memory
+  LmControl *result_device = nullptr; // set while such a solve is enqueued: where its closing kernel leaves the control block
   DeviceBuffer<SelectState> d_select;   // radix-select state of updatePointStatuses
   DeviceBuffer<double> d_pair_dist;     // camera-centre distances of all frame pairs
   DeviceBuffer<double> d_export;        // packed per-frame read-back (get_frame_update): 4 n doubles, then (1 + targets) n bytes
@@ -1230,7 +1231,7 @@ void lmSolveFusedEnqueue(W &w) {
       // the closing round only takes the decision for the last candidate (its sweep was residual-only: no system to build) and
       // leaves the solve's result in pinned host memory itself (a copy kernel behind it cost 4 us per solve)
       if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
-      fr.ctrl_host = w.h_ctrl;
+      fr.ctrl_host = w.result_device ? w.result_device : w.h_ctrl;  // (batched solves: a device slot, fetched with the batch)
       result_written_by_kernel = true;
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else {
@@ -1766,11 +1767,8 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->sr.stream) (void)hipStreamSynchronize(w->sr.stream);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
-  if (w->h_ctrl && w->h_ctrl != w->h_ctrl_pool[0] && w->h_ctrl != w->h_ctrl_pool[1]) (void)hipHostFree(w->h_ctrl);
-  for (int k = 0; k < 2; ++k) {
-    if (w->h_ctrl_pool[k]) (void)hipHostFree(w->h_ctrl_pool[k]);
-    if (w->ctrl_ready[k]) (void)hipEventDestroy(w->ctrl_ready[k]);
-  }
+  if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
+  if (w->h_results) (void)hipHostFree(w->h_results);
   if (w->h_export) (void)hipHostFree(w->h_export);
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
@@ -2653,69 +2651,63 @@ int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int host_driven) {
 }
 
 namespace {
-/** optimize_repeated with the host running ahead: up to two solves of the window are enqueued (restore -> begin -> the fused LM
- *  rounds -> 64-byte result into its own pinned slot + event) before the older one's result is awaited, so the stream never
- *  drains between solves.  Sequentially every solve ends with a host synchronisation and the next one starts with ~25 us of
+/** optimize_repeated with the host running ahead: the solves of a batch are enqueued back to back (restore -> begin -> the fused
+ *  LM rounds, every solve's closing kernel leaving its control block in its own device slot) and their results are fetched with
+ *  one copy and one synchronisation per batch, so the stream never drains between solves.  Sequentially every solve ends with a host synchronisation and the next one starts with ~25 us of
  *  enqueue latency in front of its first kernels: ~60 us of an idle GPU per 7 iterations (rocprofv3 kernel trace), which belongs to
  *  this helper's bookkeeping, not to a Gauss-Newton iteration.  A solve never runs more iterations than its budget, so the total
  *  cannot overshoot; solves that stop early are made up for by further ones, exactly as in the sequential loop. */
 void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, double &energy) {
   w.sr.use();
+  hipStream_t st = w.sr.stream;
   const int configured = w.opt.max_iterations;
-  LmControl *const saved = w.h_ctrl;
-  for (int k = 0; k < 2; ++k) {
-    if (!w.h_ctrl_pool[k]) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl_pool[k]), sizeof(LmControl), hipHostMallocDefault));
-    if (!w.ctrl_ready[k]) HIP_CHECK(hipEventCreateWithFlags(&w.ctrl_ready[k], hipEventDisableTiming));
-  }
-  struct InFlight {
-    int slot, budget;
-  };
-  InFlight q[2];
-  int head = 0, count = 0, next_slot = 0, budgeted = 0;
+  constexpr int kSlots = 32;  // solves per batch: their results are fetched with ONE copy and ONE synchronisation
+  w.d_results.reserve(kSlots, 0, st);
+  if (!w.h_results) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_results), kSlots * sizeof(LmControl), hipHostMallocDefault));
   done = 0;
   bool stalled = false, last_needs_closing = false;
-  auto restoreBudget = [&] { w.opt.max_iterations = configured; w.h_ctrl = saved ? saved : w.h_ctrl_pool[0]; };
+  auto cleanUp = [&] {
+    w.opt.max_iterations = configured;
+    w.result_device = nullptr;
+  };
   try {
-    for (;;) {
-      while (!stalled && count < 2 && done + budgeted < target) {
-        const int budget = std::min(configured, target - done - budgeted);
+    while (done < target && !stalled) {
+      int n = 0, planned = 0;
+      while (n < kSlots && done + planned < target) {
+        const int budget = std::min(configured, target - done - planned);
         if (dsopp_hip_window_restore(&w) != DSOPP_HIP_OK) fail(DSOPP_HIP_ERR_STATE, "%s", lastError().c_str());
         w.opt.max_iterations = budget;
         prepare(w);
         fusedBegin(w);
-        w.h_ctrl = w.h_ctrl_pool[next_slot];   // where this solve's result lands
+        w.result_device = w.d_results.ptr + n;  // the closing kernel of this solve leaves its control block here
         lmSolveFusedEnqueue(w);
-        HIP_CHECK(hipEventRecord(w.ctrl_ready[next_slot], w.sr.stream));
-        q[(head + count) & 1] = InFlight{next_slot, budget};
-        ++count;
-        budgeted += budget;
-        next_slot ^= 1;
+        planned += budget;
+        ++n;
       }
-      if (count == 0) break;
-      const InFlight f = q[head];
-      head ^= 1;
-      --count;
-      HIP_CHECK(hipEventSynchronize(w.ctrl_ready[f.slot]));
-      const LmControl &r = *w.h_ctrl_pool[f.slot];
-      budgeted -= f.budget;
-      energy = r.energy;
-      if (r.iteration <= 0) stalled = true;  // no progress: drain what is in flight and leave (iterations_done < target)
-      done += r.iteration;
-      last_needs_closing = r.need_final_setup != 0;
+      w.result_device = nullptr;
+      HIP_CHECK(hipMemcpyAsync(w.h_results, w.d_results.ptr, static_cast<size_t>(n) * sizeof(LmControl), hipMemcpyDeviceToHost, st));
+      w.sr.sync();
+      for (int k = 0; k < n; ++k) {
+        const LmControl &r = w.h_results[k];
+        if (r.iteration <= 0) stalled = true;  // no progress: leave (iterations_done < target)
+        done += r.iteration;
+        energy = r.energy;
+        last_needs_closing = r.need_final_setup != 0;
+      }
     }
     if (last_needs_closing) {
       // the last solve ended on a rejected step: closing evaluation at the reverted state, as lmSolveFusedFinish does
       ensurePairConstants(w);
       launchSweep(w, false, true, false);
       HIP_CHECK(hipGetLastError());
+      w.sr.sync();
     }
   } catch (...) {
-    (void)hipStreamSynchronize(w.sr.stream);
-    restoreBudget();
+    (void)hipStreamSynchronize(st);
+    cleanUp();
     throw;
   }
-  restoreBudget();
-  w.sr.sync();
+  cleanUp();
   w.begun = false;
 }
 }  // namespace
