@@ -644,6 +644,12 @@ DepthFrame makeDepthFrame(const dsopp_hip_pyramid *target_pyramid, int level, co
   return f;
 }
 
+/** per-launch tables of the batched estimate (one DepthFrame / DepthLandmarks per keyframe set) */
+struct Tables {
+  DepthFrame f[DSOPP_HIP_MAX_FRAMES];
+  DepthLandmarks l[DSOPP_HIP_MAX_FRAMES];
+};
+
 DepthLandmarks landmarkPointers(dsopp_hip_immature_set *s) {
   const size_t N = static_cast<size_t>(s->n);
   DepthLandmarks L;
@@ -691,6 +697,12 @@ int dsopp_hip_immature_set_create(int device, void *stream, int32_t n, const dou
     }
     s->d_io.upload(io.data(), 4 * N, 0, st);
     s->d_flags.upload(fl.data(), 2 * N, 0, st);
+    // the launch tables of the batched per-frame estimate (this set may be the one that leads a batch): allocated here, at
+    // keyframe time, so that the per-frame call allocates nothing (a pinned allocation in its first call cost 0.1 ms)
+    HIP_CHECK(hipHostMalloc(&s->h_tables, sizeof(Tables), hipHostMallocDefault));
+    HIP_CHECK(hipEventCreateWithFlags(&s->tables_copied, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(s->tables_copied, st));
+    s->d_tables.reserve(sizeof(Tables), 0, st);
     s->sr.sync();
     *out = s.release();
   });
@@ -804,11 +816,7 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     lead->sr.use();
     hipStream_t st = lead->sr.stream;  // the launch runs on the first set's stream, ordered against the others' below
     target_pyramid->waitReady(st);
-    struct Tables {
-      DepthFrame f[DSOPP_HIP_MAX_FRAMES];
-      DepthLandmarks l[DSOPP_HIP_MAX_FRAMES];
-    };
-    if (!lead->h_tables) {
+    if (!lead->h_tables) {  // (sets created before the tables moved into dsopp_hip_immature_set_create)
       HIP_CHECK(hipHostMalloc(&lead->h_tables, sizeof(Tables), hipHostMallocDefault));
       HIP_CHECK(hipEventCreateWithFlags(&lead->tables_copied, hipEventDisableTiming));
     } else {
