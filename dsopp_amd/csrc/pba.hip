@@ -107,6 +107,9 @@ struct dsopp_hip_window {
   bool state_dirty = true;   // host mirror newer than device
   bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
+  void *h_uncertainty = nullptr;          // pinned destination of estimateUncertainty's systems (+ frame states)
+  size_t h_uncertainty_bytes = 0;
+  hipEvent_t uncertainty_ready = nullptr; // recorded behind that transfer
   DeviceBuffer<LmControl> d_results;  // optimize_repeated: one result slot per solve of a batch ...
   LmControl *h_results = nullptr;     // ... fetched together into pinned memory
   LmControl *result_device = nullptr; // set while such a solve is enqueued: where its closing kernel leaves the control block
@@ -1460,28 +1463,48 @@ void updatePointStatuses(W &w) {
 
 /** covarianceMatrixPosePose + covarianceMatricesOfRelativePoses — problem.hpp:204-242,
  *  PBA_INT/covariance_matrices_of_relative_poses.hpp:23-62, se3_motion.hpp:151-158 */
-void estimateUncertainty(W &w) {
+/** device half of estimateUncertainty: linearisation without the robust weight at the current state and the transfer of both
+ *  systems (and of the frame states, when a device-driven solve left the host mirror behind) into the pinned buffer
+ *  `w.h_uncertainty`; `w.uncertainty_ready` is recorded behind it.  Returns whether the states travel too. */
+bool estimateUncertaintyEnqueue(W &w, bool force_state) {
   prepareDevice(w);
   if (w.fej()) firstEstimate(w);
   w.begun = true;
   stageLinearize(w, /*huber=*/false, false, true);
-  const int K = w.K(), F = w.F();
-  // ONE synchronisation for everything the host needs: both systems and (when a device-driven solve left the host mirror
-  // behind) the frame states, through pinned staging
+  const int K = w.K();
   const size_t kk = static_cast<size_t>(K) * K;
-  const bool want_state = w.host_stale && !w.state_dirty;
+  const bool want_state = force_state || (w.host_stale && !w.state_dirty);
   const size_t bytes = 2 * kk * sizeof(double) + sizeof(WindowState);
-  if (w.h_export_bytes < bytes) {
-    if (w.h_export) (void)hipHostFree(w.h_export);
-    w.h_export = nullptr;
-    HIP_CHECK(hipHostMalloc(&w.h_export, bytes, hipHostMallocDefault));
-    w.h_export_bytes = bytes;
+  // (a buffer of its own: the packed per-frame read-back of solve() uses h_export while the host is still working on this one)
+  if (w.h_uncertainty_bytes < bytes) {
+    if (w.h_uncertainty) (void)hipHostFree(w.h_uncertainty);
+    w.h_uncertainty = nullptr;
+    HIP_CHECK(hipHostMalloc(&w.h_uncertainty, bytes, hipHostMallocDefault));
+    w.h_uncertainty_bytes = bytes;
   }
-  double *Hpp = static_cast<double *>(w.h_export), *Hsc = Hpp + kk;
+  if (!w.uncertainty_ready) HIP_CHECK(hipEventCreateWithFlags(&w.uncertainty_ready, hipEventDisableTiming));
+  double *Hpp = static_cast<double *>(w.h_uncertainty), *Hsc = Hpp + kk;
   w.d_Hpp.download(Hpp, kk, 0, w.sr.stream);
   w.d_HscDownload(Hsc, kk, 0, w.sr.stream);
   if (want_state) HIP_CHECK(hipMemcpyAsync(Hsc + kk, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
-  w.sr.sync();
+  HIP_CHECK(hipEventRecord(w.uncertainty_ready, w.sr.stream));
+  return want_state;
+}
+
+void estimateUncertaintyHost(W &w, bool want_state);
+
+void estimateUncertainty(W &w) {
+  const bool want_state = estimateUncertaintyEnqueue(w, false);
+  estimateUncertaintyHost(w, want_state);
+}
+
+/** host half: waits for the transfer only (the stream may already be busy with whatever was enqueued behind it), pseudo-inverse of
+ *  the reduced system, relative covariances */
+void estimateUncertaintyHost(W &w, bool want_state) {
+  const int K = w.K(), F = w.F();
+  const size_t kk = static_cast<size_t>(K) * K;
+  double *Hpp = static_cast<double *>(w.h_uncertainty), *Hsc = Hpp + kk;
+  HIP_CHECK(hipEventSynchronize(w.uncertainty_ready));
   if (want_state) {
     std::memcpy(&w.hst, Hsc + kk, sizeof(WindowState));
     w.host_stale = false;
@@ -1769,6 +1792,8 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   if (w->h_ctrl) (void)hipHostFree(w->h_ctrl);
   if (w->h_results) (void)hipHostFree(w->h_results);
+  if (w->h_uncertainty) (void)hipHostFree(w->h_uncertainty);
+  if (w->uncertainty_ready) (void)hipEventDestroy(w->uncertainty_ready);
   if (w->h_export) (void)hipHostFree(w->h_export);
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
@@ -2156,6 +2181,50 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     double e = 0;
     int it = 0, nv = 0;
+    const bool sharded = w->allreduce && w->world > 1;
+    static const bool serial_solve = std::getenv("DSOPP_HIP_SERIAL_SOLVE") != nullptr;  // tuning aid: the step-by-step flow
+    if (w->lm_mode == 0 && !sharded && !serial_solve && w->F() > 0) {
+      // One enqueue of everything, host work under it: the LM loop leaves its result in pinned memory by itself, the closing
+      // evaluation after a rejected last step is gated by the device-side flag, the covariance linearisation and the transfer
+      // of its systems follow, then point statuses and the packed per-frame read-back — and while the GPU is busy with those the
+      // host inverts the reduced system.  (Step by step the GPU idled for the host synchronisation behind the LM loop and for
+      // the 0.1 ms of the pseudo-inverse: rocprofv3 kernel trace, scripts/trace_solve.py.)
+      w->sr.use();
+      prepare(*w);
+      HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
+      fusedBegin(*w);
+      lmSolveFusedEnqueue(*w);
+      {
+        // closing problem.calculateEnergy() at the reverted state iff the last step was rejected (lmSolveFusedFinish does this
+        // on the host's say-so; here the final control block's flag decides on the device)
+        const int *flag = &w->fused_final_ctrl->need_final_setup;
+        pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w->sr.stream>>>(w->d_frames.ptr, w->d_state.ptr, w->d_pc.ptr, w->F(), w->fej() ? 1 : 0, flag);
+        SweepExtras ex;
+        ex.run_flag = flag;
+        launchSweep(*w, false, true, false, nullptr, false, 0.0, ex);
+        w->pair_valid = false;
+      }
+      HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
+      w->solve_events_pending = true;
+      relinearize(*w);
+      bool want_state = false;
+      if (w->opt.estimate_uncertainty) want_state = estimateUncertaintyEnqueue(*w, /*force_state=*/true);
+      updatePointStatusesDevice(*w);
+      prefetchFrameUpdates(*w);
+      if (w->opt.estimate_uncertainty) estimateUncertaintyHost(*w, want_state);
+      w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
+      e = w->h_ctrl->energy;
+      it = w->h_ctrl->iteration;
+      nv = w->h_ctrl->n_valid;
+      w->export_valid = true;
+      collectTimings(*w);
+      w->begun = false;
+      w->linearized = true;
+      if (energy) *energy = e;
+      if (iterations) *iterations = it;
+      if (n_valid) *n_valid = nv;
+      return;
+    }
     runOptimize(w, e, it, nv);
     relinearize(*w);
     if (w->opt.estimate_uncertainty) estimateUncertainty(*w);
