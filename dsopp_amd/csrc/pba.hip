@@ -503,7 +503,7 @@ void syncTopology(W &w) {
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
   w.d_ctrl.reserve(2, 0, st);
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
-  w.d_Hpp.reserve(KK * KK, 0, st);
+  w.d_Hpp.reserve(2 * KK * KK, 0, st);  // (second half: full symmetric copy of H_schur for the covariance read-back, makeSolveArgs)
   w.d_bpp.reserve(KK, 0, st);
   w.d_reduce.reserve(2 * (KK * KK + KK) + 8, 0, st);  // + tail: the 4 energy scalars ride in the same collective (sharded windows)
   w.d_Hm.reserve(KK * KK, 0, st);
@@ -799,6 +799,7 @@ SolveArgs makeSolveArgs(W &w) {
   a.Hpp_raw = w.dHppRaw();
   a.bpp_raw = w.dbppRaw();
   a.Hpp_out = w.d_Hpp.ptr;
+  a.Hsc_copy = w.d_Hpp.ptr + static_cast<size_t>(w.K()) * w.K();  // written with store_system: [H_pp | H_schur] leave in one transfer
   a.bpp_out = w.d_bpp.ptr;
   a.Hsc = w.dHsc();
   a.bsc = w.dbsc();
@@ -1484,8 +1485,7 @@ bool estimateUncertaintyEnqueue(W &w, bool force_state) {
   }
   if (!w.uncertainty_ready) HIP_CHECK(hipEventCreateWithFlags(&w.uncertainty_ready, hipEventDisableTiming));
   double *Hpp = static_cast<double *>(w.h_uncertainty), *Hsc = Hpp + kk;
-  w.d_Hpp.download(Hpp, kk, 0, w.sr.stream);
-  w.d_HscDownload(Hsc, kk, 0, w.sr.stream);
+  w.d_Hpp.download(Hpp, 2 * kk, 0, w.sr.stream);  // [H_pp | symmetric H_schur], stored back to back by the assemble kernel
   if (want_state) HIP_CHECK(hipMemcpyAsync(Hsc + kk, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
   HIP_CHECK(hipEventRecord(w.uncertainty_ready, w.sr.stream));
   return want_state;
@@ -2117,9 +2117,13 @@ void prefetchFrameUpdates(dsopp_hip_window &w) {
   }
   if (!words) return;
   w.d_update.reserve(words, 0, st);
+  FrameExportBatch batch;
+  batch.n_frames = 0;
+  int max_n = 0;
   for (const auto &e : w.export_entries) {
     HostFrame &f = w.frameById(e.frame_id);
-    FrameExportArgs a;
+    FrameExportArgs &a = batch.f[batch.n_frames++];
+    max_n = std::max(max_n, f.n);
     a.idepth = f.idepth.ptr;
     a.inv_hdd = f.inv_hdd.ptr;
     a.relative_baseline = f.relative_baseline.ptr;
@@ -2130,8 +2134,8 @@ void prefetchFrameUpdates(dsopp_hip_window &w) {
     for (int t = 0; t < a.n_targets; ++t) a.status[t] = f.residuals[e.target_ids[static_cast<size_t>(t)]]->status.ptr;
     a.out_d = w.d_update.ptr + e.word_offset;
     a.out_b = reinterpret_cast<uint8_t *>(a.out_d + 4 * static_cast<size_t>(f.n));
-    exportFrameKernel<<<static_cast<unsigned>((f.n + 255) / 256), 256, 0, st>>>(a);
   }
+  exportFramesKernel<<<dim3(static_cast<unsigned>((max_n + 255) / 256), static_cast<unsigned>(batch.n_frames)), 256, 0, st>>>(batch);
   HIP_CHECK(hipGetLastError());
   if (w.h_update_bytes < words * 8) {
     if (w.h_update) (void)hipHostFree(w.h_update);

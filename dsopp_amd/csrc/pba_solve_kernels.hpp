@@ -692,6 +692,7 @@ struct SolveArgs {
   double *Hsc;                      // Schur system, upper triangle accumulated (symmetrised in place when stored)
   const double *bsc;
   double *Hpp_out, *bpp_out;        // optional store: system_pose with priors
+  double *Hsc_copy = nullptr;       // optional (with store_system): full symmetric copy of H_schur for the covariance read-back
   const double *Hm, *bm;            // marginal prior
   double *step;                     // out: K
   LmControl *ctrl;                  // nullable (host-driven stages pass lambda explicitly)
@@ -875,6 +876,10 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
         a.Hpp_out[row * K + col] = v;
         a.Hpp_out[col * K + row] = a.Hpp_raw[col * K + row] + (row == col ? prior_diag[row] : 0.0);
         if (col < row) a.Hsc[row * K + col] = hs[u];
+        if (a.Hsc_copy && col <= row) {  // the symmetrised Schur system once more, right behind H_pp: one transfer for both
+          a.Hsc_copy[row * K + col] = hs[u];
+          a.Hsc_copy[col * K + row] = hs[u];
+        }
       }
       if (col <= row) {
         // calculateStep — problem.hpp:347-351: H = H_pp + lam*diag(H_pp) + H_m - H_sc/(1+lam)

@@ -236,6 +236,24 @@ __global__ void exportFrameKernel(FrameExportArgs a) {
   for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][i] : DSOPP_HIP_STATUS_UNKNOWN;
 }
 
+/** all keyframes of the window in one launch (blockIdx.y = entry): seven 3 us kernels were bound by the host's enqueue rate */
+struct FrameExportBatch {
+  FrameExportArgs f[kMaxFrames];
+  int n_frames;
+};
+static_assert(sizeof(FrameExportBatch) <= 4096, "kernel argument block");
+__global__ void exportFramesKernel(FrameExportBatch b) {
+  const FrameExportArgs &a = b.f[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  a.out_d[i] = a.idepth[i];
+  a.out_d[a.n + i] = a.inv_hdd[i];
+  a.out_d[2 * a.n + i] = a.relative_baseline[i];
+  a.out_d[3 * a.n + i] = static_cast<double>(a.n_inliers[i]);
+  a.out_b[i] = a.flags[i];
+  for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][i] : DSOPP_HIP_STATUS_UNKNOWN;
+}
+
 /** relinearizeSystem — :310-316: the newest frame's linearisation point moves to its current estimate */
 __global__ void relinearizeKernel(WindowState *st, int f) {
   if (threadIdx.x != 0) return;
