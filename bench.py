@@ -346,7 +346,7 @@ def main():
             "timing": {"what": f"median over {len(block_times)} timed blocks of {steps_done} GN iterations each (barrier + synchronize on both sides "
                                "of every block, max over ranks per block); inside a block the LM solves (7 iterations each, the "
                                "window restored in front of every solve) are enqueued back to back, their results fetched with one copy at the "
-                               "end of the block: no host synchronisation between solves (single rank; sharded runs synchronise once per solve)",
+                               "end of the block: no host synchronisation between solves",
                        "blocks": len(block_times), "block_ms_min": min(block_times) * 1e3, "block_ms_median": block_s * 1e3,
                        "block_ms_max": max(block_times) * 1e3},
             "config": {"workload": f"{desc} ({total_points} total, {P_local} on rank 0), {args.width}x{args.height}, full clique, "

@@ -1249,7 +1249,12 @@ void lmSolveFusedEnqueue(W &w) {
   // one small read-back into pinned memory (a pageable destination makes the copy synchronous and staged); the host
   // mirror of the frame states is refreshed lazily, by the first reader (downloadState)
   if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
-  if (!result_written_by_kernel) HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  if (!result_written_by_kernel) {
+    if (w.result_device)  // batched solves of a sharded window: the slot is filled by a copy behind the closing round
+      HIP_CHECK(hipMemcpyAsync(w.result_device, cfin, sizeof(LmControl), hipMemcpyDeviceToDevice, st));
+    else
+      HIP_CHECK(hipMemcpyAsync(w.h_ctrl, cfin, sizeof(LmControl), hipMemcpyDeviceToHost, st));
+  }
   w.host_stale = true;
   w.fused_final_ctrl = cfin;
 }
@@ -2788,7 +2793,9 @@ void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, doubl
 int dsopp_hip_window_optimize_repeated(dsopp_hip_window *w, int32_t iterations_target, int32_t *iterations_done, double *last_energy) {
   if (!w || iterations_target < 0) return dsopp_hip_window_restore(nullptr);  // reports the invalid argument
   static const bool no_pipeline = std::getenv("DSOPP_HIP_NO_PIPELINE") != nullptr;  // tuning aid: one solve at a time
-  if (!no_pipeline && w->lm_mode == 0 && w->opt.force_accept && !(w->allreduce && w->world > 1) && w->F() > 0 && !w->async_pending) {
+  // (landmark-sharded windows too: their collectives are ordered on the stream, and every rank plans the same solves because the
+  // decisions are taken from all-reduced sums)
+  if (!no_pipeline && w->lm_mode == 0 && w->opt.force_accept && w->F() > 0 && !w->async_pending) {
     int done = 0;
     double e = 0;
     const int rc = guarded([&] {
