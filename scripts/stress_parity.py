@@ -1,0 +1,48 @@
+"""Randomised parity stress: windows of random size / seed / options solved by the HIP library and by the CPU oracle
+(full solve(): LM loop, relinearisation, covariances, point statuses), compared with the tolerances of tests/test_gpu_pba*.py.
+Not part of the test-suite (minutes of oracle time); run on the GPU box after changes to the solve path."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401  (its HIP runtime first)
+from dsopp_amd import capi, synthetic as syn  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"   # up to 12 frames / 9000 points: two-stage Schur build, several groups per sweep workgroup
+if BIG:
+    po.set_threads(16)
+bad = 0
+t0 = time.time()
+for case in range(N):
+    F = int(rng.integers(2, 13 if BIG else 9))
+    P = int(rng.integers(3000, 9000)) if BIG else int(rng.integers(150, 1200))
+    seed = int(rng.integers(0, 10_000))
+    kw = dict(first_estimate_jacobians=int(rng.integers(0, 2)), force_accept=int(rng.integers(0, 2)), max_iterations=int(rng.integers(1, 9)))
+    win = syn.make_window(num_frames=F, num_points=P, width=640 if BIG else 320, height=480 if BIG else 240, seed=seed)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
+    g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
+    lm_mode = int(rng.integers(0, 3))
+    g.set_lm_mode(lm_mode)
+    g.set_deterministic(bool(rng.integers(0, 2)))
+    eo, ito, nvo = o.solve()
+    eg, itg, nvg = g.solve()
+    ok = (ito, nvo) == (itg, nvg) and abs(eo - eg) <= 1e-7 * abs(eo)
+    worst = 0.0
+    for f in win.frames:
+        To, abo = o.get_pose(f.frame_id)
+        Tg, abg = g.get_pose(f.frame_id)
+        worst = max(worst, np.abs(To - Tg).max(), np.abs(abo - abg).max())
+        lo, lg = o.get_landmarks(f.frame_id), g.get_landmarks(f.frame_id, False)
+        ok = ok and np.array_equal(lo["flags"], lg["flags"]) and np.allclose(lo["idepth"], lg["idepth"], rtol=1e-6, atol=1e-9)
+    ok = ok and worst <= 1e-6
+    print(f"case {case}: F={F} P={P} seed={seed} {kw} lm_mode={lm_mode}  it {ito}/{itg} nv {nvo}/{nvg} pose diff {worst:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += 0 if ok else 1
+    g.close()
+print(f"{N - bad}/{N} cases agree, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
