@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "device_geom.hpp"
 #include "immature_set.hpp"
+#include <chrono>
 #include "pyramid.hpp"
 #include "se3_math.hpp"
 
@@ -813,6 +814,8 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
       max_n = std::max(max_n, sets[k]->n);
     }
     if (max_n == 0) return;
+    static const bool trace = std::getenv("DSOPP_HIP_TRACE") != nullptr;  // tuning aid: host-side time of this call's parts
+    const auto tr0 = std::chrono::steady_clock::now();
     lead->sr.use();
     hipStream_t st = lead->sr.stream;  // the launch runs on the first set's stream, ordered against the others' below
     target_pyramid->waitReady(st);
@@ -842,6 +845,9 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     else
       estimateDepthsBatchKernel<float><<<grid, 64, smem, st>>>(df, dl);
     HIP_CHECK(hipGetLastError());
+    if (trace)
+      std::fprintf(stderr, "[dsopp_hip] immature_sets_estimate: host side of the call %.1f us (tables + upload + launch enqueued)\n",
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
     // later per-set calls run on the sets' own streams: they must see this launch finished
     bool other_streams = false;
     for (int k = 0; k < n_sets; ++k) other_streams = other_streams || sets[k]->sr.stream != st;
