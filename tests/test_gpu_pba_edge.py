@@ -367,6 +367,33 @@ def test_deterministic_stage_api_systems_are_bit_reproducible():
     g.close()
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_optimize_repeated_equals_single_solves(small_window, deterministic):
+    """the bench helper enqueues its solves back to back (restore -> LM loop, results fetched per batch): the iteration count is
+    exact for targets that are and are not multiples of the LM budget, and the window is left in the state a single solve from
+    the snapshot with the last solve's budget leaves it in"""
+    from dsopp_amd import capi
+    g = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g, small_window)
+    g.set_deterministic(deterministic)
+    g.snapshot()
+    budget = g.options.max_iterations
+    for target, last in ((3 * budget, budget), (2 * budget + 3, 3), (2, 2)):
+        done, e_rep = g.optimize_repeated(target)
+        assert done == target
+        rep = [np.concatenate(g.get_pose(f.frame_id)) for f in small_window.frames]
+        g.restore()
+        g.set_max_iterations(last)
+        e_one, it, _ = g.optimize()
+        g.set_max_iterations(budget)
+        assert it == last
+        one = [np.concatenate(g.get_pose(f.frame_id)) for f in small_window.frames]
+        assert abs(e_rep - e_one) <= 1e-9 * abs(e_one)
+        for a, b in zip(rep, one):
+            assert np.abs(a - b).max() <= (0.0 if deterministic else 1e-9)
+    g.close()
+
+
 def test_large_window_two_stage_is_bit_reproducible():
     """windows above 96 landmark chunks take the two-stage build by themselves (C3 size: 7 frames / 20 000 points): reproducible"""
     from dsopp_amd import capi
