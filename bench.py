@@ -229,6 +229,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args)
 
+    # stdout carries exactly ONE line, the JSON of rank 0: everything else any library of this process writes to file descriptor 1
+    # (RCCL prints a five-line version banner from C stdio when a communicator comes up, flushed at exit, i.e. BEHIND the JSON
+    # line) is sent to stderr; the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from dsopp_amd import capi, distributed, synthetic as syn
 
@@ -373,7 +380,7 @@ def main():
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline
             line["speedup_vs_cpu_port"] = line["value"] / cpu_baseline["value"]
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     g.close()
     job.close()
 
