@@ -37,6 +37,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 
 # every symbol include/dsopp_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
+    "dsopp_hip_pyramid_group_build", "dsopp_hip_pyramid_group_create", "dsopp_hip_pyramid_group_destroy", "dsopp_hip_pyramid_group_get", "dsopp_hip_pyramid_group_set_level", "dsopp_hip_pyramid_group_set_mask", "dsopp_hip_window_group_accept_step", "dsopp_hip_window_group_begin", "dsopp_hip_window_group_calculate_energy", "dsopp_hip_window_group_calculate_step", "dsopp_hip_window_group_create", "dsopp_hip_window_group_create_reference_depth_maps", "dsopp_hip_window_group_destroy", "dsopp_hip_window_group_frame_ids", "dsopp_hip_window_group_get_covariance", "dsopp_hip_window_group_get_frame_state", "dsopp_hip_window_group_get_frame_update", "dsopp_hip_window_group_get_landmarks", "dsopp_hip_window_group_get_marginalized", "dsopp_hip_window_group_get_pose", "dsopp_hip_window_group_get_residuals", "dsopp_hip_window_group_get_system", "dsopp_hip_window_group_last_solve_ms", "dsopp_hip_window_group_linearize", "dsopp_hip_window_group_mark_frame_marginalized", "dsopp_hip_window_group_num_frames", "dsopp_hip_window_group_num_landmarks", "dsopp_hip_window_group_optimize", "dsopp_hip_window_group_optimize_repeated", "dsopp_hip_window_group_push_frame", "dsopp_hip_window_group_refill_reference_depth_maps", "dsopp_hip_window_group_reject_step", "dsopp_hip_window_group_restore", "dsopp_hip_window_group_set_connection", "dsopp_hip_window_group_set_deterministic", "dsopp_hip_window_group_set_landmarks", "dsopp_hip_window_group_set_lm_mode", "dsopp_hip_window_group_set_max_iterations", "dsopp_hip_window_group_shard", "dsopp_hip_window_group_size", "dsopp_hip_window_group_snapshot", "dsopp_hip_window_group_solve", "dsopp_hip_window_group_update_point_statuses",
     "dsopp_hip_window_frame_ids", "dsopp_hip_window_set_deterministic",
     "dsopp_hip_comm_unique_id", "dsopp_hip_comm_create", "dsopp_hip_comm_adopt", "dsopp_hip_comm_destroy", "dsopp_hip_comm_rank",
     "dsopp_hip_comm_allreduce", "dsopp_hip_window_set_comm",
@@ -318,10 +319,13 @@ class HipWindow:
                 p.close()
 
     def frame_ids(self):
-        ids = np.zeros(16, dtype=np.int32)
+        # sized from the window's own frame count (not from a constant mirrored here): a short buffer would make push_frame's
+        # garbage collection close pyramids the window still borrows
+        cap = max(1, self.num_frames)
+        ids = np.zeros(cap, dtype=np.int32)
         n = C.c_int32()
-        _chk(lib().dsopp_hip_window_frame_ids(self._h, 16, ids.ctypes.data_as(C.c_void_p), C.byref(n)))
-        return [int(x) for x in ids[:n.value]]
+        _chk(lib().dsopp_hip_window_frame_ids(self._h, cap, ids.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return [int(x) for x in ids[:min(n.value, cap)]]
 
     def set_landmarks(self, frame_id, uv, idepth, patch, flags):
         n = len(idepth)
@@ -547,6 +551,276 @@ class HipWindow:
         cov = np.zeros((6, 6))
         _chk(lib().dsopp_hip_window_get_covariance(self._h, int(ref_id), int(tgt_id), _p(cov)))
         return cov
+
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1, 2
+
+
+class PyramidGroup:
+    """One keyframe's image pyramid on every distinct device of a window group (dsopp_hip_pyramid_group)."""
+
+    def __init__(self, group: "HipWindowGroup", width, height, levels=1):
+        self._h = C.c_void_p()
+        self.width, self.height, self.levels = int(width), int(height), min(int(levels), 5)
+        _chk(lib().dsopp_hip_pyramid_group_create(group._h, int(width), int(height), int(levels), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_pyramid_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build(self, image_u8, lut=None, vignetting=None):
+        img = _u8(image_u8)
+        assert img.shape == (self.height, self.width)
+        _chk(lib().dsopp_hip_pyramid_group_build(self._h, _p(img, np.uint8), _p(None if lut is None else _f64(lut)), _p(_u8(vignetting), np.uint8)))
+
+    def set_level(self, level, pixelinfo):
+        _chk(lib().dsopp_hip_pyramid_group_set_level(self._h, int(level), _p(_f64(pixelinfo))))
+
+    def set_mask(self, level, mask):
+        _chk(lib().dsopp_hip_pyramid_group_set_mask(self._h, int(level), _p(_u8(mask), np.uint8)))
+
+
+class HipWindowGroup:
+    """n landmark shards of ONE sliding window on n devices behind one object (dsopp_hip_window_group): the single-process
+    multi-GPU form of the drop-in.  Same Python interface as HipWindow / oracle.pyoracle.OracleWindow; landmark arrays are the
+    whole keyframe's, the group deals them over the shards and interleaves the read-backs."""
+
+    def __init__(self, options: Options | None = None, devices=(0,), transport=TRANSPORT_AUTO):
+        self.options = options or default_pba_options()
+        self.devices = [int(d) for d in devices]
+        self._h = C.c_void_p()
+        ids = np.ascontiguousarray(self.devices, dtype=np.int32)
+        _chk(lib().dsopp_hip_window_group_create(C.byref(self.options), ids.ctypes.data_as(C.c_void_p), len(ids), int(transport), C.byref(self._h)))
+        self._pyramids = {}
+
+    def close(self):
+        if self._h:
+            lib().dsopp_hip_window_group_destroy(self._h)
+            self._h = C.c_void_p()
+        for p, owned in self._pyramids.values():
+            if owned:
+                p.close()
+        self._pyramids = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        n, t = C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_size(self._h, C.byref(n), C.byref(t)))
+        return n.value
+
+    @property
+    def transport(self):
+        n, t = C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_size(self._h, C.byref(n), C.byref(t)))
+        return t.value
+
+    @property
+    def num_frames(self) -> int:
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_group_num_frames(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def K(self) -> int:
+        return 8 * self.num_frames
+
+    def frame_ids(self):
+        cap = max(1, self.num_frames)
+        ids = np.zeros(cap, dtype=np.int32)
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_group_frame_ids(self._h, cap, ids.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return [int(x) for x in ids[:min(n.value, cap)]]
+
+    def shard_num_landmarks(self, shard, frame_id):
+        """landmarks of `frame_id` held by one shard (introspection through the shard's own window)"""
+        w, dev, n = C.c_void_p(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_shard(self._h, int(shard), C.byref(w), C.byref(dev)))
+        _chk(lib().dsopp_hip_window_num_landmarks(w, int(frame_id), C.byref(n)))
+        return n.value
+
+    def push_frame(self, frame_id, timestamp, pixelinfo, mask, intrinsics, T_w_agent, exposure, affine, fixed, is_marginalized,
+                   pyramid: PyramidGroup | None = None, level=0):
+        owned = pyramid is None
+        if pyramid is None:
+            pix = _f64(pixelinfo)
+            H, W = pix.shape[:2]
+            pyramid = PyramidGroup(self, W, H, 1)
+            pyramid.set_level(0, pix)
+            if mask is not None:
+                pyramid.set_mask(0, mask)
+            level = 0
+        self._pyramids[int(frame_id)] = (pyramid, owned)
+        _chk(lib().dsopp_hip_window_group_push_frame(self._h, int(frame_id), C.c_int64(int(timestamp)), pyramid._h, int(level),
+                                                     _p(_f64(intrinsics)), _p(_f64(T_w_agent)), C.c_double(exposure), _p(_f64(affine)),
+                                                     int(bool(fixed)), int(bool(is_marginalized))))
+        alive = set(self.frame_ids())
+        for fid in [k for k in self._pyramids if k not in alive]:
+            p, was_owned = self._pyramids.pop(fid)
+            if was_owned:
+                p.close()
+
+    def set_landmarks(self, frame_id, uv, idepth, patch, flags):
+        n = len(idepth)
+        _chk(lib().dsopp_hip_window_group_set_landmarks(self._h, int(frame_id), n, _p(_f64(uv)), _p(_f64(idepth)), _p(_f64(patch)),
+                                                        _p(_u8(flags), np.uint8)))
+
+    def set_connection(self, ref_id, tgt_id, statuses):
+        st = _u8(statuses)
+        _chk(lib().dsopp_hip_window_group_set_connection(self._h, int(ref_id), int(tgt_id), len(st), _p(st, np.uint8)))
+
+    def mark_frame_marginalized(self, frame_id):
+        _chk(lib().dsopp_hip_window_group_mark_frame_marginalized(self._h, int(frame_id)))
+
+    def solve(self):
+        e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_solve(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    def optimize(self):
+        e, it, nv = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_optimize(self._h, C.byref(e), C.byref(it), C.byref(nv)))
+        return e.value, it.value, nv.value
+
+    def optimize_repeated(self, iterations_target: int):
+        done, e = C.c_int32(), C.c_double()
+        _chk(lib().dsopp_hip_window_group_optimize_repeated(self._h, int(iterations_target), C.byref(done), C.byref(e)))
+        return done.value, e.value
+
+    def last_solve_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().dsopp_hip_window_group_last_solve_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_max_iterations(self, n: int):
+        _chk(lib().dsopp_hip_window_group_set_max_iterations(self._h, int(n)))
+        self.options.max_iterations = int(n)
+
+    def set_deterministic(self, enable: bool):
+        _chk(lib().dsopp_hip_window_group_set_deterministic(self._h, int(bool(enable))))
+
+    def set_lm_mode(self, mode: int):
+        _chk(lib().dsopp_hip_window_group_set_lm_mode(self._h, int(mode)))
+
+    def snapshot(self):
+        _chk(lib().dsopp_hip_window_group_snapshot(self._h))
+
+    def restore(self):
+        _chk(lib().dsopp_hip_window_group_restore(self._h))
+
+    # stage level
+    def begin(self):
+        _chk(lib().dsopp_hip_window_group_begin(self._h))
+
+    def calculate_energy(self):
+        e, n = C.c_double(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_calculate_energy(self._h, C.byref(e), C.byref(n)))
+        return e.value, n.value
+
+    def linearize(self):
+        _chk(lib().dsopp_hip_window_group_linearize(self._h))
+
+    def get_system(self):
+        K = self.K
+        Hpp, bpp, Hsc, bsc = np.zeros((K, K)), np.zeros(K), np.zeros((K, K)), np.zeros(K)
+        _chk(lib().dsopp_hip_window_group_get_system(self._h, _p(Hpp), _p(bpp), _p(Hsc), _p(bsc)))
+        return Hpp, bpp, Hsc, bsc
+
+    def calculate_step(self, lam):
+        step = np.zeros(self.K)
+        _chk(lib().dsopp_hip_window_group_calculate_step(self._h, C.c_double(lam), _p(step)))
+        return step
+
+    def accept_step(self):
+        a, b = C.c_double(), C.c_double()
+        _chk(lib().dsopp_hip_window_group_accept_step(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def reject_step(self):
+        _chk(lib().dsopp_hip_window_group_reject_step(self._h))
+
+    def update_point_statuses(self):
+        _chk(lib().dsopp_hip_window_group_update_point_statuses(self._h))
+
+    # getters
+    def get_frame_state(self, frame_id):
+        T0, ab0, eps, step = np.zeros(7), np.zeros(2), np.zeros(8), np.zeros(8)
+        _chk(lib().dsopp_hip_window_group_get_frame_state(self._h, int(frame_id), _p(T0), _p(ab0), _p(eps), _p(step)))
+        return T0, ab0, eps, step
+
+    def get_pose(self, frame_id):
+        T, ab = np.zeros(7), np.zeros(2)
+        _chk(lib().dsopp_hip_window_group_get_pose(self._h, int(frame_id), _p(T), _p(ab)))
+        return T, ab
+
+    def num_landmarks(self, frame_id):
+        n = C.c_int32()
+        _chk(lib().dsopp_hip_window_group_num_landmarks(self._h, int(frame_id), C.byref(n)))
+        return n.value
+
+    def get_landmarks(self, frame_id, with_hpib=True):
+        n = self.num_landmarks(frame_id)
+        K = self.K
+        out = dict(idepth=np.zeros(n), idepth_step=np.zeros(n), inv_hdd=np.zeros(n), b_d=np.zeros(n), relative_baseline=np.zeros(n),
+                   n_inliers=np.zeros(n, dtype=np.int32), flags=np.zeros(n, dtype=np.uint8))
+        hp = np.zeros((n, K)) if with_hpib else None
+        _chk(lib().dsopp_hip_window_group_get_landmarks(self._h, int(frame_id), _p(out["idepth"]), _p(out["idepth_step"]), _p(out["inv_hdd"]),
+                                                        _p(out["b_d"]), _p(out["relative_baseline"]), _p(out["n_inliers"], np.int32),
+                                                        _p(out["flags"], np.uint8), _p(hp)))
+        if with_hpib:
+            out["hpib"] = hp
+        return out
+
+    def get_frame_update(self, frame_id, target_ids):
+        n = self.num_landmarks(frame_id)
+        tids = np.ascontiguousarray(target_ids, dtype=np.int32)
+        out = dict(idepth=np.zeros(n), inv_hdd=np.zeros(n), relative_baseline=np.zeros(n), n_inliers=np.zeros(n, dtype=np.int32),
+                   flags=np.zeros(n, dtype=np.uint8))
+        st = np.zeros((len(tids), n), dtype=np.uint8)
+        _chk(lib().dsopp_hip_window_group_get_frame_update(self._h, int(frame_id), _p(out["idepth"]), _p(out["inv_hdd"]), _p(out["relative_baseline"]),
+                                                           out["n_inliers"].ctypes.data_as(C.c_void_p), _p(out["flags"], np.uint8), len(tids),
+                                                           tids.ctypes.data_as(C.c_void_p), _p(st, np.uint8)))
+        out["status"] = {int(t): st[k] for k, t in enumerate(tids)}
+        return out
+
+    def get_residuals(self, ref_id, tgt_id, full=False):
+        n = self.num_landmarks(ref_id)
+        out = dict(status=np.zeros(n, dtype=np.uint8), candidate=np.zeros(n, dtype=np.uint8), energy=np.zeros(n))
+        _chk(lib().dsopp_hip_window_group_get_residuals(self._h, int(ref_id), int(tgt_id), n, _p(out["status"], np.uint8),
+                                                        _p(out["candidate"], np.uint8), _p(out["energy"])))
+        return out
+
+    def get_marginalized(self):
+        K = self.K
+        H, b, e, sz = np.zeros((K, K)), np.zeros(K), C.c_double(), C.c_int32()
+        _chk(lib().dsopp_hip_window_group_get_marginalized(self._h, _p(H), _p(b), C.byref(e), C.byref(sz)))
+        return H, b, e.value
+
+    def get_covariance(self, ref_id, tgt_id):
+        cov = np.zeros((6, 6))
+        _chk(lib().dsopp_hip_window_group_get_covariance(self._h, int(ref_id), int(tgt_id), _p(cov)))
+        return cov
+
+    def create_reference_depth_maps(self, levels: int) -> DepthMaps:
+        h = C.c_void_p()
+        _chk(lib().dsopp_hip_window_group_create_reference_depth_maps(self._h, int(levels), C.byref(h)))
+        return DepthMaps(h, levels)
+
+    def refill_reference_depth_maps(self, maps: DepthMaps):
+        _chk(lib().dsopp_hip_window_group_refill_reference_depth_maps(self._h, maps._h))
 
 
 def estimate_depths(lms, target_pyramid: Pyramid, level, intrinsics, T_target_reference, reference_exposure=1.0, reference_affine=(0, 0),

@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function ${DSOPP_HIP_EXTRA_FLAGS:-}"
 pids=()
-for src in pyramid pba align depth_estimation comm calibration; do
+for src in pyramid pba align depth_estimation comm calibration window_group; do
   if [ -f "$HERE/$src.hip" ]; then
     $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OUT/$src.o" &
     pids+=($!)
@@ -15,6 +15,6 @@ for src in pyramid pba align depth_estimation comm calibration; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=()
-for src in pyramid pba align depth_estimation comm calibration; do [ -f "$OUT/$src.o" ] && objs+=("$OUT/$src.o"); done
+for src in pyramid pba align depth_estimation comm calibration window_group; do [ -f "$OUT/$src.o" ] && objs+=("$OUT/$src.o"); done
 $HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT/libdsopp_hip.so"
 echo "built $OUT/libdsopp_hip.so"

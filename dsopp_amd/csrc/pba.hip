@@ -2501,6 +2501,13 @@ void fillReferenceDepthMaps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
     a.status = it->second->status.ptr;
     splatDepthMapKernel<<<(a.n + 255) / 256, 256, 0, st>>>(a, tmp_id[0].ptr, tmp_w[0].ptr);
   }
+  if (w->allreduce && w->world > 1) {
+    // landmark shards: every shard splatted its own landmarks; the level-0 planes are sums over landmarks, so one collective per
+    // plane completes them on every shard (pooling and dilation below are then replicated work on the full maps)
+    const size_t n0 = static_cast<size_t>(maps->width[0]) * maps->height[0];
+    allreduceIfNeeded(*w, tmp_id[0].ptr, n0);
+    allreduceIfNeeded(*w, tmp_w[0].ptr, n0);
+  }
   // fillCoarseDepthMaps — :70-88
   for (int l = 1; l < levels; ++l) {
     const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];

@@ -428,14 +428,34 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
         part += 0.5 * ab * a.affine_reg[(tid & 7) - 6] * ab;
       }
     }
+    // frame part of the norms acceptStep reports for this candidate (problem.hpp:366-388): read by the deciding kernel from the
+    // control block
+    double nstate = 0, nstep = 0;
+    if (tid < K) {
+      nstate = epsl[tid] * epsl[tid] + ((tid & 7) >= 6 ? ab0_c * ab0_c : 0.0);
+      nstep = stpl[tid] * stpl[tid];
+    }
     part = waveSum(part);
+    nstate = waveSum(nstate);
+    nstep = waveSum(nstep);
     ldsBarrier();  // E (in A) fully consumed before the scratch below is written; stpl visible
-    if ((tid & 63) == 0) pv[tid >> 6] = part;
+    if ((tid & 63) == 0) {
+      xs[tid >> 6] = part;
+      xs[4 + (tid >> 6)] = nstate;
+      xs[8 + (tid >> 6)] = nstep;
+    }
     ldsBarrier();
     if (tid == 0) {
-      double total = a.energy_marginalized;
-      for (int w = 0; w < kSolveThreads / 64; ++w) total += pv[w];
+      static_assert(kSolveThreads / 64 == 4, "three groups of four wave sums in xs");
+      double total = a.energy_marginalized, s_state = 0, s_step = 0;
+      for (int w = 0; w < kSolveThreads / 64; ++w) {
+        total += xs[w];
+        s_state += xs[4 + w];
+        s_step += xs[8 + w];
+      }
       a.ctrl->cand_prior = total;
+      a.ctrl->frame_state_sq = s_state;
+      a.ctrl->frame_step_sq = s_step;
       a.ctrl->pending = 1;
     }
   }

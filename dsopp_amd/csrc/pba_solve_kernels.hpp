@@ -211,15 +211,16 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
       }
     }
   }
-  double st_eps = 0, st_step = 0, st_ab0 = 0;
-  if (tid < kBlk * a.F) {
+  // frame states: read (and later written) by workgroup 0 only — the norms every workgroup needs for the decision come from the
+  // control block (LmControl::frame_state_sq / frame_step_sq), a snapshot no workgroup of this launch modifies
+  double st_eps = 0, st_step = 0;
+  if (blockIdx.x == 0 && tid < kBlk * a.F) {
     const int f = tid >> 3, c = tid & 7;
     st_eps = a.st->eps[f][c];
     st_step = a.st->step[f][c];
-    if (c < 2) st_ab0 = a.st->ab0[f][c];
   }
-  // deterministic sums: energy, n_valid, |idepth step|^2, idepth . step (sweep partials) and the frame norms
-  double v[6] = {0, 0, 0, 0, 0, 0};
+  // deterministic sums: energy, n_valid, |idepth step|^2, idepth . step (sweep partials)
+  double v[4] = {0, 0, 0, 0};
   if (a.prm.use_reduced_scalars == 2) {
     if (tid < kScalarGroups) {
       const double *p = a.scalars + 4 * tid;
@@ -251,18 +252,16 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
     }
     return false;
   }
-  v[4] = st_eps * st_eps + st_ab0 * st_ab0;
-  v[5] = st_step * st_step;
   constexpr int RS = kSchurThreads + 2;
 #pragma unroll
-  for (int e = 0; e < 6; ++e) lds[e * RS + tid] = v[e];
+  for (int e = 0; e < 4; ++e) lds[e * RS + tid] = v[e];
   ldsBarrier();
   if (kStamps && a.dbg && tid == 0) s_dbg[0] = wall_clock64();
   // three-level tree (8-way per level), fixed order => deterministic
   static_assert(kSchurThreads == 512, "reduction tree below assumes 512 threads");
-  double *l2 = lds + 6 * RS;  // [6][64]
-  double *l3 = l2 + 6 * 64;   // [6][8]
-  if (tid < 6 * 64) {
+  double *l2 = lds + 6 * RS;  // [4][64]
+  double *l3 = l2 + 6 * 64;   // [4][8]
+  if (tid < 4 * 64) {
     const int e = tid >> 6, j = tid & 63;
     double s = 0;
 #pragma unroll
@@ -270,7 +269,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
     l2[e * 64 + j] = s;
   }
   ldsBarrier();
-  if (tid < 6 * 8) {
+  if (tid < 4 * 8) {
     const int e = tid >> 3, j = tid & 7;
     double s = 0;
 #pragma unroll
@@ -279,9 +278,9 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
   }
   ldsBarrier();
   if (tid == 0) {
-    double t[6];
+    double t[4];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) {
+    for (int e = 0; e < 4; ++e) {
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) s += l3[e * 8 + k];
@@ -314,7 +313,7 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
         if (fabs(cin.energy - eval_energy) / cin.energy < a.prm.function_tolerance) c.converged = 1;
         if (eval_energy < cin.energy || (a.prm.force_accept && cin.iteration < a.prm.min_iterations)) {
           accept = 1;
-          const double state_sq = t[4] + cin.idepth_sq, step_sq = t[5] + t[2];
+          const double state_sq = cin.frame_state_sq + cin.idepth_sq, step_sq = cin.frame_step_sq + t[2];
           if (step_sq < a.prm.parameter_tolerance * (state_sq + a.prm.parameter_tolerance)) c.converged = 1;
           c.energy = eval_energy;
           c.n_valid = n_valid;
@@ -1162,14 +1161,34 @@ __global__ void __launch_bounds__(kSolveThreads, 1) assembleSolveKernel(SolveArg
         part += 0.5 * ab * a.affine_reg[(tid & 7) - 6] * ab;
       }
     }
+    // frame part of the norms acceptStep reports for this candidate (problem.hpp:366-388): read by the deciding kernel from the
+    // control block
+    double nstate = 0, nstep = 0;
+    if (tid < K) {
+      nstate = epsl[tid] * epsl[tid] + ((tid & 7) >= 6 ? ab0_c * ab0_c : 0.0);
+      nstep = stpl[tid] * stpl[tid];
+    }
     part = waveSum(part);
+    nstate = waveSum(nstate);
+    nstep = waveSum(nstep);
     ldsBarrier();  // E (in A) fully consumed before the scratch below is written; stpl visible
-    if ((tid & 63) == 0) pv[tid >> 6] = part;
+    if ((tid & 63) == 0) {
+      xs[tid >> 6] = part;
+      xs[4 + (tid >> 6)] = nstate;
+      xs[8 + (tid >> 6)] = nstep;
+    }
     ldsBarrier();
     if (tid == 0) {
-      double total = a.energy_marginalized;
-      for (int w = 0; w < kSolveThreads / 64; ++w) total += pv[w];
+      static_assert(kSolveThreads / 64 == 4, "three groups of four wave sums in xs");
+      double total = a.energy_marginalized, s_state = 0, s_step = 0;
+      for (int w = 0; w < kSolveThreads / 64; ++w) {
+        total += xs[w];
+        s_state += xs[4 + w];
+        s_step += xs[8 + w];
+      }
       a.ctrl->cand_prior = total;
+      a.ctrl->frame_state_sq = s_state;
+      a.ctrl->frame_step_sq = s_step;
       a.ctrl->pending = 1;
     }
   }
@@ -1326,6 +1345,7 @@ __global__ void __launch_bounds__(kSolveThreads) lmInitKernel(LmInitArgs a) {
     c.lambda = a.prm.lambda0;
     c.energy = v[0] + prior;
     c.cand_prior = 0;
+    c.frame_state_sq = c.frame_step_sq = 0;
     c.idepth_sq = a.scalars[4];
     c.n_valid = static_cast<int>(v[1] + 0.5);
     c.converged = 0;
@@ -1361,14 +1381,16 @@ struct LmDecideArgs {
  * writes the outgoing control block.
  */
 __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) {
-  __shared__ double red[(kSchurThreads / 64) * 6];
+  __shared__ double red[(kSchurThreads / 64) * 4];
   const LmControl cin = *a.ctrl_in;
   const int tid = threadIdx.x;
   if (!cin.active) {
     if (blockIdx.x == 0 && tid == 0) *a.ctrl_out = cin;
     return;
   }
-  double v[6] = {0, 0, 0, 0, 0, 0};  // energy, n_valid, step_sq(idepth), idepth.step, state_sq(frames), step_sq(frames)
+  // energy, n_valid, step_sq(idepth), idepth.step; the frame part of the norms comes from the control block (written by the solve
+  // kernel): workgroup 0 of THIS launch moves the frame states, later workgroups must not derive their decision from them
+  double v[4] = {0, 0, 0, 0};
   if (a.prm.use_reduced_scalars) {
     if (tid == 0) {
       v[0] = a.scalars[0];
@@ -1385,13 +1407,7 @@ __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) 
       v[3] += p[47];
     }
   }
-  if (tid < kBlk * a.F) {
-    const int f = tid >> 3, c = tid & 7;
-    const double e = a.st->eps[f][c], s = a.st->step[f][c];
-    v[4] = e * e + (c < 2 ? a.st->ab0[f][c] * a.st->ab0[f][c] : 0.0);
-    v[5] = s * s;
-  }
-  blockSum<6, kSchurThreads>(v, red);
+  blockSum<4, kSchurThreads>(v, red);
   __shared__ int s_accept;
   __shared__ LmControl s_out;
   if (tid == 0) {
@@ -1408,7 +1424,7 @@ __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) 
       if (fabs(cin.energy - next_energy) / cin.energy < a.prm.function_tolerance) c.converged = 1;
       if (next_energy < cin.energy || (a.prm.force_accept && cin.iteration < a.prm.min_iterations)) {
         accept = 1;
-        const double state_sq = v[4] + cin.idepth_sq, step_sq = v[5] + v[2];
+        const double state_sq = cin.frame_state_sq + cin.idepth_sq, step_sq = cin.frame_step_sq + v[2];
         if (step_sq < a.prm.parameter_tolerance * (state_sq + a.prm.parameter_tolerance)) c.converged = 1;
         c.energy = next_energy;
         c.n_valid = n_valid;
@@ -1502,6 +1518,7 @@ __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
     c.lambda = a.prm.lambda0;
     c.energy = 0;
     c.cand_prior = prior;
+    c.frame_state_sq = c.frame_step_sq = 0;
     c.idepth_sq = idepth_sq;
     c.n_valid = 0;
     c.converged = 0;

@@ -82,6 +82,10 @@ struct LmControl {
   double energy;           // result.energy
   double cand_prior;       // prior + marginal energy of the candidate state eps + step (written by the solve kernel)
   double idepth_sq;        // running sum of idepth^2 over all landmarks of this rank (state norm part)
+  // frame part of acceptStep's norms (problem.hpp:366-388) for the PENDING candidate: |eps|^2 + |ab0|^2 and |step|^2, written by the
+  // solve kernel next to the step itself.  The decision reads them here and not from WindowState, which workgroup 0 of the deciding
+  // launch overwrites (eps += step, step = 0) while later workgroups of the same launch may not have started yet.
+  double frame_state_sq, frame_step_sq;
   int n_valid;             // result.number_of_valid_residuals
   int converged;
   int active;              // loop still running           (sweep kernels read {active, linear_system_valid} as int[2])

@@ -206,6 +206,92 @@ int dsopp_hip_comm_allreduce(dsopp_hip_comm *c, void *device_buffer, size_t coun
  * must outlive its use by the window; landmarks are sharded by the caller exactly as with dsopp_hip_window_set_allreduce. */
 int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Window group: ONE host process, n landmark shards of one sliding window on n devices
+ *
+ * The reference builds ONE solver object in ONE process (createPhotometricBundleAdjustment, src/tracker/tracker/src/fabric.cpp:58-121,
+ * moved into the tracker that src/application/dsopp_main.cpp:114-119 runs), so the multi-GPU form of the drop-in has to live behind
+ * one object too.  A group has the calls of dsopp_hip_window (same argument meaning and error codes; every dsopp_hip_window_group_X
+ * replaces what dsopp_hip_window_X replaces) and does the sharding itself:
+ *   - frames, images, poses, the marginal prior: replicated on every device (dsopp_hip_pyramid_group = one pyramid per distinct device);
+ *   - landmarks and their connection statuses: landmark j of a keyframe lives on shard j % n at local index j / n (balanced to +-1 and
+ *     stable under the appends of PROB_SRC/photometric_bundle_adjustment.cpp:109-123); the getters interleave them back;
+ *   - every Gauss-Newton iteration sums the partial combined systems with ONE collective (F(F+1)/2 * 64 + K + 4 doubles), every shard
+ *     then takes the same LM decision, solves the same K x K system and back-substitutes its own landmarks.
+ * One worker thread per shard enqueues that shard's launches.  transport: RCCL = ncclAllReduce on the shards' streams over xGMI, one
+ * rank per device (all device ids distinct); LOCAL = an event-ordered sum kernel inside the process (peer access between the
+ * devices; the only choice when shards share a device, e.g. to exercise the sharded path on a single GPU); AUTO = RCCL when the ids
+ * are distinct, else LOCAL.  A group of one shard is a plain window.
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { DSOPP_HIP_TRANSPORT_AUTO = 0, DSOPP_HIP_TRANSPORT_RCCL = 1, DSOPP_HIP_TRANSPORT_LOCAL = 2 };
+typedef struct dsopp_hip_window_group dsopp_hip_window_group;
+typedef struct dsopp_hip_pyramid_group dsopp_hip_pyramid_group;
+typedef struct dsopp_hip_depth_maps dsopp_hip_depth_maps;
+
+int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_t *device_ids, int32_t n, int32_t transport,
+                                  dsopp_hip_window_group **out);
+void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_size(const dsopp_hip_window_group *g, int32_t *n, int32_t *transport);
+/* introspection: the shard's own window (owned by the group; for read-only calls and tests) and its device */
+int dsopp_hip_window_group_shard(dsopp_hip_window_group *g, int32_t shard, dsopp_hip_window **window, int32_t *device);
+
+/* the keyframe's image pyramid on every device of the group (PixelDataFrame is one host object in the reference; here one
+ * device-resident copy per distinct device, each built on its own device from the same u8 image / adopted host levels) */
+int dsopp_hip_pyramid_group_create(dsopp_hip_window_group *g, int width, int height, int levels, dsopp_hip_pyramid_group **out);
+void dsopp_hip_pyramid_group_destroy(dsopp_hip_pyramid_group *pg);
+int dsopp_hip_pyramid_group_build(dsopp_hip_pyramid_group *pg, const uint8_t *image_host, const double *lut256, const uint8_t *vignetting_host);
+int dsopp_hip_pyramid_group_set_level(dsopp_hip_pyramid_group *pg, int level, const double *pixelinfo_host);
+int dsopp_hip_pyramid_group_set_mask(dsopp_hip_pyramid_group *pg, int level, const uint8_t *mask_host);
+int dsopp_hip_pyramid_group_get(dsopp_hip_pyramid_group *pg, int32_t shard, dsopp_hip_pyramid **pyramid);
+
+/* pushFrame / LocalFrame landmark copy / residual lists / updateLocalFrame flags — as the dsopp_hip_window_ calls of the same name;
+ * landmark arrays and status lists are the WHOLE keyframe's (the group deals them out) */
+int dsopp_hip_window_group_push_frame(dsopp_hip_window_group *g, int32_t frame_id, int64_t timestamp, const dsopp_hip_pyramid_group *pyramids,
+                                      int level, const double intrinsics[4], const double T_world_agent[7], double exposure_time,
+                                      const double affine_brightness[2], int fixed, int is_marginalized);
+int dsopp_hip_window_group_set_landmarks(dsopp_hip_window_group *g, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
+                                         const double *patch, const uint8_t *flags);
+int dsopp_hip_window_group_set_connection(dsopp_hip_window_group *g, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses);
+int dsopp_hip_window_group_mark_frame_marginalized(dsopp_hip_window_group *g, int32_t frame_id);
+int dsopp_hip_window_group_num_frames(dsopp_hip_window_group *g, int32_t *n);
+int dsopp_hip_window_group_frame_ids(dsopp_hip_window_group *g, int32_t capacity, int32_t *ids, int32_t *n);
+int dsopp_hip_window_group_num_landmarks(dsopp_hip_window_group *g, int32_t frame_id, int32_t *n);
+/* solve(number_of_threads) and the stage entry points (PBA_INT/eigen_photometric_bundle_adjustment_problem.hpp:290-402) */
+int dsopp_hip_window_group_solve(dsopp_hip_window_group *g, double *energy, int32_t *iterations, int32_t *n_valid);
+int dsopp_hip_window_group_optimize(dsopp_hip_window_group *g, double *energy, int32_t *iterations, int32_t *n_valid);
+int dsopp_hip_window_group_begin(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_calculate_energy(dsopp_hip_window_group *g, double *energy, int32_t *n_valid);
+int dsopp_hip_window_group_linearize(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_get_system(dsopp_hip_window_group *g, double *H_pp, double *b_pp, double *H_schur, double *b_schur);
+int dsopp_hip_window_group_calculate_step(dsopp_hip_window_group *g, double lambda, double *step);
+int dsopp_hip_window_group_accept_step(dsopp_hip_window_group *g, double *state_sq, double *step_sq);
+int dsopp_hip_window_group_reject_step(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_update_point_statuses(dsopp_hip_window_group *g);
+/* updateFrame / getPose / getAffineBrightness read-back; landmark arrays come back in the keyframe's own landmark order */
+int dsopp_hip_window_group_get_frame_state(dsopp_hip_window_group *g, int32_t frame_id, double T0[7], double ab0[2], double eps[8], double step[8]);
+int dsopp_hip_window_group_get_pose(dsopp_hip_window_group *g, int32_t frame_id, double T_world_agent[7], double affine_brightness[2]);
+int dsopp_hip_window_group_get_landmarks(dsopp_hip_window_group *g, int32_t frame_id, double *idepth, double *idepth_step, double *inv_hessian_idepth,
+                                         double *b_idepth, double *relative_baseline, int32_t *n_inliers, uint8_t *flags_out, double *hpib);
+int dsopp_hip_window_group_get_frame_update(dsopp_hip_window_group *g, int32_t frame_id, double *idepth, double *inv_hessian_idepth,
+                                            double *relative_baseline, int32_t *n_inliers, uint8_t *flags_out, int32_t n_targets,
+                                            const int32_t *target_ids, uint8_t *statuses);
+int dsopp_hip_window_group_get_residuals(dsopp_hip_window_group *g, int32_t reference_id, int32_t target_id, int32_t n, uint8_t *status,
+                                         uint8_t *candidate, double *energy);
+int dsopp_hip_window_group_get_marginalized(dsopp_hip_window_group *g, double *H, double *b, double *energy, int32_t *size);
+int dsopp_hip_window_group_get_covariance(dsopp_hip_window_group *g, int32_t reference_id, int32_t target_id, double cov[36]);
+/* createReferenceDepthMaps over all shards: the level-0 splat planes are summed across the shards, the maps returned live on
+ * device_ids[0] (where the tracker's aligner runs); refill needs maps this group created */
+int dsopp_hip_window_group_create_reference_depth_maps(dsopp_hip_window_group *g, int32_t levels, dsopp_hip_depth_maps **out);
+int dsopp_hip_window_group_refill_reference_depth_maps(dsopp_hip_window_group *g, dsopp_hip_depth_maps *maps);
+/* settings / measurement aids, as the dsopp_hip_window_ calls of the same name */
+int dsopp_hip_window_group_set_lm_mode(dsopp_hip_window_group *g, int mode);
+int dsopp_hip_window_group_set_deterministic(dsopp_hip_window_group *g, int enable);
+int dsopp_hip_window_group_set_max_iterations(dsopp_hip_window_group *g, int32_t max_iterations);
+int dsopp_hip_window_group_snapshot(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_restore(dsopp_hip_window_group *g);
+int dsopp_hip_window_group_optimize_repeated(dsopp_hip_window_group *g, int32_t iterations_target, int32_t *iterations_done, double *last_energy);
+int dsopp_hip_window_group_last_solve_ms(dsopp_hip_window_group *g, float *ms);
+
 /* the Levenberg-Marquardt loop of solve() alone (firstEstimateJacobians + levenberg_marquardt_algorithm::solve,
  * PROB_SRC/eigen_photometric_bundle_adjustment.cpp:83-86) without the post-processing (relinearise, covariance, statuses).
  * One loop body = one Gauss-Newton iteration = linearize + calculateStep + calculateEnergy + accept/reject. */
@@ -278,7 +364,7 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
  * (:51-53; variance = H_dd^-1 of the last linearisation when estimate_uncertainty, else 1e-5 —
  * PROB_SRC/photometric_bundle_adjustment.cpp:252-254), sum-pooled to `levels` pyramid levels (:70-88) and dilated (:90-122).
  * The maps stay in HBM; dsopp_hip_aligner_push_reference_depth_maps hands a level to the tracker without a host round trip. */
-typedef struct dsopp_hip_depth_maps dsopp_hip_depth_maps;
+/* (typedef struct dsopp_hip_depth_maps dsopp_hip_depth_maps: declared with the window group above) */
 int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t levels, dsopp_hip_depth_maps **out);
 void dsopp_hip_depth_maps_destroy(dsopp_hip_depth_maps *m);
 int dsopp_hip_depth_maps_level_size(const dsopp_hip_depth_maps *m, int32_t level, int32_t *width, int32_t *height);

@@ -44,6 +44,9 @@ def test_no_cpu_fallback():
         capi.Pyramid(64, 48, 1)
     with pytest.raises(capi.HipError):
         capi.HipAligner()
+    with pytest.raises(capi.HipError) as e:   # the single-process multi-device form: no worker thread is started without a device
+        capi.HipWindowGroup(capi.default_pba_options(), devices=[0, 1])
+    assert "no HIP device" in str(e.value) or "-4" in str(e.value)
 
 
 def test_default_options_are_the_production_values():
