@@ -260,6 +260,11 @@ using G = dsopp_hip_window_group;
 /** runs body(shard, window) on every shard's worker thread; any failure is raised on the calling thread */
 template <typename Body>
 void fanOut(G &g, Body &&body) {
+  if (g.n == 1) {  // a group of one is a plain window: no worker thread, the call runs where the caller is
+    const int rc = body(0, g.win[0]);
+    if (rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
+    return;
+  }
   g.pool.run([&](int s) -> int { return body(s, g.win[static_cast<size_t>(s)]); });
 }
 
@@ -300,7 +305,7 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
     g->users.resize(static_cast<size_t>(n));
     g->pool.barrier = &g->reducer.bar;
     g->reducer.bar.abort = &g->pool.abort;
-    g->pool.start(n, g->device);
+    if (n > 1) g->pool.start(n, g->device);
     struct Cleanup {  // a failure below must not leak threads / windows
       std::unique_ptr<G> &g;
       bool armed = true;
@@ -354,16 +359,19 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
 
 void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g) {
   if (!g) return;
+  auto release = [&](int s) -> int {
+    const size_t i = static_cast<size_t>(s);
+    if (g->shadow_maps[i]) dsopp_hip_depth_maps_destroy(g->shadow_maps[i]);
+    if (g->win[i]) dsopp_hip_window_destroy(g->win[i]);
+    if (g->comm[i]) dsopp_hip_comm_destroy(g->comm[i]);
+    if (static_cast<size_t>(s) < g->reducer.ev_in.size() && g->reducer.ev_in[i]) (void)hipEventDestroy(g->reducer.ev_in[i]);
+    return DSOPP_HIP_OK;
+  };
   try {
     if (!g->pool.threads.empty())
-      g->pool.run([&](int s) -> int {
-        const size_t i = static_cast<size_t>(s);
-        if (g->shadow_maps[i]) dsopp_hip_depth_maps_destroy(g->shadow_maps[i]);
-        if (g->win[i]) dsopp_hip_window_destroy(g->win[i]);
-        if (g->comm[i]) dsopp_hip_comm_destroy(g->comm[i]);
-        if (static_cast<size_t>(s) < g->reducer.ev_in.size() && g->reducer.ev_in[i]) (void)hipEventDestroy(g->reducer.ev_in[i]);
-        return DSOPP_HIP_OK;
-      });
+      g->pool.run(release);
+    else
+      for (int s = 0; s < g->n; ++s) release(s);
   } catch (...) {
   }
   g->pool.stop();

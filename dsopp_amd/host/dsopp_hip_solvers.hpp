@@ -73,6 +73,27 @@ class DevicePyramid {
   dsopp_hip_pyramid *p_ = nullptr;
 };
 
+/** the same image on every device of a multi-device solver (HipPhotometricBundleAdjustment with a `devices` list): one
+ *  device-resident copy per distinct device, each built on its own device */
+class DevicePyramidGroup {
+ public:
+  DevicePyramidGroup(dsopp_hip_window_group *group, int width, int height, int levels) {
+    check(dsopp_hip_pyramid_group_create(group, width, height, levels, &p_));
+  }
+  ~DevicePyramidGroup() { dsopp_hip_pyramid_group_destroy(p_); }
+  DevicePyramidGroup(const DevicePyramidGroup &) = delete;
+  DevicePyramidGroup &operator=(const DevicePyramidGroup &) = delete;
+  void build(const uint8_t *image, const double *photometric_calibration256 = nullptr, const uint8_t *vignetting = nullptr) {
+    check(dsopp_hip_pyramid_group_build(p_, image, photometric_calibration256, vignetting));
+  }
+  void setLevel(int level, const double *pixelinfo) { check(dsopp_hip_pyramid_group_set_level(p_, level, pixelinfo)); }
+  void setMask(int level, const uint8_t *mask) { check(dsopp_hip_pyramid_group_set_mask(p_, level, mask)); }
+  dsopp_hip_pyramid_group *handle() const { return p_; }
+
+ private:
+  dsopp_hip_pyramid_group *p_ = nullptr;
+};
+
 /** what the solvers read from track::landmarks::ActiveTrackingLandmark */
 struct LandmarkView {
   Vector2 projection;
@@ -91,6 +112,7 @@ struct KeyframeView {
   Vector2 affine_brightness;
   bool is_marginalized;
   const DevicePyramid *pyramids;
+  const DevicePyramidGroup *pyramid_group = nullptr;  // multi-device bundle adjustment: the image on every device of the solver
   std::vector<LandmarkView> active_landmarks;
   /** connections: other keyframe id -> statuses of THIS frame's landmarks reprojected into the other frame
    *  (FrameConnection::referenceReprojectionStatuses / targetReprojectionStatuses, whichever side this frame is) */
@@ -205,8 +227,13 @@ class DeviceDepthMaps {
 class HipPhotometricBundleAdjustment {
  public:
   /** EigenPhotometricBundleAdjustment(options, estimate_uncertainty, force_accept) — eigen_photometric_bundle_adjustment.cpp:47-57 */
-  HipPhotometricBundleAdjustment(const TrustRegionOptions &o, bool estimate_uncertainty = true, bool force_accept = true, int device = 0,
-                                 void *stream = nullptr)
+  HipPhotometricBundleAdjustment(const TrustRegionOptions &o, bool estimate_uncertainty = true, bool force_accept = true, int device = 0)
+      : HipPhotometricBundleAdjustment(o, estimate_uncertainty, force_accept, std::vector<int>{device}) {}
+  /** the single-process multi-GPU form (fabric_hip.patch: `devices: "0 1 2 3"`): the landmarks of every keyframe are sharded over
+   *  `devices`, frames / images replicated, one all-reduce of the reduced system per Gauss-Newton iteration (dsopp_hip_window_group).
+   *  `transport`: DSOPP_HIP_TRANSPORT_AUTO = RCCL between distinct devices */
+  HipPhotometricBundleAdjustment(const TrustRegionOptions &o, bool estimate_uncertainty, bool force_accept, const std::vector<int> &devices,
+                                 int transport = DSOPP_HIP_TRANSPORT_AUTO)
       : estimate_uncertainty_(estimate_uncertainty) {
     dsopp_hip_options c;
     dsopp_hip_default_pba_options(&c);
@@ -220,9 +247,12 @@ class HipPhotometricBundleAdjustment {
     c.sigma_huber_loss = o.sigma_huber_loss;
     c.estimate_uncertainty = estimate_uncertainty ? 1 : 0;
     c.force_accept = force_accept ? 1 : 0;
-    check(dsopp_hip_window_create(&c, device, stream, &w_));
+    std::vector<int32_t> ids(devices.begin(), devices.end());
+    check(dsopp_hip_window_group_create(&c, ids.data(), static_cast<int32_t>(ids.size()), transport, &g_));
+    n_shards_ = static_cast<int>(ids.size());
+    if (n_shards_ == 1) check(dsopp_hip_window_group_shard(g_, 0, &w_, nullptr));  // a group of one IS this window
   }
-  ~HipPhotometricBundleAdjustment() { dsopp_hip_window_destroy(w_); }
+  ~HipPhotometricBundleAdjustment() { dsopp_hip_window_group_destroy(g_); }
   HipPhotometricBundleAdjustment(const HipPhotometricBundleAdjustment &) = delete;
   HipPhotometricBundleAdjustment &operator=(const HipPhotometricBundleAdjustment &) = delete;
 
@@ -232,9 +262,17 @@ class HipPhotometricBundleAdjustment {
   void pushFrame(const KeyframeView &frame, size_t level, const PinholeModel &model,
                  FrameParameterization frame_parameterization = FrameParameterization::kFree) {
     const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
-    check(dsopp_hip_window_push_frame(w_, frame.keyframe_id, frame.timestamp, frame.pyramids->handle(), static_cast<int>(level), intr,
-                                      frame.t_world_agent.data(), frame.exposure_time, frame.affine_brightness.data(),
-                                      frame_parameterization == FrameParameterization::kFixed ? 1 : 0, frame.is_marginalized ? 1 : 0));
+    const int fixed = frame_parameterization == FrameParameterization::kFixed ? 1 : 0;
+    if (frame.pyramid_group) {
+      check(dsopp_hip_window_group_push_frame(g_, frame.keyframe_id, frame.timestamp, frame.pyramid_group->handle(), static_cast<int>(level), intr,
+                                              frame.t_world_agent.data(), frame.exposure_time, frame.affine_brightness.data(), fixed,
+                                              frame.is_marginalized ? 1 : 0));
+    } else {
+      if (!w_) throw SolverError(DSOPP_HIP_ERR_INVALID_ARGUMENT, "a multi-device solver needs KeyframeView::pyramid_group (the image on every device)");
+      check(dsopp_hip_window_push_frame(w_, frame.keyframe_id, frame.timestamp, frame.pyramids->handle(), static_cast<int>(level), intr,
+                                        frame.t_world_agent.data(), frame.exposure_time, frame.affine_brightness.data(), fixed,
+                                        frame.is_marginalized ? 1 : 0));
+    }
     times_[frame.timestamp] = frame.keyframe_id;
     uploadLandmarks(frame);
     uploadConnections(frame);
@@ -244,31 +282,31 @@ class HipPhotometricBundleAdjustment {
   void updateLocalFrame(const KeyframeView &frame) {
     uploadLandmarks(frame);
     uploadConnections(frame);
-    if (frame.is_marginalized) check(dsopp_hip_window_mark_frame_marginalized(w_, frame.keyframe_id));
+    if (frame.is_marginalized) check(dsopp_hip_window_group_mark_frame_marginalized(g_, frame.keyframe_id));
   }
   /** tracker::createReferenceDepthMaps(active frames, calibration) for the window this solver holds, without leaving the
    *  device (monocular_tracker.cpp:465,509 call it right after the bundle adjustment, on the same keyframes) */
   DeviceDepthMaps createReferenceDepthMaps(int levels) {
     dsopp_hip_depth_maps *m = nullptr;
-    check(dsopp_hip_window_create_reference_depth_maps(w_, levels, &m));
+    check(dsopp_hip_window_group_create_reference_depth_maps(g_, levels, &m));
     return DeviceDepthMaps(m);
   }
   /** reference_frame_depth_map_ = createReferenceDepthMaps(...) into the object the tracker already holds (no allocation) */
-  void createReferenceDepthMaps(DeviceDepthMaps &maps) { check(dsopp_hip_window_refill_reference_depth_maps(w_, maps.mutableHandle())); }
+  void createReferenceDepthMaps(DeviceDepthMaps &maps) { check(dsopp_hip_window_group_refill_reference_depth_maps(g_, maps.mutableHandle())); }
   /** solve(number_of_threads) -> final energy; number_of_threads is accepted and ignored, as in the Eigen backend */
   double solve(const size_t number_of_threads = 1) {
     (void)number_of_threads;
     double e = 0;
     int32_t it = 0, nv = 0;
-    check(dsopp_hip_window_solve(w_, &e, &it, &nv));
+    check(dsopp_hip_window_group_solve(g_, &e, &it, &nv));
     return e;
   }
   /** updateFrame(frame): poses, affine brightness, idepths, variances, inlier counts, baselines, statuses, covariances
    *  (photometric_bundle_adjustment.cpp:182-264) */
   void updateFrame(KeyframeView &frame) {
-    check(dsopp_hip_window_get_pose(w_, frame.keyframe_id, frame.t_world_agent.data(), frame.affine_brightness.data()));
+    check(dsopp_hip_window_group_get_pose(g_, frame.keyframe_id, frame.t_world_agent.data(), frame.affine_brightness.data()));
     int32_t n = 0;
-    check(dsopp_hip_window_num_landmarks(w_, frame.keyframe_id, &n));
+    check(dsopp_hip_window_group_num_landmarks(g_, frame.keyframe_id, &n));
     std::vector<double> idepth(n), inv_h(n), baseline(n);
     std::vector<int32_t> inliers(n);
     std::vector<uint8_t> flags(n);
@@ -277,7 +315,7 @@ class HipPhotometricBundleAdjustment {
     for (const auto &kv : frame.reprojection_statuses)
       if (static_cast<int32_t>(kv.second.size()) == n && n > 0) targets.push_back(kv.first);
     std::vector<uint8_t> statuses(targets.size() * static_cast<size_t>(n));
-    check(dsopp_hip_window_get_frame_update(w_, frame.keyframe_id, idepth.data(), inv_h.data(), baseline.data(), inliers.data(), flags.data(),
+    check(dsopp_hip_window_group_get_frame_update(g_, frame.keyframe_id, idepth.data(), inv_h.data(), baseline.data(), inliers.data(), flags.data(),
                                             static_cast<int32_t>(targets.size()), targets.data(), statuses.data()));
     // entries of landmarks the solver has not written yet start at the reference's defaults; entries of marginalised
     // landmarks are left as they are (photometric_bundle_adjustment.cpp:232-262 `continue`s before touching them)
@@ -305,23 +343,27 @@ class HipPhotometricBundleAdjustment {
     for (auto &kv : frame.reprojection_statuses) {
       if (kv.second.empty()) continue;
       Matrix6 cov;
-      if (estimate_uncertainty_ && dsopp_hip_window_get_covariance(w_, frame.keyframe_id, kv.first, cov.data()) == DSOPP_HIP_OK)
+      if (estimate_uncertainty_ && dsopp_hip_window_group_get_covariance(g_, frame.keyframe_id, kv.first, cov.data()) == DSOPP_HIP_OK)
         frame.covariances[kv.first] = cov;
     }
   }
   Motion getPose(time_point timestamp) const {
     Motion T;
-    check(dsopp_hip_window_get_pose(w_, idOf(timestamp), T.data(), nullptr));
+    check(dsopp_hip_window_group_get_pose(g_, idOf(timestamp), T.data(), nullptr));
     return T;
   }
   Vector2 getAffineBrightness(time_point timestamp) const {
     Vector2 ab{0, 0};
     auto it = times_.find(timestamp);
     if (it == times_.end()) return ab;  // the reference returns zero for an unknown frame
-    check(dsopp_hip_window_get_pose(w_, it->second, nullptr, ab.data()));
+    check(dsopp_hip_window_group_get_pose(g_, it->second, nullptr, ab.data()));
     return ab;
   }
+  /** the one device window of a single-device solver (nullptr for a multi-device one): what the device-resident landmark
+   *  activation reads, which needs ALL active landmarks of the window on one device */
   dsopp_hip_window *handle() const { return w_; }
+  dsopp_hip_window_group *group() const { return g_; }
+  int numDevices() const { return n_shards_; }
 
  private:
   int32_t idOf(time_point t) const {
@@ -331,28 +373,35 @@ class HipPhotometricBundleAdjustment {
   }
   void uploadLandmarks(const KeyframeView &frame) {
     const size_t n = frame.active_landmarks.size();
+    // flags of every landmark, coordinates / inverse depth / patch only of those the device does not hold yet (the C-ABI reads these
+    // arrays from its own landmark count on)
+    int32_t held = 0;
+    check(dsopp_hip_window_group_num_landmarks(g_, frame.keyframe_id, &held));
     std::vector<double> uv(2 * n), idepth(n), patch(DSOPP_HIP_PATTERN_SIZE * n);
     std::vector<uint8_t> flags(n);
     for (size_t i = 0; i < n; ++i) {
       const LandmarkView &lm = frame.active_landmarks[i];
+      flags[i] = static_cast<uint8_t>((lm.is_marginalized ? 1 : 0) | (lm.is_outlier ? 2 : 0));
+      if (i < static_cast<size_t>(held)) continue;
       uv[2 * i] = lm.projection[0];
       uv[2 * i + 1] = lm.projection[1];
       idepth[i] = lm.idepth;
       for (int k = 0; k < DSOPP_HIP_PATTERN_SIZE; ++k) patch[DSOPP_HIP_PATTERN_SIZE * i + static_cast<size_t>(k)] = lm.patch[static_cast<size_t>(k)];
-      flags[i] = static_cast<uint8_t>((lm.is_marginalized ? 1 : 0) | (lm.is_outlier ? 2 : 0));
     }
-    check(dsopp_hip_window_set_landmarks(w_, frame.keyframe_id, static_cast<int32_t>(n), uv.data(), idepth.data(), patch.data(), flags.data()));
+    check(dsopp_hip_window_group_set_landmarks(g_, frame.keyframe_id, static_cast<int32_t>(n), uv.data(), idepth.data(), patch.data(), flags.data()));
   }
   void uploadConnections(const KeyframeView &frame) {
     int32_t nf = 0;
-    check(dsopp_hip_window_num_frames(w_, &nf));
+    check(dsopp_hip_window_group_num_frames(g_, &nf));
     for (const auto &kv : frame.reprojection_statuses) {
       if (kv.second.empty()) continue;
-      const int rc = dsopp_hip_window_set_connection(w_, frame.keyframe_id, kv.first, static_cast<int32_t>(kv.second.size()), kv.second.data());
+      const int rc = dsopp_hip_window_group_set_connection(g_, frame.keyframe_id, kv.first, static_cast<int32_t>(kv.second.size()), kv.second.data());
       if (rc != DSOPP_HIP_OK && rc != DSOPP_HIP_ERR_NOT_FOUND) check(rc);
     }
   }
-  dsopp_hip_window *w_ = nullptr;
+  dsopp_hip_window_group *g_ = nullptr;
+  dsopp_hip_window *w_ = nullptr;  // shard 0's window when the group has one shard
+  int n_shards_ = 1;
   bool estimate_uncertainty_;
   std::map<time_point, int32_t> times_;
 };

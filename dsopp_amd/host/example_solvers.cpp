@@ -37,10 +37,14 @@ std::vector<uint8_t> render(double tx) {  // camera at (tx, 0, 0), identity rota
  *  over six keyframes through a four-frame window: the same call order the reference-side adapter
  *  (dsopp_amd/host/reference_adapter/hip_photometric_bundle_adjustment.cpp) forwards, including the fold-in of the
  *  marginalised frame by the next pushFrame. */
-bool trackerCallOrder() {
+bool trackerCallOrder(const std::vector<int> &devices, std::vector<double> *final_tx) {
   const int kFrames = 6, kWindow = 4, kLandmarks = 80;
   TrustRegionOptions opt{7, 1e5, 1e-8, 1e-8, {1e12, 1e8}, 1e16, 20};
-  HipPhotometricBundleAdjustment pba(opt, true, true);
+  // one device: a plain window.  Several entries: the single-process multi-device form (the YAML `devices` list of fabric_hip.patch);
+  // entries naming the same device share it through the in-process reducer (how a one-GPU box exercises the sharded path)
+  const bool sharded = devices.size() > 1;
+  HipPhotometricBundleAdjustment pba(opt, true, true, devices, sharded ? DSOPP_HIP_TRANSPORT_LOCAL : DSOPP_HIP_TRANSPORT_AUTO);
+  std::vector<std::unique_ptr<DevicePyramidGroup>> pyramid_groups;
   const PinholeModel model{fx, fy, cx, cy};
   std::mt19937 rng(7);
   std::uniform_int_distribution<int> ux(20, W - 21), uy(20, H - 21);
@@ -54,6 +58,10 @@ bool trackerCallOrder() {
     images.push_back(render(tx_gt));
     pyramids.push_back(std::make_unique<DevicePyramid>(W, H, 1));
     pyramids.back()->build(images.back().data());
+    if (sharded) {
+      pyramid_groups.push_back(std::make_unique<DevicePyramidGroup>(pba.group(), W, H, 1));
+      pyramid_groups.back()->build(images.back().data());
+    }
     KeyframeView &f = track[static_cast<size_t>(i)];
     f.keyframe_id = i;
     f.timestamp = 1000 * (i + 1);
@@ -62,6 +70,7 @@ bool trackerCallOrder() {
     f.affine_brightness = {0, 0};
     f.is_marginalized = false;
     f.pyramids = pyramids.back().get();
+    f.pyramid_group = sharded ? pyramid_groups.back().get() : nullptr;
     for (int k = 0; k < kLandmarks; ++k) {
       LandmarkView lm;
       const int u = ux(rng), v = uy(rng);
@@ -101,8 +110,11 @@ bool trackerCallOrder() {
     }
   }
   int32_t in_window = 0;
-  ok = ok && dsopp_hip_window_num_frames(pba.handle(), &in_window) == DSOPP_HIP_OK && in_window == static_cast<int32_t>(active.size()) + 1;
-  std::printf("tracker call order: %d frames in the solver's window (one of them awaiting its fold-in)\n", in_window);
+  ok = ok && dsopp_hip_window_group_num_frames(pba.group(), &in_window) == DSOPP_HIP_OK && in_window == static_cast<int32_t>(active.size()) + 1;
+  ok = ok && (pba.handle() != nullptr) == !sharded && pba.numDevices() == static_cast<int>(devices.size());
+  std::printf("tracker call order on %zu device shard(s): %d frames in the solver's window (one of them awaiting its fold-in)\n", devices.size(), in_window);
+  if (final_tx)
+    for (const KeyframeView &f : track) final_tx->push_back(f.t_world_agent[4]);
   return ok;
 }
 }  // namespace
@@ -258,6 +270,13 @@ int main() {
   std::printf("activation: %d of %zu immature landmarks activated (%d skipped, %d deleted), worst relative idepth error %.4f, distance %.3f\n", n_act,
               act[0].size(), activator.lastResult().n_skipped, activator.lastResult().n_deleted, worst, activator.minDistanceToNeighbor());
   ok = ok && n_act > 20 && worst < 0.05;
-  ok = trackerCallOrder() && ok;
+  std::vector<double> tx_single, tx_sharded;
+  ok = trackerCallOrder({0}, &tx_single) && ok;
+  // the same sequence with the window's landmarks sharded three ways behind the same solver object
+  ok = trackerCallOrder({0, 0, 0}, &tx_sharded) && ok;
+  double worst_shard = 0;
+  for (size_t i = 0; i < tx_single.size() && i < tx_sharded.size(); ++i) worst_shard = std::max(worst_shard, std::abs(tx_single[i] - tx_sharded[i]));
+  std::printf("sharded vs single-device solver over the sequence: max |tx difference| %.2e\n", worst_shard);
+  ok = ok && tx_single.size() == tx_sharded.size() && worst_shard < 1e-7;
   return ok ? 0 : 1;
 }

@@ -17,6 +17,12 @@
 // through the C-ABI, and after every solve() writes the device results back into those LocalFrames: poses and affine
 // brightness (linearisation point + state_eps), inverse depths, H_dd^-1, relative baselines, inlier counts, outlier flags,
 // connection statuses and the relative-pose covariances.  The three services then work unchanged, on current data.
+//
+// More than one GPU.  The tracker owns ONE solver object in ONE process (fabric.cpp:58-121, dsopp_main.cpp:114-119), so the
+// multi-GPU form lives behind this same class: `devices` (YAML `photometric_bundle_adjustment: {solver: hip, devices: "0 1 2 3"}`)
+// lists the HIP devices, the device side is a dsopp_hip_window_group — landmarks dealt round-robin over the devices, frames and
+// images replicated, one RCCL all-reduce of the reduced system per Gauss-Newton iteration.  A single device (the default) is a
+// group of one, i.e. a plain window on the calling thread.
 #ifndef DSOPP_HIP_PHOTOMETRIC_BUNDLE_ADJUSTMENT_HPP
 #define DSOPP_HIP_PHOTOMETRIC_BUNDLE_ADJUSTMENT_HPP
 
@@ -29,7 +35,8 @@
 #include "energy/problems/photometric_bundle_adjustment/trust_region_photometric_bundle_adjustment_options.hpp"
 
 struct dsopp_hip_window;
-struct dsopp_hip_pyramid;
+struct dsopp_hip_window_group;
+struct dsopp_hip_pyramid_group;
 
 namespace dsopp {
 namespace energy {
@@ -53,10 +60,10 @@ class HipPhotometricBundleAdjustment
    * @param trust_region_options the options EigenPhotometricBundleAdjustment takes
    * @param estimate_uncertainty estimate pose / idepth uncertainty after the optimisation
    * @param force_accept accept every LM iteration
-   * @param device HIP device index
+   * @param devices HIP device indices the landmarks are sharded over (one entry = single-GPU)
    */
   HipPhotometricBundleAdjustment(const TrustRegionPhotometricBundleAdjustmentOptions<Precision> &trust_region_options,
-                                 bool estimate_uncertainty = false, bool force_accept = false, int device = 0);
+                                 bool estimate_uncertainty = false, bool force_accept = false, const std::vector<int> &devices = {0});
   ~HipPhotometricBundleAdjustment() override;
 
   /** photometric_bundle_adjustment.hpp:55-56; as eigen_photometric_bundle_adjustment.cpp:119-141 it first folds the frames and
@@ -69,8 +76,11 @@ class HipPhotometricBundleAdjustment
    *  write-back into `frames_`.  number_of_threads is accepted and ignored, as in the Eigen backend */
   Precision solve(const size_t number_of_threads) override;
 
-  /** the device window (for the device-resident depth maps / landmark activation of INTEGRATION.md §2b-2d) */
-  dsopp_hip_window *window() const { return window_; }
+  /** the device side: all calls of the window go through the group (a group of one shard is a plain window) */
+  dsopp_hip_window_group *group() const { return group_; }
+  /** single-device set-ups only (nullptr otherwise): the one window, for the device-resident landmark activation of
+   *  INTEGRATION.md §2d, which reads ALL active landmarks of the window on one device */
+  dsopp_hip_window *window() const;
 
  private:
   /** landmark arrays and connection statuses of one local frame -> device (only what the device does not hold yet travels) */
@@ -81,11 +91,12 @@ class HipPhotometricBundleAdjustment
   /** drops the device pyramids of frames the window has erased */
   void releaseUnusedPyramids();
 
-  dsopp_hip_window *window_ = nullptr;
-  int device_ = 0;
-  /** device texel images of the keyframes in the window, by keyframe id; their lifetime is the frame's stay in the window (the
-   *  reference keeps raw pointers into the keyframe's PixelMap for the same span, local_frame.hpp:323-325) */
-  std::map<int, dsopp_hip_pyramid *> pyramids_;
+  dsopp_hip_window_group *group_ = nullptr;
+  std::vector<int> devices_;
+  /** device texel images of the keyframes in the window (one copy per device of the group), by keyframe id; their lifetime is the
+   *  frame's stay in the window (the reference keeps raw pointers into the keyframe's PixelMap for the same span,
+   *  local_frame.hpp:323-325) */
+  std::map<int, dsopp_hip_pyramid_group *> pyramids_;
 };
 
 }  // namespace problem
