@@ -8,13 +8,14 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
               production solver settings (7 LM iterations, lambda = 1e-5, Huber 20, force_accept), synthetic scene.
               All inputs (images, landmarks, statuses) are resident in HBM before the timed region starts.
   N > 1     = landmarks sharded across ranks, frames and images replicated; ONE RCCL all-reduce per GN iteration over
-              [H_pp | b_pp | H_schur | b_schur | energy scalars], enqueued by the library itself (dsopp_hip_comm: ncclAllReduce on the
-              window's stream; --comm torch routes it through a torch.distributed callback instead).  Default = weak scaling
-              (2000 points PER GPU, the window grows with N; value = world_size * GN iterations / wall time).
-              `--workload c3|c4` (or --scaling strong) fixes the TOTAL landmark count (20 000 / 7 KF, 50 000 / 12 KF) and shards
-              it: value = GN iterations of the whole window / wall time.  Every default run also reports both strong-scaling
-              configurations at its world size under "strong_scaling".  Without a launcher `--gpus N` spawns its own ranks
-              (torch.distributed.run) and refuses to run when the node has fewer than N GPUs.
+              [combined system | energy scalars], enqueued by the library itself (dsopp_hip_comm: ncclAllReduce on the
+              window's stream; --comm torch routes it through a torch.distributed callback instead).
+              Headline at N > 1 = STRONG scaling on BASELINE.json configs[3] (C3: 7 KF, 20 000 points in TOTAL, sharded): value =
+              GN iterations of the whole window / wall time, "scaling": "strong"; rank 0 first times the SAME window alone on its
+              GPU ("same_workload_1gpu") and the line carries speedup = value / same_workload_1gpu.  C1 weak scaling (2000 points
+              PER GPU) and C4 strong scaling (12 KF / 50 000) ride along as extras ("weak_scaling_c1", "strong_scaling").
+              `--workload c1|c3|c4` / `--scaling` select another headline explicitly.  Without a launcher `--gpus N` spawns its own
+              ranks (torch.distributed.run) and refuses to run when the node has fewer than N GPUs.
 Extra objects on the same line: roofline (linearisation sweep kernel, measured live with HIP events on the library's
 stream) and cpu_baseline (the oracle = CPU port of the reference algorithm, timed on the host cores of this box).
 """
@@ -177,18 +178,31 @@ def timed_blocks(job, torch, run_iterations, steps, min_seconds=0.2, max_blocks=
     return float(np.median(times)), times
 
 
-def make_sharded_window(syn, distributed, job, frames, total_points, width, height, seed):
-    """identical synthetic window on every rank (seeded); each rank keeps its landmark shard of every frame"""
-    win = syn.make_window(num_frames=frames, num_points=total_points, width=width, height=height, seed=seed)
-    distributed.shard_window(win, job.rank, job.world)
-    return win
-
-
-def run_strong_scaling(job, torch, capi, syn, distributed, name, args, dtype):
-    """BASELINE.json configs[3] / [4] with the TOTAL landmark count fixed and sharded over the ranks: whole-window GN
-    iterations / s at this world size (the driver's SCALE run collects one such figure per N)."""
-    F, total, _, desc = WORKLOADS[name]
-    win = make_sharded_window(syn, distributed, job, F, total, 640, 480, seed=1 if name == "c4" else 0)
+def run_sharded_workload(job, torch, capi, syn, distributed, name, args, dtype, scaling=None, solo_first=False):
+    """BASELINE.json configs[3] / [4] with the TOTAL landmark count fixed and sharded over the ranks (strong: whole-window GN
+    iterations / s at this world size), or C1 with 2000 points per rank (weak).  solo_first: rank 0 times the same whole window
+    alone on its GPU before the sharded run, while the other ranks wait — the same-workload single-GPU rate the speedup refers to."""
+    F, total, scaling_w, desc = WORKLOADS[name]
+    scaling = scaling or scaling_w
+    total = total if scaling == "strong" and total else (total or 2000) * (job.world if scaling == "weak" else 1)
+    full = syn.make_window(num_frames=F, num_points=total, width=640, height=480, seed=1 if name == "c4" else 0)
+    solo = None
+    if solo_first and job.world > 1:
+        if job.rank == 0:
+            g1 = capi.HipWindow(capi.default_pba_options(dtype=dtype), device=job.local_rank)
+            syn.load_window(g1, full)
+            g1.snapshot()
+            g1.optimize_repeated(7)
+            ts = []
+            for _ in range(9):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done, _ = g1.optimize_repeated(14)
+                ts.append((time.perf_counter() - t0) / done)
+            g1.close()
+            solo = 1.0 / float(np.median(ts))
+        job.barrier(torch)
+    win = distributed.shard_window(full, job.rank, job.world)
     stream = torch.cuda.Stream()
     g = capi.HipWindow(capi.default_pba_options(dtype=dtype), device=job.local_rank, stream=stream.cuda_stream)
     syn.load_window(g, win)
@@ -199,8 +213,12 @@ def run_strong_scaling(job, torch, capi, syn, distributed, name, args, dtype):
         return g.optimize_repeated(n)[0]
     run(7)
     med, times = timed_blocks(job, torch, run, 14, min_seconds=0.1, max_blocks=50)
+    per_job = job.world if scaling == "weak" else 1
     out = {"workload": f"{desc}, 640x480, {win.num_points} on this rank", "frames": F, "total_points": total, "n_gpus": job.world,
-           "gn_iterations_per_s": 14 / med, "ms_per_iteration": med / 14 * 1e3, "timed_blocks": len(times), "scaling": "strong"}
+           "gn_iterations_per_s": per_job * 14 / med, "ms_per_iteration": med / 14 * 1e3, "timed_blocks": len(times), "scaling": scaling}
+    if solo is not None:
+        out["same_workload_1gpu"] = solo
+        out["speedup"] = out["gn_iterations_per_s"] / solo
     g.close()
     return out
 
@@ -210,7 +228,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=140)
     ap.add_argument("--warmup", type=int, default=14)
-    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 (default; the metric's configuration), c3, c4")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="c1 (default at --gpus 1: the metric's configuration), c3 (default at --gpus N > 1: strong scaling), c4")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: --points per GPU (default for c1); strong: the window's total is fixed and sharded (default for c3 / c4)")
     ap.add_argument("--frames", type=int, default=None)
@@ -246,6 +265,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report one under the other's label")
     job = Job(args, torch)
     world, rank = job.world, job.rank
+    if args.workload is None:
+        # N = 1: the metric's own configuration.  N > 1: north_star asks for STRONG scaling — BASELINE.json configs[3], the 7-KF /
+        # 20 000-point window sharded over the ranks, with the same window's single-GPU rate measured beside it
+        args.workload = "c1" if world == 1 or args.scaling == "weak" else "c3"
 
     Fw, total_w, scaling_w, desc = WORKLOADS[args.workload]
     F = args.frames or Fw
@@ -256,11 +279,30 @@ def main():
     else:
         total_points = args.points or total_w or 2000
         P = total_points // world
-    win = make_sharded_window(syn, distributed, job, F, total_points, args.width, args.height, seed=0)
+    full_win = syn.make_window(num_frames=F, num_points=total_points, width=args.width, height=args.height, seed=0)
+    dtype = capi.F64 if args.dtype == "f64" else capi.F32
+    same_workload_1gpu = None
+    if world > 1 and scaling == "strong":
+        # rank 0 alone, the whole window on its one GPU, no collective: the rate the sharded run is compared with (same process,
+        # same box, same build); the other ranks wait at the barrier
+        if rank == 0:
+            g1 = capi.HipWindow(capi.default_pba_options(dtype=dtype), device=job.local_rank)
+            syn.load_window(g1, full_win)
+            g1.snapshot()
+            g1.optimize_repeated(max(args.warmup, 7))
+            ts = []
+            for _ in range(15):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done1, _ = g1.optimize_repeated(args.steps)
+                ts.append((time.perf_counter() - t0) / done1)
+            g1.close()
+            same_workload_1gpu = 1.0 / float(np.median(ts))
+        job.barrier(torch)
+    win = distributed.shard_window(full_win, job.rank, job.world)
     P_local = win.num_points
 
     stream = torch.cuda.Stream()
-    dtype = capi.F64 if args.dtype == "f64" else capi.F32
     opts = capi.default_pba_options(dtype=dtype)
     g = capi.HipWindow(opts, device=job.local_rank, stream=stream.cuda_stream)
     syn.load_window(g, win)
@@ -308,7 +350,13 @@ def main():
     extras = {}
     if not args.no_extras and args.workload == "c1" and scaling == "weak":
         # BASELINE.json configs[3] / [4] at THIS world size (total landmark count fixed, sharded): the strong-scaling figures
-        extras["strong_scaling"] = {name: run_strong_scaling(job, torch, capi, syn, distributed, name, args, dtype) for name in ("c3", "c4")}
+        extras["strong_scaling"] = {name: run_sharded_workload(job, torch, capi, syn, distributed, name, args, dtype, solo_first=True)
+                                    for name in ("c3", "c4")}
+    if not args.no_extras and world > 1 and args.workload == "c3" and scaling == "strong":
+        # the other two configurations at this world size: C1 weak (2000 points per GPU, the N = 1 headline's window on every rank)
+        # and C4 strong (12 KF / 50 000 points) with its own same-workload single-GPU rate
+        extras["weak_scaling_c1"] = run_sharded_workload(job, torch, capi, syn, distributed, "c1", args, dtype, scaling="weak")
+        extras["strong_scaling"] = {"c4": run_sharded_workload(job, torch, capi, syn, distributed, "c4", args, dtype, solo_first=True)}
     if rank == 0 and world == 1 and not args.no_extras:
         g.restore()
         extras["stages"] = run_stage_table(g, win, syn, args)
@@ -376,6 +424,12 @@ def main():
             "kernels_isolated_avg_us": isolated,
             "dominant_kernel_by_total_time": dominant,
         }
+        if same_workload_1gpu is not None:
+            # strong scaling: the same window on ONE GPU of this node (rank 0 alone, before the sharded run) and the ratio
+            line["same_workload_1gpu"] = {"value": same_workload_1gpu, "unit": "GN iterations/s",
+                                          "what": f"{desc}: the whole window ({total_points} points) on rank 0's GPU alone, no collective, "
+                                                  f"median of 15 blocks of {steps_done} iterations"}
+            line["speedup"] = line["value"] / same_workload_1gpu
         line.update(extras)
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline

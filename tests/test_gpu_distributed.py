@@ -88,27 +88,42 @@ def test_bench_script_runs_with_two_ranks():
     """bench.py's own N > 1 path end to end, started the way the driver starts it when no launcher is involved
     (`python bench.py --gpus 2`: the script spawns its ranks through torch.distributed.run): sharding, collective, MAX-over-ranks
     block timing, rank-0 JSON line.  Two ranks share this one GPU over gloo (DSOPP_BENCH_SINGLE_DEVICE=1); on a multi-GPU node the
-    same script runs one rank per GPU with the library's native ncclAllReduce."""
+    same script runs one rank per GPU with the library's native ncclAllReduce.
+    The N > 1 headline is STRONG scaling on BASELINE.json configs[3] (7 KF / 20 000 points in total, sharded) with the same window's
+    single-GPU rate measured by rank 0 alone beside it."""
     import json
     out = _run_bench(["--gpus", "2", "--steps", "28", "--warmup", "7", "--no-extras", "--no-cpu"], {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 28 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["total_points"] == 4000 and "roofline" in d and d["config"]["ranks"] == 2
-    assert d["timing"]["blocks"] >= 1 and abs(d["value"] - 2 * 28 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["n_gpus"] == 2 and d["steps"] == 28 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["name"] == "c3" and d["config"]["total_points"] == 20000 and d["config"]["points_per_gpu"] == 10000
+    assert "roofline" in d and d["config"]["ranks"] == 2
+    assert d["timing"]["blocks"] >= 1 and abs(d["value"] - 28 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["same_workload_1gpu"]["value"] > 0 and abs(d["speedup"] - d["value"] / d["same_workload_1gpu"]["value"]) <= 1e-9 * d["speedup"]
 
 
-def test_bench_strong_scaling_workload_two_ranks():
-    """--workload c3: the TOTAL landmark count (20 000) is fixed and sharded; value counts whole-window iterations"""
+def test_bench_weak_scaling_workload_two_ranks():
+    """--workload c1: the N = 1 headline's window (2000 points) on EVERY rank, value = ranks x iterations / time"""
     import json
-    out = _run_bench(["--gpus", "2", "--steps", "14", "--warmup", "7", "--workload", "c3", "--no-extras", "--no-cpu"],
+    out = _run_bench(["--gpus", "2", "--steps", "28", "--warmup", "7", "--workload", "c1", "--no-extras", "--no-cpu"],
                      {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert d["scaling"] == "strong" and d["config"]["total_points"] == 20000 and d["config"]["points_per_gpu"] == 10000
-    assert abs(d["value"] - 14 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["scaling"] == "weak" and d["config"]["total_points"] == 4000 and d["config"]["ranks"] == 2 and "speedup" not in d
+    assert abs(d["value"] - 2 * 28 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_strong_scaling_workload_two_ranks():
+    """--workload c4: the dense configuration (12 KF / 50 000 points in total) sharded; value counts whole-window iterations"""
+    import json
+    out = _run_bench(["--gpus", "2", "--steps", "14", "--warmup", "7", "--workload", "c4", "--no-extras", "--no-cpu"],
+                     {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["total_points"] == 50000 and d["config"]["points_per_gpu"] == 25000 and d["config"]["frames"] == 12
+    assert abs(d["value"] - 14 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"] and d["speedup"] > 0
 
 
 def test_bench_refuses_more_ranks_than_gpus():
