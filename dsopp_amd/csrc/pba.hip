@@ -849,9 +849,15 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
  *  ordered sum per entry.  `ctrl` (nullable) is the control block whose `active` gates both launches and whose lambda damps the
  *  system; the LM decision is NOT taken here (decideApplyKernel runs in front of / behind it). */
 void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false, const ReduceSchurArgs *decide = nullptr) {
-  const int F = w.F(), K = w.K();
+  const int F = w.F();
   hipStream_t st = w.sr.stream;
-  ensureDynamicLds(reinterpret_cast<const void *>(schurTwoStageKernel), w.sr.device, 96 * 1024);
+  using TwoStageKernel = void (*)(TwoStageArgs);
+  static const TwoStageKernel kernels[6] = {nullptr, schurTwoStageKernel<2>, schurTwoStageKernel<2>, schurTwoStageKernel<3>, schurTwoStageKernel<4>,
+                                            schurTwoStageKernel<5>};
+  const int tpw = twoStageTilesPerWave(F);
+  if (tpw < 1 || tpw > kMaxTilesPerWave) fail(DSOPP_HIP_ERR_CAPACITY, "window of %d frames exceeds the Schur kernel's tile budget", F);
+  const TwoStageKernel two_stage_kernel = kernels[tpw];
+  ensureDynamicLds(reinterpret_cast<const void *>(two_stage_kernel), w.sr.device, 96 * 1024);
   const int n_chunks = w.opt.optimize_idepths ? w.n_schur_blocks : 0;
   // two workgroups fit per compute unit (64 landmarks x K doubles of LDS each): twice as many workgroups as the chip has units,
   // each taking its share of the chunks
@@ -890,7 +896,7 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
   c.n_schur_wgs = n_wgs;
   const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
-    schurTwoStageKernel<<<n_wgs + F * F, kSchurThreads, std::max(std::max(schurSmemBytes(K), pair_smem), decide ? kDecideSmemBytes : size_t(0)), st>>>(a);
+    two_stage_kernel<<<n_wgs + F * F, kSchurThreads, std::max(std::max(twoStageSmemBytes(F), pair_smem), decide ? kDecideSmemBytes : size_t(0)), st>>>(a);
     combineSystemKernel<<<static_cast<unsigned>((twoStagePartialCount(F) + kCombineEntries - 1) / kCombineEntries), kCombineEntries * kCombineSlices, 0, st>>>(c);
   });
   HIP_CHECK(hipGetLastError());

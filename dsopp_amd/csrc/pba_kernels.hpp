@@ -49,24 +49,33 @@ __device__ inline void buildProjectionMatrices(const Rigid &T, const FrameDev &f
   }
 }
 
-__device__ inline double linearisationScale(const FrameDev *frames, const WindowState *st, int r, int t) {
+// (the frame table / window state pointers of the functions below are templates: callers hand them over as address_space(1)
+// pointers — glb() — so that every access is a global load instead of a FLAT one)
+template <typename FramesPtr, typename StatePtr>
+__device__ __forceinline__ double linearisationScale(FramesPtr frames, StatePtr st, int r, int t) {
   return (frames[t].exposure / frames[r].exposure) * exp(st->ab0[t][0] - st->ab0[r][0]);
 }
 
 /** exp of the twist eps_f + step_f (sign = +1) or of its negative (sign = -1) */
-__device__ inline Rigid frameIncrement(const WindowState *st, int f, double sign) {
+template <typename StatePtr>
+__device__ __forceinline__ Rigid frameIncrement(StatePtr st, int f, double sign) {
   double xi[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) xi[i] = sign * (st->eps[f][i] + st->step[f][i]);
   return rigidExp(xi);
 }
 
 /** evaluate_jacobians.hpp:36-66 (per-pair prologue) + first_estimate_jacobians.hpp:22-31.
  *  Er = exp(eps_r + step_r), Emt = exp(-(eps_t + step_t)) may be supplied by the caller (shared through LDS). */
-__device__ inline void computePairConst(const FrameDev *frames, const WindowState *st, PairConst *pc, int r, int t, int F, bool fej,
-                                        const Rigid *Er = nullptr, const Rigid *Emt = nullptr) {
-  PairConst &P = pc[r * kMaxFrames + t];
-  const FrameDev &fr = frames[r];
-  const FrameDev &ft = frames[t];
+/** (forced inline: as an out-of-line function its pointer arguments were generic — 134 FLAT accesses — and the Rigid temporaries
+ *  lived in scratch; it runs on F^2 lanes of ONE workgroup at the head of every solve) */
+__device__ __forceinline__ void computePairConst(const FrameDev *frames_generic, const WindowState *st_generic, PairConst *pc_generic, int r, int t,
+                                                 int F, bool fej, const Rigid *Er = nullptr, const Rigid *Emt = nullptr) {
+  const auto frames = glb(frames_generic);
+  const auto st = glb(st_generic);
+  auto &P = glb(pc_generic)[r * kMaxFrames + t];
+  const auto &fr = frames[r];
+  const auto &ft = frames[t];
   const bool valid = (r != t) && fr.status[t] != nullptr;
   P.valid = valid ? 1 : 0;
   if (!valid) return;
@@ -96,13 +105,31 @@ __device__ inline void computePairConst(const FrameDev *frames, const WindowStat
   P.s = (ft.exposure / fr.exposure) * exp(a_t - a_r);
   P.b_t = b_t;
   P.b_r = b_r;
-  double Ucur[12];
-  buildProjectionMatrices(T_tr, fr, ft, Ucur, P.M);
-  const Rigid &Tlin = fej ? T_tr0 : T_tr;
-  buildProjectionMatrices(Tlin, fr, ft, P.U, nullptr);
+  // (projection matrices / adjoint are built in registers and stored: the helpers take generic pointers)
+  const double fxr = fr.fx, fyr = fr.fy, cxr = fr.cx, cyr = fr.cy, fxt = ft.fx, fyt = ft.fy, cxt = ft.cx, cyt = ft.cy;
+  FrameDev ir{}, it{};
+  ir.fx = fxr;
+  ir.fy = fyr;
+  ir.cx = cxr;
+  ir.cy = cyr;
+  it.fx = fxt;
+  it.fy = fyt;
+  it.cx = cxt;
+  it.cy = cyt;
+  double Ucur[12], Mcur[12], Ulin[12], adj[36];
+  buildProjectionMatrices(T_tr, ir, it, Ucur, Mcur);
+  const Rigid Tlin = fej ? T_tr0 : T_tr;
+  buildProjectionMatrices(Tlin, ir, it, Ulin, nullptr);
+  rigidAdj(Tlin, adj);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    P.M[i] = Mcur[i];
+    P.U[i] = Ulin[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) P.Adj[i] = adj[i];
 #pragma unroll
   for (int i = 0; i < 3; ++i) P.tl[i] = Tlin.t[i];
-  rigidAdj(Tlin, P.Adj);
   P.fxt = ft.fx;
   P.fyt = ft.fy;
   P.cxt = ft.cx;

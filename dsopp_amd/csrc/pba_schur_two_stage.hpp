@@ -47,6 +47,24 @@ struct TwoStageArgs {
 };
 #define TS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1 && chunk == first_chunk) a.dbg[i] = wall_clock64(); } while (0)
 
+/** tiles a wave accumulates: ceil(upper-triangular tiles / 8 waves) */
+__host__ __device__ inline int twoStageTilesPerWave(int F) {
+  const int nt = ((kBlk * F + 15) & ~15) >> 4;
+  return (nt * (nt + 1) / 2 + kSchurThreads / 64 - 1) / (kSchurThreads / 64);
+}
+
+/** LDS row stride of the two-stage kernel: a compile-time constant per tiles-per-wave class (every stride is >= Kp and = 16 mod 32,
+ *  the conflict-free condition of schurRowStride).  With a run-time stride every one of the 16 x 3 operand reads of a tile needs its
+ *  own address register (the compiler hoists them out of the chunk loop and spills them); with a constant they are immediate offsets. */
+__host__ __device__ constexpr int twoStageRowStride(int tpw) { return tpw <= 2 ? 80 : (tpw <= 4 ? 112 : 144); }
+inline size_t twoStageSmemBytes(int F) {
+  return (static_cast<size_t>(kSchurLandmarks) * twoStageRowStride(twoStageTilesPerWave(F)) + 2 * kSchurLandmarks + 40 * static_cast<size_t>(kMaxFrames)) * sizeof(double);
+}
+
+// TPW = tiles per wave, a template argument so that the accumulators are a fixed set of registers (with the generic bound of 5 tiles
+// the 12-frame window carried 16 unused accumulator registers and a select chain per tile: 23 spilled VGPRs under the 128-register
+// cap that two resident workgroups per compute unit need)
+template <int TPW>
 __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStageArgs a) {  // 2 workgroups of 8 waves per compute unit
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (a.fused_decide) {
@@ -141,7 +159,7 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
   }
   // ---- Schur workgroup: chunks [first, last) of 64 landmarks each, tiles kept in registers across them
   const int Kp = (K + 15) & ~15;
-  const int stride = schurRowStride(Kp);
+  constexpr int stride = twoStageRowStride(TPW);
   double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
   double *wgt = hrow + kSchurLandmarks * stride;        // inv per landmark (0 = excluded)
   double *wbd = wgt + kSchurLandmarks;                  // inv * bd
@@ -150,9 +168,22 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nt = Kp >> 4, n_tiles = nt * (nt + 1) / 2;
   const int li = lane & 15, lk = lane >> 4;
-  f64x4 acc[kMaxTilesPerWave];
+  f64x4 acc[TPW];
+  // LDS offsets of this wave's tiles (row block ti, column block tj), decoded once; wave-uniform, kept in scalar registers
+  int off_a[TPW], off_b[TPW];
+  const int lane_off = lk * stride + li;
 #pragma unroll
-  for (int q = 0; q < kMaxTilesPerWave; ++q) acc[q] = f64x4{0, 0, 0, 0};
+  for (int q = 0; q < TPW; ++q) {
+    acc[q] = f64x4{0, 0, 0, 0};
+    const int tile = __builtin_amdgcn_readfirstlane(wave) + q * (kSchurThreads / 64);
+    int ti = 0, rem = tile < n_tiles ? tile : 0;
+    while (rem >= nt - ti) {
+      rem -= nt - ti;
+      ++ti;
+    }
+    off_a[q] = __builtin_amdgcn_readfirstlane(16 * ti);
+    off_b[q] = __builtin_amdgcn_readfirstlane(16 * (ti + rem));
+  }
   double bs_acc = 0;  // b_schur entry threadIdx.x when the tiles have no spare column
   const int first_chunk = blockIdx.x * a.chunks_per_wg, last_chunk = min(first_chunk + a.chunks_per_wg, a.n_chunks);
   int staged_r = -1;
@@ -250,22 +281,15 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     __syncthreads();
     TS_STAMP(3);
     // phase 2: this wave's tiles += A^T W A over the chunk (v_mfma_f64_16x16x4_f64), operands of a tile requested up front
-    int q = 0;
-    for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
-      int ti = 0, rem = tile;
-      while (rem >= nt - ti) {
-        rem -= nt - ti;
-        ++ti;
-      }
-      const int tj = ti + rem;
-      const double *pa = hrow + lk * stride + 16 * ti + li;
-      const double *pb = hrow + lk * stride + 16 * tj + li;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+      if (wave + q * (kSchurThreads / 64) >= n_tiles) break;
+      const double *pa = hrow + lane_off + off_a[q];
+      const double *pb = hrow + lane_off + off_b[q];
       // operands in two batches of 8 steps (24 words in flight): with all 16 steps preloaded the kernel needs 168 registers and
       // only ONE workgroup fits per compute unit; at <= 128 two fit, and the second hides the first one's memory round trips
       constexpr int kHalf = kSchurLandmarks / 8;
-      f64x4 c4 = acc[0];
-#pragma unroll
-      for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
+      f64x4 c4 = acc[q];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         double av[kHalf], bv[kHalf], wv[kHalf];
@@ -279,8 +303,8 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
 #pragma unroll
         for (int s4 = 0; s4 < kHalf; ++s4) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(wv[s4] * av[s4], bv[s4], c4, 0, 0, 0);
       }
-#pragma unroll
-      for (int qq = 0; qq < kMaxTilesPerWave; ++qq) acc[qq] = (qq == q) ? c4 : acc[qq];
+      acc[q] = c4;
+      __builtin_amdgcn_sched_barrier(0);  // one tile's operands at a time: hoisting the next tile's LDS reads above costs the registers
     }
     TS_STAMP(4);
     if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) {
@@ -300,13 +324,12 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
   // ---- this workgroup's partial system, written once, in the MFMA's own layout: [tile][reg][lane] (coalesced 512-byte stores
   // per wave), then K entries of b_schur when the tiles have no spare column
   double *out = a.schur_partials + static_cast<size_t>(blockIdx.x) * twoStagePartialCount(F);
-  int q = 0;
-  for (int tile = wave; tile < n_tiles; tile += kSchurThreads / 64, ++q) {
-    f64x4 c4 = acc[0];
 #pragma unroll
-    for (int qq = 1; qq < kMaxTilesPerWave; ++qq) c4 = (qq == q) ? acc[qq] : c4;
+  for (int q = 0; q < TPW; ++q) {
+    const int tile = wave + q * (kSchurThreads / 64);
+    if (tile >= n_tiles) break;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[static_cast<size_t>(tile) * 256 + reg * 64 + lane] = c4[reg];
+    for (int reg = 0; reg < 4; ++reg) out[static_cast<size_t>(tile) * 256 + reg * 64 + lane] = acc[q][reg];
   }
   if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) out[static_cast<size_t>(n_tiles) * 256 + threadIdx.x] = bs_acc;
   if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) a.dbg[7] = wall_clock64();

@@ -2,12 +2,12 @@
 # rocprofv3 kernel-trace statistics of every workload DESIGN.md quotes a kernel time for.  Run on the GPU box from the repo root:
 #   bash scripts/collect_profiles.sh [tag]      -> gpurun_out/profiles_<tag>/<workload>_kernel_stats.csv (copy into profiles/)
 set -uo pipefail
-TAG="${1:-r02}"
+TAG="${1:-r03}"
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$ROOT/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for what in c1 large tracker depth activation; do
+for what in c1 c1_isolated large tracker depth activation; do
   d="$OUT/raw_$what"
   rm -rf "$d"
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o prof -- python "$ROOT/scripts/profile_target.py" "$what" > "$OUT/$what.log" 2>&1)

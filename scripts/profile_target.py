@@ -1,6 +1,10 @@
 """One workload per process for `rocprofv3 --kernel-trace --stats` (scripts/collect_profiles.sh): the kernel_stats csv of each run
 is what DESIGN.md's per-kernel figures are recomputed from.
    c1         the bench's C1 loop (7 KF / 2000 points): 140 GN iterations
+   c1_isolated  the roofline kernel alone, as bench.py times it: 200 back-to-back launches of the in-loop linearisation sweep
+              (sweepKernel<double, LIN, FEJ, HUBER, BACKSUB>) on the C1 window — the only launches of that instantiation in the
+              process, so the csv's average for it IS the figure `roofline.avg_launch_us` quotes (in the c1 csv the same kernel
+              runs inside the loop, between dependent launches, and averages ~10 % longer)
    large      12 KF / 50 000 points on one GPU: 3 LM solves + isolated kernel launches
    tracker    C2: 1280x1024, 5 levels, 20 frames of pyramid + estimatePose
    depth      7 x 2000 immature landmarks against one 640x480 frame
@@ -22,6 +26,14 @@ if what == "c1":
     g.snapshot()
     g.optimize_repeated(14)
     g.optimize_repeated(140)
+    g.close()
+elif what == "c1_isolated":
+    win = syn.make_window(7, 2000, 640, 480, seed=0)
+    g = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g, win)
+    g.snapshot()
+    g.restore()
+    print("sweep_linearize_loop", g.time_kernel("sweep_linearize_loop", 200))
     g.close()
 elif what == "large":
     win = syn.make_window(12, 50000, 640, 480, seed=1)

@@ -238,13 +238,16 @@ def test_gpu_depth_maps_and_device_scan():
 
 
 @pytest.mark.gpu
-def test_gpu_estimate_pose_matches_oracle_chain():
+@pytest.mark.parametrize("size", [(320, 240, 4), (1280, 1024, 4), (1280, 1024, 5)])
+def test_gpu_estimate_pose_matches_oracle_chain(size):
     """the tracker's coarse-to-fine estimatePose (monocular_tracker.cpp:179-245) in one C call against the same chain
-    stepped by hand through the oracle: window solve -> reference depth maps -> per level {scan, align}"""
+    stepped by hand through the oracle: window solve -> reference depth maps -> per level {scan, align} — also at the full C2 size
+    of BASELINE.json (1280 x 1024) with the 4 pyramid levels the production Camera requests (src/sensors/camera/src/camera.cpp:43-45)
+    and with the 5 that kMaxPyramidDepth allows (src/features/include/features/camera/pixel_data_frame.hpp:26)"""
     from dsopp_amd import capi
     from oracle import pyoracle as po
-    W, H, L = 320, 240, 4
-    win = syn.make_window(num_frames=4, num_points=800, width=W, height=H, seed=17)
+    W, H, L = size
+    win = syn.make_window(num_frames=4, num_points=800 if W == 320 else 2000, width=W, height=H, seed=17)
     o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
     g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
     o.solve()

@@ -144,6 +144,38 @@ def test_large_baseline_configurations(frames, points):
     g.close()
 
 
+@pytest.mark.parametrize("frames", [13, 16])
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_window_at_capacity(frames, deterministic):
+    """windows of 13 and of DSOPP_HIP_MAX_FRAMES = 16 keyframes (K = 104 / 128: four and five MFMA tiles per wave in the Schur
+    build, two lanes-rows per lane in the solve's back-substitution): the full solve against the oracle in both summation modes;
+    a 17th keyframe is refused with DSOPP_HIP_ERR_CAPACITY and the window stays as it was"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    # a slower camera than the default: 16 keyframes of the default motion leave the scene
+    base = syn.BASE_MOTION.copy()
+    syn.BASE_MOTION[:] = base * 0.4
+    try:
+        win = syn.make_window(num_frames=frames + 1, num_points=(frames + 1) * 120, width=320, height=240, seed=70 + frames)
+    finally:
+        syn.BASE_MOTION[:] = base
+    extra = win.frames.pop()
+    po.set_threads(8)
+    o = _load(po.OracleWindow(po.default_pba_options()), win)
+    g = _load(capi.HipWindow(capi.default_pba_options()), win)
+    g.set_deterministic(deterministic)
+    assert g.num_frames == frames
+    if frames == 16:
+        intr = win.scene.intrinsics
+        with pytest.raises(capi.HipError, match="-5"):
+            g.push_frame(extra.frame_id, extra.timestamp, extra.pixelinfo, None, intr, syn.mat_to_params(extra.T_w_c_init), extra.exposure,
+                         extra.affine_init, False, False)
+        assert g.num_frames == 16 and g.frame_ids() == [f.frame_id for f in win.frames]
+    _compare_solve(o, g, win)
+    po.set_threads(1)
+    g.close()
+
+
 def test_snapshot_restore_is_idempotent(small_window):
     """restore() + optimize() must reproduce the first solve bit for bit (deterministic reductions, no atomics-order effects
     on the accepted state beyond the stated tolerance)"""
