@@ -732,16 +732,19 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   const int tid = threadIdx.x;
   const int G = gridDim.x;
   unsigned pass_global = 0;  // barriers passed so far (identical in every workgroup)
-  double T_cur[12], ab_cur[2] = {a.ab0[0], a.ab0[1]};
-#pragma unroll
-  for (int i = 0; i < 12; ++i) T_cur[i] = a.T_tr0[i];
+  // current estimate (T_target_reference rows, affine brightness): in LDS, not in every thread's registers — 28 VGPRs less, and the
+  // per-entry initialisation of the control block below needs no dynamically indexed private array (= scratch)
+  __shared__ double s_T_cur[12], s_ab_cur[2];
+  if (tid < 12) s_T_cur[tid] = a.T_tr0[tid];
+  if (tid < 2) s_ab_cur[tid] = a.ab0[tid];
   if (tid == 0) s_failed = 0;
   int levels_done = 0, success = 1, lm_iterations = 0;
   for (int lvl = a.n_levels - 1; lvl >= 0; --lvl) {
     const AlignLevelDev &L = a.level[lvl];
+    __syncthreads();  // s_T_cur / s_ab_cur of the previous level (or the start) are in place
     AlignFrameDev tgt = L.tgt;
-    tgt.ab0[0] = ab_cur[0];
-    tgt.ab0[1] = ab_cur[1];
+    tgt.ab0[0] = s_ab_cur[0];
+    tgt.ab0[1] = s_ab_cur[1];
     AlignParams prm;
     prm.sigma_huber = a.sigma_huber;
     prm.affine_reg[0] = a.affine_reg[0];
@@ -754,23 +757,29 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     prm.n_points = L.n_points;
     prm.n_blocks = G;
     __syncthreads();  // previous level's reads of sc are done
-    if (tid == 0) {
-      // reset(); pushFrame(reference); pushFrame(target, current estimate): the control block dsopp_hip_aligner_solve prepares
-      AlignControl c;
-      for (int i = 0; i < 12; ++i) c.T_tr[i] = c.cand_T[i] = T_cur[i];
-      c.ab_eps[0] = c.ab_eps[1] = c.cand_ab[0] = c.cand_ab[1] = 0;
-      for (int i = 0; i < 64; ++i) c.H[i] = c.H_used[i] = 0;
-      for (int i = 0; i < 8; ++i) c.b[i] = c.step[i] = 0;
-      c.lambda = a.lambda0;
-      c.energy = 0;
-      c.n_valid = 0;
-      c.converged = 0;
-      c.active = 1;
-      c.iteration = 0;
-      c.have_candidate = 0;
-      c.linear_system_valid = 0;
-      c.pad0 = c.pad1 = 0;
-      sc = c;
+    // reset(); pushFrame(reference); pushFrame(target, current estimate): the control block dsopp_hip_aligner_solve prepares, written
+    // straight into LDS one entry per thread (as a private AlignControl filled by one lane it lived in 1.4 KB of scratch)
+    if (tid < 64) {
+      sc.H[tid] = 0;
+      sc.H_used[tid] = 0;
+    } else if (tid < 64 + 12) {
+      sc.T_tr[tid - 64] = s_T_cur[tid - 64];
+    } else if (tid < 64 + 24) {
+      sc.cand_T[tid - 76] = s_T_cur[tid - 76];
+    } else if (tid < 64 + 32) {
+      sc.b[tid - 88] = 0;
+      sc.step[tid - 88] = 0;
+    } else if (tid == 96) {
+      sc.ab_eps[0] = sc.ab_eps[1] = sc.cand_ab[0] = sc.cand_ab[1] = 0;
+      sc.lambda = a.lambda0;
+      sc.energy = 0;
+      sc.n_valid = 0;
+      sc.converged = 0;
+      sc.active = 1;
+      sc.iteration = 0;
+      sc.have_candidate = 0;
+      sc.linear_system_valid = 0;
+      sc.pad0 = sc.pad1 = 0;
     }
     __syncthreads();
     // up to kPreload points per thread are read once per level (all of them when the level has <= kPreload * G * 256 points)
@@ -923,31 +932,35 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       break;
     }
     // accepted: the next finer level starts from this estimate
-    Rigid Tfin;
+    __syncthreads();  // every thread has read the verdict's inputs from sc
+    if (tid == 0) {
+      Rigid Tfin;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = sc.T_tr[4 * i + j];
-      Tfin.t[i] = sc.T_tr[4 * i + 3];
+        for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = sc.T_tr[4 * i + j];
+        Tfin.t[i] = sc.T_tr[4 * i + 3];
+      }
+      rigidNormalize(Tfin);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) s_T_cur[4 * i + j] = Tfin.R[3 * i + j];
+        s_T_cur[4 * i + 3] = Tfin.t[i];
+      }
+      s_ab_cur[0] += sc.ab_eps[0];
+      s_ab_cur[1] += sc.ab_eps[1];
     }
-    rigidNormalize(Tfin);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) T_cur[4 * i + j] = Tfin.R[3 * i + j];
-      T_cur[4 * i + 3] = Tfin.t[i];
-    }
-    ab_cur[0] += sc.ab_eps[0];
-    ab_cur[1] += sc.ab_eps[1];
   }
+  __syncthreads();
   if (blockIdx.x == 0 && tid == 0) {
     a.out->levels_done = levels_done;
     a.out->success = success;
     a.out->failed = 0;
     a.out->lm_iterations = lm_iterations;
-    for (int i = 0; i < 12; ++i) a.out->T_tr[i] = T_cur[i];
-    a.out->ab[0] = ab_cur[0];
-    a.out->ab[1] = ab_cur[1];
+    for (int i = 0; i < 12; ++i) a.out->T_tr[i] = s_T_cur[i];
+    a.out->ab[0] = s_ab_cur[0];
+    a.out->ab[1] = s_ab_cur[1];
   }
 }
 

@@ -1233,6 +1233,13 @@ void lmSolveFusedEnqueue(W &w) {
         const ReduceSchurArgs dec = makeDecideArgs(w, cin, fr);
         launchTwoStage(w, cout, fr.ublk_parity, 0.0, false, &dec);
       }
+    } else if (w.allreduce && r + 1 == rounds) {
+      // landmark shards, closing round: its sweep was residual-only, no system exists — only the four energy scalars of the last
+      // candidate are summed across the shards (they sit where the decision expects them: behind the combined system's slot)
+      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.combCount(), cin);
+      HIP_CHECK(hipGetLastError());
+      allreduceIfNeeded(w, w.d_reduce.ptr + w.combCount(), 4);
+      launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);

@@ -252,38 +252,47 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
     }
     return false;
   }
+  // landmark-sharded windows hand over the four sums ready-made (all-reduced): no reduction at all.  (Uniform branch: a launch
+  // argument.)
+  const bool direct = a.prm.use_reduced_scalars == 1;
   constexpr int RS = kSchurThreads + 2;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) lds[e * RS + tid] = v[e];
-  ldsBarrier();
-  if (kStamps && a.dbg && tid == 0) s_dbg[0] = wall_clock64();
-  // three-level tree (8-way per level), fixed order => deterministic
   static_assert(kSchurThreads == 512, "reduction tree below assumes 512 threads");
   double *l2 = lds + 6 * RS;  // [4][64]
   double *l3 = l2 + 6 * 64;   // [4][8]
-  if (tid < 4 * 64) {
-    const int e = tid >> 6, j = tid & 63;
-    double s = 0;
+  if (!direct) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += lds[e * RS + 8 * j + k];
-    l2[e * 64 + j] = s;
-  }
-  ldsBarrier();
-  if (tid < 4 * 8) {
-    const int e = tid >> 3, j = tid & 7;
-    double s = 0;
+    for (int e = 0; e < 4; ++e) lds[e * RS + tid] = v[e];
+    ldsBarrier();
+    if (kStamps && a.dbg && tid == 0) s_dbg[0] = wall_clock64();
+    // three-level tree (8-way per level), fixed order => deterministic
+    if (tid < 4 * 64) {
+      const int e = tid >> 6, j = tid & 63;
+      double s = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += l2[e * 64 + 8 * j + k];
-    l3[e * 8 + j] = s;
+      for (int k = 0; k < 8; ++k) s += lds[e * RS + 8 * j + k];
+      l2[e * 64 + j] = s;
+    }
+    ldsBarrier();
+    if (tid < 4 * 8) {
+      const int e = tid >> 3, j = tid & 7;
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += l2[e * 64 + 8 * j + k];
+      l3[e * 8 + j] = s;
+    }
+    ldsBarrier();
   }
-  ldsBarrier();
   if (tid == 0) {
     double t[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       double s = 0;
+      if (direct) {
+        s = v[e];
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += l3[e * 8 + k];
+        for (int k = 0; k < 8; ++k) s += l3[e * 8 + k];
+      }
       t[e] = s;
     }
     LmControl c = cin;
