@@ -823,8 +823,14 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
           for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
           AlignSweepCtx<S> x;
           alignSweepSetup<S>(x, L.ref, tgt, sc, prm);
+          // point q of a thread exists on this level only when the level has more than q * G * 256 points: a grid-uniform test.
+          // (alignPoint is predicated, not branched: without the test a level of <= G * 256 points — every level of the C2
+          // workload — ran the whole second evaluation on a dummy texel in every pass, half of the sweep's 2.4 us)
 #pragma unroll
-          for (int q = 0; q < kPreload; ++q) alignPoint<S>(x, ru[q], rv[q], rid[q], rint[q], first + q * G * kAlignThreads < L.n_points, acc);
+          for (int q = 0; q < kPreload; ++q) {
+            if (q > 0 && L.n_points <= q * G * kAlignThreads) break;
+            alignPoint<S>(x, ru[q], rv[q], rid[q], rint[q], first + q * G * kAlignThreads < L.n_points, acc);
+          }
         } else {
           alignSweep<S>(L.ref, tgt, L.pu, L.pv, L.pid, L.pint, sc, prm, first, G * kAlignThreads, acc);
         }
