@@ -12,6 +12,7 @@
 // Work is laid out so that a wavefront shares one frame pair: pair constants are wave-uniform (scalar registers),
 // landmark SoA reads are coalesced, the image is a gather of 2 x 64 B segments per pattern pixel.
 #pragma once
+#include <type_traits>
 #include "device_geom.hpp"
 #include "pba_types.hpp"
 
@@ -68,7 +69,12 @@ __device__ __forceinline__ Rigid frameIncrement(StatePtr st, int f, double sign)
 /** evaluate_jacobians.hpp:36-66 (per-pair prologue) + first_estimate_jacobians.hpp:22-31.
  *  Er = exp(eps_r + step_r), Emt = exp(-(eps_t + step_t)) may be supplied by the caller (shared through LDS). */
 /** (forced inline: as an out-of-line function its pointer arguments were generic — 134 FLAT accesses — and the Rigid temporaries
- *  lived in scratch; it runs on F^2 lanes of ONE workgroup at the head of every solve) */
+ *  lived in scratch; it runs on F^2 lanes of ONE workgroup at the head of every solve).
+ *  PART selects what is computed and stored: 0 everything; 1 the members that move with the state (M, s, b_t, b_r) and `valid`;
+ *  2 the members of the linearisation point (T0rel, U, tl, Adj, camera, s0, b_r0, sigma_r).  The head of a solve runs the two
+ *  halves of a pair on two different waves: the one workgroup is bound by its instruction stream (~2100 instructions per lane),
+ *  and two SIMDs run the two halves side by side. */
+template <int PART = 0>
 __device__ __forceinline__ void computePairConst(const FrameDev *frames_generic, const WindowState *st_generic, PairConst *pc_generic, int r, int t,
                                                  int F, bool fej, const Rigid *Er = nullptr, const Rigid *Emt = nullptr) {
   const auto frames = glb(frames_generic);
@@ -77,7 +83,7 @@ __device__ __forceinline__ void computePairConst(const FrameDev *frames_generic,
   const auto &fr = frames[r];
   const auto &ft = frames[t];
   const bool valid = (r != t) && fr.status[t] != nullptr;
-  P.valid = valid ? 1 : 0;
+  if (PART != 2) P.valid = valid ? 1 : 0;
   if (!valid) return;
   Rigid Tr0, Tt0;
 #pragma unroll
@@ -91,60 +97,71 @@ __device__ __forceinline__ void computePairConst(const FrameDev *frames_generic,
     Tt0.t[i] = st->T0_t[t][i];
   }
   const Rigid T_tr0 = rigidMul(rigidInverse(Tt0), Tr0);
+  if (PART != 1) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) P.T0rel[4 * i + j] = T_tr0.R[3 * i + j];
-    P.T0rel[4 * i + 3] = T_tr0.t[i];
+      for (int j = 0; j < 3; ++j) P.T0rel[4 * i + j] = T_tr0.R[3 * i + j];
+      P.T0rel[4 * i + 3] = T_tr0.t[i];
+    }
   }
-  const Rigid T_tr = rigidMul(Emt ? *Emt : frameIncrement(st, t, -1.0), rigidMul(T_tr0, Er ? *Er : frameIncrement(st, r, 1.0)));
-  const double a_r = st->ab0[r][0] + st->eps[r][6] + st->step[r][6];
-  const double b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
-  const double a_t = st->ab0[t][0] + st->eps[t][6] + st->step[t][6];
-  const double b_t = st->ab0[t][1] + st->eps[t][7] + st->step[t][7];
-  P.s = (ft.exposure / fr.exposure) * exp(a_t - a_r);
-  P.b_t = b_t;
-  P.b_r = b_r;
   // (projection matrices / adjoint are built in registers and stored: the helpers take generic pointers)
-  const double fxr = fr.fx, fyr = fr.fy, cxr = fr.cx, cyr = fr.cy, fxt = ft.fx, fyt = ft.fy, cxt = ft.cx, cyt = ft.cy;
   FrameDev ir{}, it{};
-  ir.fx = fxr;
-  ir.fy = fyr;
-  ir.cx = cxr;
-  ir.cy = cyr;
-  it.fx = fxt;
-  it.fy = fyt;
-  it.cx = cxt;
-  it.cy = cyt;
-  double Ucur[12], Mcur[12], Ulin[12], adj[36];
-  buildProjectionMatrices(T_tr, ir, it, Ucur, Mcur);
-  const Rigid Tlin = fej ? T_tr0 : T_tr;
-  buildProjectionMatrices(Tlin, ir, it, Ulin, nullptr);
-  rigidAdj(Tlin, adj);
-#pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    P.M[i] = Mcur[i];
-    P.U[i] = Ulin[i];
+  ir.fx = fr.fx;
+  ir.fy = fr.fy;
+  ir.cx = fr.cx;
+  ir.cy = fr.cy;
+  it.fx = ft.fx;
+  it.fy = ft.fy;
+  it.cx = ft.cx;
+  it.cy = ft.cy;
+  const bool need_current = PART != 2 || !fej;  // without first-estimate Jacobians the linearisation point IS the current state
+  Rigid T_tr = T_tr0;
+  double b_r = 0, s_cur = 0;
+  if (need_current) {
+    T_tr = rigidMul(Emt ? *Emt : frameIncrement(st, t, -1.0), rigidMul(T_tr0, Er ? *Er : frameIncrement(st, r, 1.0)));
+    const double a_r = st->ab0[r][0] + st->eps[r][6] + st->step[r][6];
+    const double a_t = st->ab0[t][0] + st->eps[t][6] + st->step[t][6];
+    b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
+    s_cur = (ft.exposure / fr.exposure) * exp(a_t - a_r);
   }
+  if (PART != 2) {
+    const double b_t = st->ab0[t][1] + st->eps[t][7] + st->step[t][7];
+    P.s = s_cur;
+    P.b_t = b_t;
+    P.b_r = b_r;
+    double Ucur[12], Mcur[12];
+    buildProjectionMatrices(T_tr, ir, it, Ucur, Mcur);
 #pragma unroll
-  for (int i = 0; i < 36; ++i) P.Adj[i] = adj[i];
+    for (int i = 0; i < 12; ++i) P.M[i] = Mcur[i];
+  }
+  if (PART != 1) {
+    const Rigid Tlin = fej ? T_tr0 : T_tr;
+    double Ulin[12], adj[36];
+    buildProjectionMatrices(Tlin, ir, it, Ulin, nullptr);
+    rigidAdj(Tlin, adj);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) P.tl[i] = Tlin.t[i];
-  P.fxt = ft.fx;
-  P.fyt = ft.fy;
-  P.cxt = ft.cx;
-  P.cyt = ft.cy;
-  if (fej) {
-    P.s0 = linearisationScale(frames, st, r, t);
-    P.b_r0 = st->ab0[r][1];
-    int last = -1;
-    for (int k = 0; k < F; ++k)
-      if (k != r && fr.status[k] != nullptr) last = k;
-    P.sigma_r = linearisationScale(frames, st, r, last);
-  } else {
-    P.s0 = P.s;
-    P.b_r0 = b_r;
-    P.sigma_r = P.s;
+    for (int i = 0; i < 12; ++i) P.U[i] = Ulin[i];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) P.Adj[i] = adj[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.tl[i] = Tlin.t[i];
+    P.fxt = ft.fx;
+    P.fyt = ft.fy;
+    P.cxt = ft.cx;
+    P.cyt = ft.cy;
+    if (fej) {
+      P.s0 = linearisationScale(frames, st, r, t);
+      P.b_r0 = st->ab0[r][1];
+      int last = -1;
+      for (int k = 0; k < F; ++k)
+        if (k != r && fr.status[k] != nullptr) last = k;
+      P.sigma_r = linearisationScale(frames, st, r, last);
+    } else {
+      P.s0 = s_cur;
+      P.b_r0 = b_r;
+      P.sigma_r = s_cur;
+    }
   }
 }
 
@@ -172,7 +189,8 @@ __device__ inline void refreshPairCurrent(const FrameDev *frames, const WindowSt
   P.b_r = st->ab0[r][1] + st->eps[r][7] + st->step[r][7];
 }
 
-__global__ void pairSetupKernel(const FrameDev *frames, const WindowState *st, PairConst *pc, int F, int fej, const int *run_flag) {
+__global__ void __launch_bounds__(kMaxFrames *kMaxFrames) pairSetupKernel(const FrameDev *frames, const WindowState *st, PairConst *pc, int F, int fej,
+                                                                          const int *run_flag) {
   if (run_flag && !*run_flag) return;
   const int idx = threadIdx.x;
   if (idx >= F * F) return;
@@ -186,6 +204,28 @@ __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+/** wave sum without LDS traffic: DPP within the rows of 16 lanes (xor 1, xor 2, half mirror, mirror), then the four row totals
+ *  read with v_readlane and added in row order.  Every lane receives the same, order-fixed total.  (__shfl_xor is six dependent
+ *  ds_bpermute round trips.) */
+__device__ __forceinline__ double waveSumDpp(double v) {
+  auto mov = [](double x, auto ctrl_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value;
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  };
+  v += mov(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += mov(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += mov(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += mov(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  auto row = [&](int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+  };
+  return ((row(0) + row(16)) + row(32)) + row(48);
 }
 
 /** sums `N` per-thread doubles over the block; result valid in thread 0's `vals` */

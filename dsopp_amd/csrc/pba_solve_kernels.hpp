@@ -1518,7 +1518,18 @@ __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
     const int F = a.sa.F, tid = threadIdx.x;
     if (tid < 2 * F) s_inc[tid] = frameIncrement(a.sa.st, tid < F ? tid : tid - F, tid < F ? 1.0 : -1.0);
     __syncthreads();
-    if (tid < F * F) computePairConst(a.pair_frames, a.sa.st, a.pair_pc, tid / F, tid % F, F, a.pair_fej != 0, &s_inc[tid / F], &s_inc[F + tid % F]);
+    if (2 * F * F <= kSolveThreads - 64) {
+      // the two halves of a pair's constants on two different waves (SIMDs): wave 0.. the state-dependent half, from thread 64 +
+      // ... the linearisation-point half (rounded up to a wave boundary so that no wave runs both instruction streams)
+      const int second = (F * F + 63) & ~63;
+      if (tid < F * F)
+        computePairConst<1>(a.pair_frames, a.sa.st, a.pair_pc, tid / F, tid % F, F, a.pair_fej != 0, &s_inc[tid / F], &s_inc[F + tid % F]);
+      else if (tid >= second && tid < second + F * F)
+        computePairConst<2>(a.pair_frames, a.sa.st, a.pair_pc, (tid - second) / F, (tid - second) % F, F, a.pair_fej != 0, &s_inc[(tid - second) / F],
+                            &s_inc[F + (tid - second) % F]);
+    } else if (tid < F * F) {
+      computePairConst<0>(a.pair_frames, a.sa.st, a.pair_pc, tid / F, tid % F, F, a.pair_fej != 0, &s_inc[tid / F], &s_inc[F + tid % F]);
+    }
     __syncthreads();  // (priorEnergyBlock below has its own scratch; keep the phases apart)
   }
   const double prior = priorEnergyBlock(a.sa, false, reinterpret_cast<double *>(smem_raw), threadIdx.x);
