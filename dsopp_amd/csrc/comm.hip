@@ -124,6 +124,13 @@ int dsopp_hip_comm_create(const uint8_t id[DSOPP_HIP_COMM_ID_BYTES], int rank, i
 int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out) {
   return guarded([&] {
     if (!nccl_comm || !out) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) fail(DSOPP_HIP_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= count) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, count);
+    HIP_CHECK(hipSetDevice(device));
+    // The handle is passed to the librccl instance THIS library resolved (the one already loaded in the process, else /opt/rocm's): it
+    // must have been created by that same instance — a communicator of a statically linked or differently named RCCL build is a
+    // foreign object here (include/dsopp_hip.h says so)
     auto c = std::make_unique<dsopp_hip_comm>();
     c->comm = static_cast<ncclComm_t>(nccl_comm);
     c->owned = false;

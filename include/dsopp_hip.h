@@ -192,7 +192,10 @@ int dsopp_hip_window_set_allreduce(dsopp_hip_window *w, dsopp_hip_allreduce_fn f
  * Replaces the mutex reduction of the per-thread partial systems (PBA_INT/hessian_block_evaluation.hpp:101-145,178-235) across
  * GPUs.  Rank 0 obtains an id (dsopp_hip_comm_unique_id), hands it to the other ranks by any means (MPI, a file, a socket),
  * then EVERY rank calls dsopp_hip_comm_create (collective).  dsopp_hip_comm_adopt wraps an ncclComm_t the host program
- * already owns (not destroyed with the wrapper).  librccl is loaded on first use only. */
+ * already owns (not destroyed with the wrapper): the communicator must come from the SAME loaded librccl this library resolves
+ * (the instance already mapped into the process — e.g. PyTorch's — else /opt/rocm/lib/librccl.so.1); a handle of another RCCL
+ * build (statically linked, differently named) must not be adopted.  `device` is the device the communicator's rank runs on.
+ * librccl is loaded on first use only. */
 #define DSOPP_HIP_COMM_ID_BYTES 128
 typedef struct dsopp_hip_comm dsopp_hip_comm;
 int dsopp_hip_comm_unique_id(uint8_t id[DSOPP_HIP_COMM_ID_BYTES]);
@@ -312,8 +315,10 @@ int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int mode);
  * landmarks accumulate H_schur with fp64 atomics (fewest launches; the sum order, hence the last bits, vary from run to run — the
  * reference's own reduction under a mutex, hessian_block_evaluation.hpp:101-145, has the same property), larger windows use the
  * two-stage build (per-workgroup partial systems, then one ordered sum per entry: no atomics, bit-reproducible, and faster there).
- * 1: the two-stage build at every size — a solve is then bit-reproducible from run to run at the cost of two more launches per
- * Gauss-Newton iteration. */
+ * 1: the two-stage build at every size — the fused LM loop (lm_mode 0, the default), the host-driven loop (lm_mode 1) and the stage
+ * entry point dsopp_hip_window_linearize are then bit-reproducible from run to run, at the cost of two more launches per Gauss-Newton
+ * iteration.  Not covered: the unfused device loop (lm_mode 2, a debugging aid) and the fold-in of marginalised landmarks inside
+ * push_frame, which keep the atomic accumulation. */
 int dsopp_hip_window_set_deterministic(dsopp_hip_window *w, int enable);
 /* TrustRegion...Options::max_iterations of an existing window */
 int dsopp_hip_window_set_max_iterations(dsopp_hip_window *w, int32_t max_iterations);
