@@ -371,6 +371,9 @@ void syncTopology(W &w) {
     FrameDev &d = fd[static_cast<size_t>(r)];
     const LevelView lv = f.pyramid->view(f.level);
     d.texels = hbm(lv.texels);
+    static const bool no_iplane = std::getenv("DSOPP_HIP_NO_IPLANE") != nullptr;  // tuning aid (A/B of the counter traffic)
+    d.iplane = no_iplane ? nullptr : hbm(f.pyramid->intensityPlane(f.level, st));
+    d.itiles = f.pyramid->itilesX(f.level);
     d.width = lv.width;
     d.height = lv.height;
     d.fx = f.intr[0];
@@ -476,6 +479,8 @@ void syncTopology(W &w) {
       sb.width_t = dt.width;
       sb.height_t = dt.height;
       sb.texels_t = dt.texels;
+      sb.iplane_t = dt.iplane;
+      sb.itiles_t = dt.itiles;
       for (int k = 0; k < F; ++k)
         if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
     }

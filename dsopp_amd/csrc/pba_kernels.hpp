@@ -582,13 +582,26 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
     const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
     const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
-    const Texel<S> t00 = loadTexel(p), t10 = loadTexel(p + 1), t01 = loadTexel(p + W), t11 = loadTexel(p + W + 1);
-    const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
-    ok = (m != S(0));
-    sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
-    if (LIN) {
-      sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
-      sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
+    if (!LIN && std::is_same<S, double>::value && be.iplane_t != nullptr) {
+      // residual-only sweep: 8 bytes per pixel from the tiled intensity plane (mask in the lowest mantissa bit) instead of
+      // four 32-byte texels of which only {I, mask} are used
+      const auto ip = (GlobalPtr<const unsigned long long>)be.iplane_t;
+      const int tiles = be.itiles_t;
+      auto at = [&](int x, int y) { return ip[(static_cast<size_t>(y >> 1) * tiles + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3)]; };
+      const unsigned long long b00 = at(ix, iy), b10 = at(ix + 1, iy), b01 = at(ix, iy + 1), b11 = at(ix + 1, iy + 1);
+      const unsigned long long bm = ry ? (rx ? b11 : b01) : (rx ? b10 : b00);
+      ok = (bm & 1ull) != 0;
+      auto val = [](unsigned long long b) { return static_cast<S>(__longlong_as_double(static_cast<long long>(b & ~1ull))); };
+      sI = w11 * val(b11) + w01 * val(b01) + w10 * val(b10) + w00 * val(b00);
+    } else {
+      const Texel<S> t00 = loadTexel(p), t10 = loadTexel(p + 1), t01 = loadTexel(p + W), t11 = loadTexel(p + W + 1);
+      const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
+      ok = (m != S(0));
+      sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
+      if (LIN) {
+        sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
+        sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
+      }
     }
   }
   SWEEP_STAMP(3);

@@ -27,6 +27,8 @@ constexpr uint8_t kFlagMarginalized = 1, kFlagOutlier = 2, kFlagToMarginalize = 
  *  of ResidualPoint's 259 scalars only status, candidate status, energy and the FEJ validity bit are kept. */
 struct FrameDev {
   const hbm_void *texels;  // Texel<S>* of the level this frame was pushed with
+  const hbm_void *iplane;  // tiled intensity plane of that level (nullptr: none), itiles tiles per row
+  int itiles, pad_i;
   int width, height;
   double fx, fy, cx, cy;
   double exposure;
@@ -112,6 +114,11 @@ struct SweepBlock {
   const hbm_u8 *flags, *status, *fej_valid;
   hbm_u8 *cand;
   const hbm_void *texels_t;  // Texel<S>* of the target frame's level
+  // tiled intensity plane of the target level (pyramid.hpp; nullptr: none — f32 storage or switched off): what residual-only
+  // sweeps sample instead of the texels; itiles_t = 4 x 2 tiles per image row
+  const hbm_void *iplane_t;
+  int itiles_t;
+  int pad_t;
 };
 
 /** one thread block of the Schur kernel = a chunk of landmarks of one frame.  The descriptor repeats the frame's

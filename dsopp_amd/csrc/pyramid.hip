@@ -116,6 +116,20 @@ __global__ void getLevelKernel(const Texel<S> *tex, double *pixelinfo, size_t n)
   pixelinfo[3 * i + 2] = static_cast<double>(tex[i].Iy);
 }
 
+/** texels -> tiled intensity plane (pyramid.hpp): one thread per pixel of the padded tile grid */
+__global__ void buildIntensityPlaneKernel(const Texel<double> *__restrict__ tex, int W, int H, int tiles_x, int tiles_y,
+                                          unsigned long long *__restrict__ out) {
+  const int x = blockIdx.x * kTileX + threadIdx.x;
+  const int y = blockIdx.y * kTileY + threadIdx.y;
+  if (x >= 4 * tiles_x || y >= 2 * tiles_y) return;
+  unsigned long long bits = 0;
+  if (x < W && y < H) {
+    const Texel<double> t = tex[static_cast<size_t>(y) * W + x];
+    bits = (static_cast<unsigned long long>(__double_as_longlong(t.I)) & ~1ull) | (t.mask != 0.0 ? 1ull : 0ull);
+  }
+  out[(static_cast<size_t>(y >> 1) * tiles_x + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3)] = bits;
+}
+
 template <typename S>
 void buildTyped(dsopp_hip_pyramid *p, const uint8_t *img_dev, const uint8_t *vig_dev, const double *lut_dev, double vmax) {
   hipStream_t st = p->sr.stream;
@@ -149,6 +163,27 @@ void checkLevel(dsopp_hip_pyramid *p, int level) {
 }  // namespace dsopp_hip
 
 using namespace dsopp_hip;
+
+const void *dsopp_hip_pyramid::intensityPlane(int level, hipStream_t consumer) const {
+  if (dtype != DSOPP_HIP_F64 || level < 0 || level >= levels) return nullptr;
+  std::lock_guard<std::mutex> lock(iplane_mutex);
+  const int tx = itilesX(level), ty = itilesY(level);
+  if (!iplane_valid[level]) {
+    if (!iplane[level]) HIP_CHECK(hipMalloc(&iplane[level], static_cast<size_t>(tx) * ty * 8 * sizeof(double)));
+    if (!iplane_ready[level]) HIP_CHECK(hipEventCreateWithFlags(&iplane_ready[level], hipEventDisableTiming));
+    waitReady(consumer);  // the texels' last build
+    dim3 block(kTileX, kTileY), grid((4 * tx + kTileX - 1) / kTileX, (2 * ty + kTileY - 1) / kTileY);
+    buildIntensityPlaneKernel<<<grid, block, 0, consumer>>>(static_cast<const Texel<double> *>(texels[level]), w(level), h(level), tx, ty,
+                                                            static_cast<unsigned long long *>(iplane[level]));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(iplane_ready[level], consumer));
+    iplane_stream[level] = consumer;
+    iplane_valid[level] = true;
+  } else if (consumer != iplane_stream[level]) {
+    HIP_CHECK(hipStreamWaitEvent(consumer, iplane_ready[level], 0));
+  }
+  return iplane[level];
+}
 
 extern "C" {
 
@@ -204,6 +239,8 @@ void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p) {
   for (int l = 0; l < DSOPP_HIP_MAX_LEVELS; ++l) {
     if (p->texels[l]) (void)hipFree(p->texels[l]);
     if (p->planes[l]) (void)hipFree(p->planes[l]);
+    if (p->iplane[l]) (void)hipFree(p->iplane[l]);
+    if (p->iplane_ready[l]) (void)hipEventDestroy(p->iplane_ready[l]);
   }
   if (p->staging_u8) (void)hipFree(p->staging_u8);
   if (p->staging_vig) (void)hipFree(p->staging_vig);

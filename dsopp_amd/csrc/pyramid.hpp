@@ -11,6 +11,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <mutex>
+
 // Pointer members of descriptors that live in device memory: in the device pass they are typed as address_space(1) pointers, so
 // every access through them is a global_load / global_store instead of a FLAT access (the compiler cannot know where a pointer
 // it read from memory points to); in the host pass they are ordinary pointers of the same size.
@@ -95,7 +97,22 @@ struct dsopp_hip_pyramid {
   void markReady() {
     if (!ready) HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(ready, sr.stream));
+    std::lock_guard<std::mutex> lock(iplane_mutex);
+    for (bool &v : iplane_valid) v = false;  // the texels changed: the intensity planes derived from them are stale
   }
+  // Intensity planes (f64 pyramids; built on demand by the first consumer, pyramid.hip: intensityPlane): 8 bytes per pixel —
+  // the intensity with the CameraMask bit in the lowest mantissa bit — tiled 4 x 2 pixels per 64-byte segment.  What the
+  // residual-only sweeps read instead of the 32-byte texels: a bilinear footprint then lies in 1.9 segments on average
+  // instead of 3, and a pattern's 8 footprints share them.
+  mutable void *iplane[DSOPP_HIP_MAX_LEVELS] = {nullptr};
+  mutable bool iplane_valid[DSOPP_HIP_MAX_LEVELS] = {false};
+  mutable hipEvent_t iplane_ready[DSOPP_HIP_MAX_LEVELS] = {nullptr};
+  mutable hipStream_t iplane_stream[DSOPP_HIP_MAX_LEVELS] = {nullptr};
+  mutable std::mutex iplane_mutex;
+  int itilesX(int l) const { return (w(l) + 3) / 4; }
+  int itilesY(int l) const { return (h(l) + 1) / 2; }
+  /** the level's intensity plane, valid for everything enqueued on `consumer` after the call (nullptr for f32 pyramids) */
+  const void *intensityPlane(int level, hipStream_t consumer) const;
   /** everything enqueued on `consumer` after this call sees the texels of the last build (no host synchronisation) */
   void waitReady(hipStream_t consumer) const {
     if (ready && consumer != sr.stream) HIP_CHECK(hipStreamWaitEvent(consumer, ready, 0));
