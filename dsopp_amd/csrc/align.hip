@@ -86,26 +86,28 @@ __device__ inline double rsqrtNewton(double x) {
   return r;
 }
 
-/** 8x8 NormalLinearSystem::solve (Jacobi preconditioner + Cholesky with zero-pivot guard), single thread */
+/** 8x8 NormalLinearSystem::solve, single thread.  The reference solves the Jacobi-scaled system p H p, p = 1 / sqrt(diag + 10)
+ *  (normal_linear_system.cpp:10-16,52-59) with a pivoted LDL^T; a Cholesky factorisation is invariant under symmetric diagonal
+ *  scaling, so the scaling itself is not carried out (as in the window's K x K solve, pba_solve_combined.hpp) — only the zero-pivot
+ *  guard refers to the scaled pivot d / (diag + 10).  The control step runs on one wave at one instruction per ~4.7 cycles: the
+ *  160 instructions of the scaling were 0.35 us of every LM pass. */
 __device__ inline void solve8(const double *Hin, double lambda, const double *bin, double *x) {
   // the system is H + lambda * diag(H) (calculateStep, eigen_pose_alignment.cpp:194-198), formed on the fly
-  double p[8], A[36], y[8], linv[8], dg[8];
+  double A[36], y[8], linv[8], guard[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) A[i * (i + 1) / 2 + j] = Hin[8 * i + j];
     const double hii = Hin[8 * i + i];
-    dg[i] = hii + hii * lambda;
-    p[i] = rsqrtNewton(dg[i] + 10.0);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-#pragma unroll
-    for (int j = 0; j <= i; ++j) A[i * (i + 1) / 2 + j] = p[i] * (i == j ? dg[i] : Hin[8 * i + j]) * p[j];
-    y[i] = p[i] * bin[i];
+    const double dg = hii + hii * lambda;
+    A[i * (i + 1) / 2 + i] = dg;
+    guard[i] = 1e-300 * (dg + 10.0);
+    y[i] = bin[i];
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const double d = A[k * (k + 1) / 2 + k];
-    const bool ok = d > 1e-300;
+    const bool ok = d > guard[k];
     const double inv = ok ? rsqrtNewton(ok ? d : 1.0) : 0.0;
     linv[k] = inv;
     A[k * (k + 1) / 2 + k] = ok ? d * inv : 0.0;
@@ -131,7 +133,7 @@ __device__ inline void solve8(const double *Hin, double lambda, const double *bi
     y[i] = s * linv[i];
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = p[i] * y[i];
+  for (int i = 0; i < 8; ++i) x[i] = y[i];
 }
 
 /** sample the reference intensities of the points: PatternPatch::getIntensities with PatternSize 1 (local_frame.hpp:384-388) */
