@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(kLoopThreads) alignLoopKernel(AlignFrameDev re
 // Level transitions (reset; push the keyframe's points of the next finer level; push the target with the current estimate;
 // accept the level when rmse < 2.5 * rmse_last[level]) run on the device as well: identical in every workgroup.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kPyramidMaxWorkgroups = 64;
+constexpr int kPyramidMaxWorkgroups = 32;  // participants: one per CU (100 KB of LDS each); an XCD has 32 CUs
 // Cross-workgroup exchange of the persistent kernel: every partial sum is its own ready flag.  The host fills the three rotating
 // partial buffers with a NaN bit pattern no sum can take (both 32-bit halves equal, so one 32-bit fill does it); a workgroup
 // re-arms its slots of the buffer after next before it publishes into the current one; consumers poll the values themselves.
@@ -697,6 +697,8 @@ struct AlignPyramidResult {
   int success;       // every level passed its energy test
   int failed;        // a bounded spin timed out: nothing in here is valid
   int lm_iterations; // sum over the levels
+  int same_xcd;      // all participants ran on one XCD: passes after the first exchanged through that XCD's L2
+  int pad_r;
   double rmse[DSOPP_HIP_MAX_LEVELS];
   int iterations[DSOPP_HIP_MAX_LEVELS];
   int n_valid[DSOPP_HIP_MAX_LEVELS];
@@ -705,7 +707,7 @@ struct AlignPyramidResult {
   long long stamps[8];  // -DDSOPP_HIP_STAMPS: wall_clock64 at the phase boundaries of one pass (level 0, third pass) of workgroup 0
 };
 #ifdef DSOPP_HIP_STAMPS
-#define AP_STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && lvl == 0 && pass == 2) a.out->stamps[i] = wall_clock64(); } while (0)
+#define AP_STAMP(i) do { if (blk == 0 && tid == 0 && lvl == 0 && pass == 2) a.out->stamps[i] = wall_clock64(); } while (0)
 #else
 #define AP_STAMP(i) do { } while (0)
 #endif
@@ -720,6 +722,7 @@ struct AlignPyramidArgs {
   double *partials;        // [2][gridDim.x][kAlignPartial]
   unsigned *failed;        // == kPyramidFailed once a workgroup gave up waiting (anything else: running); behind the partial buffers
   AlignPyramidResult *out;
+  int spread;              // launch = spread x participants; every spread-th workgroup takes part (8: one XCD, 1: no placement attempt)
 };
 
 using gu32 = __attribute__((address_space(1))) unsigned;
@@ -732,7 +735,19 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   __shared__ double tot[kAlignPartial];
   __shared__ int s_failed;
   const int tid = threadIdx.x;
-  const int G = gridDim.x;
+  // XCD co-location (speed only): the host launches `spread` x G workgroups and every spread-th one takes part — the dispatcher
+  // deals workgroups round-robin over the 8 XCDs, so with spread = 8 the participants tend to share ONE XCD and its L2.  Whether
+  // they really do is measured, not assumed: every participant publishes its XCC id in the first pass (agent-scope stores, valid
+  // for any placement) and only when all ids agree do the later passes publish with plain stores, which stay in that L2 where the
+  // L1-bypassing polls of the others find them without a trip over the fabric.
+  if (static_cast<int>(blockIdx.x) % a.spread != 0) return;
+  const int blk = static_cast<int>(blockIdx.x) / a.spread;
+  const int G = static_cast<int>(gridDim.x) / a.spread;
+  unsigned xcc_id = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+  xcc_id &= 0xFu;
+  __shared__ int s_same_xcd;  // set after the first pass of the launch
+  if (tid == 0) s_same_xcd = 0;
   unsigned pass_global = 0;  // barriers passed so far (identical in every workgroup)
   // current estimate (T_target_reference rows, affine brightness): in LDS, not in every thread's registers — 28 VGPRs less, and the
   // per-entry initialisation of the control block below needs no dynamically indexed private array (= scratch)
@@ -791,7 +806,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     if (preloaded) {
 #pragma unroll
       for (int q = 0; q < kPreload; ++q) {
-        const int i = blockIdx.x * kAlignThreads + tid + q * G * kAlignThreads;
+        const int i = blk * kAlignThreads + tid + q * G * kAlignThreads;
         const int ic = i < L.n_points ? i : (L.n_points > 0 ? L.n_points - 1 : 0);
         const bool have = L.n_points > 0;
         ru[q] = have ? static_cast<S>(L.pu[ic]) : S(0);
@@ -811,13 +826,19 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       AP_STAMP(1);
       // re-arm this workgroup's slots of the buffer the NEXT pass publishes into (its last readers finished two passes ago);
       // the stores complete behind the sweep and are waited for before this pass's sums go out
+      const bool local_xcd = s_same_xcd != 0;  // (written once, behind barriers, after the first pass)
+      auto publish = [&](double *addr, unsigned long long bits) {
+        if (local_xcd)
+          *(gu64 *)addr = bits;  // plain store: the line stays in this XCD's L2, which all participants share
+        else
+          __hip_atomic_store((gu64 *)addr, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
       if (tid < kAlignPartial)
-        __hip_atomic_store((gu64 *)(a.partials + (static_cast<size_t>((pass_global + 1u) % kPyramidBuffers) * G + blockIdx.x) * kAlignPartial + tid),
-                           kPyramidSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish(a.partials + (static_cast<size_t>((pass_global + 1u) % kPyramidBuffers) * G + blk) * kAlignPartial + tid, kPyramidSentinel);
       // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
-      const int first = blockIdx.x * kAlignThreads + tid;
-      double *dst = a.partials + (static_cast<size_t>(pass_global % kPyramidBuffers) * G + blockIdx.x) * kAlignPartial;
-      if (static_cast<int>(blockIdx.x) * kAlignThreads < L.n_points) {
+      const int first = blk * kAlignThreads + tid;
+      double *dst = a.partials + (static_cast<size_t>(pass_global % kPyramidBuffers) * G + blk) * kAlignPartial;
+      if (blk * kAlignThreads < L.n_points) {
         double acc[kAlignPartial];
         if (preloaded) {
           // this thread's points live in registers for the whole level: a pass starts with the texel gather
@@ -858,12 +879,14 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         s += alignDpp<0x4E>(s);
         // (the re-arming stores of the previous pass target these addresses from other lanes: they were drained by the
         // s_waitcnt below in that pass, ahead of the barriers in between)
-        if (row_idx < kAlignPartial && quarter == 0)
-          __hip_atomic_store((gu64 *)(dst + row_idx), static_cast<unsigned long long>(__double_as_longlong(s)),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // slots 46 / 47 (unused by the sums) carry x = XCC id + 1 and x^2: all ids are equal iff G * sum x^2 == (sum x)^2
+        if (row_idx == 46) s = static_cast<double>(xcc_id + 1u);
+        if (row_idx == 47) s = static_cast<double>((xcc_id + 1u) * (xcc_id + 1u));
+        if (row_idx < kAlignPartial && quarter == 0) publish(dst + row_idx, static_cast<unsigned long long>(__double_as_longlong(s)));
       } else if (tid < kAlignPartial) {
         // no points on this level for this workgroup: it still takes part in the exchange
-        __hip_atomic_store((gu64 *)(dst + tid), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double idv = tid == 46 ? static_cast<double>(xcc_id + 1u) : (tid == 47 ? static_cast<double>((xcc_id + 1u) * (xcc_id + 1u)) : 0.0);
+        publish(dst + tid, static_cast<unsigned long long>(__double_as_longlong(idv)));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (sums and re-arming)
       __syncthreads();                                   // ... and red[] is free for the sums below
@@ -912,7 +935,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         }
         __syncthreads();
         if (s_failed) {  // a workgroup never showed up (GPU shared with other work): the host falls back to launch-per-iteration
-          if (blockIdx.x == 0 && tid == 0) a.out->failed = 1;
+          if (blk == 0 && tid == 0) a.out->failed = 1;
           return;
         }
         if (tid < kAlignPartial) {
@@ -922,6 +945,8 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
           tot[tid] = t;
         }
         __syncthreads();
+        // first pass of the launch: do all participants sit on one XCD?  (identical sums in every workgroup -> identical verdict)
+        if (pass_global == 0 && tid == 0 && a.spread > 1) s_same_xcd = (static_cast<double>(G) * tot[47] == tot[46] * tot[46]) ? 1 : 0;
       }
       AP_STAMP(5);
       ++pass_global;
@@ -930,7 +955,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     ++levels_done;
     const double rmse = sqrt(sc.energy / static_cast<double>(sc.n_valid));  // NaN without a valid residual: fails the test below
     lm_iterations += sc.iteration;
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blk == 0 && tid == 0) {
       a.out->rmse[lvl] = rmse;
       a.out->iterations[lvl] = sc.iteration;
       a.out->n_valid[lvl] = sc.n_valid;
@@ -961,7 +986,8 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     }
   }
   __syncthreads();
-  if (blockIdx.x == 0 && tid == 0) {
+  if (blk == 0 && tid == 0) {
+    a.out->same_xcd = s_same_xcd;
     a.out->levels_done = levels_done;
     a.out->success = success;
     a.out->failed = 0;
@@ -1598,19 +1624,21 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         args.out = a->d_pyr_out.ptr;
         // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill per call
         HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
+        static const int spread_override = std::getenv("DSOPP_HIP_ALIGN_SPREAD") ? std::atoi(std::getenv("DSOPP_HIP_ALIGN_SPREAD")) : 0;  // tuning aid
+        args.spread = spread_override > 0 ? spread_override : 8;
         if (a->opt.dtype == DSOPP_HIP_F64)
-          alignPyramidKernel<double><<<G, kAlignThreads, 0, st>>>(args);
+          alignPyramidKernel<double><<<G * args.spread, kAlignThreads, 0, st>>>(args);
         else
-          alignPyramidKernel<float><<<G, kAlignThreads, 0, st>>>(args);
+          alignPyramidKernel<float><<<G * args.spread, kAlignThreads, 0, st>>>(args);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(a->h_pyr_out, a->d_pyr_out.ptr, sizeof(AlignPyramidResult), hipMemcpyDeviceToHost, st));
         a->sr.sync();
         const AlignPyramidResult &o = *a->h_pyr_out;
 #ifdef DSOPP_HIP_STAMPS
         if (std::getenv("DSOPP_HIP_TRACE"))
-          std::fprintf(stderr, "alignPyramid pass (level 0): decide %.2f  sweep %.2f  wg-reduce+store %.2f  arrive+wait %.2f  global sum %.2f us (G = %d)\n",
+          std::fprintf(stderr, "alignPyramid pass (level 0): decide %.2f  sweep %.2f  wg-reduce+store %.2f  arrive+wait %.2f  global sum %.2f us (G = %d, one XCD: %d)\n",
                        (o.stamps[1] - o.stamps[0]) / 100.0, (o.stamps[2] - o.stamps[1]) / 100.0, (o.stamps[3] - o.stamps[2]) / 100.0,
-                       (o.stamps[4] - o.stamps[3]) / 100.0, (o.stamps[5] - o.stamps[4]) / 100.0, G);
+                       (o.stamps[4] - o.stamps[3]) / 100.0, (o.stamps[5] - o.stamps[4]) / 100.0, G, o.same_xcd);
 #endif
         if (o.failed) {
           a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
