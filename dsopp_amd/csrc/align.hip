@@ -76,6 +76,16 @@ __device__ inline void mat34Compose(const double *A, const double *B, double *C)
   }
 }
 
+/** 1 / x for the projective divisions of the sweep: v_rcp_f64 (2^-23 relative) + two Newton steps, ~1 ulp — 5 instructions on the
+ *  path to the texel addresses instead of the ~13 of an IEEE division (as the window's sweeps, pba_kernels.hpp: fastRcp) */
+__device__ __forceinline__ double alignRcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float alignRcp(float x) { return 1.0f / x; }
+
 /** 1/sqrt(x) for x > 0: hardware estimate + two Newton steps (~1 ulp); a libm sqrt + division pair costs ~180 cycles on
  *  the single thread that runs the LM control, this a dozen instructions */
 __device__ inline double rsqrtNewton(double x) {
@@ -91,18 +101,19 @@ __device__ inline double rsqrtNewton(double x) {
  *  scaling, so the scaling itself is not carried out (as in the window's K x K solve, pba_solve_combined.hpp) — only the zero-pivot
  *  guard refers to the scaled pivot d / (diag + 10).  The control step runs on one wave at one instruction per ~4.7 cycles: the
  *  160 instructions of the scaling were 0.35 us of every LM pass. */
-__device__ inline void solve8(const double *Hin, double lambda, const double *bin, double *x) {
+template <typename GetH, typename GetB>
+__device__ __forceinline__ void solve8Impl(GetH getH /* (i, j), j <= i */, GetB getB, double lambda, double *x) {
   // the system is H + lambda * diag(H) (calculateStep, eigen_pose_alignment.cpp:194-198), formed on the fly
   double A[36], y[8], linv[8], guard[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j < i; ++j) A[i * (i + 1) / 2 + j] = Hin[8 * i + j];
-    const double hii = Hin[8 * i + i];
+    for (int j = 0; j < i; ++j) A[i * (i + 1) / 2 + j] = getH(i, j);
+    const double hii = getH(i, i);
     const double dg = hii + hii * lambda;
     A[i * (i + 1) / 2 + i] = dg;
     guard[i] = 1e-300 * (dg + 10.0);
-    y[i] = bin[i];
+    y[i] = getB(i);
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -134,6 +145,27 @@ __device__ inline void solve8(const double *Hin, double lambda, const double *bi
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = y[i];
+}
+
+/** from the stored 8 x 8 system (row-major H, b) */
+__device__ inline void solve8(const double *Hin, double lambda, const double *bin, double *x) {
+  solve8Impl([&](int i, int j) { return Hin[8 * i + j]; }, [&](int i) { return bin[i]; }, lambda, x);
+}
+
+/** straight from a pass's sums (packed upper triangle 36 | b 8) plus the affine prior (eigen_pose_alignment.cpp:174-190): what the
+ *  control step solves when it has just taken a new system — without the round trip of writing the expanded system to LDS and
+ *  reading it back */
+__device__ inline void solve8FromSums(const double *red, const double *affine_reg, double tab0, double tab1, double lambda, double *x) {
+  solve8Impl(
+      [&](int i, int j) {
+        const double v = red[j * 8 - j * (j - 1) / 2 + (i - j)];
+        return (i == j && i >= 6) ? v + affine_reg[i - 6] : v;
+      },
+      [&](int i) {
+        const double v = red[36 + i];
+        return i == 6 ? v + affine_reg[0] * tab0 : (i == 7 ? v + affine_reg[1] * tab1 : v);
+      },
+      lambda, x);
 }
 
 /** sample the reference intensities of the points: PatternPatch::getIntensities with PatternSize 1 (local_frame.hpp:384-388) */
@@ -307,10 +339,13 @@ __device__ inline void alignDecideWave(AlignControl &c, const double *red, const
   int have_candidate_n = have_candidate;
   if (active) {
     c.H_used[lane] = h;
-    // the stores above are this wave's own and LDS executes a wave's instructions in order: the solve's reads see them
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    solve8(c.H, lambda, c.b, stepn);
+    if (take_system) {
+      // the new system is solved from the sums it came from (same values, entry for entry, as the expansion stored above)
+      solve8FromSums(red, prm.affine_reg, tab0, tab1, lambda, stepn);
+    } else {
+      // (kept system: nothing was stored to c.H / c.b in this step)
+      solve8(c.H, lambda, c.b, stepn);
+    }
     const Rigid E = rigidExp(stepn);
     double Em[12];
 #pragma unroll
@@ -356,7 +391,8 @@ __device__ inline void alignDecideWave(AlignControl &c, const double *red, const
 template <typename S>
 struct AlignSweepCtx {
   S U[12], M[12];
-  S s_scale, b_t, b_r, Wr, Hr, Wt, Ht, fxt, fyt;
+  S b_t, b_r, Wr, Hr, Wt, Ht, fxt, fyt;
+  double s_ratio, s_arg;  // brightness scale = s_ratio * exp(s_arg): evaluated by the point code behind its texel loads
   const Texel<S> *img;
   int W;
   double sigma;
@@ -385,7 +421,8 @@ __device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const Align
     x.M[8 + j] = S(Ud[8 + j]);
   }
   const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
-  x.s_scale = S((tgt.exposure / ref.exposure) * exp(tab0 - ref.ab0[0]));
+  x.s_ratio = tgt.exposure / ref.exposure;
+  x.s_arg = tab0 - ref.ab0[0];
   x.b_t = S(tab1);
   x.b_r = S(ref.ab0[1]);
   x.Wr = S(ref.width);
@@ -409,12 +446,14 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   const S px = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
   const S py = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
   const S pz = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
-  const S ta = px / pz, tb = py / pz;
+  const S ipz = alignRcp(pz);
+  const S ta = px * ipz, tb = py * ipz;
   good = good && (pz > S(0)) && insideROI(ta, tb, x.Wt, x.Ht);
   const S tu = good ? ta : S(4), tv = good ? tb : S(4);
   const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
   const Texel<S> *p = x.img + static_cast<size_t>(iy) * x.W + ix;
   const Texel<S> t00 = p[0], t10 = p[1], t01 = p[x.W], t11 = p[x.W + 1];
+  const S s_scale = S(x.s_ratio * exp(x.s_arg));  // (behind the loads: ~50 instructions that do not depend on them)
   const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy), dxdy = dx * dy;
   const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
   const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
@@ -423,7 +462,7 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   const S sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
   const S sIx = w11 * t11.Ix + w01 * t01.Ix + w10 * t10.Ix + w00 * t00.Ix;
   const S sIy = w11 * t11.Iy + w01 * t01.Iy + w10 * t10.Iy + w00 * t00.Iy;
-  const S right = x.s_scale * (iref - x.b_r);
+  const S right = s_scale * (iref - x.b_r);
   const double r = static_cast<double>((sI - x.b_t) - right);
   const double r2 = r * r, sig = x.sigma;
   const bool lin = r2 > sig * sig;
@@ -435,7 +474,7 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   const S X = U[0] * u + U[1] * v + (U[2] + U[3] * idepth);
   const S Y = U[4] * u + U[5] * v + (U[6] + U[7] * idepth);
   const S Z = U[8] * u + U[9] * v + (U[10] + U[11] * idepth);
-  const S rho = valid ? S(1) / Z : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
+  const S rho = valid ? alignRcp(Z) : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
   const S fxt = x.fxt, fyt = x.fyt, b0b1 = b0 * b1;
   double d[8];
   d[0] = -static_cast<double>(sIx * (fxt * nid));
