@@ -1660,7 +1660,7 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         if (!a->h_pyr_out) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_pyr_out), sizeof(AlignPyramidResult), hipHostMallocDefault));
         args.partials = a->d_pyr_partials.ptr;
         args.failed = reinterpret_cast<unsigned *>(a->d_pyr_partials.ptr + n_partial);
-        args.out = a->d_pyr_out.ptr;
+        args.out = a->h_pyr_out;  // pinned host memory: the kernel leaves its result there itself (no copy kernel behind it)
         // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill per call
         HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
         static const int spread_override = std::getenv("DSOPP_HIP_ALIGN_SPREAD") ? std::atoi(std::getenv("DSOPP_HIP_ALIGN_SPREAD")) : 0;  // tuning aid
@@ -1670,7 +1670,6 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         else
           alignPyramidKernel<float><<<G * args.spread, kAlignThreads, 0, st>>>(args);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(a->h_pyr_out, a->d_pyr_out.ptr, sizeof(AlignPyramidResult), hipMemcpyDeviceToHost, st));
         a->sr.sync();
         const AlignPyramidResult &o = *a->h_pyr_out;
 #ifdef DSOPP_HIP_STAMPS

@@ -88,6 +88,138 @@ __global__ void __launch_bounds__(kTileX *kTileY) pyramidLevelKernel(const S *__
   tex[i] = t;
 }
 
+// ---- all levels in ONE launch (no vignette).  Level 0 as before, one thread per texel.  The upper levels by "region" workgroups:
+// a workgroup owns kUpperTile x kUpperTile texels of the TOP level and everything below them — it samples the 8-bit image once
+// into the level-1 values of its region (+ the halo the gradients of the levels above need), forms levels 2 .. TOP from those in
+// LDS by the same 2 x 2 means in the same association order as the level-by-level chain (scaling by 0.25 is exact: the texels are
+// bit-identical), and writes the texels of every level inside its region.  No level waits for its parent's launch: the chain of 5
+// dependent kernels (38 us at 1280 x 1024, the four upper ones pure launch latency) becomes one kernel as long as level 0.
+constexpr int kUpperTile = 4;
+
+struct AllLevelsArgs {
+  const uint8_t *img;
+  const double *lut;
+  int levels;
+  int width[DSOPP_HIP_MAX_LEVELS], height[DSOPP_HIP_MAX_LEVELS];
+  int tiles0_x;                    // level-0 workgroups per row (kTileX x kTileY texels each)
+  int n_upper, upper_tiles_x;      // region workgroups come first in the grid
+  void *tex[DSOPP_HIP_MAX_LEVELS];
+  void *plane[DSOPP_HIP_MAX_LEVELS];
+};
+
+template <typename S>
+__device__ __forceinline__ S sample0(const AllLevelsArgs &a, int x, int y) {
+  const uint8_t v = a.img[static_cast<size_t>(y) * a.width[0] + x];
+  return a.lut ? static_cast<S>(a.lut[v]) : static_cast<S>(v);
+}
+
+template <typename S>
+__device__ __forceinline__ void storeTexel(const AllLevelsArgs &a, int lvl, int x, int y, S c, S l, S r, S u, S d) {
+  const int W = a.width[lvl], H = a.height[lvl];
+  const S sx = (x == 0 || x == W - 1) ? S(1) : S(0.5);
+  const S sy = (y == 0 || y == H - 1) ? S(1) : S(0.5);
+  const size_t i = static_cast<size_t>(y) * W + x;
+  Texel<S> *tex = static_cast<Texel<S> *>(a.tex[lvl]);
+  static_cast<S *>(a.plane[lvl])[i] = c;  // (kept current: a later chain build or set_level reads the parents' planes)
+  Texel<S> t;
+  t.I = c;
+  t.mask = tex[i].mask;  // mask lane is owned by set_mask (initialised to 1)
+  t.Ix = sx * (r - l);
+  t.Iy = sy * (d - u);
+  tex[i] = t;
+}
+
+/** region workgroup, TOP = index of the coarsest level (1 .. 4).  Level l of the region: n_l = (kUpperTile + 2) << (TOP - l) values per
+ *  side, origin o_l = (tile * kUpperTile - 1) << (TOP - l) in level-l pixels, so that value (rx, ry) of level l is the mean of the
+ *  values (2 rx .. 2 rx + 1, 2 ry .. 2 ry + 1) of level l - 1. */
+template <typename S, int TOP>
+__device__ __forceinline__ void upperLevelsRegion(const AllLevelsArgs &a, int tile, S *lds) {
+  constexpr int kThreads = kTileX * kTileY;
+  const int tid = threadIdx.y * kTileX + threadIdx.x;
+  const int tx = tile % a.upper_tiles_x, ty = tile / a.upper_tiles_x;
+  S *v[TOP + 1];
+  {
+    S *p = lds;
+#pragma unroll
+    for (int l = 1; l <= TOP; ++l) {
+      v[l] = p;
+      const int n = (kUpperTile + 2) << (TOP - l);
+      p += n * n;
+    }
+  }
+  // ---- level 1 from the image: every value once, independent loads
+  {
+    constexpr int n1 = (kUpperTile + 2) << (TOP - 1);
+    const int ox = (tx * kUpperTile - 1) * (1 << (TOP - 1)), oy = (ty * kUpperTile - 1) * (1 << (TOP - 1));
+    const int W1 = a.width[1], H1 = a.height[1];
+    for (int idx = tid; idx < n1 * n1; idx += kThreads) {
+      const int rx = idx % n1, ry = idx / n1;
+      const int X = ox + rx, Y = oy + ry;
+      S val = S(0);
+      if (X >= 0 && Y >= 0 && X < W1 && Y < H1) {
+        // boxValue's order: ((p00 + p11) + p01) + p10 with p01 = (2X + 1, 2Y), p10 = (2X, 2Y + 1)
+        const S p00 = sample0<S>(a, 2 * X, 2 * Y), p11 = sample0<S>(a, 2 * X + 1, 2 * Y + 1);
+        const S p01 = sample0<S>(a, 2 * X + 1, 2 * Y), p10 = sample0<S>(a, 2 * X, 2 * Y + 1);
+        val = S(0.25) * (p00 + p11 + p01 + p10);
+      }
+      v[1][idx] = val;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 1; l <= TOP; ++l) {
+    const int n = (kUpperTile + 2) << (TOP - l);
+    if (l > 1) {
+      const int np = 2 * n;
+      for (int idx = tid; idx < n * n; idx += kThreads) {
+        const int rx = idx % n, ry = idx / n;
+        const S *q = v[l - 1] + (2 * ry) * np + 2 * rx;
+        v[l][idx] = S(0.25) * (q[0] + q[np + 1] + q[1] + q[np]);
+      }
+      __syncthreads();
+    }
+    // texels of level l inside the region (the halo belongs to the neighbours)
+    const int h = 1 << (TOP - l), m = kUpperTile << (TOP - l);
+    const int ox = (tx * kUpperTile - 1) * h, oy = (ty * kUpperTile - 1) * h;
+    const int W = a.width[l], H = a.height[l];
+    for (int idx = tid; idx < m * m; idx += kThreads) {
+      const int rx = h + idx % m, ry = h + idx / m;
+      const int X = ox + rx, Y = oy + ry;
+      if (X >= W || Y >= H) continue;
+      const S *q = v[l] + ry * n + rx;
+      const S c = q[0];
+      const S lft = (X == 0) ? c : q[-1], rgt = (X == W - 1) ? c : q[1];
+      const S up = (Y == 0) ? c : q[-n], dn = (Y == H - 1) ? c : q[n];
+      storeTexel<S>(a, l, X, Y, c, lft, rgt, up, dn);
+    }
+  }
+}
+
+template <typename S>
+__global__ void __launch_bounds__(kTileX *kTileY) pyramidAllLevelsKernel(AllLevelsArgs a) {
+  // LDS of a region workgroup at TOP = 4: (48^2 + 24^2 + 12^2 + 6^2) values
+  __shared__ S lds[((kUpperTile + 2) * 8) * ((kUpperTile + 2) * 8) + ((kUpperTile + 2) * 4) * ((kUpperTile + 2) * 4) +
+                   ((kUpperTile + 2) * 2) * ((kUpperTile + 2) * 2) + (kUpperTile + 2) * (kUpperTile + 2)];
+  const int b = blockIdx.x;
+  if (b < a.n_upper) {  // the region workgroups first: they run longer, level 0 fills the chip behind them
+    switch (a.levels) {
+      case 5: upperLevelsRegion<S, 4>(a, b, lds); break;
+      case 4: upperLevelsRegion<S, 3>(a, b, lds); break;
+      case 3: upperLevelsRegion<S, 2>(a, b, lds); break;
+      default: upperLevelsRegion<S, 1>(a, b, lds); break;
+    }
+    return;
+  }
+  const int t0 = b - a.n_upper;
+  const int W = a.width[0], H = a.height[0];
+  const int x = (t0 % a.tiles0_x) * kTileX + threadIdx.x, y = (t0 / a.tiles0_x) * kTileY + threadIdx.y;
+  if (x >= W || y >= H) return;
+  const S c = sample0<S>(a, x, y);
+  const S l = (x == 0) ? c : sample0<S>(a, x - 1, y), r = (x == W - 1) ? c : sample0<S>(a, x + 1, y);
+  const S u = (y == 0) ? c : sample0<S>(a, x, y - 1), d = (y == H - 1) ? c : sample0<S>(a, x, y + 1);
+  storeTexel<S>(a, 0, x, y, c, l, r, u, d);
+}
+
 template <typename S>
 __global__ void fillMaskKernel(Texel<S> *tex, const uint8_t *mask, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -134,6 +266,33 @@ template <typename S>
 void buildTyped(dsopp_hip_pyramid *p, const uint8_t *img_dev, const uint8_t *vig_dev, const double *lut_dev, double vmax) {
   hipStream_t st = p->sr.stream;
   dim3 block(kTileX, kTileY);
+  static const bool no_fused = std::getenv("DSOPP_HIP_PYRAMID_CHAIN") != nullptr;  // tuning aid: always the level-by-level chain
+  if (!vig_dev && !no_fused) {
+    // no vignette: every level straight from the 8-bit image in one launch (with a vignette every level-0 value costs a division,
+    // which the nested means would repeat 4^l times: the chain below stays)
+    AllLevelsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.img = img_dev;
+    a.lut = lut_dev;
+    a.levels = p->levels;
+    for (int l = 0; l < p->levels; ++l) {
+      a.width[l] = p->w(l);
+      a.height[l] = p->h(l);
+      a.tex[l] = p->texels[l];
+      a.plane[l] = p->planes[l];
+    }
+    a.tiles0_x = (p->w(0) + kTileX - 1) / kTileX;
+    const int tiles0 = a.tiles0_x * ((p->h(0) + kTileY - 1) / kTileY);
+    if (p->levels > 1) {
+      // regions are counted on level 1 (the finest upper level): every level-1 texel must lie in some region
+      const int side1 = kUpperTile << (p->levels - 2);
+      a.upper_tiles_x = (p->w(1) + side1 - 1) / side1;
+      a.n_upper = a.upper_tiles_x * ((p->h(1) + side1 - 1) / side1);
+    }
+    pyramidAllLevelsKernel<S><<<static_cast<unsigned>(a.n_upper + tiles0), block, 0, st>>>(a);
+    HIP_CHECK(hipGetLastError());
+    return;
+  }
   {
     dim3 grid((p->w(0) + kTileX - 1) / kTileX, (p->h(0) + kTileY - 1) / kTileY);
     pyramidLevel0Kernel<S><<<grid, block, 0, st>>>(img_dev, vig_dev, lut_dev, vmax, p->w(0), p->h(0), static_cast<S *>(p->planes[0]),

@@ -41,6 +41,34 @@ def test_pyramid_bit_exact(two_frames):
     p.close()
 
 
+@pytest.mark.parametrize("size", [(326, 250), (643, 481), (97, 70), (1280, 1024)])
+def test_pyramid_one_launch_is_bit_exact_at_any_size(size):
+    """without a vignette every level is built in ONE launch (region workgroups regenerate the upper levels from the 8-bit image with
+    the chain's nested 2 x 2 means): bit-identical to the scalar definition for 1 .. 5 levels, at sizes that are not multiples of
+    the region or of 2^levels (odd widths drop their last column at every halving, downscale_image.hpp:16-33), with and without
+    the photometric LUT, and after a mask was set (the mask lane survives a rebuild)"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    W, H = size
+    rng = np.random.default_rng(W + H)
+    img = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    lut = np.cumsum(rng.uniform(0.5, 1.5, 256))
+    for levels in ((5, 3, 1) if W > 1000 else (5, 4, 3, 2, 1)):
+        if (W >> (levels - 1)) < 3 or (H >> (levels - 1)) < 3:
+            continue
+        for kwargs in (dict(), dict(lut=lut)):
+            infos, _ = po.build_pyramid(img, levels=levels, **kwargs)
+            p = capi.Pyramid(W, H, levels=levels)
+            mask = (rng.uniform(size=(H >> (levels - 1), W >> (levels - 1))) > 0.2).astype(np.uint8)
+            p.set_mask(levels - 1, mask)
+            p.build(img, **kwargs)
+            for l in range(levels):
+                got = p.get_level(l)
+                assert got.shape == infos[l].shape
+                assert np.array_equal(got, infos[l]), (size, levels, kwargs.keys(), l, np.abs(got - infos[l]).max())
+            p.close()
+
+
 def _depth_map(frame, level, n, seed):
     H, W = frame.depth.shape
     h, w = H >> level, W >> level
