@@ -80,7 +80,16 @@ struct dsopp_hip_window {
   // two-stage (atomic-free, order-deterministic) build of the combined system: pba_schur_two_stage.hpp
   DeviceBuffer<double> d_schur_partials, d_pair_out;
   bool deterministic = false;  // dsopp_hip_window_set_deterministic: the two-stage build at every window size
-  bool twoStage() const { return deterministic || n_schur_blocks > kTwoStageMinChunks; }
+  /** chunks of 64 landmarks above which the atomic-free two-stage build replaces the atomic accumulation.  Landmark-sharded windows
+   *  switch later: their two-stage path cannot fuse the decision into the build (it needs the all-reduced sums) and carries three
+   *  small launches more per iteration (scalar groups, their final sum, the separate decision), which the atomics' contention only
+   *  outweighs on larger shards (shard of 6 250 landmarks / 12 frames: 108 us per iteration two-stage, measured) */
+  int twoStageMinChunks() const {
+    static const int override_chunks = std::getenv("DSOPP_HIP_TWO_STAGE_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_TWO_STAGE_MIN_CHUNKS")) : 0;  // tuning aid
+    if (override_chunks > 0) return override_chunks;
+    return allreduce ? 2 * kTwoStageMinChunks : kTwoStageMinChunks;
+  }
+  bool twoStage() const { return deterministic || n_schur_blocks > twoStageMinChunks(); }
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
@@ -1201,7 +1210,7 @@ void lmSolveFusedEnqueue(W &w) {
     ex.combined = true;
     ex.write_fej = r == 0 && sweep_takes_fej;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
-    if (w.n_schur_blocks > kTwoStageMinChunks && r + 1 < rounds) {
+    if (w.n_schur_blocks > w.twoStageMinChunks() && r + 1 < rounds) {
       // large windows: the back-substitution fused into the sweep re-reads a landmark's whole Schur row for every one of its
       // (landmark, target) items — (F - 1) x the traffic (12 frames / 50 000 landmarks: 196 against 131 us).  One kernel per
       // landmark in front of the sweep instead.
