@@ -27,6 +27,15 @@ def test_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
 
 
+def test_reference_adapters_pass_the_lint():
+    """the reference-side adapters cannot be compiled here (no Eigen / Sophus / glog / OpenCV); scripts/adapter_lint.py checks what can be
+    checked without a compiler: every C-ABI call exists with the declared arity, every include resolves in the reference tree and
+    every member touched on a reference object is declared in the header of its type"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "adapter_lint.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_host_mirror_solves_on_gpu(tmp_path):
     exe = _build(tmp_path)
