@@ -917,9 +917,17 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
 }
 
 /** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
-void launchSolveCombined(W &w, double lambda, LmControl *ctrl) {
+void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr) {
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel), w.sr.device, 150 * 1024);
   SolveCombArgs a;
+  if (decide_from) {
+    // landmark-sharded windows: decision + accept / reject as the prologue of this launch (workgroups 1 .. chunks: the landmarks)
+    a.dec_in = decide_from;
+    a.dec_scalars = w.d_reduce.ptr + w.combCount();  // the four sums travelled behind the combined system in the collective
+    a.dec_table = w.d_schur_table.ptr;
+    a.dec_blocks = w.n_schur_blocks;
+    a.dec_prm = *decide_prm;
+  }
   a.frames = w.d_frames.ptr;
   a.st = w.d_state.ptr;
   a.pc = w.d_pc.ptr;
@@ -937,7 +945,8 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl) {
   a.fej = w.fej() ? 1 : 0;
   a.use_marginal = w.marg_nonzero ? 1 : 0;
   a.dbg_stamps = w.dbg_stamps;
-  timedLaunch(w, DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE, [&] { solveCombinedKernel<<<1, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
+  timedLaunch(w, DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE,
+              [&] { solveCombinedKernel<<<1 + a.dec_blocks, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
   if (!w.fej()) {
     // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
     pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);
@@ -1221,6 +1230,7 @@ void lmSolveFusedEnqueue(W &w) {
     } else {
       launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
     }
+    bool decided_by_solve = false;
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
@@ -1238,7 +1248,7 @@ void lmSolveFusedEnqueue(W &w) {
         sweepScalarGroupsFinalKernel<<<1, 64, 0, st>>>(w.d_scalars.ptr + 16, w.d_reduce.ptr + w.combCount());
         HIP_CHECK(hipGetLastError());
         allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4);
-        launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
+        decided_by_solve = true;  // (not the closing round: this branch requires r + 1 < rounds)
       } else {
         fr.prm.use_reduced_scalars = 2;
         fr.scalars = w.d_scalars.ptr + 16;
@@ -1256,8 +1266,9 @@ void lmSolveFusedEnqueue(W &w) {
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else if (w.allreduce) {
       // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
+      // (the decision — a function of the all-reduced sums alone — is the prologue of the solve launch: no kernel of its own)
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
-      launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
+      decided_by_solve = true;
     } else if (r + 1 == rounds) {
       // the closing round only takes the decision for the last candidate (its sweep was residual-only: no system to build) and
       // leaves the solve's result in pinned host memory itself (a copy kernel behind it cost 4 us per solve)
@@ -1268,7 +1279,12 @@ void lmSolveFusedEnqueue(W &w) {
     } else {
       launchReduceSchur(w, false, cin, &fr);
     }
-    if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout);
+    if (r + 1 < rounds) {
+      if (decided_by_solve)
+        launchSolveCombined(w, 0.0, cout, cin, &fr.prm);
+      else
+        launchSolveCombined(w, 0.0, cout);
+    }
   }
   LmControl *cfin = ctrl + (rounds & 1);
   HIP_CHECK(hipGetLastError());

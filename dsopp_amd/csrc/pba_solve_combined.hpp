@@ -31,6 +31,15 @@ struct SolveCombArgs {
   int fej;
   int use_marginal;
   long long *dbg_stamps;  // compiled in with -DDSOPP_HIP_STAMPS only
+  // Landmark-sharded windows: the LM decision for the pending candidate runs HERE instead of in a kernel of its own between the
+  // collective and the solve.  Its inputs are the incoming control block and the four all-reduced sums — no reduction — so every
+  // workgroup of this launch evaluates it for itself (lmDecision): workgroup 0 moves the frame states, publishes the outgoing control
+  // block (`ctrl`) and solves; workgroups 1 .. dec_blocks apply accept / reject to the landmarks of one 64-landmark chunk each.
+  const LmControl *dec_in = nullptr;  // nullable = no decision here (single-GPU windows decide in the reduction kernel)
+  const double *dec_scalars = nullptr;  // {energy, n_valid, |idepth step|^2, idepth . step}, summed over all ranks
+  const SchurBlock *dec_table = nullptr;
+  int dec_blocks = 0;
+  LmParams dec_prm;
 };
 #define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
@@ -61,7 +70,71 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   // ---- everything is requested before anything waits: the kernel start costs one memory round trip
   int c_active = 1, c_relin = 0;
   double lam = a.lambda;
-  if (a.ctrl) {
+  const bool decides = a.dec_in != nullptr;
+  double dec_eps = 0, dec_step = 0;
+  int dec_accept = 0;
+  if (decides) {
+    __shared__ LmControl s_dec_out;
+    __shared__ int s_dec_accept, s_dec_proceed;
+    const LmControl cin = *a.dec_in;
+    const double t[4] = {a.dec_scalars[0], a.dec_scalars[1], a.dec_scalars[2], a.dec_scalars[3]};
+    if (blockIdx.x == 0 && tid < K) {  // (frame states: read and written by workgroup 0 only)
+      dec_eps = a.st->eps[tid >> 3][tid & 7];
+      dec_step = a.st->step[tid >> 3][tid & 7];
+    }
+    if (!cin.active) {  // the loop has ended: the control block is handed on unchanged
+      if (blockIdx.x == 0 && tid == 0) *a.ctrl = cin;
+      return;
+    }
+    if (tid == 0) {
+      LmControl c;
+      int accept = 0, proceed = 0;
+      lmDecision(cin, t, a.dec_prm, c, accept, proceed);
+      s_dec_out = c;
+      s_dec_accept = accept;
+      s_dec_proceed = proceed;
+    }
+    ldsBarrier();
+    dec_accept = s_dec_accept;
+    if (blockIdx.x > 0) {
+      // acceptStep / rejectStep of the landmarks of one chunk (problem.hpp:364-402): 8 threads per landmark, thread `sub` owns the
+      // targets sub and sub + 8; 32 landmarks per pass of the 256 threads
+      if (!cin.pending) return;
+      const SchurBlock &be = a.dec_table[blockIdx.x - 1];
+      for (int l = tid >> 3; l < kSchurLandmarks; l += kSolveThreads / 8) {
+        const int sub = tid & 7, i = be.offset + l;
+        if (i >= be.n) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int t2 = sub + 8 * h;
+          if (t2 < F && be.status[t2] != nullptr && i < be.n_res[t2]) {
+            if (dec_accept)
+              be.status[t2][i] = be.cand[t2][i];
+            else
+              be.cand[t2][i] = be.status[t2][i];
+          }
+        }
+        if (sub == 0) {
+          if (dec_accept) be.idepth[i] += be.idepth_step[i];
+          be.idepth_step[i] = 0;
+        }
+      }
+      return;
+    }
+    // workgroup 0: the frame states and the outgoing control block, then the solve at the decided state
+    if (cin.pending && tid < K) {
+      if (dec_accept) {
+        dec_eps += dec_step;
+        a.st->eps[tid >> 3][tid & 7] = dec_eps;
+      }
+      a.st->step[tid >> 3][tid & 7] = 0;
+    }
+    if (tid == 0) *a.ctrl = s_dec_out;
+    if (!s_dec_proceed) return;
+    c_active = 1;
+    c_relin = s_dec_out.relin;
+    lam = s_dec_out.lambda;
+  } else if (a.ctrl) {
     c_active = a.ctrl->active;
     c_relin = a.ctrl->relin;
     lam = a.ctrl->lambda;
@@ -101,7 +174,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   int fixed_c = 0, tomarg_c = 0;
   if (tid < K) {
     const int f = tid >> 3, i = tid & 7;
-    eps_c = a.st->eps[f][i];
+    eps_c = decides ? dec_eps : a.st->eps[f][i];  // (decided here: the accepted state is already in registers)
     fixed_c = a.frames[f].fixed;
     tomarg_c = a.frames[f].to_marginalize;
     ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];

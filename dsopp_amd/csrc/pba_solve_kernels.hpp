@@ -170,6 +170,62 @@ __device__ inline void applyDecision(const ReduceSchurArgs &a, const ApplyRegs &
   }
 }
 
+/** The Levenberg-Marquardt decision for the pending candidate (levenberg_marquardt_algorithm.hpp:93-123) from the four sums of the
+ *  sweep that evaluated it: t = {energy, n_valid, |idepth step|^2, idepth . step} (already summed over all landmarks — and over all
+ *  ranks of a sharded window).  Pure function of its arguments: every workgroup (and every rank) that evaluates it gets the same
+ *  outgoing control block `c`, `accept` and `proceed` (a linear system has to be built / solved from the sweep's output). */
+__device__ inline void lmDecision(const LmControl &cin, const double (&t)[4], const LmParams &prm, LmControl &c, int &accept, int &proceed) {
+  c = cin;
+  accept = 0;
+  proceed = 0;
+  const double eval_energy = t[0] + cin.cand_prior;
+  const int n_valid = static_cast<int>(t[1] + 0.5);
+  if (!cin.pending) {
+    if (cin.relin) {
+      // re-linearisation at the reverted state after a rejected step: nothing to decide
+      c.relin = 0;
+      proceed = 1;
+    } else {
+      // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
+      c.idepth_sq = t[2];  // the opening sweep sums idepth^2 into the step-norm slot
+      c.energy = eval_energy;
+      c.n_valid = n_valid;
+      c.active = (prm.max_iterations > 0 && n_valid > 0) ? 1 : 0;
+      proceed = c.active;
+    }
+  } else {
+    c.iteration = cin.iteration + 1;
+    c.pending = 0;
+    if (n_valid == 0) {
+      c.active = 0;  // problem.rejectStep(); break;
+      c.need_final_setup = 1;
+    } else {
+      if (fabs(cin.energy - eval_energy) / cin.energy < prm.function_tolerance) c.converged = 1;
+      if (eval_energy < cin.energy || (prm.force_accept && cin.iteration < prm.min_iterations)) {
+        accept = 1;
+        const double state_sq = cin.frame_state_sq + cin.idepth_sq, step_sq = cin.frame_step_sq + t[2];
+        if (step_sq < prm.parameter_tolerance * (state_sq + prm.parameter_tolerance)) c.converged = 1;
+        c.energy = eval_energy;
+        c.n_valid = n_valid;
+        c.lambda = cin.lambda / prm.decrease_on_accept;
+        c.idepth_sq = cin.idepth_sq + 2.0 * t[3] + t[2];
+        c.need_final_setup = 0;
+        proceed = 1;
+      } else {
+        c.need_final_setup = 1;
+        if (prm.force_accept) {
+          c.active = 0;  // problem.calculateEnergy(); return result;
+        } else {
+          c.lambda = cin.lambda * prm.increase_on_reject;
+          c.relin = 1;  // the sweep's output belongs to the rejected state: re-linearise at the reverted one
+        }
+      }
+      if (c.converged || c.iteration >= prm.max_iterations) c.active = 0;
+    }
+    if (!c.active) proceed = 0;
+  }
+}
+
 __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, long long *dbg_out, ApplyRegs &ar) {
   __shared__ LmControl s_out;
   __shared__ int s_accept, s_proceed;
@@ -295,54 +351,9 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
       }
       t[e] = s;
     }
-    LmControl c = cin;
+    LmControl c;
     int accept = 0, proceed = 0;
-    const double eval_energy = t[0] + cin.cand_prior;
-    const int n_valid = static_cast<int>(t[1] + 0.5);
-    if (!cin.pending) {
-      if (cin.relin) {
-        // re-linearisation at the reverted state after a rejected step: nothing to decide
-        c.relin = 0;
-        proceed = 1;
-      } else {
-        // result = problem.calculateEnergy() before the loop (levenberg_marquardt_algorithm.hpp:82)
-        c.idepth_sq = t[2];  // the opening sweep sums idepth^2 into the step-norm slot
-        c.energy = eval_energy;
-        c.n_valid = n_valid;
-        c.active = (a.prm.max_iterations > 0 && n_valid > 0) ? 1 : 0;
-        proceed = c.active;
-      }
-    } else {
-      c.iteration = cin.iteration + 1;
-      c.pending = 0;
-      if (n_valid == 0) {
-        c.active = 0;  // problem.rejectStep(); break;
-        c.need_final_setup = 1;
-      } else {
-        if (fabs(cin.energy - eval_energy) / cin.energy < a.prm.function_tolerance) c.converged = 1;
-        if (eval_energy < cin.energy || (a.prm.force_accept && cin.iteration < a.prm.min_iterations)) {
-          accept = 1;
-          const double state_sq = cin.frame_state_sq + cin.idepth_sq, step_sq = cin.frame_step_sq + t[2];
-          if (step_sq < a.prm.parameter_tolerance * (state_sq + a.prm.parameter_tolerance)) c.converged = 1;
-          c.energy = eval_energy;
-          c.n_valid = n_valid;
-          c.lambda = cin.lambda / a.prm.decrease_on_accept;
-          c.idepth_sq = cin.idepth_sq + 2.0 * t[3] + t[2];
-          c.need_final_setup = 0;
-          proceed = 1;
-        } else {
-          c.need_final_setup = 1;
-          if (a.prm.force_accept) {
-            c.active = 0;  // problem.calculateEnergy(); return result;
-          } else {
-            c.lambda = cin.lambda * a.prm.increase_on_reject;
-            c.relin = 1;  // the sweep's output belongs to the rejected state: re-linearise at the reverted one
-          }
-        }
-        if (c.converged || c.iteration >= a.prm.max_iterations) c.active = 0;
-      }
-      if (!c.active) proceed = 0;
-    }
+    lmDecision(cin, t, a.prm, c, accept, proceed);
     s_accept = accept;
     s_proceed = proceed;
     s_out = c;
