@@ -119,6 +119,7 @@ struct dsopp_hip_window {
   void *h_uncertainty = nullptr;          // pinned destination of estimateUncertainty's systems (+ frame states)
   size_t h_uncertainty_bytes = 0;
   hipEvent_t uncertainty_ready = nullptr; // recorded behind that transfer
+  bool restore_in_begin = false;      // optimize_repeated: the restore to the snapshot rides in the next solve's opening kernel
   DeviceBuffer<LmControl> d_results;  // optimize_repeated: one result slot per solve of a batch ...
   LmControl *h_results = nullptr;     // ... fetched together into pinned memory
   LmControl *result_device = nullptr; // set while such a solve is enqueued: where its closing kernel leaves the control block
@@ -1160,6 +1161,30 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
 }
 
 
+/** dsopp_hip_window_restore, host half: checks that the snapshot matches the window and puts the host-side mirror back */
+void restoreHostSide(W &w) {
+  if (!w.snap_valid || w.snap_F != w.F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
+  w.sr.use();
+  for (auto &fp : w.frames) {
+    if (fp->snap_n != fp->n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", fp->id);
+    for (auto &kv : fp->residuals)
+      if (kv.second->snap_n != kv.second->n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", fp->id);
+  }
+  syncTopology(w);
+  w.hst = w.snap_state;
+  w.state_dirty = false;
+  w.host_stale = false;
+  w.pair_valid = false;
+  w.begun = false;
+}
+
+/** ... device half (optimize_repeated lets the opening kernel of the next solve do this instead: lmBeginKernel) */
+void launchRestore(W &w) {
+  restoreKernel<<<w.n_schur_blocks + 1, kSchurLandmarks, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_schur_table.ptr, w.F(), w.d_state.ptr, w.d_state_snap.ptr,
+                                                                        w.n_schur_blocks);
+  HIP_CHECK(hipGetLastError());
+}
+
 /**
  * Same algorithm, three launches per Gauss-Newton iteration.  A linearisation sweep at the candidate state x + step
  * already contains the candidate's energy (NEW_EVALUATION_POINT) and, if the step is accepted, IS the next linearisation:
@@ -1202,7 +1227,18 @@ void lmSolveFusedEnqueue(W &w) {
     ia.n_schur_blocks = w.n_schur_blocks;
     ia.ctrl = ctrl;
     ia.prm = prm;
-    lmBeginKernel<<<1, kSolveThreads, (static_cast<size_t>(w.K()) + 16) * sizeof(double), st>>>(ia);
+    int begin_blocks = 1;
+    if (w.restore_in_begin) {
+      w.restore_in_begin = false;
+      if (begin_sets_pairs) {
+        ia.restore_state = w.d_state.ptr;
+        ia.sa.st = w.d_state_snap.ptr;
+        begin_blocks += w.n_schur_blocks + 1;
+      } else {
+        launchRestore(w);
+      }
+    }
+    lmBeginKernel<<<begin_blocks, kSolveThreads, (static_cast<size_t>(w.K()) + 16) * sizeof(double), st>>>(ia);
   }
   HIP_CHECK(hipGetLastError());
   // one round per iteration + the opening evaluation; without force_accept a rejected step costs one more round (the
@@ -2797,16 +2833,22 @@ void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, doubl
   auto cleanUp = [&] {
     w.opt.max_iterations = configured;
     w.result_device = nullptr;
+    w.restore_in_begin = false;
   };
   try {
     while (done < target && !stalled) {
       int n = 0, planned = 0;
       while (n < kSlots && done + planned < target) {
         const int budget = std::min(configured, target - done - planned);
-        if (dsopp_hip_window_restore(&w) != DSOPP_HIP_OK) fail(DSOPP_HIP_ERR_STATE, "%s", lastError().c_str());
+        restoreHostSide(w);
         w.opt.max_iterations = budget;
+        // nothing is enqueued between here and the solve's opening kernel when the solve takes the first-estimate path and no
+        // upload is pending: the device half of the restore then rides in that kernel (one launch less per solve)
+        const bool ride = w.fej() && budget > 0 && !w.topology_dirty && !w.marg_dirty && w.d_state.ptr != nullptr;
+        if (!ride) launchRestore(w);
         prepare(w);
         fusedBegin(w);
+        w.restore_in_begin = ride;
         w.result_device = w.d_results.ptr + n;  // the closing kernel of this solve leaves its control block here
         lmSolveFusedEnqueue(w);
         planned += budget;
@@ -2921,24 +2963,9 @@ int dsopp_hip_window_restore(dsopp_hip_window *w) {
   return guarded([&] {
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
-    if (!w->snap_valid || w->snap_F != w->F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
-    w->sr.use();
-    for (auto &fp : w->frames) {
-      if (fp->snap_n != fp->n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", fp->id);
-      for (auto &kv : fp->residuals)
-        if (kv.second->snap_n != kv.second->n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", fp->id);
-    }
-    syncTopology(*w);
-    hipStream_t st = w->sr.stream;
+    restoreHostSide(*w);
     // one enqueue, no host synchronisation: one kernel over all landmarks + the frame-state block
-    restoreKernel<<<w->n_schur_blocks + 1, kSchurLandmarks, 0, st>>>(w->d_frames.ptr, w->d_schur_table.ptr, w->F(), w->d_state.ptr, w->d_state_snap.ptr,
-                                                                 w->n_schur_blocks);
-    HIP_CHECK(hipGetLastError());
-    w->hst = w->snap_state;
-    w->state_dirty = false;
-    w->host_stale = false;
-    w->pair_valid = false;
-    w->begun = false;
+    launchRestore(*w);
   });
 }
 

@@ -1328,6 +1328,10 @@ struct LmInitArgs {
   const FrameDev *pair_frames = nullptr;
   PairConst *pair_pc = nullptr;
   int pair_fej = 0;
+  // nullable: the solve starts from the window's snapshot (optimize_repeated) — workgroups >= 1 put the landmarks back (one chunk
+  // each), the last workgroup copies the frame states, workgroup 0 reads them from the snapshot itself, so nothing in this launch waits for a copy
+  // (sa.st then IS the snapshot — this kernel only reads the states — and restore_state the live block the copy goes to)
+  WindowState *restore_state = nullptr;
 };
 
 /** sum of idepth^2 over this rank's landmarks (state norm of acceptStep, problem.hpp:379); grid = schur blocks */
@@ -1495,16 +1499,9 @@ __global__ void __launch_bounds__(kSchurThreads) lmDecideKernel(LmDecideArgs a) 
   }
 }
 
-/** dsopp_hip_window_restore: idepths, flags and connection statuses back to the snapshot; grid = schur blocks */
-__global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, WindowState *state,
-                              const WindowState *state_snap, int n_schur_blocks) {
-  if (static_cast<int>(blockIdx.x) == n_schur_blocks) {
-    // last workgroup: the frame states (one launch restores everything; no separate device-to-device copy)
-    constexpr int kWords = static_cast<int>(sizeof(WindowState) / sizeof(double));
-    for (int k = threadIdx.x; k < kWords; k += blockDim.x) reinterpret_cast<double *>(state)[k] = reinterpret_cast<const double *>(state_snap)[k];
-    return;
-  }
-  const SchurBlock be = table[blockIdx.x];
+/** one chunk of 64 landmarks back to the snapshot: idepths, flags and connection statuses (threads >= 64 idle) */
+__device__ __forceinline__ void restoreLandmarkChunk(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, int chunk) {
+  const SchurBlock be = table[chunk];
   const FrameDev &fr = frames[be.r];
   const int i = be.offset + threadIdx.x;
   if (threadIdx.x >= kSchurLandmarks || i >= fr.n) return;
@@ -1519,9 +1516,35 @@ __global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBl
   }
 }
 
+__device__ __forceinline__ void restoreFrameStates(WindowState *state, const WindowState *state_snap) {
+  constexpr int kWords = static_cast<int>(sizeof(WindowState) / sizeof(double));
+  for (int k = threadIdx.x; k < kWords; k += blockDim.x) reinterpret_cast<double *>(state)[k] = reinterpret_cast<const double *>(state_snap)[k];
+}
+
+/** dsopp_hip_window_restore: idepths, flags and connection statuses back to the snapshot; grid = schur blocks */
+__global__ void restoreKernel(const FrameDev *__restrict__ frames, const SchurBlock *__restrict__ table, int F, WindowState *state,
+                              const WindowState *state_snap, int n_schur_blocks) {
+  if (static_cast<int>(blockIdx.x) == n_schur_blocks) {
+    // last workgroup: the frame states (one launch restores everything; no separate device-to-device copy)
+    restoreFrameStates(state, state_snap);
+    return;
+  }
+  restoreLandmarkChunk(frames, table, F, blockIdx.x);
+}
+
 /** fused loop: control block before the first sweep (prior energy of the initial state goes to cand_prior); one workgroup */
 __global__ void __launch_bounds__(kSolveThreads) lmBeginKernel(LmInitArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (a.restore_state) {
+    if (blockIdx.x > 0) {
+      // (the frame states are copied by a workgroup of their own: stores in workgroup 0 would sit in front of its loads in vmcnt)
+      if (static_cast<int>(blockIdx.x) <= a.n_schur_blocks)
+        restoreLandmarkChunk(a.sa.frames, a.schur_table, a.sa.F, blockIdx.x - 1);
+      else
+        restoreFrameStates(a.restore_state, a.sa.st);
+      return;
+    }
+  }
   const double idepth_sq = 0;  // set by the decide step of the opening round (sum idepth^2 rides in the sweep's partials)
   if (a.pair_frames) {
     // the 2 F frame increments exp(+-(eps + step)) once per frame, shared through LDS, instead of twice per ordered pair
