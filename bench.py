@@ -13,7 +13,9 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JS
               Headline at N > 1 = STRONG scaling on BASELINE.json configs[3] (C3: 7 KF, 20 000 points in TOTAL, sharded): value =
               GN iterations of the whole window / wall time, "scaling": "strong"; rank 0 first times the SAME window alone on its
               GPU ("same_workload_1gpu") and the line carries speedup = value / same_workload_1gpu.  C1 weak scaling (2000 points
-              PER GPU) and C4 strong scaling (12 KF / 50 000) ride along as extras ("weak_scaling_c1", "strong_scaling").
+              PER GPU) and C4 strong scaling (12 KF / 50 000) ride along as extras ("weak_scaling_c1", "strong_scaling"), and so
+              does "window_group": the same C3 window driven by ONE process over all N devices through dsopp_hip_window_group
+              (scripts/group_bench.py, started by rank 0 after the timed part) — the form the reference's single solver object takes.
               `--workload c1|c3|c4` / `--scaling` select another headline explicitly.  Without a launcher `--gpus N` spawns its own
               ranks (torch.distributed.run) and refuses to run when the node has fewer than N GPUs.
 Extra objects on the same line: roofline (linearisation sweep kernel, measured live with HIP events on the library's
@@ -242,6 +244,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the large-window roofline, the tracker (C2) timing and the other extras")
+    ap.add_argument("--no-group", action="store_true", help="N > 1: skip the single-process window-group measurement (row g-1)")
+    ap.add_argument("--group-timeout", type=int, default=150, help="seconds the window-group process may take")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -357,6 +361,10 @@ def main():
         # and C4 strong (12 KF / 50 000 points) with its own same-workload single-GPU rate
         extras["weak_scaling_c1"] = run_sharded_workload(job, torch, capi, syn, distributed, "c1", args, dtype, scaling="weak")
         extras["strong_scaling"] = {"c4": run_sharded_workload(job, torch, capi, syn, distributed, "c4", args, dtype, solo_first=True)}
+    if world > 1 and not args.no_group:
+        extras_group = run_window_group(job, args)
+        if extras_group is not None:
+            extras["window_group"] = extras_group
     if rank == 0 and world == 1 and not args.no_extras:
         g.restore()
         extras["stages"] = run_stage_table(g, win, syn, args)
@@ -448,6 +456,48 @@ def main():
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     g.close()
     job.close()
+
+
+def run_window_group(job, args):
+    """Row g-1 on this node: after the timed part rank 0 starts ONE more process that drives all N devices through the single-process
+    window group (scripts/group_bench.py: one solver object, worker thread per device, RCCL between them) on the C3 window, while the
+    other ranks wait on the rendezvous store — a host-side wait, their GPUs stay idle.  Reported next to the headline, never instead
+    of it; a failure or a timeout is reported as such and does not fail the bench."""
+    import datetime
+    import subprocess
+    key = "dsopp_window_group_done"
+    try:
+        store = job.dist.distributed_c10d._get_default_store()
+    except Exception:  # noqa: BLE001
+        store = None
+    out = None
+    if job.rank == 0:
+        devices = ",".join("0" if job.single_device else str(d) for d in range(job.world))
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devices, "--workload", "c3", "--blocks", "7"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.group_timeout)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                out = json.loads(lines[-1])
+            else:
+                out = {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            out = {"error": f"no result within {args.group_timeout} s (process killed)"}
+        except Exception as exc:  # noqa: BLE001
+            out = {"error": repr(exc)}
+        out["command"] = " ".join(cmd[1:])
+        out["wall_s"] = time.perf_counter() - t0
+        if store is not None:
+            store.set(key, "1")
+    elif store is not None:
+        try:
+            store.wait([key], datetime.timedelta(seconds=args.group_timeout + 120))
+        except Exception:  # noqa: BLE001
+            pass
+    if store is None:
+        job.barrier(job.torch)
+    return out
 
 
 def load_profile_kernel_avg_us(csv_name, needle):

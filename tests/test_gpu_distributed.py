@@ -102,12 +102,19 @@ def test_bench_script_runs_with_two_ranks():
     assert "roofline" in d and d["config"]["ranks"] == 2
     assert d["timing"]["blocks"] >= 1 and abs(d["value"] - 28 / (d["timing"]["block_ms_median"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["same_workload_1gpu"]["value"] > 0 and abs(d["speedup"] - d["value"] / d["same_workload_1gpu"]["value"]) <= 1e-9 * d["speedup"]
+    # row g-1 beside it: rank 0 started ONE more process that drives "all devices" (here device 0 twice, in-process reducer) through
+    # the single-process window group; its sharded solve must agree with the single-window solve it ran next to it
+    wg = d["window_group"]
+    assert "error" not in wg, wg
+    assert wg["devices"] == [0, 0] and wg["transport"].startswith("local") and wg["value"] > 0 and wg["same_workload_1gpu"] > 0
+    assert wg["iterations"][0] == wg["iterations"][1] and wg["valid_residuals"][0] == wg["valid_residuals"][1]
+    assert wg["max_pose_difference_vs_single_window"] <= 1e-7 and wg["relative_energy_difference"] <= 1e-7
 
 
 def test_bench_weak_scaling_workload_two_ranks():
     """--workload c1: the N = 1 headline's window (2000 points) on EVERY rank, value = ranks x iterations / time"""
     import json
-    out = _run_bench(["--gpus", "2", "--steps", "28", "--warmup", "7", "--workload", "c1", "--no-extras", "--no-cpu"],
+    out = _run_bench(["--gpus", "2", "--steps", "28", "--warmup", "7", "--workload", "c1", "--no-extras", "--no-cpu", "--no-group"],
                      {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
@@ -118,7 +125,7 @@ def test_bench_weak_scaling_workload_two_ranks():
 def test_bench_strong_scaling_workload_two_ranks():
     """--workload c4: the dense configuration (12 KF / 50 000 points in total) sharded; value counts whole-window iterations"""
     import json
-    out = _run_bench(["--gpus", "2", "--steps", "14", "--warmup", "7", "--workload", "c4", "--no-extras", "--no-cpu"],
+    out = _run_bench(["--gpus", "2", "--steps", "14", "--warmup", "7", "--workload", "c4", "--no-extras", "--no-cpu", "--no-group"],
                      {"DSOPP_BENCH_SINGLE_DEVICE": "1"})
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
