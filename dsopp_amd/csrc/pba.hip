@@ -919,7 +919,8 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
 
 /** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
 void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr) {
-  ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel), w.sr.device, 150 * 1024);
+  ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<256>), w.sr.device, 150 * 1024);
+  ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<512>), w.sr.device, 150 * 1024);
   SolveCombArgs a;
   if (decide_from) {
     // landmark-sharded windows: decision + accept / reject as the prologue of this launch (workgroups 1 .. chunks: the landmarks)
@@ -947,7 +948,12 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
   a.use_marginal = w.marg_nonzero ? 1 : 0;
   a.dbg_stamps = w.dbg_stamps;
   timedLaunch(w, DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE,
-              [&] { solveCombinedKernel<<<1 + a.dec_blocks, kSolveThreads, solveSmemBytes(w.K()), w.sr.stream>>>(a); });
+              [&] {
+                if (w.F() > 8)
+                  solveCombinedKernel<512><<<1 + a.dec_blocks, 512, solveSmemBytes(w.K()), w.sr.stream>>>(a);
+                else
+                  solveCombinedKernel<256><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(a);
+              });
   if (!w.fej()) {
     // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
     pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);

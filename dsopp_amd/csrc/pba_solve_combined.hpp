@@ -52,7 +52,12 @@ __device__ __forceinline__ void combBlockDecode(int b, int &bi, int &bj) {
   bj = b - r * (r + 1) / 2;
 }
 
-__global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCombArgs a) {
+/** THREADS = 256 up to 8 frames (K <= 64: one row per lane of the panel wave); 512 above: the trailing update of the early block
+ *  columns of a 9..16-frame system is longer than the panel wave's factor step with three waves (12 frames: Cholesky 20 us), and the
+ *  combined system arrives in two rounds of batched loads instead of three.  Every matrix entry is produced by one thread with a
+ *  fixed summation order, so the two instantiations give bit-identical results. */
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int F = a.F, K = kBlk * F;
   const int N = K + 1;   // augmented with the right-hand side row
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
       // targets sub and sub + 8; 32 landmarks per pass of the 256 threads
       if (!cin.pending) return;
       const SchurBlock &be = a.dec_table[blockIdx.x - 1];
-      for (int l = tid >> 3; l < kSchurLandmarks; l += kSolveThreads / 8) {
+      for (int l = tid >> 3; l < kSchurLandmarks; l += THREADS / 8) {
         const int sub = tid & 7, i = be.offset + l;
         if (i >= be.n) continue;
 #pragma unroll
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     pp.exposure_r = fr.exposure;
     pp.exposure_t = ft.exposure;
   }
-  double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < kSolveThreads)
+  double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < THREADS)
   int fixed_c = 0, tomarg_c = 0;
   if (tid < K) {
     const int f = tid >> 3, i = tid & 7;
@@ -188,14 +193,14 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   auto loadBatch = [&](int base) {
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      const int e = base + tid + kSolveThreads * u;
+      const int e = base + tid + THREADS * u;
       hv[u] = a.comb[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
       hm[u] = 0;
     }
     if (a.use_marginal) {
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
-        const int e = min(base + tid + kSolveThreads * u, n_entries - 1);
+        const int e = min(base + tid + THREADS * u, n_entries - 1);
         int bi, bj;
         combBlockDecode(e >> 6, bi, bj);
         hm[u] = a.Hm[(8 * bi + ((e >> 3) & 7)) * K + 8 * bj + (e & 7)];
@@ -221,7 +226,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
   auto storeBatch = [&](int base) {
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      const int e = base + tid + kSolveThreads * u;
+      const int e = base + tid + THREADS * u;
       if (e >= n_entries) continue;
       int bi, bj;
       combBlockDecode(e >> 6, bi, bj);
@@ -238,7 +243,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     }
   };
   storeBatch(0);
-  for (int base = kBatch * kSolveThreads; base < n_entries; base += kBatch * kSolveThreads) {
+  for (int base = kBatch * THREADS; base < n_entries; base += kBatch * THREADS) {
     loadBatch(base);
     storeBatch(base);
   }
@@ -348,7 +353,7 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     if (kb + 1 < F) {
       // all waves: block column kb+1 (rows k1 .. N-1, columns k1 .. k1+7) -= panel kb contribution (one element per thread)
       const int n_el = (N - k1) * kBlk;
-      for (int e = tid; e < n_el; e += kSolveThreads) {
+      for (int e = tid; e < n_el; e += THREADS) {
         const int row = k1 + (e >> 3), col = k1 + (e & 7);
         if (col > row) continue;
         const double *li = A + row * ld + k0, *lj = A + col * ld + k0;
@@ -362,9 +367,9 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     if (wave == 0) {
       if (kb + 1 < F) factorAndPanel(kb + 1);
     } else {
-      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (192 threads as a 12 x 16 tile)
+      // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (the other waves as a 12 x 16 / 28 x 16 tile)
       const int t = tid - 64, tr = t >> 4, tc = t & 15;
-      for (int row = k2 + tr; row < N; row += 12) {
+      for (int row = k2 + tr; row < N; row += (THREADS - 64) / 16) {
         const double *li = A + row * ld + k0;
         double lic[kBlk];
 #pragma unroll
@@ -402,27 +407,45 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
           if (TWO) o1[c] = j1 < K ? A[(kb * kBlk + c) * ld + j1] : 0.0;
         }
       };
+      // Unknowns 64 .. K-1 (windows of more than 8 frames) are carried by y1: while they are eliminated (frame blocks >= 8) every
+      // step updates both halves; from block 7 down nothing above lane 63 is read again, so the loop is the one-register loop of
+      // a small window (no second load, multiply, broadcast pair or update per step: 9.0 -> about 5 us at 12 frames).
+      auto sweepBlocks = [&](auto upper_tag, int kb_from, int kb_to) {
+        constexpr bool UPPER = decltype(upper_tag)::value;
+        for (int kb = kb_from; kb >= kb_to; --kb) {
+          if (kb > 0) {
+#pragma unroll
+            for (int c = 0; c < kBlk; ++c) {
+              n0[c] = A[((kb - 1) * kBlk + c) * ld + j0];  // lanes beyond the row read into the next row: in bounds, never used
+              if (UPPER) n1[c] = j1 < K ? A[((kb - 1) * kBlk + c) * ld + j1] : 0.0;
+            }
+          }
+          double xo[kBlk];
+#pragma unroll
+          for (int c = kBlk - 1; c >= 0; --c) {
+            const int k = kb * kBlk + c;
+            const double xk = UPPER ? readLane(y1 * gi1, k & 63) : readLane(y0 * gi0, k);
+            xo[c] = xk;
+            y0 -= g0[c] * xk;
+            if (UPPER) y1 -= g1[c] * xk;
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < kBlk; ++c) xs[kb * kBlk + c] = xo[c];
+          }
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) {
+            g0[c] = n0[c];
+            if (UPPER) g1[c] = n1[c];
+          }
+        }
+      };
       loadBlock(F - 1, g0, g1);
-      for (int kb = F - 1; kb >= 0; --kb) {
-        if (kb > 0) loadBlock(kb - 1, n0, n1);
-        double xo[kBlk];
-#pragma unroll
-        for (int c = kBlk - 1; c >= 0; --c) {
-          const int k = kb * kBlk + c;
-          const double xk = (!TWO || k < 64) ? readLane(y0 * gi0, k & 63) : readLane(y1 * gi1, k & 63);
-          xo[c] = xk;
-          y0 -= g0[c] * xk;
-          if (TWO) y1 -= g1[c] * xk;
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int c = 0; c < kBlk; ++c) xs[kb * kBlk + c] = xo[c];
-        }
-#pragma unroll
-        for (int c = 0; c < kBlk; ++c) {
-          g0[c] = n0[c];
-          if (TWO) g1[c] = n1[c];
-        }
+      if (TWO) {
+        sweepBlocks(std::true_type{}, F - 1, 8);
+        sweepBlocks(std::false_type{}, 7, 0);
+      } else {
+        sweepBlocks(std::false_type{}, F - 1, 0);
       }
     };
     // (Measured and dropped: back-substitution by frame blocks with inverted diagonal blocks, x_blk = W^T y_blk then y -= L_blk^T x_blk,
@@ -514,17 +537,17 @@ __global__ void __launch_bounds__(kSolveThreads, 1) solveCombinedKernel(SolveCom
     ldsBarrier();  // E (in A) fully consumed before the scratch below is written; stpl visible
     if ((tid & 63) == 0) {
       xs[tid >> 6] = part;
-      xs[4 + (tid >> 6)] = nstate;
-      xs[8 + (tid >> 6)] = nstep;
+      xs[THREADS / 64 + (tid >> 6)] = nstate;
+      xs[2 * (THREADS / 64) + (tid >> 6)] = nstep;
     }
     ldsBarrier();
     if (tid == 0) {
-      static_assert(kSolveThreads / 64 == 4, "three groups of four wave sums in xs");
+      constexpr int kWaves = THREADS / 64;  // three groups of kWaves wave sums in xs
       double total = a.energy_marginalized, s_state = 0, s_step = 0;
-      for (int w = 0; w < kSolveThreads / 64; ++w) {
+      for (int w = 0; w < kWaves; ++w) {
         total += xs[w];
-        s_state += xs[4 + w];
-        s_step += xs[8 + w];
+        s_state += xs[kWaves + w];
+        s_step += xs[2 * kWaves + w];
       }
       a.ctrl->cand_prior = total;
       a.ctrl->frame_state_sq = s_state;
