@@ -1261,11 +1261,19 @@ void lmSolveFusedEnqueue(W &w) {
     ex.combined = true;
     ex.write_fej = r == 0 && sweep_takes_fej;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
-    if (w.n_schur_blocks > w.twoStageMinChunks() && r + 1 < rounds) {
+    const bool large = w.n_schur_blocks > w.twoStageMinChunks();
+    if (large && r + 1 == rounds) {
+      // closing round of a large window: the same split (the residual-only sweep with the back-substitution fused in took 115 us
+      // at 12 frames / 50 000 landmarks against 10 + 47 us as two kernels)
+      launchBacksub(w, 0.0, cin, ex.ublk_read, /*gate_on_pending=*/true);
+      ex.fused_lin_backsub = false;
+      ex.external_backsub = true;
+      launchSweep(w, false, true, false, cin, false, 0.0, ex);
+    } else if (large) {
       // large windows: the back-substitution fused into the sweep re-reads a landmark's whole Schur row for every one of its
       // (landmark, target) items — (F - 1) x the traffic (12 frames / 50 000 landmarks: 196 against 131 us).  One kernel per
       // landmark in front of the sweep instead.
-      launchBacksub(w, 0.0, cin, ex.ublk_read, /*gate_on_pending=*/true);
+      if (r > 0) launchBacksub(w, 0.0, cin, ex.ublk_read, /*gate_on_pending=*/true);  // (no step is pending in the opening round)
       ex.fused_lin_backsub = false;
       ex.external_backsub = true;
       launchSweep(w, true, true, false, cin, false, 0.0, ex);
@@ -1302,7 +1310,12 @@ void lmSolveFusedEnqueue(W &w) {
     } else if (w.allreduce && r + 1 == rounds) {
       // landmark shards, closing round: its sweep was residual-only, no system exists — only the four energy scalars of the last
       // candidate are summed across the shards (they sit where the decision expects them: behind the combined system's slot)
-      sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.combCount(), cin);
+      if (large) {
+        sweepScalarGroupsKernel<<<kScalarGroups, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr + 16, cin);
+        sweepScalarGroupsFinalKernel<<<1, 64, 0, st>>>(w.d_scalars.ptr + 16, w.d_reduce.ptr + w.combCount());
+      } else {
+        sweepScalarsKernel<<<1, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_reduce.ptr + w.combCount(), cin);
+      }
       HIP_CHECK(hipGetLastError());
       allreduceIfNeeded(w, w.d_reduce.ptr + w.combCount(), 4);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
@@ -1317,6 +1330,14 @@ void lmSolveFusedEnqueue(W &w) {
       if (!w.h_ctrl) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_ctrl), sizeof(LmControl), hipHostMallocDefault));
       fr.ctrl_host = w.result_device ? w.result_device : w.h_ctrl;  // (batched solves: a device slot, fetched with the batch)
       result_written_by_kernel = true;
+      if (large) {
+        // tens of thousands of sweep blocks: their scalars in 64 fixed groups first (every workgroup of the decision adds 64 x 4
+        // numbers instead of walking all blocks: 31.5 -> about 10 us at 12 frames / 50 000 landmarks)
+        sweepScalarGroupsKernel<<<kScalarGroups, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr + 16, cin);
+        HIP_CHECK(hipGetLastError());
+        fr.prm.use_reduced_scalars = 2;
+        fr.scalars = w.d_scalars.ptr + 16;
+      }
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else {
       launchReduceSchur(w, false, cin, &fr);
