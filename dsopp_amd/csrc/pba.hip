@@ -80,16 +80,21 @@ struct dsopp_hip_window {
   // two-stage (atomic-free, order-deterministic) build of the combined system: pba_schur_two_stage.hpp
   DeviceBuffer<double> d_schur_partials, d_pair_out;
   bool deterministic = false;  // dsopp_hip_window_set_deterministic: the two-stage build at every window size
-  /** chunks of 64 landmarks above which the atomic-free two-stage build replaces the atomic accumulation.  Landmark-sharded windows
-   *  switch later: their two-stage path cannot fuse the decision into the build (it needs the all-reduced sums) and carries three
-   *  small launches more per iteration (scalar groups, their final sum, the separate decision), which the atomics' contention only
-   *  outweighs on larger shards (shard of 6 250 landmarks / 12 frames: 108 us per iteration two-stage, measured) */
+  /** chunks of 64 landmarks above which the atomic-free two-stage build replaces the atomic accumulation (its three small launches
+   *  more per iteration — scalar groups, ordered sum, separate back-substitution — are outweighed by the atomics' contention only
+   *  from about 12 000 landmarks; the same bound serves landmark shards: shard of 6 250 landmarks / 12 frames 108 us two-stage) */
   int twoStageMinChunks() const {
     static const int override_chunks = std::getenv("DSOPP_HIP_TWO_STAGE_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_TWO_STAGE_MIN_CHUNKS")) : 0;  // tuning aid
     if (override_chunks > 0) return override_chunks;
-    return allreduce ? 2 * kTwoStageMinChunks : kTwoStageMinChunks;
+    return kTwoStageMinChunks;
   }
   bool twoStage() const { return deterministic || n_schur_blocks > twoStageMinChunks(); }
+  /** chunks above which calculateIdepths runs as its own kernel in front of the sweep instead of inside it (the fused form re-reads a
+   *  landmark's Schur row once per (landmark, target) item) */
+  int backsubSplitMinChunks() const {
+    static const int override_chunks = std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS")) : 0;  // tuning aid
+    return override_chunks > 0 ? override_chunks : twoStageMinChunks();
+  }
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
@@ -520,7 +525,9 @@ void syncTopology(W &w) {
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
   w.d_Hpp.reserve(2 * KK * KK, 0, st);  // (second half: full symmetric copy of H_schur for the covariance read-back, makeSolveArgs)
   w.d_bpp.reserve(KK, 0, st);
-  w.d_reduce.reserve(2 * (KK * KK + KK) + 8, 0, st);  // + tail: the 4 energy scalars ride in the same collective (sharded windows)
+  // + tail: the sweep's energy scalars sit behind the combined system (4 sums, or 4 x kScalarGroups group sums) and ride in the same
+  // collective on landmark-sharded windows
+  w.d_reduce.reserve(2 * (KK * KK + KK) + 8 + 4 * kScalarGroups, 0, st);
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
@@ -729,25 +736,7 @@ enum class ReduceMode { kFused, kAccumulateOnly, kDecideOnly };
 constexpr size_t kDecideSmemBytes = size_t((6 * (kSchurThreads + 2) + 6 * 72) * 8);
 
 /** arguments of the LM decision (fusedDecideApply + applyDecision) when it runs as the prologue of another kernel */
-ReduceSchurArgs makeDecideArgs(W &w, const LmControl *cin, const FusedReduce &fr) {
-  ReduceSchurArgs a{};
-  a.frames = w.d_frames.ptr;
-  a.pc = w.d_pc.ptr;
-  a.schur_table = w.d_schur_table.ptr;
-  a.partials = w.d_partials.ptr;
-  a.ctrl = cin;
-  a.ctrl_out = fr.ctrl_out;
-  a.st = w.d_state.ptr;
-  a.F = w.F();
-  a.n_schur_blocks = 0;
-  a.n_sweep_blocks = w.n_sweep_blocks;
-  a.scalars = fr.scalars ? fr.scalars : w.d_scalars.ptr;
-  a.prm = fr.prm;
-  a.dbg = nullptr;
-  return a;
-}
-
-void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense, const ReduceSchurArgs *decide);
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense, double *group_sums);
 void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedReduce *fused = nullptr, ReduceMode mode = ReduceMode::kFused) {
   const int K = w.K(), F = w.F();
   hipStream_t st = w.sr.stream;
@@ -863,7 +852,7 @@ void launchAssemble(W &w, double lambda, bool do_solve, bool add_priors, bool st
 /** two-stage build of the combined system (large windows / deterministic mode): partial systems without atomics, then one
  *  ordered sum per entry.  `ctrl` (nullable) is the control block whose `active` gates both launches and whose lambda damps the
  *  system; the LM decision is NOT taken here (decideApplyKernel runs in front of / behind it). */
-void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false, const ReduceSchurArgs *decide = nullptr) {
+void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda, bool dense = false, double *group_sums = nullptr) {
   const int F = w.F();
   hipStream_t st = w.sr.stream;
   using TwoStageKernel = void (*)(TwoStageArgs);
@@ -897,8 +886,8 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
   a.chunks_per_wg = chunks_per_wg;
   a.n_schur_wgs = n_wgs;
   a.ublk_parity = ublk_parity;
-  a.fused_decide = decide ? 1 : 0;
-  if (decide) a.dec = *decide;
+  a.group_sums = group_sums;
+  a.n_sweep_blocks = w.n_sweep_blocks;
   CombineArgs c;
   c.pc = w.d_pc.ptr;
   c.schur_partials = w.d_schur_partials.ptr;
@@ -911,14 +900,15 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
   c.n_schur_wgs = n_wgs;
   const size_t pair_smem = (48 + 64 + kPairBlk + 8 * 48) * sizeof(double);
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
-    two_stage_kernel<<<n_wgs + F * F, kSchurThreads, std::max(std::max(twoStageSmemBytes(F), pair_smem), decide ? kDecideSmemBytes : size_t(0)), st>>>(a);
+    two_stage_kernel<<<n_wgs + F * F + (group_sums ? kScalarGroups : 0), kSchurThreads, std::max(twoStageSmemBytes(F), pair_smem), st>>>(a);
     combineSystemKernel<<<static_cast<unsigned>((twoStagePartialCount(F) + kCombineEntries - 1) / kCombineEntries), kCombineEntries * kCombineSlices, 0, st>>>(c);
   });
   HIP_CHECK(hipGetLastError());
 }
 
 /** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
-void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr) {
+void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr,
+                         bool decide_from_groups = false) {
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<256>), w.sr.device, 150 * 1024);
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<512>), w.sr.device, 150 * 1024);
   SolveCombArgs a;
@@ -928,6 +918,7 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
     a.dec_scalars = w.d_reduce.ptr + w.combCount();  // the four sums travelled behind the combined system in the collective
     a.dec_table = w.d_schur_table.ptr;
     a.dec_blocks = w.n_schur_blocks;
+    a.dec_groups = decide_from_groups ? kScalarGroups : 0;
     a.dec_prm = *decide_prm;
   }
   a.frames = w.d_frames.ptr;
@@ -1261,7 +1252,7 @@ void lmSolveFusedEnqueue(W &w) {
     ex.combined = true;
     ex.write_fej = r == 0 && sweep_takes_fej;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
-    const bool large = w.n_schur_blocks > w.twoStageMinChunks();
+    const bool large = w.n_schur_blocks > w.backsubSplitMinChunks();
     if (large && r + 1 == rounds) {
       // closing round of a large window: the same split (the residual-only sweep with the back-substitution fused in took 115 us
       // at 12 frames / 50 000 landmarks against 10 + 47 us as two kernels)
@@ -1286,27 +1277,18 @@ void lmSolveFusedEnqueue(W &w) {
     fr.ctrl_out = cout;
     fr.prm = prm;
     fr.combined = true;  // (the sharded accumulate pass reads lambda from the incoming control block: constant, decrease = increase = 1)
+    bool decide_from_groups = false;
     if (w.twoStage() && r + 1 < rounds) {
-      // large windows / deterministic mode: the combined system without atomics (pba_schur_two_stage.hpp)
-      // the sweep's energy scalars in 64 fixed groups first: with tens of thousands of sweep blocks no workgroup of the
-      // decision kernel should walk them all by itself
-      sweepScalarGroupsKernel<<<kScalarGroups, 256, 0, st>>>(w.d_partials.ptr, w.n_sweep_blocks, w.d_scalars.ptr + 16, cin);
-      HIP_CHECK(hipGetLastError());
-      if (w.allreduce) {
-        // landmark shards: local partial systems -> ordered sum -> ONE collective over [system | energy scalars] -> decision
-        launchTwoStage(w, cin, fr.ublk_parity, 0.0);
-        sweepScalarGroupsFinalKernel<<<1, 64, 0, st>>>(w.d_scalars.ptr + 16, w.d_reduce.ptr + w.combCount());
-        HIP_CHECK(hipGetLastError());
-        allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4);
-        decided_by_solve = true;  // (not the closing round: this branch requires r + 1 < rounds)
-      } else {
-        fr.prm.use_reduced_scalars = 2;
-        fr.scalars = w.d_scalars.ptr + 16;
-        // decision + accept / reject from the sweep's energy as the prologue of the partial-system kernel; the ordered sum then
-        // damps with the lambda of the published control block
-        const ReduceSchurArgs dec = makeDecideArgs(w, cin, fr);
-        launchTwoStage(w, cout, fr.ublk_parity, 0.0, false, &dec);
-      }
+      // large windows / deterministic mode: the combined system without atomics (pba_schur_two_stage.hpp).  kScalarGroups extra
+      // workgroups of the same launch sum the sweep's energy scalars in fixed groups behind the combined system's slot; the
+      // decision — a function of those sums and the control block alone — and its accept / reject are the prologue of the solve
+      // launch (lambda is constant: decrease = increase = 1, so the ordered sum can damp with the incoming control block's).
+      // Landmark shards send the group sums along in their ONE collective.
+      double *groups = w.d_reduce.ptr + w.combCount();
+      launchTwoStage(w, cin, fr.ublk_parity, 0.0, false, groups);
+      allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4 * kScalarGroups);
+      decided_by_solve = true;
+      decide_from_groups = true;
     } else if (w.allreduce && r + 1 == rounds) {
       // landmark shards, closing round: its sweep was residual-only, no system exists — only the four energy scalars of the last
       // candidate are summed across the shards (they sit where the decision expects them: behind the combined system's slot)
@@ -1344,7 +1326,7 @@ void lmSolveFusedEnqueue(W &w) {
     }
     if (r + 1 < rounds) {
       if (decided_by_solve)
-        launchSolveCombined(w, 0.0, cout, cin, &fr.prm);
+        launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups);
       else
         launchSolveCombined(w, 0.0, cout);
     }

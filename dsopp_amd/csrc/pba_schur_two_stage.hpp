@@ -8,16 +8,17 @@
 //            writes ONE partial system, without atomics; the frame-pair workgroups write their derived blocks to per-pair slots;
 //   stage 2  combineSystemKernel: one thread per entry of the combined system sums the partial systems and the pair blocks in a
 //            fixed order, applies the damping and writes the entry once.
-// Same arithmetic per landmark as reduceSchurKernel (hessian_block_evaluation.hpp:96-164,169-236); the LM decision runs in
-// decideApplyKernel in front (the kernel sequence of the landmark-sharded windows).  Selected when a window has more 64-landmark
-// chunks than kTwoStageMinChunks, or always with dsopp_hip_window_set_deterministic.
+// Same arithmetic per landmark as reduceSchurKernel (hessian_block_evaluation.hpp:96-164,169-236).  Inside the fused loop the launch
+// carries kScalarGroups more workgroups that pre-sum the sweep's energy scalars, and the LM decision taken from them is the prologue
+// of the solve launch behind stage 2 (pba_solve_combined.hpp).  Selected when a window has more 64-landmark chunks than
+// kTwoStageMinChunks, or always with dsopp_hip_window_set_deterministic.
 #pragma once
 #include "pba_solve_kernels.hpp"
 
 namespace dsopp_hip {
 
 constexpr int kPairOut = 208;  // per ordered frame pair: T^T G T [64] | G T [64] | T^T q [8] | G [64] | q [8]
-constexpr int kTwoStageMinChunks = 96;
+constexpr int kTwoStageMinChunks = 192;  // 7 frames: 59.4 (atomics) against 67.2 us at 125 chunks, equal at 188, 96.6 against 90.5 at 313 (scripts/threshold_sweep.py)
 constexpr int kMaxTilesPerWave = 5;  // K <= 128: 36 upper-triangular 16 x 16 tiles over 8 waves
 
 /** doubles of one partial Schur system: the upper-triangular 16 x 16 tiles in MFMA layout + b_schur */
@@ -39,11 +40,11 @@ struct TwoStageArgs {
   int n_chunks, chunks_per_wg, n_schur_wgs;
   int ublk_parity;
   long long *dbg;  // nullable tuning aid (-DDSOPP_HIP_STAMPS): phase stamps of workgroup 1, first chunk
-  // unsharded fused loop: the LM decision for the pending candidate and its accept / reject stores run as this kernel's prologue
-  // (every workgroup decides from the 64 group sums of the sweep's scalars, applies it to the landmarks of ITS chunks; workgroup 0
-  // also to the frames, and publishes the outgoing control block) instead of as a kernel of their own in front
-  int fused_decide;
-  ReduceSchurArgs dec;  // ctrl (incoming), ctrl_out, prm, scalars, st, F of that decision
+  // fused loop: kScalarGroups further workgroups sum the sweep's four energy scalars into fixed groups
+  // (group_sums[g][4]) for the decision, which is the prologue of the SOLVE launch — nothing in this launch waits for it, and the
+  // separate scalar-groups launch in front of it is gone
+  double *group_sums = nullptr;
+  int n_sweep_blocks = 0;
 };
 #define TS_STAMP(i) do { if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1 && chunk == first_chunk) a.dbg[i] = wall_clock64(); } while (0)
 
@@ -67,44 +68,30 @@ inline size_t twoStageSmemBytes(int F) {
 template <int TPW>
 __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStageArgs a) {  // 2 workgroups of 8 waves per compute unit
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (a.fused_decide) {
-    ReduceSchurArgs d = a.dec;
-    d.n_schur_blocks = 0;  // (no per-block preloads in the decision: this workgroup owns several chunks, handled below)
-    ApplyRegs ar;
-    ar.pending = 0;
-    ar.publish = 0;
-    long long dbg2[2] = {0, 0};
-    const bool proceed = fusedDecideApply(d, reinterpret_cast<double *>(smem_raw), dbg2, ar);
-    applyDecision(d, ar);  // frames + control block (workgroup 0)
-    if (ar.pending && static_cast<int>(blockIdx.x) < a.n_schur_wgs) {
-      // acceptStep / rejectStep of the landmarks of this workgroup's chunks (problem.hpp:364-402): 8 threads per landmark, thread
-      // `sub` owns the targets sub and sub + 8
-      const int c0 = blockIdx.x * a.chunks_per_wg, c1 = min(c0 + a.chunks_per_wg, a.n_chunks);
-      for (int chunk = c0; chunk < c1; ++chunk) {
-        const SchurBlock &be = a.schur_table[chunk];
-        const int l = threadIdx.x >> 3, sub = threadIdx.x & 7, i = be.offset + l;
-        if (i >= be.n) continue;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int t = sub + 8 * h;
-          if (t < a.F && be.status[t] != nullptr && i < be.n_res[t]) {
-            if (ar.accept)
-              be.status[t][i] = be.cand[t][i];
-            else
-              be.cand[t][i] = be.status[t][i];
-          }
-        }
-        if (sub == 0) {
-          if (ar.accept) be.idepth[i] += be.idepth_step[i];
-          be.idepth_step[i] = 0;
-        }
-      }
+  if (a.ctrl && !a.ctrl->active) return;
+  const int F = a.F, K = kBlk * F;
+  if (static_cast<int>(blockIdx.x) >= a.n_schur_wgs + F * F) {
+    // ---- scalar group: energy, n_valid, |idepth step|^2, idepth . step of a fixed share of the sweep's workgroups (fixed order)
+    const int g = blockIdx.x - a.n_schur_wgs - F * F;
+    const int per = (a.n_sweep_blocks + kScalarGroups - 1) / kScalarGroups;
+    const int b0 = g * per, b1 = min(b0 + per, a.n_sweep_blocks);
+    double v[4] = {0, 0, 0, 0};
+    for (int b = b0 + threadIdx.x; b < b1; b += kSchurThreads) {
+      const double *p = a.partials + static_cast<size_t>(b) * kPartial;
+      v[0] += p[44];
+      v[1] += p[45];
+      v[2] += p[46];
+      v[3] += p[47];
     }
-    if (!proceed) return;
-  } else if (a.ctrl && !a.ctrl->active) {
+    blockSum<4, kSchurThreads>(v, reinterpret_cast<double *>(smem_raw));
+    if (threadIdx.x == 0) {
+      a.group_sums[4 * g + 0] = v[0];
+      a.group_sums[4 * g + 1] = v[1];
+      a.group_sums[4 * g + 2] = v[2];
+      a.group_sums[4 * g + 3] = v[3];
+    }
     return;
   }
-  const int F = a.F, K = kBlk * F;
   if (static_cast<int>(blockIdx.x) >= a.n_schur_wgs) {
     // ---- frame pair: deterministic sum of the sweep's partials, derived blocks, one slot per pair (no atomics)
     const int p = blockIdx.x - a.n_schur_wgs;

@@ -39,6 +39,7 @@ struct SolveCombArgs {
   const double *dec_scalars = nullptr;  // {energy, n_valid, |idepth step|^2, idepth . step}, summed over all ranks
   const SchurBlock *dec_table = nullptr;
   int dec_blocks = 0;
+  int dec_groups = 0;  // 0: dec_scalars holds the four sums; kScalarGroups: it holds that many group sums [g][4] (added here, fixed order)
   LmParams dec_prm;
 };
 #define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
@@ -82,7 +83,33 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     __shared__ LmControl s_dec_out;
     __shared__ int s_dec_accept, s_dec_proceed;
     const LmControl cin = *a.dec_in;
-    const double t[4] = {a.dec_scalars[0], a.dec_scalars[1], a.dec_scalars[2], a.dec_scalars[3]};
+    double t[4] = {0, 0, 0, 0};
+    if (a.dec_groups) {
+      // 64 group sums per scalar -> 8 sums of 8 -> one (fixed order: identical in every workgroup and from run to run)
+      __shared__ double s_grp[4 * 8];
+      if (tid < 32) {
+        const int e = tid >> 3, j = tid & 7;
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += a.dec_scalars[4 * (8 * j + k) + e];
+        s_grp[e * 8 + j] = sacc;
+      }
+      ldsBarrier();
+      if (tid == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          double sacc = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sacc += s_grp[e * 8 + j];
+          t[e] = sacc;
+        }
+      }
+    } else {
+      t[0] = a.dec_scalars[0];
+      t[1] = a.dec_scalars[1];
+      t[2] = a.dec_scalars[2];
+      t[3] = a.dec_scalars[3];
+    }
     if (blockIdx.x == 0 && tid < K) {  // (frame states: read and written by workgroup 0 only)
       dec_eps = a.st->eps[tid >> 3][tid & 7];
       dec_step = a.st->step[tid >> 3][tid & 7];

@@ -311,7 +311,7 @@ int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t 
  * 2: unfused device-side loop (5 launches per iteration).  Same arithmetic in all three; 1 and 2 are kept for debugging and
  * as parity cross-checks of the fused control logic */
 int dsopp_hip_window_set_lm_mode(dsopp_hip_window *w, int mode);
-/* Summation order of the reduced normal equations inside the fused LM loop.  0 (default): windows of up to 96 chunks of 64
+/* Summation order of the reduced normal equations inside the fused LM loop.  0 (default): windows of up to 192 chunks of 64
  * landmarks accumulate H_schur with fp64 atomics (fewest launches; the sum order, hence the last bits, vary from run to run — the
  * reference's own reduction under a mutex, hessian_block_evaluation.hpp:101-145, has the same property), larger windows use the
  * two-stage build (per-workgroup partial systems, then one ordered sum per entry: no atomics, bit-reproducible, and faster there).

@@ -7,6 +7,7 @@ is what DESIGN.md's per-kernel figures are recomputed from.
               runs inside the loop, between dependent launches, and averages ~10 % longer)
    large      12 KF / 50 000 points on one GPU: 3 LM solves + isolated kernel launches
    large_loop the same window, fused loop only (5 solves)
+   c3_loop    7 KF / 20 000 points, fused loop only
    tracker    C2: 1280x1024, 5 levels, 20 frames of pyramid + estimatePose
    depth      7 x 2000 immature landmarks against one 640x480 frame
    activation 6 x (286 active + 1500 immature) landmarks against a new keyframe"""
@@ -45,6 +46,14 @@ elif what == "large":
     g.restore()
     for k in ("sweep_linearize", "sweep_linearize_loop", "sweep_energy", "schur", "assemble_solve"):
         print(k, g.time_kernel(k, 20))
+    g.close()
+elif what == "c3_loop":
+    win = syn.make_window(7, 20000, 640, 480, seed=0)
+    g = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g, win)
+    g.snapshot()
+    g.optimize_repeated(7)
+    g.optimize_repeated(28)
     g.close()
 elif what == "large_loop":
     # only the fused loop (for a kernel-by-kernel timeline of one solve at this size: scripts/one_solve_timeline.py)

@@ -427,7 +427,7 @@ def test_optimize_repeated_equals_single_solves(small_window, deterministic):
 
 
 def test_large_window_two_stage_is_bit_reproducible():
-    """windows above 96 landmark chunks take the two-stage build by themselves (C3 size: 7 frames / 20 000 points): reproducible"""
+    """windows above 192 landmark chunks take the two-stage build by themselves (C3 size: 7 frames / 20 000 points): reproducible"""
     from dsopp_amd import capi
     win = syn.make_window(num_frames=7, num_points=20000, width=640, height=480, seed=0)
     g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
