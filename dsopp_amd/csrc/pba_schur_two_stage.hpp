@@ -334,7 +334,7 @@ struct CombineArgs {
   int F, n_schur_wgs;
 };
 
-constexpr int kCombineEntries = 32, kCombineSlices = 8;  // a workgroup of 256 threads: 32 entries x 8 slices of the partial systems
+constexpr int kCombineEntries = 32, kCombineSlices = 16;  // a workgroup of 512 threads: 32 entries x 16 slices of the partial systems
 
 /** pair-block part of entry (row R, col C), R >= C, of the combined system (without the damping of the diagonal).  Slots of
  *  unconnected pairs hold zeros (stage 1), so every slot is added, in frame order, with all loads in flight together. */
@@ -379,8 +379,8 @@ __device__ inline double pairRhs(const CombineArgs &a, int c) {
 }
 
 /** stage 2: one thread group per word of the partial systems (coalesced reads in the MFMA tile layout): 32 words per workgroup,
- *  8 threads per word — thread `slice` adds the partial systems slice, slice + 8, ... with eight loads in flight (one thread
- *  walking all partial systems of a word is a chain of L2 round trips), the eight slice sums are then added in slice order: a
+ *  16 threads per word — thread `slice` adds the partial systems slice, slice + 16, ... with sixteen loads in flight (one thread
+ *  walking all partial systems of a word is a chain of L2 round trips), the slice sums are then added in slice order: a
  *  fixed order for a given window, hence bit-reproducible.  The word's owner maps it to its entry (row >= col) of the combined
  *  system, adds the pair blocks in fixed order and the damping, and writes the entry — every entry exactly once. */
 __global__ void __launch_bounds__(kCombineEntries * kCombineSlices) combineSystemKernel(CombineArgs a) {
@@ -409,33 +409,40 @@ __global__ void __launch_bounds__(kCombineEntries * kCombineSlices) combineSyste
     row = e - n_tiles * 256;
     col = K;
   }
+  // everything that does not depend on the partial sums is requested first (slice 0 owns the entry): damping, pair blocks
+  const bool owner = slice == 0 && row >= 0;
+  double lam = 0, pair = 0;
+  if (owner) {
+    lam = a.ctrl ? a.ctrl->lambda : a.lambda;
+    pair = col == K ? pairRhs(a, row) : pairEntry(a, col, row);
+  }
   double s = 0;
   if (row >= 0) {
+    // every round has kDepth loads in flight per thread, the last one included (indices beyond the last partial system are clamped
+    // and their values dropped): 313 partial systems are 2 rounds — as a batched loop with a scalar tail they were 4 + 7 round trips
     const double *src = a.schur_partials + e;
-    constexpr int kDepth = 8;
-    int w = slice;
-    for (; w + (kDepth - 1) * kCombineSlices < a.n_schur_wgs; w += kDepth * kCombineSlices) {
+    constexpr int kDepth = 16;
+    const int last = a.n_schur_wgs - 1;
+    for (int w = slice; w <= last; w += kDepth * kCombineSlices) {
       double v[kDepth];
 #pragma unroll
-      for (int q = 0; q < kDepth; ++q) v[q] = src[static_cast<size_t>(w + q * kCombineSlices) * count];
+      for (int q = 0; q < kDepth; ++q) v[q] = src[static_cast<size_t>(min(w + q * kCombineSlices, last)) * count];
 #pragma unroll
-      for (int q = 0; q < kDepth; ++q) s += v[q];
+      for (int q = 0; q < kDepth; ++q) s += (w + q * kCombineSlices <= last) ? v[q] : 0.0;
     }
-    for (; w < a.n_schur_wgs; w += kCombineSlices) s += src[static_cast<size_t>(w) * count];
   }
   part[slice][le] = s;
   __syncthreads();
-  if (slice != 0 || row < 0) return;
+  if (!owner) return;
   double schur = 0;
 #pragma unroll
   for (int q = 0; q < kCombineSlices; ++q) schur += part[q][le];
   if (a.dense) {
     double *Hpp = a.dense, *bpp = Hpp + static_cast<size_t>(K) * K, *Hs = bpp + K, *bs = Hs + static_cast<size_t>(K) * K;
     if (col == K) {
-      bpp[row] = pairRhs(a, row);
+      bpp[row] = pair;
       bs[row] = schur;
     } else {
-      const double pair = pairEntry(a, col, row);
       Hpp[static_cast<size_t>(col) * K + row] = pair;
       Hpp[static_cast<size_t>(row) * K + col] = pair;
       Hs[static_cast<size_t>(col) * K + row] = schur;
@@ -443,12 +450,10 @@ __global__ void __launch_bounds__(kCombineEntries * kCombineSlices) combineSyste
     }
     return;
   }
-  const double lam = a.ctrl ? a.ctrl->lambda : a.lambda;
   const double sc = -1.0 / (1.0 + lam);
   if (col == K) {
-    a.comb[combBlockCount(F) * 64 + row] = pairRhs(a, row) + sc * schur;
+    a.comb[combBlockCount(F) * 64 + row] = pair + sc * schur;
   } else {
-    double pair = pairEntry(a, col, row);
     if (row == col) pair *= 1.0 + lam;
     a.comb[combIndex(col, row)] = pair + sc * schur;
   }

@@ -79,6 +79,73 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   const bool decides = a.dec_in != nullptr;
   double dec_eps = 0, dec_step = 0;
   int dec_accept = 0;
+  // Workgroup 0 requests everything that does not depend on the decision — pair constants, frame flags, right-hand side, the first
+  // batch of the combined system — BEFORE it takes the decision: the decision's own loads, its LDS tree and its scalar chain then
+  // run under these loads' round trip instead of in front of it (the other workgroups only apply the decision and leave).
+  const bool main_wg = blockIdx.x == 0;
+  struct {
+    int valid;
+    Rigid T0;
+    double fxr, fyr, cxr, cyr, fxt, fyt, cxt, cyt, exposure_r, exposure_t;
+  } pp;
+  pp.valid = 0;
+  const bool fast_refresh = a.fej != 0;
+  if (main_wg && fast_refresh && tid < F * F) {
+    const int r = tid / F, t = tid - F * (tid / F);
+    const PairConst &P = a.pc[r * kMaxFrames + t];
+    pp.valid = P.valid;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
+      pp.T0.t[i] = P.T0rel[4 * i + 3];
+    }
+    const FrameDev &fr = a.frames[r];
+    const FrameDev &ft = a.frames[t];
+    pp.fxr = fr.fx;
+    pp.fyr = fr.fy;
+    pp.cxr = fr.cx;
+    pp.cyr = fr.cy;
+    pp.fxt = ft.fx;
+    pp.fyt = ft.fy;
+    pp.cxt = ft.cx;
+    pp.cyt = ft.cy;
+    pp.exposure_r = fr.exposure;
+    pp.exposure_t = ft.exposure;
+  }
+  double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < THREADS)
+  int fixed_c = 0, tomarg_c = 0;
+  if (main_wg && tid < K) {
+    const int f = tid >> 3, i = tid & 7;
+    if (!decides) eps_c = a.st->eps[f][i];
+    fixed_c = a.frames[f].fixed;
+    tomarg_c = a.frames[f].to_marginalize;
+    ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];
+    rhs_c = a.comb[combBlockCount(F) * 64 + tid];
+    if (a.use_marginal) bm_c = a.bm[tid];
+  }
+  // the block-packed lower triangle: entry e = tid + 256 u, coalesced.  kBatch loads are in flight per thread.
+  const int n_entries = combBlockCount(F) * 64;
+  constexpr int kBatch = 8;
+  double hv[kBatch], hm[kBatch];
+  auto loadBatch = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const int e = base + tid + THREADS * u;
+      hv[u] = a.comb[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
+      hm[u] = 0;
+    }
+    if (a.use_marginal) {
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int e = min(base + tid + THREADS * u, n_entries - 1);
+        int bi, bj;
+        combBlockDecode(e >> 6, bi, bj);
+        hm[u] = a.Hm[(8 * bi + ((e >> 3) & 7)) * K + 8 * bj + (e & 7)];
+      }
+    }
+  };
+  if (main_wg) loadBatch(0);
   if (decides) {
     __shared__ LmControl s_dec_out;
     __shared__ int s_dec_accept, s_dec_proceed;
@@ -171,70 +238,8 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     c_relin = a.ctrl->relin;
     lam = a.ctrl->lambda;
   }
+  if (decides) eps_c = dec_eps;  // (decided here: the accepted state is already in registers)
   SC_STAMP(0);
-  struct {
-    int valid;
-    Rigid T0;
-    double fxr, fyr, cxr, cyr, fxt, fyt, cxt, cyt, exposure_r, exposure_t;
-  } pp;
-  pp.valid = 0;
-  const bool fast_refresh = a.fej != 0;
-  if (fast_refresh && tid < F * F) {
-    const int r = tid / F, t = tid - F * (tid / F);
-    const PairConst &P = a.pc[r * kMaxFrames + t];
-    pp.valid = P.valid;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
-      pp.T0.t[i] = P.T0rel[4 * i + 3];
-    }
-    const FrameDev &fr = a.frames[r];
-    const FrameDev &ft = a.frames[t];
-    pp.fxr = fr.fx;
-    pp.fyr = fr.fy;
-    pp.cxr = fr.cx;
-    pp.cyr = fr.cy;
-    pp.fxt = ft.fx;
-    pp.fyt = ft.fy;
-    pp.cxt = ft.cx;
-    pp.cyt = ft.cy;
-    pp.exposure_r = fr.exposure;
-    pp.exposure_t = ft.exposure;
-  }
-  double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < THREADS)
-  int fixed_c = 0, tomarg_c = 0;
-  if (tid < K) {
-    const int f = tid >> 3, i = tid & 7;
-    eps_c = decides ? dec_eps : a.st->eps[f][i];  // (decided here: the accepted state is already in registers)
-    fixed_c = a.frames[f].fixed;
-    tomarg_c = a.frames[f].to_marginalize;
-    ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];
-    rhs_c = a.comb[combBlockCount(F) * 64 + tid];
-    if (a.use_marginal) bm_c = a.bm[tid];
-  }
-  // the block-packed lower triangle: entry e = tid + 256 u, coalesced.  kBatch loads are in flight per thread.
-  const int n_entries = combBlockCount(F) * 64;
-  constexpr int kBatch = 8;
-  double hv[kBatch], hm[kBatch];
-  auto loadBatch = [&](int base) {
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      const int e = base + tid + THREADS * u;
-      hv[u] = a.comb[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
-      hm[u] = 0;
-    }
-    if (a.use_marginal) {
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const int e = min(base + tid + THREADS * u, n_entries - 1);
-        int bi, bj;
-        combBlockDecode(e >> 6, bi, bj);
-        hm[u] = a.Hm[(8 * bi + ((e >> 3) & 7)) * K + 8 * bj + (e & 7)];
-      }
-    }
-  };
-  loadBatch(0);
   // opaque to the optimiser: stops it from testing these loaded flags (and waiting for them) above the loads
   asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(pp.valid), "+v"(c_active), "+v"(c_relin));
   int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness (evaluateLinearSystemPrior, problem.hpp:39-62)
