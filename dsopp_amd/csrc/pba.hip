@@ -1271,7 +1271,6 @@ void lmSolveFusedEnqueue(W &w) {
     } else {
       launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, true, 0.0, ex);
     }
-    bool decided_by_solve = false;
     FusedReduce fr;
     fr.ublk_parity = r & 1;
     fr.ctrl_out = cout;
@@ -1287,7 +1286,6 @@ void lmSolveFusedEnqueue(W &w) {
       double *groups = w.d_reduce.ptr + w.combCount();
       launchTwoStage(w, cin, fr.ublk_parity, 0.0, false, groups);
       allreduceIfNeeded(w, w.d_reduce.ptr, w.combCount() + 4 * kScalarGroups);
-      decided_by_solve = true;
       decide_from_groups = true;
     } else if (w.allreduce && r + 1 == rounds) {
       // landmark shards, closing round: its sweep was residual-only, no system exists — only the four energy scalars of the last
@@ -1301,11 +1299,6 @@ void lmSolveFusedEnqueue(W &w) {
       HIP_CHECK(hipGetLastError());
       allreduceIfNeeded(w, w.d_reduce.ptr + w.combCount(), 4);
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
-    } else if (w.allreduce) {
-      // landmark shards: accumulate the local systems, ONE collective over [systems | energy scalars], then decide
-      // (the decision — a function of the all-reduced sums alone — is the prologue of the solve launch: no kernel of its own)
-      launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
-      decided_by_solve = true;
     } else if (r + 1 == rounds) {
       // the closing round only takes the decision for the last candidate (its sweep was residual-only: no system to build) and
       // leaves the solve's result in pinned host memory itself (a copy kernel behind it cost 4 us per solve)
@@ -1322,14 +1315,13 @@ void lmSolveFusedEnqueue(W &w) {
       }
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kDecideOnly);
     } else {
-      launchReduceSchur(w, false, cin, &fr);
+      // K2: the local systems accumulated with atomics + one extra workgroup that sums the sweep's four energy scalars behind them
+      // (landmark shards: ONE collective over [system | scalars]); K3 then takes the decision — a function of those sums and the
+      // control block alone — as its prologue.  (Until round 3 the unsharded K2 decided in its own prologue: every workgroup waited
+      // for a round trip over the sweep's scalars before it started to build; 41.4 -> 40.1 us per iteration at C1.)
+      launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
     }
-    if (r + 1 < rounds) {
-      if (decided_by_solve)
-        launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups);
-      else
-        launchSolveCombined(w, 0.0, cout);
-    }
+    if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups);  // K3: decision prologue + solve
   }
   LmControl *cfin = ctrl + (rounds & 1);
   HIP_CHECK(hipGetLastError());

@@ -394,21 +394,13 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const long long rs_t0 = (kStamps && a.dbg) ? wall_clock64() : 0;
   long long rs_dbg[2] = {0, 0};
-  ApplyRegs ar;
-  ar.pending = 0;
-  ar.publish = 0;
-  if (a.ctrl_out) {
-    if (!fusedDecideApply(a, reinterpret_cast<double *>(smem_raw), rs_dbg, ar)) {
-      applyDecision(a, ar);
-      return;
-    }
-  } else if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) {
-    return;
-  }
+  // (inside the fused loop the LM decision for the pending candidate is the prologue of the SOLVE launch behind this one — it needs
+  // the sums of all of the sweep's energy scalars, which the extra workgroup below produces while the others build the system)
+  if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) return;
   const int F = a.F, K = kBlk * F;
-  // damping of the system being built: the decision just taken (fused), the incoming control block (sharded accumulate
-  // pass: the PBA's LM keeps lambda constant, eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
-  const double comb_lam = a.ctrl_out ? ar.out->lambda : (a.ctrl ? a.ctrl->lambda : a.comb_lambda);
+  // damping of the system being built: the incoming control block (the PBA's LM keeps lambda constant,
+  // eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
+  const double comb_lam = a.ctrl ? a.ctrl->lambda : a.comb_lambda;
   if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {
     // ---- landmark-sharded windows: one extra workgroup sums the sweep's 4 energy scalars (fixed order) into the tail of
     // the reduction buffer, so that they travel in the same collective as the systems (no separate kernel for it)
@@ -453,7 +445,6 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       }
       if (lane < 48) wsum[wave * 48 + lane] = sw;
     }
-    applyDecision(a, ar);
     ldsBarrier();
     if (threadIdx.x >= 64 || !valid) return;
     double s = 0;
@@ -675,12 +666,10 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
     }
     RS_STAMP(5);
   }
-  applyDecision(a, ar);
 }
 
-/** Landmark-sharded windows: the decide / apply prologue of reduceSchurKernel as a kernel of its own.  With shards the
- *  decision needs the all-reduced energy, so the fused loop accumulates the local systems first (reduceSchurKernel
- *  without ctrl_out), all-reduces [systems | scalars] in ONE collective and only then decides.  grid = schur blocks (>= 1). */
+/** The LM decision for the pending candidate + its accept / reject as a kernel of its own: the closing round of a solve (nothing
+ *  is built or solved behind it).  grid = schur blocks (>= 1). */
 __global__ void __launch_bounds__(kSchurThreads) decideApplyKernel(ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   long long dbg_unused[2] = {0, 0};
