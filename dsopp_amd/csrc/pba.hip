@@ -1397,12 +1397,12 @@ void updatePointStatusesDevice(W &w) {
   const int F = w.F();
   w.d_select.reserve(1, 0, st);
   w.d_pair_dist.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames, 0, st);
-  selectInitKernel<<<1, 256, 0, st>>>(w.d_select.ptr);
+  selectInitKernel<<<1, 1024, 0, st>>>(w.d_select.ptr);
   const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
   if (w.n_sweep_blocks) {
     const int per_group = kSelectThreads / kItemsPerBlock;
     const int grid = (w.n_fine_blocks + per_group - 1) / per_group;
-    for (int pass = 7; pass >= 0; --pass)  // each pass advances the select state from the previous pass's histogram itself
+    for (int pass = kSelectPasses - 1; pass >= 0; --pass)  // each pass advances the select state from the previous pass's histogram itself
       selectHistKernel<<<grid, kSelectThreads, 0, st>>>(w.d_frames.ptr, w.fineTable(), w.n_fine_blocks, w.d_select.ptr, pass);
   }
   pairDistanceKernel<<<1, 256, 0, st>>>(w.d_state.ptr, F, w.d_pair_dist.ptr, w.n_sweep_blocks ? w.d_select.ptr : nullptr, half_sigma_sq);

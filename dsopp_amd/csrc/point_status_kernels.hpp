@@ -1,5 +1,5 @@
 // updatePointStatuses on the device (PROB_SRC/photometric_bundle_adjustment.cpp:321-406) and relinearizeSystem (:310-316).
-// The 3rd-quartile threshold is an exact order statistic: an 8-pass most-significant-byte radix select over the IEEE-754
+// The 3rd-quartile threshold is an exact order statistic: a 5-pass most-significant-digit radix select (13-bit digits) over the IEEE-754
 // bit patterns of the (non-negative) residual energies, then one pass per landmark applies it.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -10,18 +10,26 @@
 
 namespace dsopp_hip {
 
+// Digit width of the radix select: 13 bits -> 5 passes over the 64-bit keys (8-bit digits were 8 launches of ~4.5 us each with as
+// much host enqueue time between them; the histogram of a pass is 8192 words: 32 KB of LDS per workgroup, 96 KB of state in HBM).
+constexpr int kSelectBits = 13;
+constexpr int kSelectBins = 1 << kSelectBits;
+constexpr int kSelectPasses = (64 + kSelectBits - 1) / kSelectBits;  // 5; the top digit holds the 12 bits 52 .. 63
+
 struct SelectState {
   // the state after the scan of pass k lives in slot k & 1: a histogram kernel reads one slot and writes the other, so a
   // workgroup that starts late never sees a half-advanced state
-  unsigned long long prefix[2];  // bits fixed so far (from the most significant byte down)
+  unsigned long long prefix[2];  // bits fixed so far (from the most significant digit down)
   unsigned long long mask[2];    // which bits of `prefix` are fixed
   unsigned int rank[2];          // rank of the wanted element among the keys matching the prefix
   unsigned int n_ok[2];
   double threshold;           // result: selected energy + sigma^2 / 2 (0 when there is no kOk residual)
+  double pad_;                // (the histograms start at byte 64: 16-byte vector loads)
   // three histograms in rotation: the kernel of pass p accumulates into hist[p % 3], reads the finished hist[(p + 1) % 3] of the
   // previous pass (to advance prefix / rank itself: no separate scan launch) and clears hist[(p + 2) % 3] for the next one
-  unsigned int hist[3][256];
+  unsigned int hist[3][kSelectBins];
 };
+static_assert(offsetof(SelectState, hist) % 16 == 0, "histogram alignment");
 
 __global__ void selectInitKernel(SelectState *s) {
   if (threadIdx.x < 2) {
@@ -31,7 +39,7 @@ __global__ void selectInitKernel(SelectState *s) {
     s->n_ok[threadIdx.x] = 0;
     s->threshold = 0;
   }
-  for (int b = 0; b < 3; ++b) s->hist[b][threadIdx.x] = 0;
+  for (int k = threadIdx.x; k < 3 * kSelectBins; k += blockDim.x) (&s->hist[0][0])[k] = 0;
 }
 
 /** eligible = residual status kOk of a non-marginalised landmark towards a non-marginalised target frame (:340-352) */
@@ -45,30 +53,49 @@ __device__ inline bool eligibleEnergy(const SweepBlock &be, const FrameDev *fram
 }
 
 /** what the scan step of pass `done` does to the select state: picks the bucket of hist that holds the wanted rank and
- *  narrows prefix / mask / rank (pass 7 also fixes n_ok and the third-quartile rank, :358).  Executed by one lane; every
- *  workgroup of the next pass computes it for itself from the stored state + the finished histogram. */
+ *  narrows prefix / mask / rank (the top pass also fixes n_ok and the third-quartile rank, :358).  Every workgroup of the next
+ *  pass computes it for itself from the stored state + the finished histogram. */
 struct SelectLocal {
   unsigned long long prefix, mask;
   unsigned int rank, n_ok;
 };
-/** cooperative: called by ALL threads of a workgroup of >= 256 threads; `scan` is 256 words of LDS.  (A single lane walking
- *  the histogram in global memory paid one dependent round trip per bin: 10 - 15 us per pass.) */
+/** cooperative: called by ALL THREADS threads of a workgroup; `scan` is THREADS words of LDS.  A thread owns kSelectBins / THREADS
+ *  consecutive bins: their sum enters a workgroup scan, the thread whose range holds the rank walks its own bins.  (A single lane
+ *  walking the histogram in global memory paid one dependent round trip per bin: 10 - 15 us per pass.) */
+template <int THREADS>
 __device__ inline SelectLocal selectAdvance(const SelectState *s, int done, unsigned int *scan) {
+  constexpr int PER = kSelectBins / THREADS;
+  static_assert(PER * THREADS == kSelectBins && PER % 4 == 0, "bins per thread");
   const int t = threadIdx.x;
-  const int in = (done + 1) & 1;  // S_{done + 1}; for done == 7 that is the initial all-zero state
+  const int in = (done + 1) & 1;  // S_{done + 1}; for the top pass that is the initial all-zero state
   SelectLocal l{s->prefix[in], s->mask[in], s->rank[in], s->n_ok[in]};
-  const unsigned int mine = t < 256 ? s->hist[done % 3][t] : 0u;
-  if (t < 256) scan[t] = mine;
+  unsigned int mine[PER];
+  unsigned int sum = 0;
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(&s->hist[done % 3][t * PER]);
+#pragma unroll
+    for (int k = 0; k < PER / 4; ++k) {
+      const uint4 v = src[k];
+      mine[4 * k + 0] = v.x;
+      mine[4 * k + 1] = v.y;
+      mine[4 * k + 2] = v.z;
+      mine[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sum += mine[k];
+  }
+  scan[t] = sum;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
-    const unsigned int v = (t < 256 && t >= off) ? scan[t - off] : 0u;
+  for (int off = 1; off < THREADS; off <<= 1) {  // inclusive scan of the per-thread sums
+    const unsigned int v = t >= off ? scan[t - off] : 0u;
     __syncthreads();
-    if (t < 256) scan[t] += v;
+    scan[t] += v;
     __syncthreads();
   }
-  if (done == 7) {
+  const unsigned int incl = scan[t], excl = incl - sum;
+  if (done == kSelectPasses - 1) {
     l = SelectLocal{0, 0, 0, 0};
-    const unsigned int n = scan[255];
+    const unsigned int n = scan[THREADS - 1];
     l.n_ok = n;
     l.rank = static_cast<unsigned int>(static_cast<double>(n) * 0.75);  // third_quartile index, :358
     if (n == 0) {
@@ -76,44 +103,60 @@ __device__ inline SelectLocal selectAdvance(const SelectState *s, int done, unsi
       l.prefix = 1;
     }
   }
-  __shared__ int s_bucket;
-  if (t == 0) s_bucket = 255;
+  __shared__ unsigned int s_bucket, s_cum;
+  if (t == 0) {
+    s_bucket = kSelectBins - 1;
+    s_cum = 0;
+  }
   __syncthreads();
-  if (l.n_ok > 0) {
-    // the first bin whose inclusive count exceeds the rank (bins with that property form a suffix: take the smallest index)
-    if (t < 256 && l.rank < scan[t] && (t == 0 || !(l.rank < scan[t - 1]))) s_bucket = t;
+  if (l.n_ok > 0 && l.rank >= excl && l.rank < incl) {
+    // the first bin whose inclusive count exceeds the rank lies in this thread's range
+    unsigned int c = excl;
+    int found = PER - 1;
+    unsigned int cum = excl;
+    bool done_walk = false;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (!done_walk && l.rank < c + mine[k]) {
+        found = k;
+        cum = c;
+        done_walk = true;
+      }
+      c += mine[k];
+    }
+    s_bucket = static_cast<unsigned int>(t * PER + found);
+    s_cum = cum;
   }
   __syncthreads();
   if (l.n_ok > 0) {
-    const int bucket = s_bucket;
-    const unsigned int cum = bucket > 0 ? scan[bucket - 1] : 0u;
-    l.rank -= cum;
-    l.prefix |= static_cast<unsigned long long>(bucket) << (8 * done);
-    l.mask |= 0xFFull << (8 * done);
+    l.rank -= s_cum;
+    l.prefix |= static_cast<unsigned long long>(s_bucket) << (kSelectBits * done);
+    l.mask |= static_cast<unsigned long long>(kSelectBins - 1) << (kSelectBits * done);
   }
   __syncthreads();
   return l;
 }
 
-/** one histogram pass of the radix select; byte index `pass` (7 = most significant).  For pass < 7 the workgroup first
- *  advances the select state by the previous pass's histogram (workgroup 0 also stores it and clears the histogram of the
- *  next pass): 8 launches per select instead of 16. */
+/** one histogram pass of the radix select; digit index `pass` (kSelectPasses - 1 = most significant).  Below the top pass the
+ *  workgroup first advances the select state by the previous pass's histogram (workgroup 0 also stores it and clears the histogram
+ *  of the next pass): one launch per digit. */
 constexpr int kSelectThreads = 1024;
 __global__ void __launch_bounds__(kSelectThreads) selectHistKernel(const FrameDev *__restrict__ frames, const SweepBlock *__restrict__ table, int n_entries,
                                                                   SelectState *s, int pass) {
-  __shared__ unsigned int lh[256];  // workgroup-private histogram: one global atomic per non-empty bin and workgroup
-  const SelectLocal l = pass == 7 ? SelectLocal{0, 0, 0, 0} : selectAdvance(s, pass + 1, lh);
-  if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+  __shared__ unsigned int lh[kSelectBins];  // workgroup-private histogram: one global atomic per non-empty bin and workgroup
+  __shared__ unsigned int scan[kSelectThreads];
+  const SelectLocal l = pass == kSelectPasses - 1 ? SelectLocal{0, 0, 0, 0} : selectAdvance<kSelectThreads>(s, pass + 1, scan);
+  for (int k = threadIdx.x; k < kSelectBins; k += kSelectThreads) lh[k] = 0;
   __syncthreads();
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0 && pass < 7) {  // S_{pass + 1}
+    if (threadIdx.x == 0 && pass < kSelectPasses - 1) {  // S_{pass + 1}
       const int out = (pass + 1) & 1;
       s->prefix[out] = l.prefix;
       s->mask[out] = l.mask;
       s->rank[out] = l.rank;
       s->n_ok[out] = l.n_ok;
     }
-    for (int k = threadIdx.x; k < 256; k += kSelectThreads) s->hist[(pass + 2) % 3][k] = 0;
+    for (int k = threadIdx.x; k < kSelectBins; k += kSelectThreads) s->hist[(pass + 2) % 3][k] = 0;
   }
   const int entry = blockIdx.x * (kSelectThreads / kItemsPerBlock) + (threadIdx.x / kItemsPerBlock);
   const bool in_range = entry < n_entries;
@@ -121,11 +164,11 @@ __global__ void __launch_bounds__(kSelectThreads) selectHistKernel(const FrameDe
   const int i = be.offset + threadIdx.x % kItemsPerBlock;
   unsigned long long key = 0;
   const bool counts = in_range && eligibleEnergy(be, frames, i, key) && (key & l.mask) == l.prefix;
-  // The upper bytes of the energies are nearly constant (same sign / exponent range), so almost every key of a pass lands in
+  // The upper bits of the energies are nearly constant (same sign / exponent range), so almost every key of a pass lands in
   // ONE bucket: per-lane atomics on one address serialise (12 000 of them took 109 us; one per wavefront from 190 wavefronts
   // still 50 us across the XCDs).  A wavefront adds the lanes sharing the bucket of its first counting lane with one LDS
   // atomic, the rest per lane, and the workgroup flushes its non-empty bins once.
-  const unsigned int bucket = static_cast<unsigned int>((key >> (8 * pass)) & 0xFFull);
+  const unsigned int bucket = static_cast<unsigned int>((key >> (kSelectBits * pass)) & static_cast<unsigned long long>(kSelectBins - 1));
   const unsigned long long active = __ballot(counts);
   if (active != 0) {
     const int leader = __ffsll(static_cast<long long>(active)) - 1;
@@ -135,12 +178,14 @@ __global__ void __launch_bounds__(kSelectThreads) selectHistKernel(const FrameDe
     if (counts && bucket != common) atomicAdd(&lh[bucket], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&s->hist[pass % 3][threadIdx.x], lh[threadIdx.x]);
+  for (int k = threadIdx.x; k < kSelectBins; k += kSelectThreads)
+    if (lh[k]) atomicAdd(&s->hist[pass % 3][k], lh[k]);
 }
 
 /** closing step of the select (after the pass-0 histogram): the selected key is the threshold energy (:360) */
+template <int THREADS>
 __device__ inline void selectFinish(SelectState *s, double half_sigma_sq, unsigned int *scan) {
-  const SelectLocal l = selectAdvance(s, 0, scan);
+  const SelectLocal l = selectAdvance<THREADS>(s, 0, scan);
   if (threadIdx.x == 0) {
     s->prefix[0] = l.prefix;
     s->mask[0] = l.mask;
@@ -156,7 +201,7 @@ __global__ void pairDistanceKernel(const WindowState *st, int F, double *dist /*
   __shared__ double c[kMaxFrames][3];
   const int f = threadIdx.x;
   __shared__ unsigned int scan[256];
-  if (select) selectFinish(select, half_sigma_sq, scan);  // the single-workgroup step between select and apply (256 threads)
+  if (select) selectFinish<256>(select, half_sigma_sq, scan);  // the single-workgroup step between select and apply (256 threads)
   if (f < F) {
     Rigid T0;
 #pragma unroll
