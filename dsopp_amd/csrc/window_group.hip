@@ -290,7 +290,8 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
       if (device_ids[i] < 0 || device_ids[i] >= count) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device_ids[i], count);
       for (int j = 0; j < i; ++j) distinct = distinct && device_ids[j] != device_ids[i];
     }
-    if (transport == DSOPP_HIP_TRANSPORT_AUTO) transport = (distinct && n > 1) ? DSOPP_HIP_TRANSPORT_RCCL : DSOPP_HIP_TRANSPORT_LOCAL;
+    const bool automatic = transport == DSOPP_HIP_TRANSPORT_AUTO;
+    if (automatic) transport = (distinct && n > 1) ? DSOPP_HIP_TRANSPORT_RCCL : DSOPP_HIP_TRANSPORT_LOCAL;
     if (transport == DSOPP_HIP_TRANSPORT_RCCL && !distinct)
       fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "RCCL needs one device per shard (two shards share a device): use DSOPP_HIP_TRANSPORT_LOCAL");
     auto g = std::make_unique<G>();
@@ -317,14 +318,29 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
       return dsopp_hip_window_create(options, g->device[static_cast<size_t>(s)], nullptr, &g->win[static_cast<size_t>(s)]);
     });
     if (n > 1 && transport == DSOPP_HIP_TRANSPORT_RCCL) {
-      uint8_t id[DSOPP_HIP_COMM_ID_BYTES];
-      if (const int rc = dsopp_hip_comm_unique_id(id); rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
-      // ncclCommInitRank blocks until every rank has joined: all workers call it together
-      fanOut(*g, [&](int s, dsopp_hip_window *w) {
-        const int rc = dsopp_hip_comm_create(id, s, n, g->device[static_cast<size_t>(s)], &g->comm[static_cast<size_t>(s)]);
-        return rc != DSOPP_HIP_OK ? rc : dsopp_hip_window_set_comm(w, g->comm[static_cast<size_t>(s)]);
-      });
-    } else if (n > 1) {
+      try {
+        uint8_t id[DSOPP_HIP_COMM_ID_BYTES];
+        if (const int rc = dsopp_hip_comm_unique_id(id); rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
+        // ncclCommInitRank blocks until every rank has joined: all workers call it together
+        fanOut(*g, [&](int s, dsopp_hip_window *w) {
+          const int rc = dsopp_hip_comm_create(id, s, n, g->device[static_cast<size_t>(s)], &g->comm[static_cast<size_t>(s)]);
+          return rc != DSOPP_HIP_OK ? rc : dsopp_hip_window_set_comm(w, g->comm[static_cast<size_t>(s)]);
+        });
+      } catch (const Error &) {
+        // AUTO only: a node without a usable librccl (the library is dlopen'ed) still gets its group — the in-process reducer
+        // over peer access.  An explicit DSOPP_HIP_TRANSPORT_RCCL request fails loudly instead.
+        if (!automatic) throw;
+        fanOut(*g, [&](int s, dsopp_hip_window *w) {
+          (void)dsopp_hip_window_set_comm(w, nullptr);
+          if (g->comm[static_cast<size_t>(s)]) dsopp_hip_comm_destroy(g->comm[static_cast<size_t>(s)]);
+          g->comm[static_cast<size_t>(s)] = nullptr;
+          return static_cast<int>(DSOPP_HIP_OK);
+        });
+        transport = DSOPP_HIP_TRANSPORT_LOCAL;
+        g->transport = transport;
+      }
+    }
+    if (n > 1 && transport == DSOPP_HIP_TRANSPORT_LOCAL) {
       LocalReducer &r = g->reducer;
       r.n = n;
       r.device = g->device;

@@ -224,7 +224,8 @@ int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm);
  * One worker thread per shard enqueues that shard's launches.  transport: RCCL = ncclAllReduce on the shards' streams over xGMI, one
  * rank per device (all device ids distinct); LOCAL = an event-ordered sum kernel inside the process (peer access between the
  * devices; the only choice when shards share a device, e.g. to exercise the sharded path on a single GPU); AUTO = RCCL when the ids
- * are distinct, else LOCAL.  A group of one shard is a plain window.
+ * are distinct (falling back to LOCAL when no communicator can be created, e.g. no librccl on the node — an explicit RCCL request
+ * fails instead), else LOCAL.  dsopp_hip_window_group_size reports the transport in use.  A group of one shard is a plain window.
  * ---------------------------------------------------------------------------------------------------------------- */
 enum { DSOPP_HIP_TRANSPORT_AUTO = 0, DSOPP_HIP_TRANSPORT_RCCL = 1, DSOPP_HIP_TRANSPORT_LOCAL = 2 };
 typedef struct dsopp_hip_window_group dsopp_hip_window_group;
