@@ -225,6 +225,40 @@ def test_reject_path_without_force_accept(lm_mode, fej):
     g.close()
 
 
+@pytest.mark.parametrize("variant", ["deterministic", "group2"])
+@pytest.mark.parametrize("fej", [1, 0])
+def test_reject_path_on_the_two_stage_and_the_sharded_loop(variant, fej):
+    """the same reject / re-linearise bookkeeping where the LM decision is taken from group sums (atomic-free two-stage build, here
+    forced by the deterministic mode) and from all-reduced sums (a window group of two landmark shards): in both the decision is the
+    prologue of the solve launch and the rejected candidate's system has already been built when it is taken"""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=4, num_points=300, width=320, height=240, seed=42)   # rejects from the 5th step on (see above)
+    kw = dict(force_accept=0, max_iterations=14, first_estimate_jacobians=fej)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
+    if variant == "group2":
+        g = capi.HipWindowGroup(capi.default_pba_options(**kw), devices=[0, 0], transport=capi.TRANSPORT_LOCAL)
+    else:
+        g = capi.HipWindow(capi.default_pba_options(**kw))
+    syn.load_window(g, win)
+    if variant == "deterministic":
+        g.set_deterministic(True)
+    eo, ito, nvo = o.optimize()
+    eg, itg, nvg = g.optimize()
+    assert (ito, nvo) == (itg, nvg), (ito, itg, nvo, nvg)
+    assert abs(eo - eg) <= 1e-7 * abs(eo)
+    for f in win.frames:
+        To, abo = o.get_pose(f.frame_id)
+        Tg, abg = g.get_pose(f.frame_id)
+        assert np.abs(To - Tg).max() <= 1e-7 and np.abs(abo - abg).max() <= 1e-7
+        assert np.abs(g.get_landmarks(f.frame_id, False)["idepth"] - o.get_landmarks(f.frame_id)["idepth"]).max() <= 1e-7
+    for fr in win.frames:
+        for ft in win.frames:
+            if fr.frame_id != ft.frame_id:
+                assert np.array_equal(o.get_residuals(fr.frame_id, ft.frame_id)["status"], g.get_residuals(fr.frame_id, ft.frame_id)["status"])
+    g.close()
+
+
 @pytest.mark.parametrize("fej", [1, 0])
 def test_affine_brightness_and_exposure(fej):
     """non-trivial photometric parameters: per-frame affine brightness (a, b) in the images and in the initial state,
