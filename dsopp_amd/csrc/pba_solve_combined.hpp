@@ -124,6 +124,15 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     rhs_c = a.comb[combBlockCount(F) * 64 + tid];
     if (a.use_marginal) bm_c = a.bm[tid];
   }
+  // the prior energy of the candidate (kernel tail) is evaluated by the threads 64 .. 64 + K - 1, i.e. on other waves than the
+  // pair-constant refresh it runs beside; their operands are requested here with everything else
+  const int pc = tid - 64;
+  const bool prior_thread = main_wg && pc >= 0 && pc < K;
+  double ab0_p = 0, bm_p = 0;
+  if (prior_thread) {
+    ab0_p = a.st->ab0[pc >> 3][(pc & 7) < 6 ? 0 : (pc & 7) - 6];
+    if (a.use_marginal) bm_p = a.bm[pc];
+  }
   // the block-packed lower triangle: entry e = tid + 256 u, coalesced.  kBatch loads are in flight per thread.
   const int n_entries = combBlockCount(F) * 64;
   constexpr int kBatch = 8;
@@ -497,6 +506,25 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
   }
   SC_STAMP(3);
+  // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312) and the frame part of the
+  // norms acceptStep reports for this candidate (problem.hpp:366-388; read by the next decision from the control block): one
+  // entry per thread of the waves behind wave 0, which meanwhile refreshes the pair constants
+  double part = 0, nstate = 0, nstep = 0;
+  auto priorMath = [&] {
+    if (!a.ctrl || !prior_thread) return;
+    const double xc = epsl[pc] + stpl[pc];
+    if (a.use_marginal) {
+      double sacc = 0;
+      for (int k = 0; k < K; ++k) sacc += a.Hm[pc * K + k] * (epsl[k] + stpl[k]);
+      part += bm_p * xc + 0.5 * xc * sacc;
+    }
+    if ((pc & 7) >= 6) {
+      const double ab = ab0_p + xc;
+      part += 0.5 * ab * a.affine_reg[(pc & 7) - 6] * ab;
+    }
+    nstate = epsl[pc] * epsl[pc] + ((pc & 7) >= 6 ? ab0_p * ab0_p : 0.0);
+    nstep = stpl[pc] * stpl[pc];
+  };
   if (fast_refresh) {
     // FEJ: only the current reprojection / brightness constants move with the state; all inputs are in registers / LDS
     ldsBarrier();
@@ -537,32 +565,15 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       P.b_t = ab0l[2 * t + 1] + epsl[kBlk * t + 7] + stpl[kBlk * t + 7];
       P.b_r = ab0l[2 * r + 1] + epsl[kBlk * r + 7] + stpl[kBlk * r + 7];
     }
+    priorMath();  // (waves 1..: beside the pair constants of wave 0)
+  } else {
+    ldsBarrier();  // the new step is visible
+    priorMath();
   }
   // (without first-estimate Jacobians every pair constant moves with the state: the host launches pairSetupKernel behind this
   // kernel, as it does behind assembleSolveKernel)
   SC_STAMP(4);
   if (a.ctrl) {
-    // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312)
-    double part = 0;
-    if (tid < K) {
-      const double xc = epsl[tid] + stpl[tid];
-      if (a.use_marginal) {
-        double sacc = 0;
-        for (int k = 0; k < K; ++k) sacc += a.Hm[tid * K + k] * (epsl[k] + stpl[k]);
-        part += bm_c * xc + 0.5 * xc * sacc;
-      }
-      if ((tid & 7) >= 6) {
-        const double ab = ab0_c + xc;
-        part += 0.5 * ab * a.affine_reg[(tid & 7) - 6] * ab;
-      }
-    }
-    // frame part of the norms acceptStep reports for this candidate (problem.hpp:366-388): read by the deciding kernel from the
-    // control block
-    double nstate = 0, nstep = 0;
-    if (tid < K) {
-      nstate = epsl[tid] * epsl[tid] + ((tid & 7) >= 6 ? ab0_c * ab0_c : 0.0);
-      nstep = stpl[tid] * stpl[tid];
-    }
     part = waveSum(part);
     nstate = waveSum(nstate);
     nstep = waveSum(nstep);
