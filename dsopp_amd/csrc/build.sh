@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds the HIP library for gfx950 in-tree: dsopp_amd/lib/libdsopp_hip.so
+# Builds the HIP library for gfx950 in-tree: dsopp_amd/lib/libdsopp_hip.so (+ libdsopp_hip_tools.so: counter-calibration kernels)
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
@@ -15,6 +15,8 @@ for src in pyramid pba align depth_estimation comm calibration window_group; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=()
-for src in pyramid pba align depth_estimation comm calibration window_group; do [ -f "$OUT/$src.o" ] && objs+=("$OUT/$src.o"); done
+for src in pyramid pba align depth_estimation comm window_group; do [ -f "$OUT/$src.o" ] && objs+=("$OUT/$src.o"); done
 $HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT/libdsopp_hip.so"
+# measurement aids that are not part of the product (gather kernels of known geometry for the counter calibration, scripts/pmc_target.py)
+[ -f "$OUT/calibration.o" ] && $HIPCC --offload-arch=gfx950 -shared -fPIC "$OUT/calibration.o" -o "$OUT/libdsopp_hip_tools.so"
 echo "built $OUT/libdsopp_hip.so"

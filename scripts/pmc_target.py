@@ -10,6 +10,7 @@
      (the same launches bench.py times).
 Usage: pmc_target.py [c1|large]"""
 import ctypes as C
+import os
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -45,7 +46,8 @@ patterns = {
     "pair": (base + 2 * rng.integers(0, 2, n_lanes), 2, 0),
     "footprint": (base + rng.integers(0, 3, n_lanes), 2, W),
 }
-fn = capi.lib().dsopp_hip_debug_gather_calibration
+tools = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dsopp_amd", "lib", "libdsopp_hip_tools.so"))  # not part of the product library
+fn = tools.dsopp_hip_debug_gather_calibration
 for name, (idx, per_lane, stride) in patterns.items():
     d_idx = torch.from_numpy(idx.astype(np.int64)).to(torch.int32).cuda()  # texel indices < 2^25
     torch.cuda.synchronize()
