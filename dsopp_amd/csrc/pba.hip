@@ -1186,8 +1186,11 @@ void launchRestore(W &w) {
  * Same algorithm, three launches per Gauss-Newton iteration.  A linearisation sweep at the candidate state x + step
  * already contains the candidate's energy (NEW_EVALUATION_POINT) and, if the step is accepted, IS the next linearisation:
  *   round r:  K1  linearise at eps + step_r (step_0 = 0)  [+ calculateIdepths for step_r]
- *             K2' decide step_r from K1's energy, apply accept/reject, then pose-pose + Schur reduction
- *             K3  solve -> step_{r+1}
+ *             K2  pose-pose + Schur reduction into the combined system (lambda of the incoming control block: constant),
+ *                 + one workgroup (64 on the two-stage path) that adds up K1's energy scalars
+ *             K3  prologue: decide step_r from those sums, apply accept / reject (workgroups >= 1: the landmarks);
+ *                 workgroup 0: solve -> step_{r+1}
+ * (large windows: calculateIdepths as a kernel of its own in front of K1, K2 = partial systems + ordered sum, two launches)
  * max_iterations + 1 rounds, one host synchronisation.  A rejected step without force_accept costs one extra round (the
  * sweep re-linearises at the reverted state, which reproduces the system the reference keeps via linear_system_valid).
  * The Schur rows are double-buffered because K1 reads the previous round's rows while writing this round's.
