@@ -14,14 +14,14 @@ from oracle import pyoracle as po  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-BIG = len(sys.argv) > 3 and sys.argv[3] == "big"   # up to 12 frames / 9000 points: two-stage Schur build, several groups per sweep workgroup
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"   # up to 12 frames / 16 000 points: above 12 288 the two-stage Schur build, several groups per sweep workgroup
 if BIG:
     po.set_threads(16)
 bad = 0
 t0 = time.time()
 for case in range(N):
     F = int(rng.integers(2, 13 if BIG else 9))
-    P = int(rng.integers(3000, 9000)) if BIG else int(rng.integers(150, 1200))
+    P = int(rng.integers(6000, 16000)) if BIG else int(rng.integers(150, 1200))
     seed = int(rng.integers(0, 10_000))
     kw = dict(first_estimate_jacobians=int(rng.integers(0, 2)), force_accept=int(rng.integers(0, 2)), max_iterations=int(rng.integers(1, 9)))
     win = syn.make_window(num_frames=F, num_points=P, width=640 if BIG else 320, height=480 if BIG else 240, seed=seed)
