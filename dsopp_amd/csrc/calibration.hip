@@ -1,4 +1,5 @@
-// Counter calibration aid (NOT part of the C-ABI in include/dsopp_hip.h; used by scripts/pmc_target.py only): a gather with the
+// Counter calibration aid (NOT part of the C-ABI in include/dsopp_hip.h nor of libdsopp_hip.so: libdsopp_hip_tools.so, used by
+// scripts/pmc_target.py only): a gather with the
 // access shape of the sweeps' bilinear sampling — every lane reads whole 32-byte texels at data-dependent positions — over a
 // buffer of known geometry, so that FETCH_SIZE of the TCC counters can be converted to bytes for THIS access pattern
 // (MI355X_MICROARCH.md §HBM: the counter is calibrated for wide streaming reads only).
@@ -32,11 +33,10 @@ using namespace dsopp_hip;
 
 extern "C" int dsopp_hip_debug_gather_calibration(const void *texels, const uint32_t *indices, size_t n, int per_lane, size_t row_stride, void *scratch,
                                                   void *stream) {
-  return guarded([&] {
-    if (!texels || !indices || !scratch || per_lane < 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
-    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
-    gatherCalibrationKernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const Texel<double> *>(texels), indices, n, per_lane, row_stride,
-                                                                              static_cast<double *>(scratch));
-    HIP_CHECK(hipGetLastError());
-  });
+  // (self-contained: this file is linked into libdsopp_hip_tools.so, without the product library's error plumbing)
+  if (!texels || !indices || !scratch || per_lane < 1) return -1;
+  const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+  gatherCalibrationKernel<<<grid, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const Texel<double> *>(texels), indices, n, per_lane, row_stride,
+                                                                            static_cast<double *>(scratch));
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
