@@ -26,8 +26,13 @@ for case in range(N):
     kw = dict(first_estimate_jacobians=int(rng.integers(0, 2)), force_accept=int(rng.integers(0, 2)), max_iterations=int(rng.integers(1, 9)))
     win = syn.make_window(num_frames=F, num_points=P, width=640 if BIG else 320, height=480 if BIG else 240, seed=seed)
     o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
-    g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
-    lm_mode = int(rng.integers(0, 3))
+    # one time in three the single-process window group (1..4 landmark shards on this GPU, in-process reducer) instead of a window
+    shards = int(rng.integers(1, 5)) if rng.integers(0, 3) == 0 else 0
+    if shards:
+        g = syn.load_window(capi.HipWindowGroup(capi.default_pba_options(**kw), devices=[0] * shards, transport=capi.TRANSPORT_LOCAL), win)
+    else:
+        g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
+    lm_mode = int(rng.integers(0, 2 if shards else 3))   # (lm_mode 2, the unfused device loop, is a single-window debugging aid)
     g.set_lm_mode(lm_mode)
     g.set_deterministic(bool(rng.integers(0, 2)))
     eo, ito, nvo = o.solve()
@@ -41,7 +46,7 @@ for case in range(N):
         lo, lg = o.get_landmarks(f.frame_id), g.get_landmarks(f.frame_id, False)
         ok = ok and np.array_equal(lo["flags"], lg["flags"]) and np.allclose(lo["idepth"], lg["idepth"], rtol=1e-6, atol=1e-9)
     ok = ok and worst <= 1e-6
-    print(f"case {case}: F={F} P={P} seed={seed} {kw} lm_mode={lm_mode}  it {ito}/{itg} nv {nvo}/{nvg} pose diff {worst:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {case}: F={F} P={P} seed={seed} {kw} lm_mode={lm_mode} shards={shards}  it {ito}/{itg} nv {nvo}/{nvg} pose diff {worst:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
     g.close()
 print(f"{N - bad}/{N} cases agree, {time.time() - t0:.0f} s")
