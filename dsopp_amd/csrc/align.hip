@@ -737,7 +737,7 @@ struct AlignPyramidResult {
   int failed;        // a bounded spin timed out: nothing in here is valid
   int lm_iterations; // sum over the levels
   int same_xcd;      // all participants ran on one XCD: passes after the first exchanged through that XCD's L2
-  int pad_r;
+  int end_phase;     // buffer phase (pass counter mod 3) the NEXT launch has to start with: the slots stay armed across launches
   double rmse[DSOPP_HIP_MAX_LEVELS];
   int iterations[DSOPP_HIP_MAX_LEVELS];
   int n_valid[DSOPP_HIP_MAX_LEVELS];
@@ -758,9 +758,10 @@ struct AlignPyramidArgs {
   double sigma_huber, affine_reg[2], function_tolerance, parameter_tolerance, decrease_on_accept, increase_on_reject, lambda0;
   double T_tr0[12];
   double ab0[2];
-  double *partials;        // [2][gridDim.x][kAlignPartial]
+  double *partials;        // [kPyramidBuffers][kPyramidMaxWorkgroups][kAlignPartial]
   unsigned *failed;        // == kPyramidFailed once a workgroup gave up waiting (anything else: running); behind the partial buffers
   AlignPyramidResult *out;
+  int start_phase;         // pass counter (mod 3) this launch continues from: which of the three buffers its first pass publishes into
   int spread;              // launch = spread x participants; every spread-th workgroup takes part (8: one XCD, 1: no placement attempt)
 };
 
@@ -872,11 +873,16 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         else
           __hip_atomic_store((gu64 *)addr, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       };
+      // (the slot layout does not depend on G and the pass counter continues from the previous launch, so the buffers stay armed from
+      // launch to launch and the host fills them only once: a workgroup re-arms its own slot and the slots blk + G, blk + 2 G, ...
+      // no participant of THIS launch owns — a previous launch with more participants may have left sums there)
+      const unsigned buf_pass = static_cast<unsigned>(a.start_phase) + pass_global;
       if (tid < kAlignPartial)
-        publish(a.partials + (static_cast<size_t>((pass_global + 1u) % kPyramidBuffers) * G + blk) * kAlignPartial + tid, kPyramidSentinel);
+        for (int slot = blk; slot < kPyramidMaxWorkgroups; slot += G)
+          publish(a.partials + (static_cast<size_t>((buf_pass + 1u) % kPyramidBuffers) * kPyramidMaxWorkgroups + slot) * kAlignPartial + tid, kPyramidSentinel);
       // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
       const int first = blk * kAlignThreads + tid;
-      double *dst = a.partials + (static_cast<size_t>(pass_global % kPyramidBuffers) * G + blk) * kAlignPartial;
+      double *dst = a.partials + (static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups + blk) * kAlignPartial;
       if (blk * kAlignThreads < L.n_points) {
         double acc[kAlignPartial];
         if (preloaded) {
@@ -935,7 +941,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       {
         constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
         const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
-        const double *src = a.partials + static_cast<size_t>(pass_global % kPyramidBuffers) * G * kAlignPartial + e;
+        const double *src = a.partials + static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial + e;
         if (grp < kGroups) {
           // all loads of this thread are issued before the first test: clamped indices + a 0 / 1 factor instead of predicated
           // loads (G <= 64: at most 13 per thread, one round trip per poll)
@@ -1027,6 +1033,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   __syncthreads();
   if (blk == 0 && tid == 0) {
     a.out->same_xcd = s_same_xcd;
+    a.out->end_phase = static_cast<int>((static_cast<unsigned>(a.start_phase) + pass_global) % kPyramidBuffers);
     a.out->levels_done = levels_done;
     a.out->success = success;
     a.out->failed = 0;
@@ -1063,6 +1070,7 @@ struct dsopp_hip_aligner {
 
   DeviceBuffer<AlignPyramidResult> d_pyr_out;
   AlignPyramidResult *h_pyr_out = nullptr;     // pinned
+  int pyr_phase = -1;  // buffer phase the next persistent launch starts with; -1: the exchange buffers have to be (re)armed by a fill first
   bool pyramid_kernel_disabled = false;        // a bounded spin timed out once (GPU shared with other work): stay on the launch-per-iteration path
   bool have_rotation_prior = false;  // setRotationPrior, cleared by reset() (eigen_pose_alignment.cpp:254-263)
   double rotation_prior[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -1661,8 +1669,15 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         args.partials = a->d_pyr_partials.ptr;
         args.failed = reinterpret_cast<unsigned *>(a->d_pyr_partials.ptr + n_partial);
         args.out = a->h_pyr_out;  // pinned host memory: the kernel leaves its result there itself (no copy kernel behind it)
-        // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill per call
-        HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
+        // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill — before the first
+        // launch and after a failed one only; a launch leaves the buffers armed for its successor (the pass counter continues, the
+        // kernel re-arms by its rotation rule), which saves two fill kernels (10 us) per tracked frame
+        if (a->pyr_phase < 0) {
+          HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
+          a->pyr_phase = 0;
+        }
+        args.start_phase = a->pyr_phase;
+        a->pyr_phase = -1;  // (until this launch has reported how it left the buffers)
         static const int spread_override = std::getenv("DSOPP_HIP_ALIGN_SPREAD") ? std::atoi(std::getenv("DSOPP_HIP_ALIGN_SPREAD")) : 0;  // tuning aid
         args.spread = spread_override > 0 ? spread_override : 8;
         if (a->opt.dtype == DSOPP_HIP_F64)
@@ -1682,6 +1697,7 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
           a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
           return;
         }
+        a->pyr_phase = o.end_phase;  // the buffers are armed for a launch that continues the pass counter from here
         fast = 1;
         lm_iterations += o.lm_iterations;
         success = o.success != 0;

@@ -371,3 +371,51 @@ def test_estimate_pose_persistent_launch_equals_launch_per_iteration(size):
     assert np.allclose(r0["rmse"], s0["rmse"], rtol=1e-12) and np.allclose(r1["rmse"], s1["rmse"], rtol=1e-12)
     for obj in (maps, pr, pt, g):
         obj.close()
+
+
+@pytest.mark.gpu
+def test_persistent_launches_with_changing_participant_counts():
+    """The exchange buffers of the persistent alignment launch stay armed from launch to launch (the pass counter continues, a
+    workgroup re-arms by rotation; the host fills them once).  The number of participating workgroups follows the depth maps' point
+    counts, so ONE aligner is driven alternately against a sparse and a dense window's maps — few, many, few, many participants,
+    failed hypotheses in between — and every call must reproduce the launch-per-iteration path of a fresh aligner."""
+    from dsopp_amd import capi
+    W, H, L = 640, 480, 4
+    scenes = []
+    for n_points, seed in ((160, 31), (6000, 32)):
+        win = syn.make_window(num_frames=4, num_points=n_points, width=W, height=H, seed=seed)
+        g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+        g.solve()
+        maps = g.create_reference_depth_maps(L)
+        newest, target = win.frames[-1], win.frames[-2]
+        pr, pt = capi.Pyramid(W, H, L), capi.Pyramid(W, H, L)
+        pr.build(newest.image_u8)
+        pt.build(target.image_u8)
+        T_ref, ab_ref = g.get_pose(newest.frame_id)
+        T_good = syn.mat_to_params(target.T_w_c_init)
+        T_bad = syn.mat_to_params(target.T_w_c_gt @ syn.se3_exp(np.array([1.5, -1.0, 0.8, 0.3, -0.4, 0.25])))
+        scenes.append(dict(win=win, g=g, maps=maps, pr=pr, pt=pt, T_ref=T_ref, ab_ref=ab_ref, newest=newest, hyp=np.stack([T_bad, T_good])))
+
+    def call(a, sc, k):
+        rmse_last = np.full(L, 1e10)
+        r = a.estimate_pose(sc["newest"].timestamp, sc["T_ref"], sc["pr"], sc["maps"], 1.0, sc["ab_ref"], sc["newest"].timestamp + 1 + k, sc["pt"], 1.0,
+                            sc["win"].scene.intrinsics, sc["hyp"][1:] if k % 2 == 0 else sc["hyp"], np.zeros(2), rmse_last)
+        return r, rmse_last
+
+    persistent = capi.HipAligner(capi.default_align_options())
+    persistent.set_lm_path(0)
+    order = [0, 1, 0, 0, 1, 1, 0, 1]
+    for k, which in enumerate(order):
+        sc = scenes[which]
+        ra, rmse_a = call(persistent, sc, k)
+        fresh = capi.HipAligner(capi.default_align_options())
+        fresh.set_lm_path(1)
+        rb, rmse_b = call(fresh, sc, k)
+        fresh.close()
+        assert ra["success"] == rb["success"] and ra["tries"] == rb["tries"] and ra["lm_iterations"] == rb["lm_iterations"], (k, which, ra, rb)
+        assert np.abs(ra["T_w_target"] - rb["T_w_target"]).max() <= 1e-12, (k, which)
+        assert np.allclose(rmse_a, rmse_b, rtol=1e-12), (k, which)
+    persistent.close()
+    for sc in scenes:
+        for obj in (sc["maps"], sc["pr"], sc["pt"], sc["g"]):
+            obj.close()
