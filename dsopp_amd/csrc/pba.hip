@@ -1386,10 +1386,10 @@ Rigid poseOf(const W &w, int f) {
 /** relinearizeSystem — PROB_SRC/photometric_bundle_adjustment.cpp:310-316 (on the device state; the host mirror follows lazily) */
 void relinearize(W &w) {
   prepareDevice(w);
-  relinearizeKernel<<<1, 64, 0, w.sr.stream>>>(w.d_state.ptr, w.F() - 1);
+  relinearizeKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), w.fej() ? 1 : 0, w.F() - 1);
   HIP_CHECK(hipGetLastError());
   w.host_stale = true;
-  w.pair_valid = false;
+  w.pair_valid = true;  // (set up by the same launch)
 }
 
 /** updatePointStatuses on the device: exact 3rd-quartile order statistic by an 8-pass radix select over the energies where
@@ -1398,9 +1398,11 @@ void updatePointStatusesDevice(W &w) {
   prepareDevice(w);
   hipStream_t st = w.sr.stream;
   const int F = w.F();
-  w.d_select.reserve(1, 0, st);
+  if (!w.d_select.ptr) {
+    w.d_select.reserve(1, 0, st);
+    selectInitKernel<<<1, 1024, 0, st>>>(w.d_select.ptr);  // once: every select leaves the state ready for the next (selectFinish)
+  }
   w.d_pair_dist.reserve(static_cast<size_t>(kMaxFrames) * kMaxFrames, 0, st);
-  selectInitKernel<<<1, 1024, 0, st>>>(w.d_select.ptr);
   const double half_sigma_sq = w.opt.sigma_huber_loss * w.opt.sigma_huber_loss / 2;
   if (w.n_sweep_blocks) {
     const int per_group = kSelectThreads / kItemsPerBlock;

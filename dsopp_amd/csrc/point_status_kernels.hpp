@@ -193,6 +193,9 @@ __device__ inline void selectFinish(SelectState *s, double half_sigma_sq, unsign
     s->n_ok[0] = l.n_ok;
     s->threshold = l.n_ok > 0 ? __longlong_as_double(static_cast<long long>(l.prefix)) + half_sigma_sq : 0.0;
   }
+  // leave the state as the next select needs it: only the top pass's histogram has to be zero when that pass starts (every other
+  // one is cleared by the pass before it), and it still holds this select's second-last pass — no initialisation launch per select
+  for (int k = threadIdx.x; k < kSelectBins; k += THREADS) s->hist[(kSelectPasses - 1) % 3][k] = 0;
 }
 
 /** current camera-centre distances between all frame pairs: |t_r - t_t| of T = T0 exp(eps) (:380-382) */
@@ -300,8 +303,7 @@ __global__ void exportFramesKernel(FrameExportBatch b) {
 }
 
 /** relinearizeSystem — :310-316: the newest frame's linearisation point moves to its current estimate */
-__global__ void relinearizeKernel(WindowState *st, int f) {
-  if (threadIdx.x != 0) return;
+__device__ inline void relinearizeFrame(WindowState *st, int f) {
   Rigid T0;
   for (int i = 0; i < 9; ++i) T0.R[i] = st->T0_R[f][i];
   for (int i = 0; i < 3; ++i) T0.t[i] = st->T0_t[f][i];
@@ -314,6 +316,16 @@ __global__ void relinearizeKernel(WindowState *st, int f) {
   st->ab0[f][0] += st->eps[f][6];
   st->ab0[f][1] += st->eps[f][7];
   for (int a = 0; a < kBlk; ++a) st->eps[f][a] = 0;
+}
+
+/** relinearizeSystem and, in the same launch, the pair constants at the new linearisation point (the covariance linearisation of
+ *  solve() — or the next solve — needs them next: one launch instead of two).  One workgroup of kMaxFrames^2 threads. */
+__global__ void __launch_bounds__(kMaxFrames *kMaxFrames) relinearizeKernel(const FrameDev *frames, WindowState *st, PairConst *pc, int F, int fej, int f) {
+  if (threadIdx.x == 0) relinearizeFrame(st, f);
+  __syncthreads();  // (one workgroup, one L1: the new state is visible to its other waves)
+  const int idx = threadIdx.x;
+  if (idx >= F * F) return;
+  computePairConst(frames, st, pc, idx / F, idx % F, F, fej != 0);
 }
 
 }  // namespace dsopp_hip
