@@ -77,6 +77,11 @@ struct AbortableBarrier {
     std::lock_guard<std::mutex> lk(m);
     cv.notify_all();
   }
+  /** between two jobs of the pool (no worker is inside wait()): workers that gave up during an aborted job left their arrivals behind */
+  void reset() {
+    std::lock_guard<std::mutex> lk(m);
+    arrived = 0;
+  }
 };
 
 struct LocalReducer {
@@ -194,6 +199,7 @@ struct ShardPool {
       std::lock_guard<std::mutex> lk(m);
       job = std::move(fn);
       remaining = n;
+      if (abort.load() && barrier) barrier->reset();  // the previous job was aborted inside a collective
       abort.store(false);
       ++generation;
     }
