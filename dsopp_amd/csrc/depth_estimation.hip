@@ -101,6 +101,15 @@ __device__ inline double triInverseDepth(const Tri &t, double px, double py) {
   return idepth;
 }
 
+/** 1 / x for the projective divisions of the discrete search: v_rcp_f64 + two Newton steps (~1 ulp, 5 instructions instead of ~13 per
+ *  IEEE division; as the window's sweeps, pba_kernels.hpp: fastRcp).  x = 0 -> inf -> NaN, rejected by the z > 0 / ROI tests. */
+__device__ __forceinline__ double depthRcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 /** checked single-point reprojection (ArrayReprojector<..., true>::reproject, camera_reproject.hpp:270-293) */
 __device__ inline bool reproject1(const DepthFrame &f, double u, double v, double idepth, double &tu, double &tv) {
   const double W = f.width, H = f.height;
@@ -406,7 +415,8 @@ __device__ __forceinline__ void estimateDepthsBody(const DepthFrame &f, const De
         const double x = f.M[0] * u + f.M[1] * v + (f.M[2] + f.M[3] * pt.idepth);
         const double y = f.M[4] * u + f.M[5] * v + (f.M[6] + f.M[7] * pt.idepth);
         const double z = f.M[8] * u + f.M[9] * v + (f.M[10] + f.M[11] * pt.idepth);
-        const double tu = x / z, tv = y / z;
+        const double iz = depthRcp(z);  // (two divisions per pattern pixel were a quarter of the discrete search's instructions)
+        const double tu = x * iz, tv = y * iz;
         ok = ok && (z > 0) && insideROI(tu, tv, static_cast<double>(W), static_cast<double>(H));
         if (ok) {
           const double r = (sampleI(img, W, tu, tv) - f.b_t) - precalc[k];
@@ -574,8 +584,16 @@ __device__ __forceinline__ void estimateDepthsBody(const DepthFrame &f, const De
   finish(2 * error_step * 10.0, kImGood);
 }
 
+#ifndef DSOPP_DEPTH_WAVES
+#define DSOPP_DEPTH_WAVES 4  // 141 -> 128 registers: 4 waves per SIMD, 90.9 -> 88.9 us at 14 000 landmarks (5 and 6 spill: 105 / 130 us)
+#endif
+#if DSOPP_DEPTH_WAVES > 0
+#define DSOPP_DEPTH_BOUNDS __launch_bounds__(64, DSOPP_DEPTH_WAVES)
+#else
+#define DSOPP_DEPTH_BOUNDS __launch_bounds__(64)
+#endif
 template <typename S>
-__global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLandmarks L) {
+__global__ void DSOPP_DEPTH_BOUNDS estimateDepthsKernel(DepthFrame f, DepthLandmarks L) {
   extern __shared__ double energies[];  // [f.max_line]
   estimateDepthsBody<S>(f, L, blockIdx.x, energies);
 }
@@ -583,7 +601,7 @@ __global__ void __launch_bounds__(64) estimateDepthsKernel(DepthFrame f, DepthLa
 /** the same over several keyframes' sets in one launch (blockIdx.y = set): the estimator runs for every keyframe of the
  *  window on every frame (monocular_tracker.cpp:74-102), so one dispatch fills the machine instead of seven partial ones */
 template <typename S>
-__global__ void __launch_bounds__(64) estimateDepthsBatchKernel(const DepthFrame *__restrict__ frames, const DepthLandmarks *__restrict__ landmarks) {
+__global__ void DSOPP_DEPTH_BOUNDS estimateDepthsBatchKernel(const DepthFrame *__restrict__ frames, const DepthLandmarks *__restrict__ landmarks) {
   extern __shared__ double energies[];
   const DepthFrame f = frames[blockIdx.y];
   if (static_cast<int>(blockIdx.x) >= f.n) return;
