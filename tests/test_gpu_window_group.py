@@ -308,3 +308,24 @@ def test_group_of_one_is_a_plain_window_and_bad_arguments_are_refused():
     e, it, nv = gg.solve()
     assert it > 0 and nv > 0
     gg.close()
+
+
+def test_group_large_window_takes_the_two_stage_sharded_path():
+    """12 keyframes / 50 000 landmarks (BASELINE.json configs[4]) on two shards: each shard is above the two-stage threshold, so the
+    shards build their partial systems without atomics, send the sweep's energy scalars as 64 group sums in the one collective, the
+    solve launch decides from them, and the closing round sums through the group kernels — the sharded solve must reproduce the single
+    window's (same iteration count, same residual count, poses and energy to rounding)"""
+    from dsopp_amd import capi
+    win = syn.make_window(num_frames=12, num_points=50000, width=640, height=480, seed=1)
+    g1, gg = _single_and_group(win, 2)
+    e1, it1, nv1 = g1.optimize()
+    e2, it2, nv2 = gg.optimize()
+    assert (it1, nv1) == (it2, nv2) and it1 == 7 and abs(e1 - e2) <= 1e-9 * abs(e1)
+    for f in win.frames:
+        (T1, ab1), (T2, ab2) = g1.get_pose(f.frame_id), gg.get_pose(f.frame_id)
+        assert np.abs(T1 - T2).max() <= 1e-9 and np.abs(ab1 - ab2).max() <= 1e-9, f.frame_id
+    f = win.frames[3]
+    l1, l2 = g1.get_landmarks(f.frame_id, False), gg.get_landmarks(f.frame_id, False)
+    assert _close(l2["idepth"], l1["idepth"], 1e-9, 1e-12)
+    g1.close()
+    gg.close()
