@@ -13,7 +13,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdsopp_hip.so")
+# DSOPP_HIP_LIB: measurement aid — another build of the same library (an earlier round's, for before / after counters in one run)
+LIB_PATH = os.environ.get("DSOPP_HIP_LIB") or os.path.join(_HERE, "lib", "libdsopp_hip.so")
 
 F64, F32 = 0, 1
 NUM_KERNEL_CLASSES = 11

@@ -648,9 +648,6 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.dbg = (w.dbg_sweep && lin == w.dbg_sweep_lin) ? w.dbg_sweep : nullptr;
   dim3 grid(static_cast<unsigned>(w.n_sweep_blocks)), block(kSweepThreads);
   hipStream_t st = w.sr.stream;
-  // more than ~3 workgroups per CU: the LDS of the workgroup reduction bounds the occupancy, take the two-pass variant
-  static const int small_lds_override = std::getenv("DSOPP_HIP_SWEEP_SMALL_LDS") ? std::atoi(std::getenv("DSOPP_HIP_SWEEP_SMALL_LDS")) : -1;
-  const bool small_lds = small_lds_override >= 0 ? small_lds_override != 0 : w.n_sweep_blocks > 3 * 256;
   const FrameDev *fr = w.d_frames.ptr;
   const PairConst *pc = w.d_pc.ptr;
   const SweepBlock *tb = w.d_sweep_table.ptr;
@@ -660,15 +657,10 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
     if (opening) {
       // opening linearisation of a fused solve: first-estimate snapshot taken by the sweep itself, no back-substitution
-      if (small_lds)
-        sweepKernel<S, true, true, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-      else
-        sweepKernel<S, true, true, true, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      sweepKernel<S, true, true, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
     } else if (lin && ex.fused_lin_backsub) {
       // fused LM loop: linearisation at the candidate state = its energy evaluation + calculateIdepths in one pass
-      if (w.fej() && small_lds)
-        sweepKernel<S, true, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-      else if (w.fej())
+      if (w.fej())
         sweepKernel<S, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
       else
         sweepKernel<S, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
@@ -683,9 +675,7 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
       else
         sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
     } else if (w.fej()) {
-      if (huber && small_lds)
-        sweepKernel<S, true, true, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
-      else if (huber)
+      if (huber)
         sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
       else
         sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);

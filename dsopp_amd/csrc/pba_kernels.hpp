@@ -360,48 +360,98 @@ __device__ __forceinline__ double fastRsqrt(double x) {
   return y;
 }
 
-constexpr int kRedStride = kSweepThreads + 2;  // even (16-byte aligned rows), 4-bank skew between rows for ds_read_b128
+using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-/**
- * Workgroup sum of acc[FIRST .. FIRST+COUNT) through an LDS transpose: every lane stores its COUNT values as columns
- * (conflict-free ds_write_b64), then lane e < COUNT adds up row e with ds_read_b128 and writes partials[FIRST + e].
- * (A shuffle tree of 48 doubles costs 288 dependent ds_bpermute round trips — measured 10 us per workgroup.)
- */
-template <int FIRST, int COUNT>
-__device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], double *lds /* [COUNT][kRedStride] */,
-                                                 double *__restrict__ out /* [kPartial] */) {
-  const int t = threadIdx.x;
+// ---- the per-pair Gram G = sum w g^T g, q = sum w g^T r on the f64 matrix cores -------------------------------------------
+// Until round 4 every lane kept the 36 + 8 running sums of its own pattern pixel in registers (96 VGPRs: the sweep ran at 2 waves per
+// SIMD, VALU busy 37 %, bound by its own dependent latencies) and the workgroup summed 48 x 128 values through an LDS transpose.  Now a
+// lane hands the two 8-vectors of its pixel
+//     a = w [g0 .. g6, r]      b = [g0 .. g6, 1]                               (g7 = 1: evaluate_jacobians.hpp:181)
+// to the wave through LDS and v_mfma_f64_16x16x4_f64 contracts them over the pixels: E = sum_p a(p) b(p)^T holds
+//     E[i][j] = G[i][j] (i, j < 7),  E[i][7] = G[i][7],  E[7][j] = q[j],  E[7][7] = q[7];
+// only G[7][7] = sum w is left to a scalar.  One instruction contracts 4 values of k; its 16 rows / columns carry TWO pixel sets
+// (rows and columns 0..7: pixels 0..3 of an item, 8..15: pixels 4..7), whose products sit in the two diagonal 8 x 8 blocks of the
+// result (the off-diagonal blocks are cross terms nobody reads): 8 instructions per 64 pixels, 8 accumulator registers per lane
+// instead of 96, and the sum over lanes is the instruction's own.  (hessian_block_evaluation.hpp:74-83 is what this accumulates.)
+constexpr int kGramStride = 18;  // doubles per pixel: a[8] | b[8] | pad 2 — 144 B: the two 8-double runs a 16-lane read touches
+                                 // (pixels 4 apart) fall on disjoint halves of the 32 banks, b128 stores of 8 adjacent lanes cover all
+constexpr int kSweepScalars = 5; // energy, n_valid, |idepth step|^2, idepth . step, sum of weights (= G[7][7])
+
+/** hands (a, b) of this lane's pixel to the wave: its row of the wave's exchange buffer */
+__device__ __forceinline__ void gramPublish(const double (&a)[kBlk], const double (&b)[kBlk], double *wave_rows /* [64][kGramStride] */) {
+  const int lane = threadIdx.x & 63;
+  double2 *row = reinterpret_cast<double2 *>(wave_rows + lane * kGramStride);
 #pragma unroll
-  for (int e = 0; e < COUNT; ++e) lds[e * kRedStride + t] = acc[FIRST + e];
+  for (int c = 0; c < kBlk / 2; ++c) {
+    row[c] = double2{a[2 * c], a[2 * c + 1]};
+    row[kBlk / 2 + c] = double2{b[2 * c], b[2 * c + 1]};
+  }
+}
+
+/** adds the products of the 64 published pixels to acc.  The sweep calls this for group g - 1 right behind the texel requests of
+ *  group g: the eight dependent matrix instructions (64 cycles each) and the LDS round trip in front of them run in the shadow of
+ *  the gather's memory latency instead of on the group's own critical path.  (LDS instructions of one wave execute in order: these
+ *  reads see the wave's stores, and the next group's stores come after them — no barrier, only the compiler is kept in line.) */
+__device__ __forceinline__ void gramContract(const double *wave_rows /* [64][kGramStride] */, f64x4 &acc) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // operand lane l = (m = l & 15, k = l >> 4) of step s reads value m & 7 of pixel 8 s + 4 (m >> 3) + k
+  const double *src = wave_rows + (4 * ((lane & 15) >> 3) + (lane >> 4)) * kGramStride + (lane & 7);
+  double av[8], bv[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    av[s] = src[8 * s * kGramStride];
+    bv[s] = src[8 * s * kGramStride + kBlk];
+  }
+  asm volatile("" ::: "memory");  // (all sixteen operands are requested before the first instruction waits for one)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+/** end of a sweep workgroup: the waves' Gram accumulators and scalars -> partials[kPartial] of the workgroup (fixed order) */
+template <bool LIN>
+__device__ __forceinline__ void gramScalarsStore(const f64x4 &acc, const double (&sc)[kSweepScalars], double *lds /* [waves][64 + kSweepScalars] */,
+                                                 double *__restrict__ out) {
+  constexpr int kWaves = kSweepThreads / 64, kSlot = 64 + kSweepScalars;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // result layout of the instruction: register v of lane l = entry (row (l >> 4) + 4 v, column l & 15).  Lanes with column < 8 hold
+  // the first set's block in registers 0, 1; the second set's block (rows / columns 8..15) sits in registers 2, 3 of the lanes 8 to
+  // the right in the same row of 16 (row_ror:8)
+  const double e0 = acc[0] + dppMove<0x128>(acc[2]), e1 = acc[1] + dppMove<0x128>(acc[3]);
+  double s[kSweepScalars];
+#pragma unroll
+  for (int i = 0; i < kSweepScalars; ++i) s[i] = waveSumDpp(sc[i]);
+  const int col = lane & 15, r4 = lane >> 4;
+  if (LIN && col < 8) {
+    lds[wave * kSlot + 8 * r4 + col] = e0;             // E[r4][col]
+    lds[wave * kSlot + 8 * (r4 + 4) + col] = e1;       // E[r4 + 4][col]
+  }
+  if (lane < kSweepScalars) {
+    double v = s[0];
+#pragma unroll
+    for (int i = 1; i < kSweepScalars; ++i) v = lane == i ? s[i] : v;
+    lds[wave * kSlot + 64 + lane] = v;
+  }
   ldsBarrier();
-  // two adjacent lanes per row (each sums one half, fixed order), combined with one DPP swap: both waves take part
-  // instead of 48 lanes of one wave walking 128 entries each
-  if (2 * COUNT <= kSweepThreads) {
-    const int row_idx = t >> 1, half = t & 1;
-    double s = 0;
-    if (row_idx < COUNT) {
-      const double2 *row = reinterpret_cast<const double2 *>(lds + row_idx * kRedStride) + half * (kSweepThreads / 4);
-      double s0 = 0, s1 = 0;
-#pragma unroll 8
-      for (int j = 0; j < kSweepThreads / 4; ++j) {
-        const double2 p = row[j];
-        s0 += p.x;
-        s1 += p.y;
-      }
-      s = s0 + s1;
+  if (threadIdx.x < kSlot && (LIN || threadIdx.x >= 64)) {  // (residual-only sweeps: the four scalars alone)
+    const int e = threadIdx.x;
+    double v = lds[e];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) v += lds[w * kSlot + e];
+    // where entry e goes: E[i][j] -> G upper triangle (i <= j < 7, and column 7), q (row 7); scalars -> 44..47, sum w -> G[7][7]
+    int idx = -1;
+    if (e < 64) {
+      const int i = e >> 3, j = e & 7;
+      if (i < 7) idx = j >= i ? triIdx(i, j) : -1;
+      else idx = 36 + j;
+    } else {
+      idx = e - 64 < 4 ? 44 + (e - 64) : (LIN ? triIdx(7, 7) : -1);
     }
-    const double other = dppMove<0xB1>(s);  // quad_perm [1,0,3,2]: the neighbour lane's half
-    if (row_idx < COUNT && half == 0) out[FIRST + row_idx] = s + other;
-  } else if (t < COUNT) {
-    const double2 *row = reinterpret_cast<const double2 *>(lds + t * kRedStride);
-    double s0 = 0, s1 = 0;
-#pragma unroll 8
-    for (int j = 0; j < kSweepThreads / 2; ++j) {
-      const double2 p = row[j];
-      s0 += p.x;
-      s1 += p.y;
-    }
-    out[FIRST + t] = s0 + s1;
+    if (idx >= 0) out[idx] = v;
   }
 }
 
@@ -418,13 +468,14 @@ __device__ __forceinline__ void blockReduceStore(const double (&acc)[kPartial], 
  * 1 reprojection -> 4 texel loads (2 x 64 B segments) -> 1 Jacobian row -> reductions, so a C1-sized sweep is one
  * memory round trip deep per stage instead of eight.
  */
-template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool SMALL_LDS = false, bool WFEJ = false>
+template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool WFEJ = false>
 __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
-  // SMALL_LDS (large windows: many workgroups per CU): the 48 partials cross LDS in two halves of 24 — 25 KB instead of 50 KB
-  // per workgroup, which is what bounds the occupancy of the linearisation sweep (3 -> 6 workgroups per CU)
-  __shared__ __attribute__((aligned(16))) double red_lds[(LIN ? (SMALL_LDS ? kPartial / 2 : kPartial) : 4) * kRedStride];
+  // LIN: the exchange buffer of the Gram accumulation (gramAccumulate: one row of kGramStride doubles per pattern pixel);
+  // the four energy scalars (+ sum of weights) cross the workgroup through kSweepScalars doubles per wave
+  __shared__ __attribute__((aligned(16))) double gram_lds[LIN ? kSweepThreads * kGramStride : 2];
+  __shared__ double scalar_lds[(kSweepThreads / 64) * (64 + kSweepScalars)];
   // ---- round trip 1: block descriptor + LM control block (scalar loads, all requested before any of them is tested)
   const SweepBlock be = table[blockIdx.x];
   int c_active = 1, c_lsv = 0, c_pending = 1, run = 1;
@@ -457,9 +508,10 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   const int ox = static_cast<int>((0x21420312u >> (4 * k)) & 0xFu) - 2;
   const int oy = static_cast<int>((0x01222334u >> (4 * k)) & 0xFu) - 2;
 
-  double acc[kPartial];
+  double sc[kSweepScalars];  // energy, n_valid, |idepth step|^2, idepth . step, sum of weights
 #pragma unroll
-  for (int e = 0; e < kPartial; ++e) acc[e] = 0;
+  for (int e = 0; e < kSweepScalars; ++e) sc[e] = 0;
+  f64x4 gram = {0, 0, 0, 0};
 
   // Large windows (hundreds of thousands of items) give a workgroup several groups of 16 items of its frame pair
   // (SweepBlock::n_groups, chosen by the host): the 48 workgroup sums are reduced once per workgroup instead of once per 16
@@ -473,33 +525,29 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     double idepth_d, idepth_step_d, idepth_fej_d;
   };
   auto loadItemWords = [&](int item, bool in_bounds) {
+    // lanes past the pair's last residual read the block's first item instead (a valid index): they are inactive below and nothing
+    // of what they load is used — no exec-masked region, no default values to materialise
+    const int j = in_bounds ? item : be.offset;
     ItemWords w;
-    w.flg = 0;
-    w.status = DSOPP_HIP_STATUS_OOB;
-    w.cand = DSOPP_HIP_STATUS_OOB;
+    w.flg = g_flags[j];
+    w.u = static_cast<S>(g_uv[2 * j]);
+    w.v = static_cast<S>(g_uv[2 * j + 1]);
+    w.idepth_d = g_idepth[j];
+    w.idepth_step_d = g_idepth_step[j];
+    w.status = g_status[j];
+    w.cand = g_cand[j];
+    w.patch_k = static_cast<S>(g_patch[kPat * j + k]);
     w.fej_bit = 1;
-    w.u = w.v = w.patch_k = S(0);
-    w.idepth_d = w.idepth_step_d = w.idepth_fej_d = 0;
-    if (in_bounds) {
-      w.flg = g_flags[item];
-      w.u = static_cast<S>(g_uv[2 * item]);
-      w.v = static_cast<S>(g_uv[2 * item + 1]);
-      w.idepth_d = g_idepth[item];
-      w.idepth_step_d = g_idepth_step[item];
-      w.status = g_status[item];
-      w.cand = g_cand[item];
-      w.patch_k = static_cast<S>(g_patch[kPat * item + k]);
-      if (FEJ) {
-        constexpr bool fresh_fej = LIN && WFEJ;
-        if (prm.use_fej_flag && !fresh_fej) w.fej_bit = g_fej_valid[item];  // evaluate_jacobians.hpp:94
-        if (LIN) w.idepth_fej_d = fresh_fej ? w.idepth_d : g_idepth_fej[item];
-      }
+    w.idepth_fej_d = 0;
+    if (FEJ) {
+      constexpr bool fresh_fej = LIN && WFEJ;
+      if (prm.use_fej_flag && !fresh_fej) w.fej_bit = g_fej_valid[j];  // evaluate_jacobians.hpp:94
+      if (LIN) w.idepth_fej_d = fresh_fej ? w.idepth_d : g_idepth_fej[j];
     }
     return w;
   };
-  const bool prefetching = be.n_groups > 1;
-  ItemWords nxt{};
-  if (prefetching) {
+  ItemWords nxt;
+  {
     const int i0 = be.offset + (threadIdx.x >> 3);
     nxt = loadItemWords(i0, i0 < be.n_res);
   }
@@ -525,7 +573,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   for (int c = 0; c < kBlk; ++c) hrow[c] = srow[c] = 0;
   const size_t plane = ublkPlane(be.cap);
   {
-    const ItemWords cur = prefetching ? nxt : loadItemWords(i, inb);
+    const ItemWords cur = nxt;
     flg = cur.flg;
     u = cur.u;
     v = cur.v;
@@ -610,26 +658,24 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   ok = ok && insideROI(tu, tv, Wt, Ht);
 
   // ---- the next group's item words go out in front of this group's texel gather (in-order return: they land with it)
-  if (prefetching) {
+  if (grp + 1 < be.n_groups) {  // (wave-uniform)
     const int in = i + kItemsPerBlock;
-    nxt = loadItemWords(in, grp + 1 < be.n_groups && in < be.n_res);
+    nxt = loadItemWords(in, in < be.n_res);
     asm volatile("" ::: "memory");  // (keeps the compiler from sinking these loads to their uses in the next iteration)
   }
   // ---- bilinear gather of the stored (I, Ix, Iy) triplet + mask lookup at the rounded position
   // (pixel_map.hpp:20-40, camera_mask.hpp:64-66); a lane only touches the image when its own pixel is inside the ROI
   S sI = S(0), sIx = S(0), sIy = S(0);
-  if (ok) {
-    const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(be.texels_t);
-    const int W = be.width_t;
-    const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
-    const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy);
-    const S dxdy = dx * dy;
-    const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
-    const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
-    const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
-    if (!LIN && std::is_same<S, double>::value && be.iplane_t != nullptr) {
+  double *const gram_rows = gram_lds + (LIN ? (threadIdx.x >> 6) * 64 * kGramStride : 0);
+  if (!LIN && std::is_same<S, double>::value && be.iplane_t != nullptr) {
+    if (ok) {
       // residual-only sweep: 8 bytes per pixel from the tiled intensity plane (mask in the lowest mantissa bit) instead of
       // four 32-byte texels of which only {I, mask} are used
+      const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
+      const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy);
+      const S dxdy = dx * dy;
+      const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+      const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
       const auto ip = (GlobalPtr<const unsigned long long>)be.iplane_t;
       const int tiles = be.itiles_t;
       auto at = [&](int x, int y) { return ip[(static_cast<size_t>(y >> 1) * tiles + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3)]; };
@@ -638,8 +684,31 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       ok = (bm & 1ull) != 0;
       auto val = [](unsigned long long b) { return static_cast<S>(__longlong_as_double(static_cast<long long>(b & ~1ull))); };
       sI = w11 * val(b11) + w01 * val(b01) + w10 * val(b10) + w00 * val(b00);
-    } else {
-      const Texel<S> t00 = loadTexel(p), t10 = loadTexel(p + 1), t01 = loadTexel(p + W), t11 = loadTexel(p + W + 1);
+    }
+  } else {
+    // the four texels are requested ...
+    Texel<S> t00{}, t10{}, t01{}, t11{};
+    const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
+    if (ok) {
+      const Texel<S> *__restrict__ img = static_cast<const Texel<S> *>(be.texels_t);
+      const int W = be.width_t;
+      const Texel<S> *p = img + static_cast<size_t>(iy) * W + ix;
+      t00 = loadTexel(p);
+      t10 = loadTexel(p + 1);
+      t01 = loadTexel(p + W);
+      t11 = loadTexel(p + W + 1);
+    }
+    // ... and while they travel the wave contracts the previous group's Gram rows (gramContract)
+    if (LIN && grp > 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      gramContract(gram_rows, gram);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ok) {
+      const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy);
+      const S dxdy = dx * dy;
+      const S w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = S(1) - dx - dy + dxdy;
+      const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
       const S m = ry ? (rx ? t11.mask : t01.mask) : (rx ? t10.mask : t00.mask);
       ok = (m != S(0));
       sI = w11 * t11.I + w01 * t01.I + w10 * t10.I + w00 * t00.I;
@@ -696,8 +765,11 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
 
   if (LIN) {
     double gj[kBlk + 2];  // w * g (8), then hdd, bd contributions
+    double ga[kBlk], gb[kBlk];  // this pixel's rows of the pair's Gram accumulation (gramAccumulate): zero unless evaluated
 #pragma unroll
     for (int a = 0; a < kBlk + 2; ++a) gj[a] = 0;
+#pragma unroll
+    for (int a = 0; a < kBlk; ++a) ga[a] = gb[a] = 0;
     if (evaluate) {
       // geometric Jacobians at the linearisation point (FEJ: idepth snapshot) — camera_reproject.hpp:339-365
       const S idj = FEJ ? static_cast<S>(idepth_fej_d) : idepth;
@@ -724,21 +796,22 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
       g[7] = S(1);
       const double jdd = static_cast<double>(Iu * du_id + Iv * dv_id);  // evaluate_jacobians.hpp:165-174
       const double rk = static_cast<double>(res);
-      int e = 0;
 #pragma unroll
       for (int a = 0; a < kBlk; ++a) {
         const double wga = wgt * static_cast<double>(g[a]);
-        if (accumulate) {
-#pragma unroll
-          for (int b = a; b < kBlk; ++b) acc[e + (b - a)] += wga * static_cast<double>(g[b]);
-          acc[36 + a] += wga * rk;
-        }
-        e += kBlk - a;
         gj[a] = wga * jdd;
+        if (a < kBlk - 1) {
+          ga[a] = accumulate ? wga : 0.0;
+          gb[a] = static_cast<double>(g[a]);
+        }
       }
+      ga[kBlk - 1] = accumulate ? wgt * rk : 0.0;
+      gb[kBlk - 1] = 1.0;
+      if (accumulate) sc[4] += wgt;
       gj[8] = wgt * jdd * jdd;
       gj[9] = wgt * jdd * rk;
     }
+    gramPublish(ga, gb, gram_rows);
     // per-item Schur quantities: sum over the 8 pixels; h_p block of target t is w * J_t^T J_d = -u
     // (hessian_block_evaluation.hpp:207-208), zero for invalid residuals (:190-192).  Transposed butterfly: in every step a lane
     // keeps one value of a pair and hands the other to its partner, so the 8 totals end up one per lane (lane k holds entry
@@ -774,28 +847,21 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     g_energy[i] = energy;
     g_cand[i] = cand;
     if (accumulate) {
-      acc[44] += energy;
-      acc[45] += energy > 0 ? 1.0 : 0.0;
+      sc[0] += energy;
+      sc[1] += energy > 0 ? 1.0 : 0.0;
     }
     if ((!LIN || BACKSUB || prm.external_backsub) && be.owns_landmark_sums) {
       // per-landmark norms of acceptStep (problem.hpp:379-381), counted once per landmark
       // (the opening round of the fused loop has no step yet: slot 46 carries sum idepth^2, the initial state norm)
-      acc[46] += (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;
-      acc[47] += idepth_d * idepth_step_d;
+      sc[2] += (prm.gate_on_pending && !c_pending) ? idepth_d * idepth_d : idepth_step_d * idepth_step_d;
+      sc[3] += idepth_d * idepth_step_d;
     }
   }
   }  // groups
+  if (LIN) gramContract(gram_lds + (threadIdx.x >> 6) * 64 * kGramStride, gram);  // the last group's rows
   SWEEP_STAMP(4);
   double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
-  if (LIN && SMALL_LDS) {
-    blockReduceStore<0, kPartial / 2>(acc, red_lds, out);
-    ldsBarrier();  // the first half has been read
-    blockReduceStore<kPartial / 2, kPartial / 2>(acc, red_lds, out);
-  } else if (LIN) {
-    blockReduceStore<0, kPartial>(acc, red_lds, out);
-  } else {
-    blockReduceStore<44, 4>(acc, red_lds, out);
-  }
+  gramScalarsStore<LIN>(gram, sc, scalar_lds, out);
   SWEEP_STAMP(5);
   SWEEP_STAMP(6);
   if (kStamps && prm.dbg && threadIdx.x == 0) {

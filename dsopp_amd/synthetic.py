@@ -12,6 +12,8 @@ needs no image resampling: for every pixel the ray/surface intersection is found
 from __future__ import annotations
 
 import dataclasses
+import os
+
 import numpy as np
 
 # Pattern offsets (x_i, y_i): src/common/pattern/include/common/pattern/pattern.hpp:21-32
@@ -240,6 +242,15 @@ def make_window(num_frames: int = 7, num_points: int = 2000, width: int = 640, h
             ok = grad[cand[:, 1], cand[:, 0]] > min_gradient
             uv = np.concatenate([uv, cand[ok].astype(np.float64)])
         uv = uv[:n]
+        order = os.environ.get("DSOPP_SYN_ORDER", "random")  # experiment: order of the landmarks within a frame
+        if order == "clump":  # experiment: every landmark inside one 48 x 48 window (cache-resident gather)
+            uv = np.stack([200 + (uv[:, 0] % 48), 200 + (uv[:, 1] % 48)], axis=1)
+        if order == "raster":
+            uv = uv[np.lexsort((uv[:, 0], uv[:, 1]))]
+        elif order.startswith("tile"):  # tiles of T x T pixels in raster order, raster inside a tile
+            T = int(order[4:] or 32)
+            key = (uv[:, 1] // T) * 100000 + (uv[:, 0] // T)
+            uv = uv[np.lexsort((uv[:, 0], uv[:, 1], key))]
         ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
         idepth_gt = 1.0 / depth[vi, ui]
         idepth_init = idepth_gt * (1 + rng.uniform(-idepth_noise, idepth_noise, n))
