@@ -520,7 +520,7 @@ def profile_roofline(b_lin):
     out = {}
     for key, csv_name in (("isolated_launches", os.path.join("r03", "c_c1_isolated_kernel_stats.csv")), ("in_loop", os.path.join("r03", "c_c1_kernel_stats.csv"))):
         for alt in (csv_name, csv_name.replace("c_c1", "b_c1"), csv_name.replace("c_c1", "a_c1")):
-            r = load_profile_kernel_avg_us(alt, "sweepKernel<double, true, true, true, true, false, false>")
+            r = load_profile_kernel_avg_us(alt, "sweepKernel<double, true, true, true, true, false>")
             if r:
                 out[key] = {"source": f"profiles/{alt}", "avg_us": r[0], "calls": r[1], "frac": b_lin / (r[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                 break

@@ -15,7 +15,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("dsopp_hip::", "").replace("void ", "")[:60]
     acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for n, cs in acc.items():
-    if not any(k in n for k in ("sweepKernel<double, true, true, true, false, true, false", "sweepKernel<double, false", "schurTwoStage", "solveCombined", "backsub", "combineSystem")): continue
+    if not any(k in n for k in ("sweepKernel<double, true, true, true, false, false", "sweepKernel<double, false", "schurTwoStage", "solveCombined", "backsub", "combineSystem")): continue
     print(n, {c: round(sum(v) / len(v), 2) for c, v in cs.items()})
 PY
 done

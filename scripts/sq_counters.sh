@@ -8,13 +8,14 @@ target=$1; out=$2; filt=${3:-.}
 mkdir -p gpurun_out
 rm -f /tmp/sq_*.json
 i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+if [ -n "$COUNTER_SETS" ]; then IFS=';' read -ra SETS <<< "$COUNTER_SETS"; else SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_CYCLES" \
-           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+           "GRBM_GUI_ACTIVE GRBM_COUNT"); fi
+for set in "${SETS[@]}"; do
   d=/tmp/pmc_$i
   rm -rf $d
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o pmc -- python $GRAFT_REPO_ROOT/scripts/profile_target.py $target > /tmp/pmc.log 2>&1) || { echo "set [$set] failed: $(grep -i -m2 "error\|invalid\|not" /tmp/pmc.log)"; i=$((i+1)); continue; }
+  (cd /tmp && timeout ${PASS_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o pmc -- python $GRAFT_REPO_ROOT/scripts/profile_target.py $target > /tmp/pmc.log 2>&1) || { echo "set [$set] failed: $(grep -i -m2 "error\|invalid\|not" /tmp/pmc.log)"; i=$((i+1)); continue; }
   f=$(find $d -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "set [$set]: no counter file"; i=$((i+1)); continue; }
   python - "$f" "$filt" /tmp/sq_$i.json <<'PY'
