@@ -763,6 +763,11 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
   a.scalars_out = mode == ReduceMode::kAccumulateOnly ? w.d_reduce.ptr + reduce_count : nullptr;
+  // landmark shards: whether a shard builds with atomics or in two stages is decided by ITS chunk count, which may differ between
+  // ranks by a chunk — so both paths hand the collective the same thing: [system | kScalarGroups groups of four sums]
+  const bool grouped_tail = mode == ReduceMode::kAccumulateOnly && w.allreduce != nullptr;
+  a.scalars_out_groups = grouped_tail ? kScalarGroups : 0;
+  static_assert(4 * kScalarGroups <= kSchurThreads, "one workgroup writes the grouped tail");
   if (fused) a.prm = fused->prm;
   if (fused && fused->scalars) a.scalars = fused->scalars;
   a.ctrl_host = fused ? fused->ctrl_host : nullptr;
@@ -781,7 +786,7 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
   // (in the fused loop the 4 energy scalars of the sweep sit right behind the systems and travel with them)
-  allreduceIfNeeded(w, w.d_reduce.ptr, reduce_count + (mode == ReduceMode::kAccumulateOnly ? 4 : 0));
+  allreduceIfNeeded(w, w.d_reduce.ptr, reduce_count + (mode == ReduceMode::kAccumulateOnly ? (grouped_tail ? 4 * kScalarGroups : 4) : 0));
   (void)K;
 }
 
@@ -1313,6 +1318,7 @@ void lmSolveFusedEnqueue(W &w) {
       // control block alone — as its prologue.  (Until round 3 the unsharded K2 decided in its own prologue: every workgroup waited
       // for a round trip over the sweep's scalars before it started to build; 41.4 -> 40.1 us per iteration at C1.)
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
+      decide_from_groups = w.allreduce != nullptr;  // (shards: the grouped tail, see launchReduceSchur)
     }
     if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups);  // K3: decision prologue + solve
   }

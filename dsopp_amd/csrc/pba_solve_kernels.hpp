@@ -108,7 +108,9 @@ struct ReduceSchurArgs {
   const double *scalars;  // multi-GPU: all-reduced {energy, n_valid, step^2, idepth.step}
   int n_sweep_blocks;
   int total_blocks;
-  double *scalars_out;  // nullable: accumulate-only launches of sharded windows write {energy, n_valid, |step|^2, idepth.step} here
+  double *scalars_out;  // nullable: accumulate-only launches write {energy, n_valid, |step|^2, idepth.step} here
+  int scalars_out_groups = 0;  // landmark shards: the sums are group 0 of kScalarGroups groups of four, the other groups are zeroed — the
+                               // layout a shard on the two-stage path sends, so that every rank's collective has the same size and meaning
   // fused LM loop: ONE combined system instead of the four above (nullable = off).  Block-packed lower triangle of
   //   A = H_pp (1 + lambda on the diagonal) - H_schur / (1 + lambda)        (calculateStep, problem.hpp:347-351, without priors)
   // as combBlockCount(F) 8 x 8 blocks (bi >= bj) of 64 doubles, followed by b = b_pp - b_schur / (1 + lambda) (K doubles): the solve
@@ -420,6 +422,8 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
       double sacc = 0;
       for (int j = 0; j < kSchurThreads; ++j) sacc += lds[threadIdx.x * (kSchurThreads + 2) + j];
       a.scalars_out[threadIdx.x] = sacc;
+    } else if (static_cast<int>(threadIdx.x) < 4 * a.scalars_out_groups) {
+      a.scalars_out[threadIdx.x] = 0;
     }
     return;
   }

@@ -329,3 +329,38 @@ def test_group_large_window_takes_the_two_stage_sharded_path():
     assert _close(l2["idepth"], l1["idepth"], 1e-9, 1e-12)
     g1.close()
     gg.close()
+
+
+_STRADDLE_SCRIPT = r"""
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+# 4 frames x 129 landmarks on 2 shards: shard 0 holds 65 landmarks of every frame (2 chunks of 64 each: 8 chunks), shard 1 holds 64
+# (4 chunks).  With the two-stage build above 5 chunks, shard 0 builds its system in two stages and shard 1 with atomics: the two
+# paths must hand the ONE collective per iteration the same count and layout (round-3 advisor finding, high).
+win = syn.make_window(num_frames=4, num_points=516, width=320, height=240, seed=11)
+assert all(len(f.uv) == 129 for f in win.frames)
+for lm_mode in (0, 2):
+    g1 = capi.HipWindow(capi.default_pba_options()); syn.load_window(g1, win)
+    gg = capi.HipWindowGroup(capi.default_pba_options(), devices=[0, 0], transport=capi.TRANSPORT_LOCAL); syn.load_window(gg, win)
+    assert [gg.shard_num_landmarks(s, win.frames[0].frame_id) for s in (0, 1)] == [65, 64]
+    g1.set_lm_mode(lm_mode); gg.set_lm_mode(lm_mode)
+    e1, it1, nv1 = g1.solve()
+    e2, it2, nv2 = gg.solve()
+    assert (it1, nv1) == (it2, nv2) and abs(e1 - e2) <= 1e-7 * abs(e1), (lm_mode, e1, e2, it1, it2, nv1, nv2)
+    for f in win.frames:
+        assert np.abs(g1.get_pose(f.frame_id)[0] - gg.get_pose(f.frame_id)[0]).max() <= 1e-7
+    g1.close(); gg.close()
+print("straddle ok")
+"""
+
+
+def test_shards_straddling_the_two_stage_threshold():
+    """One shard above, one below the chunk count that selects the atomic-free build (DSOPP_HIP_TWO_STAGE_MIN_CHUNKS is read once per
+    process, hence the subprocess): their per-iteration collective has one size and one layout whichever path a shard takes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSOPP_HIP_TWO_STAGE_MIN_CHUNKS="5", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _STRADDLE_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "straddle ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
