@@ -380,6 +380,10 @@ def main():
         g.restore()
         extras["roofline_large"] = run_large_window_roofline(capi, syn, dtype, s_bytes)
         extras["f32_mode"] = run_f32_mode(capi, syn, win, F, P_local)
+        # ... and where fp32 texels halve the gathered bytes: the 12 KF / 50 000-point window (not a headline: the reference's scalar is double)
+        f32_large = run_large_window_roofline(capi, syn, capi.F32, 4)
+        extras["f32_mode"]["large_window"] = {k: f32_large[k] for k in ("workload", "kernels_isolated_avg_us", "algorithmic_bytes_per_launch", "achieved", "frac",
+                                                                      "gn_iterations_per_s")}
         extras["tracker"] = run_tracker_timing(capi, syn, torch, no_cpu=args.no_cpu)
         # the same with the 4 pyramid levels the production camera requests (src/sensors/camera/src/camera.cpp:43-45)
         t4 = run_tracker_timing(capi, syn, torch, no_cpu=args.no_cpu, levels=4)
@@ -395,6 +399,11 @@ def main():
         cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
 
     if rank == 0:
+        # `roofline.frac` is priced with the rocprofv3 figure of the kernel AS THE LOOP RUNS IT (committed kernel_stats csv of the same
+        # command under profiles/): the event-bracketed back-to-back launches measured above are the live cross-check (`frac_events`)
+        prof_roof = profile_roofline(b_lin) if (F, P_local, args.dtype) == (7, 2000, "f64") else None
+        in_loop = (prof_roof or {}).get("in_loop")
+        frac_events = achieved / HBM_PEAK_GBS
         ms_per_step = block_s / steps_done * 1e3
         per_job = world if scaling == "weak" else 1   # weak: every rank advances its own 2000-point share of the window
         line = {
@@ -403,7 +412,8 @@ def main():
             "unit": "GN iterations/s",
             "n_gpus": world,
             "steps": steps_done,
-            "warmup": warmup,
+            "warmup": args.warmup,  # as given; a warm-up shorter than one LM solve (7 iterations) is rounded up to one:
+            "warmup_effective": warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": scaling,
@@ -422,9 +432,14 @@ def main():
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
                        "exchange": job.transport, "ranks": world},
             "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN, FEJ, HUBER, BACKSUB>: the in-loop variant)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
+                         "achieved": (b_lin / (in_loop["avg_us"] * 1e-6) / 1e9) if in_loop else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": in_loop["frac"] if in_loop else frac_events,
+                         "frac_source": (f"{in_loop['source']}: average duration of the kernel inside the bench loop under rocprofv3 --kernel-trace --stats "
+                                         f"({in_loop['calls']} launches)") if in_loop else "HIP events of this run (no committed kernel_stats csv found)",
+                         "frac_events": frac_events, "achieved_events": achieved,
+                         "traffic": traffic, "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": lin_avg_s * 1e6,
+                         "mfma": load_mfma_utilisation(),
                          # whole Gauss-Newton iteration against the same roof: SURVEY.md §8d's B_gn = B_lin + B_en over the
                          # driver-timed time per iteration (launch gaps, reduction and dense solve included)
                          "iteration_frac": (b_lin + b_en) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -432,7 +447,7 @@ def main():
                          # the same 200 isolated launches under `rocprofv3 --kernel-trace --stats` (scripts/profile_target.py c1_isolated,
                          # committed csv): rocprof's per-dispatch duration of back-to-back launches includes each launch's ramp, which
                          # overlaps the previous kernel's tail, so its average sits ~10 % above the event-bracketed wall time per launch
-                         "profile": profile_roofline(b_lin),
+                         "profile": prof_roof,
                          "what_the_fraction_is": "algorithmic bytes (no texel reuse counted) over kernel time against the 8 TB/s HBM3E peak; "
                                                  "the C1 working set (69 MB of texels) fits the 256 MB Infinity Cache, whose hits the TCC_EA "
                                                  "counters behind `traffic` include: a latency-bound gather, not DRAM streaming",
@@ -518,20 +533,36 @@ def load_profile_kernel_avg_us(csv_name, needle):
 
 def profile_roofline(b_lin):
     out = {}
-    for key, csv_name in (("isolated_launches", os.path.join("r03", "c_c1_isolated_kernel_stats.csv")), ("in_loop", os.path.join("r03", "c_c1_kernel_stats.csv"))):
-        for alt in (csv_name, csv_name.replace("c_c1", "b_c1"), csv_name.replace("c_c1", "a_c1")):
-            r = load_profile_kernel_avg_us(alt, "sweepKernel<double, true, true, true, true, false>")
+    for key, csv_name in (("isolated_launches", "c1_isolated_kernel_stats.csv"), ("in_loop", "c1_kernel_stats.csv")):
+        # newest round first; the template argument list of the sweep lost an argument in round 4
+        for alt, needle in ((os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, true, false>"),
+                            (os.path.join("r03", "c_" + csv_name), "sweepKernel<double, true, true, true, true, false, false>")):
+            r = load_profile_kernel_avg_us(alt, needle)
             if r:
                 out[key] = {"source": f"profiles/{alt}", "avg_us": r[0], "calls": r[1], "frac": b_lin / (r[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                 break
     return out or None
 
 
+def load_mfma_utilisation():
+    """f64 matrix-core figures of the kernels that use them, from the committed SQ counter passes (scripts/mfma_utilisation.py ->
+    profiles/r04/mfma_utilisation.json): instruction counts, busy cycles of the matrix pipe against the kernel's cycles, achieved
+    TFLOP/s against AMD's 78.6 TFLOP/s fp64-matrix figure for MI355X (MI355X_MICROARCH.md lists no fp64 row)"""
+    path = os.path.join(ROOT, "profiles", "r04", "mfma_utilisation.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        d["source"] = "profiles/r04/mfma_utilisation.json"
+        return d
+    except (OSError, ValueError):
+        return None
+
+
 def load_pmc_traffic(F, P, args):
     """per-launch HBM bytes of the in-loop linearisation sweep from the committed counter run (profiles/, newest round first)"""
     if (F, P, args.width, args.height, args.dtype, args.workload) != (7, 2000, 640, 480, "f64", "c1"):
         return None, None
-    for name in (os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in (os.path.join("r04", "pmc_traffic_c1.json"), os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_file = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_file):
             continue
