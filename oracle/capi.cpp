@@ -573,5 +573,12 @@ int orc_pinv_drop(int n, const double *H, int nullspaces, double *out) {
   std::memcpy(out, r.a.data(), sizeof(double) * r.a.size());
   return 0;
 }
+/* relativeTransformationUncertainty (se3_motion.hpp:151-158) on its own, so that tests/test_oracle_uncertainty.py can hold it against
+ * a finite-difference statement of the same propagation */
+int orc_relative_transformation_uncertainty(const double T_w_1[7], const double T_w_2[7], const double *sigma_11, const double *sigma_22,
+                                            const double *sigma_12, double *out36) {
+  relativeTransformationUncertainty(SE3::fromParams(T_w_1), SE3::fromParams(T_w_2), sigma_11, sigma_22, sigma_12, out36);
+  return 0;
+}
 
 }  // extern "C"

@@ -160,6 +160,9 @@ int orc_reproject_pattern(const double ref_intr[4], int ref_w, int ref_h, const 
 int orc_solve_system(int n, const double *H, const double *b, double *x);
 int orc_reduce_system(int n, double *H, double *b, int n_elim, const int32_t *elim, double *H_out, double *b_out);
 int orc_pinv_drop(int n, const double *H, int nullspaces, double *out);
+/* covariance of the relative pose of two frames from the blocks of their joint covariance — se3_motion.hpp:151-158 */
+int orc_relative_transformation_uncertainty(const double T_w_1[7], const double T_w_2[7], const double *sigma_11, const double *sigma_22,
+                                            const double *sigma_12, double *out36);
 
 #ifdef __cplusplus
 }

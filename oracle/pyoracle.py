@@ -470,3 +470,10 @@ def pinv_drop(H, nullspaces):
     out = np.zeros((n, n))
     lib().orc_pinv_drop(n, _p(_f64(H)), int(nullspaces), _p(out))
     return out
+
+
+def relative_transformation_uncertainty(T_w_1, T_w_2, sigma_11, sigma_22, sigma_12):
+    """Motion::relativeTransformationUncertainty (se3_motion.hpp:151-158) as the oracle restates it"""
+    out = np.zeros((6, 6))
+    lib().orc_relative_transformation_uncertainty(_p(_f64(T_w_1)), _p(_f64(T_w_2)), _p(_f64(sigma_11)), _p(_f64(sigma_22)), _p(_f64(sigma_12)), _p(out))
+    return out
