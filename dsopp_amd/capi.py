@@ -40,7 +40,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void
 SYMBOLS = [
     "dsopp_hip_pyramid_group_build", "dsopp_hip_pyramid_group_create", "dsopp_hip_pyramid_group_destroy", "dsopp_hip_pyramid_group_get", "dsopp_hip_pyramid_group_set_level", "dsopp_hip_pyramid_group_set_mask", "dsopp_hip_window_group_accept_step", "dsopp_hip_window_group_begin", "dsopp_hip_window_group_calculate_energy", "dsopp_hip_window_group_calculate_step", "dsopp_hip_window_group_create", "dsopp_hip_window_group_create_reference_depth_maps", "dsopp_hip_window_group_destroy", "dsopp_hip_window_group_frame_ids", "dsopp_hip_window_group_get_covariance", "dsopp_hip_window_group_get_frame_state", "dsopp_hip_window_group_get_frame_update", "dsopp_hip_window_group_get_landmarks", "dsopp_hip_window_group_get_marginalized", "dsopp_hip_window_group_get_pose", "dsopp_hip_window_group_get_residuals", "dsopp_hip_window_group_get_system", "dsopp_hip_window_group_last_solve_ms", "dsopp_hip_window_group_linearize", "dsopp_hip_window_group_mark_frame_marginalized", "dsopp_hip_window_group_num_frames", "dsopp_hip_window_group_num_landmarks", "dsopp_hip_window_group_optimize", "dsopp_hip_window_group_optimize_repeated", "dsopp_hip_window_group_push_frame", "dsopp_hip_window_group_refill_reference_depth_maps", "dsopp_hip_window_group_reject_step", "dsopp_hip_window_group_restore", "dsopp_hip_window_group_set_connection", "dsopp_hip_window_group_set_deterministic", "dsopp_hip_window_group_set_landmarks", "dsopp_hip_window_group_set_lm_mode", "dsopp_hip_window_group_set_max_iterations", "dsopp_hip_window_group_shard", "dsopp_hip_window_group_size", "dsopp_hip_window_group_snapshot", "dsopp_hip_window_group_solve", "dsopp_hip_window_group_update_point_statuses",
     "dsopp_hip_window_frame_ids", "dsopp_hip_window_set_deterministic",
-    "dsopp_hip_comm_unique_id", "dsopp_hip_comm_create", "dsopp_hip_comm_adopt", "dsopp_hip_comm_destroy", "dsopp_hip_comm_rank",
+    "dsopp_hip_comm_unique_id", "dsopp_hip_comm_create", "dsopp_hip_comm_adopt", "dsopp_hip_comm_destroy", "dsopp_hip_comm_abort", "dsopp_hip_comm_rank",
     "dsopp_hip_comm_allreduce", "dsopp_hip_window_set_comm",
     "dsopp_hip_window_optimize_async", "dsopp_hip_window_optimize_wait",
     "dsopp_hip_immature_sets_estimate",

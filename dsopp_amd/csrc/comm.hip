@@ -21,6 +21,7 @@ struct dsopp_hip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   bool owned = true;
+  bool aborted = false;  // dsopp_hip_comm_abort: the handle only waits to be destroyed
 };
 
 namespace dsopp_hip {
@@ -30,6 +31,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
@@ -60,6 +62,7 @@ RcclApi &rccl() {
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
     api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
@@ -78,6 +81,10 @@ void rcclCheck(ncclResult_t r, const char *what) {
 /** the dsopp_hip_allreduce_fn the window calls when a native communicator is attached (pba.hip: allreduceIfNeeded) */
 int nativeAllreduce(void *user, void *device_buffer, size_t count, void *stream) {
   auto *c = static_cast<dsopp_hip_comm *>(user);
+  if (c->aborted) {
+    lastError() = "communicator was aborted (dsopp_hip_comm_abort): the collective is not enqueued";
+    return -3;
+  }
   const ncclResult_t r = rccl().AllReduce(device_buffer, device_buffer, count, ncclDouble, ncclSum, c->comm, static_cast<hipStream_t>(stream));
   if (r != ncclSuccess) {
     lastError() = std::string("ncclAllReduce failed: ") + rccl().GetErrorString(r);
@@ -138,6 +145,21 @@ int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out) {
     rcclCheck(rccl().CommCount(c->comm, &c->world), "ncclCommCount");
     rcclCheck(rccl().CommUserRank(c->comm, &c->rank), "ncclCommUserRank");
     *out = c.release();
+  });
+}
+
+int dsopp_hip_comm_abort(dsopp_hip_comm *c) {
+  return guarded([&] {
+    if (!c) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null communicator");
+    if (c->aborted) return;
+    c->aborted = true;
+    // ncclCommAbort releases the kernels of collectives the OTHER ranks already enqueued and that would wait for this rank for ever
+    // (a rank that failed between two collectives never enqueues its side); afterwards the communicator can only be destroyed
+    if (c->owned && c->comm && rccl().CommAbort) {
+      (void)hipSetDevice(c->device);
+      (void)rccl().CommAbort(c->comm);
+      c->comm = nullptr;
+    }
   });
 }
 

@@ -147,13 +147,17 @@ struct ShardPool {
   bool quit = false;
   std::vector<int> rc;
   std::vector<std::string> err;
+  std::vector<char> secondary;  // the shard failed AFTER another one had raised the abort flag: a consequence, not the cause
   std::atomic<bool> abort{false};
   AbortableBarrier *barrier = nullptr;
+  std::function<void()> on_abort;  // first failure of a job: release what the other shards may be blocked in (RCCL: abort the communicators)
+  std::function<void()> on_reset;  // in front of the job that follows an aborted one
 
   void start(int count, const std::vector<int> &devices) {
     n = count;
     rc.assign(static_cast<size_t>(n), 0);
     err.assign(static_cast<size_t>(n), std::string());
+    secondary.assign(static_cast<size_t>(n), 0);
     for (int i = 0; i < n; ++i)
       threads.emplace_back([this, i, dev = devices[static_cast<size_t>(i)]] {
         (void)hipSetDevice(dev);
@@ -179,15 +183,18 @@ struct ShardPool {
             code = DSOPP_HIP_ERR_INVALID_ARGUMENT;
             msg = e.what();
           }
+          bool was_aborting = false;
           if (code != DSOPP_HIP_OK) {
             // the other shards may be waiting for this one inside a collective: let their barrier give up
-            abort.store(true);
+            was_aborting = abort.exchange(true);
             if (barrier) barrier->wake();
+            if (!was_aborting && on_abort) on_abort();
           }
           {
             std::lock_guard<std::mutex> lk(m);
             rc[static_cast<size_t>(i)] = code;
             err[static_cast<size_t>(i)] = msg;
+            secondary[static_cast<size_t>(i)] = was_aborting ? 1 : 0;
             if (--remaining == 0) cv_done.notify_all();
           }
         }
@@ -199,7 +206,10 @@ struct ShardPool {
       std::lock_guard<std::mutex> lk(m);
       job = std::move(fn);
       remaining = n;
-      if (abort.load() && barrier) barrier->reset();  // the previous job was aborted inside a collective
+      if (abort.load()) {  // the previous job was aborted inside a collective
+        if (barrier) barrier->reset();
+        if (on_reset) on_reset();
+      }
       abort.store(false);
       ++generation;
     }
@@ -208,10 +218,11 @@ struct ShardPool {
       std::unique_lock<std::mutex> lk(m);
       cv_done.wait(lk, [&] { return remaining == 0; });
     }
-    // a shard that gave up inside a collective because ANOTHER shard failed reports the callback error: prefer the root cause
+    // a shard that gave up inside a collective because ANOTHER shard failed reports the callback error: prefer the root cause (the
+    // shard that raised the abort flag; every later failure of the job is marked secondary)
     int first = -1;
     for (int i = 0; i < n; ++i)
-      if (rc[static_cast<size_t>(i)] != DSOPP_HIP_OK && (first < 0 || err[static_cast<size_t>(first)].find("allreduce callback") != std::string::npos)) first = i;
+      if (rc[static_cast<size_t>(i)] != DSOPP_HIP_OK && (first < 0 || (secondary[static_cast<size_t>(first)] && !secondary[static_cast<size_t>(i)]))) first = i;
     if (first >= 0) fail(rc[static_cast<size_t>(first)], "shard %d: %s", first, err[static_cast<size_t>(first)].c_str());
   }
   void stop() {
@@ -243,6 +254,8 @@ struct dsopp_hip_window_group {
   LocalReducer reducer;
   std::vector<ShardUser> users;
   ShardPool pool;
+  bool pooled = false;               // calls go through the worker threads (n > 1, or DSOPP_HIP_GROUP_FORCE_POOL for a group of one)
+  std::atomic<bool> poisoned{false};  // RCCL transport: a shard failed and the communicators were aborted — the group only waits to be destroyed
   // per-shard marshalling buffers (one set per worker thread, reused between calls)
   struct Scratch {
     std::vector<double> a, b, c, d, e, h;
@@ -266,7 +279,9 @@ using G = dsopp_hip_window_group;
 /** runs body(shard, window) on every shard's worker thread; any failure is raised on the calling thread */
 template <typename Body>
 void fanOut(G &g, Body &&body) {
-  if (g.n == 1) {  // a group of one is a plain window: no worker thread, the call runs where the caller is
+  if (g.poisoned.load())
+    fail(DSOPP_HIP_ERR_STATE, "this window group is unusable: a shard failed outside a collective and the RCCL communicators were aborted (destroy the group)");
+  if (!g.pooled) {  // a group of one is a plain window: no worker thread, the call runs where the caller is
     const int rc = body(0, g.win[0]);
     if (rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
     return;
@@ -312,7 +327,14 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
     g->users.resize(static_cast<size_t>(n));
     g->pool.barrier = &g->reducer.bar;
     g->reducer.bar.abort = &g->pool.abort;
-    if (n > 1) g->pool.start(n, g->device);
+    // DSOPP_HIP_GROUP_FORCE_POOL: a group of ONE shard goes through the worker thread and, with DSOPP_HIP_TRANSPORT_RCCL, through a
+    // one-rank communicator (ncclCommInitRank from the worker, ncclAllReduce per Gauss-Newton iteration) — the code a multi-device group
+    // runs, executable on a one-GPU box (tests/test_gpu_window_group.py)
+    static const bool force_pool = std::getenv("DSOPP_HIP_GROUP_FORCE_POOL") != nullptr && std::atoi(std::getenv("DSOPP_HIP_GROUP_FORCE_POOL")) != 0;
+    g->pooled = n > 1 || force_pool;
+    if (g->pooled) g->pool.start(n, g->device);
+    G *const gp = g.get();
+    g->pool.on_reset = [gp] { gp->reducer.failed.store(0); };
     struct Cleanup {  // a failure below must not leak threads / windows
       std::unique_ptr<G> &g;
       bool armed = true;
@@ -323,7 +345,7 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
     fanOut(*g, [&](int s, dsopp_hip_window *) {
       return dsopp_hip_window_create(options, g->device[static_cast<size_t>(s)], nullptr, &g->win[static_cast<size_t>(s)]);
     });
-    if (n > 1 && transport == DSOPP_HIP_TRANSPORT_RCCL) {
+    if (g->pooled && transport == DSOPP_HIP_TRANSPORT_RCCL) {
       try {
         uint8_t id[DSOPP_HIP_COMM_ID_BYTES];
         if (const int rc = dsopp_hip_comm_unique_id(id); rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
@@ -344,6 +366,16 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
         });
         transport = DSOPP_HIP_TRANSPORT_LOCAL;
         g->transport = transport;
+      }
+      if (transport == DSOPP_HIP_TRANSPORT_RCCL) {
+        // a shard that fails BETWEEN two collectives never enqueues its side of the next one: the other shards' ncclAllReduce kernels
+        // would wait for it for ever and their stream synchronisation with them.  The first failure aborts every communicator
+        // (ncclCommAbort releases the enqueued kernels), the call returns that shard's error and the group is unusable from then on.
+        g->pool.on_abort = [gp] {
+          gp->poisoned.store(true);
+          for (dsopp_hip_comm *c : gp->comm)
+            if (c) (void)dsopp_hip_comm_abort(c);
+        };
       }
     }
     if (n > 1 && transport == DSOPP_HIP_TRANSPORT_LOCAL) {
@@ -390,6 +422,7 @@ void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g) {
     return DSOPP_HIP_OK;
   };
   try {
+    g->poisoned.store(false);  // (the release job itself must run)
     if (!g->pool.threads.empty())
       g->pool.run(release);
     else
@@ -408,7 +441,7 @@ int dsopp_hip_window_group_size(const dsopp_hip_window_group *g, int32_t *n, int
   return guarded([&] {
     checkGroup(g);
     if (n) *n = g->n;
-    if (transport) *transport = g->n > 1 ? g->transport : DSOPP_HIP_TRANSPORT_LOCAL;
+    if (transport) *transport = g->pooled ? g->transport : DSOPP_HIP_TRANSPORT_LOCAL;
   });
 }
 

@@ -202,6 +202,10 @@ int dsopp_hip_comm_unique_id(uint8_t id[DSOPP_HIP_COMM_ID_BYTES]);
 int dsopp_hip_comm_create(const uint8_t id[DSOPP_HIP_COMM_ID_BYTES], int rank, int world_size, int device, dsopp_hip_comm **out);
 int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out);
 void dsopp_hip_comm_destroy(dsopp_hip_comm *c);
+/* ncclCommAbort: releases collectives the other ranks have enqueued and that this rank will never join (it failed between two of
+ * them); the handle can only be destroyed afterwards, a window it is attached to fails its next collective with an error instead of
+ * enqueueing it.  What dsopp_hip_window_group does with every shard's communicator when one shard fails. */
+int dsopp_hip_comm_abort(dsopp_hip_comm *c);
 int dsopp_hip_comm_rank(const dsopp_hip_comm *c, int *rank, int *world_size);
 /* in-place sum of `count` doubles in device memory across the ranks, ordered on `stream` (a hipStream_t) */
 int dsopp_hip_comm_allreduce(dsopp_hip_comm *c, void *device_buffer, size_t count, void *stream);

@@ -364,3 +364,38 @@ def test_shards_straddling_the_two_stage_threshold():
     env = dict(os.environ, DSOPP_HIP_TWO_STAGE_MIN_CHUNKS="5", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", _STRADDLE_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "straddle ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_FORCED_POOL_SCRIPT = r"""
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+win = syn.make_window(num_frames=4, num_points=400, width=320, height=240, seed=13)
+for lm_mode in (0, 1):
+    g1 = capi.HipWindow(capi.default_pba_options()); syn.load_window(g1, win)
+    # ONE shard on device 0 with the RCCL transport: with DSOPP_HIP_GROUP_FORCE_POOL the group does not collapse into a plain window —
+    # its calls run on the shard's worker thread, the communicator is created there (ncclCommInitRank, one rank) and every Gauss-Newton
+    # iteration sums its system through ncclAllReduce on the shard's stream
+    gg = capi.HipWindowGroup(capi.default_pba_options(), devices=[0], transport=capi.TRANSPORT_RCCL); syn.load_window(gg, win)
+    assert gg.size == 1 and gg.transport == capi.TRANSPORT_RCCL, (gg.size, gg.transport)
+    g1.set_lm_mode(lm_mode); gg.set_lm_mode(lm_mode)
+    e1, it1, nv1 = g1.solve()
+    e2, it2, nv2 = gg.solve()
+    assert (it1, nv1) == (it2, nv2) and abs(e1 - e2) <= 1e-9 * abs(e1), (lm_mode, e1, e2)
+    for f in win.frames:
+        assert np.abs(g1.get_pose(f.frame_id)[0] - gg.get_pose(f.frame_id)[0]).max() <= 1e-9
+    a, b = win.frames[0].frame_id, win.frames[2].frame_id
+    assert np.abs(g1.get_covariance(a, b) - gg.get_covariance(a, b)).max() <= 1e-6 * np.abs(g1.get_covariance(a, b)).max()
+    g1.close(); gg.close()
+print("forced pool ok")
+"""
+
+
+def test_group_of_one_through_the_worker_thread_and_rccl():
+    """the RCCL transport of the group (worker thread -> ncclCommInitRank -> per-iteration ncclAllReduce) executed with one rank"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSOPP_HIP_GROUP_FORCE_POOL="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _FORCED_POOL_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced pool ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
