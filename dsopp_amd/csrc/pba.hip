@@ -33,6 +33,7 @@ struct HostFrame {
   int id = 0;
   int64_t timestamp = 0;
   const dsopp_hip_pyramid *pyramid = nullptr;
+  unsigned pyramid_generation = 0;  // the pyramid's rewrite count when the frame's sweep descriptors (texels, intensity plane) were built
   int level = 0;
   double intr[4] = {0, 0, 0, 0};
   double exposure = 1;
@@ -388,6 +389,7 @@ void syncTopology(W &w) {
     d.texels = hbm(lv.texels);
     static const bool no_iplane = std::getenv("DSOPP_HIP_NO_IPLANE") != nullptr;  // tuning aid (A/B of the counter traffic)
     d.iplane = no_iplane ? nullptr : hbm(f.pyramid->intensityPlane(f.level, st));
+    f.pyramid_generation = f.pyramid->generation;
     d.itiles = f.pyramid->itilesX(f.level);
     d.width = lv.width;
     d.height = lv.height;
@@ -566,8 +568,16 @@ void uploadMarginal(W &w) {
   w.marg_dirty = false;
 }
 
+/** a pyramid a keyframe borrows was rewritten (build / set_level / set_mask) since the sweep descriptors were made: the residual-only
+ *  sweeps would keep sampling the old intensity plane while the linearising sweeps read the new texels — rebuild the descriptors */
+void checkPyramidGenerations(W &w) {
+  for (const auto &fp : w.frames)
+    if (fp->pyramid && fp->pyramid->generation != fp->pyramid_generation) w.topology_dirty = true;
+}
+
 void prepare(W &w) {
   w.sr.use();
+  checkPyramidGenerations(w);
   downloadState(w);  // no-op unless a device-driven solve left the host mirror behind
   syncTopology(w);
   uploadState(w);
@@ -579,6 +589,7 @@ void prepare(W &w) {
  *  its refresh (a read-back + synchronisation) is left to the first reader */
 void prepareDevice(W &w) {
   w.sr.use();
+  checkPyramidGenerations(w);
   if (w.state_dirty || w.topology_dirty || w.marg_dirty || !w.d_state.ptr) prepare(w);
 }
 

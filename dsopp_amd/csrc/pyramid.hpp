@@ -99,6 +99,7 @@ struct dsopp_hip_pyramid {
     HIP_CHECK(hipEventRecord(ready, sr.stream));
     std::lock_guard<std::mutex> lock(iplane_mutex);
     for (bool &v : iplane_valid) v = false;  // the texels changed: the intensity planes derived from them are stale
+    ++generation;  // (a window that borrowed this pyramid compares it before its next sweep and rebuilds the plane it samples)
   }
   // Intensity planes (f64 pyramids; built on demand by the first consumer, pyramid.hip: intensityPlane): 8 bytes per pixel —
   // the intensity with the CameraMask bit in the lowest mantissa bit — tiled 4 x 2 pixels per 64-byte segment.  What the
@@ -106,6 +107,7 @@ struct dsopp_hip_pyramid {
   // instead of 3, and a pattern's 8 footprints share them.
   mutable void *iplane[DSOPP_HIP_MAX_LEVELS] = {nullptr};
   mutable bool iplane_valid[DSOPP_HIP_MAX_LEVELS] = {false};
+  unsigned generation = 0;  // number of rewrites of the texels (markReady)
   mutable hipEvent_t iplane_ready[DSOPP_HIP_MAX_LEVELS] = {nullptr};
   mutable hipStream_t iplane_stream[DSOPP_HIP_MAX_LEVELS] = {nullptr};
   mutable std::mutex iplane_mutex;

@@ -250,7 +250,15 @@ struct dsopp_hip_window_group {
   std::vector<int> device;
   std::vector<dsopp_hip_window *> win;
   std::vector<dsopp_hip_comm *> comm;
-  std::vector<dsopp_hip_depth_maps *> shadow_maps;  // depth maps of the shards > 0 (their side of the collective fill)
+  // depth maps of the shards > 0 (their side of the collective fill), keyed by the shard-0 object the caller holds: a refill of maps from
+  // an EARLIER create call must meet the shadows made with them (their levels / sizes), not the latest ones.  The caller destroys the
+  // shard-0 object itself; its shadows are dropped when the group goes, or when more than kMaxShadowSets sets have accumulated.
+  struct ShadowSet {
+    dsopp_hip_depth_maps *key = nullptr;
+    std::vector<dsopp_hip_depth_maps *> of_shard;
+  };
+  std::vector<ShadowSet> shadow_sets;
+  static constexpr size_t kMaxShadowSets = 4;
   LocalReducer reducer;
   std::vector<ShardUser> users;
   ShardPool pool;
@@ -322,7 +330,6 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
     g->device.assign(device_ids, device_ids + n);
     g->win.assign(static_cast<size_t>(n), nullptr);
     g->comm.assign(static_cast<size_t>(n), nullptr);
-    g->shadow_maps.assign(static_cast<size_t>(n), nullptr);
     g->scratch.resize(static_cast<size_t>(n));
     g->users.resize(static_cast<size_t>(n));
     g->pool.barrier = &g->reducer.bar;
@@ -415,7 +422,8 @@ void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g) {
   if (!g) return;
   auto release = [&](int s) -> int {
     const size_t i = static_cast<size_t>(s);
-    if (g->shadow_maps[i]) dsopp_hip_depth_maps_destroy(g->shadow_maps[i]);
+    for (auto &set : g->shadow_sets)
+      if (i > 0 && i < set.of_shard.size() && set.of_shard[i]) dsopp_hip_depth_maps_destroy(set.of_shard[i]);  // ([0] is the caller's)
     if (g->win[i]) dsopp_hip_window_destroy(g->win[i]);
     if (g->comm[i]) dsopp_hip_comm_destroy(g->comm[i]);
     if (static_cast<size_t>(s) < g->reducer.ev_in.size() && g->reducer.ev_in[i]) (void)hipEventDestroy(g->reducer.ev_in[i]);
@@ -832,10 +840,26 @@ int dsopp_hip_window_group_create_reference_depth_maps(dsopp_hip_window_group *g
       for (auto *m : made) dsopp_hip_depth_maps_destroy(m);
       throw;
     }
-    for (int s = 1; s < g->n; ++s) {  // kept: the next refill needs a destination on every shard
-      if (g->shadow_maps[static_cast<size_t>(s)]) dsopp_hip_depth_maps_destroy(g->shadow_maps[static_cast<size_t>(s)]);
-      g->shadow_maps[static_cast<size_t>(s)] = made[static_cast<size_t>(s)];
+    // kept: a refill of these maps needs its destination on every shard
+    auto drop = [&](dsopp_hip_window_group::ShadowSet &set) {
+      fanOut(*g, [&](int s, dsopp_hip_window *) {
+        if (s && set.of_shard[static_cast<size_t>(s)]) dsopp_hip_depth_maps_destroy(set.of_shard[static_cast<size_t>(s)]);
+        return static_cast<int>(DSOPP_HIP_OK);
+      });
+    };
+    for (size_t k = 0; k < g->shadow_sets.size();) {  // (an address the allocator handed out again: the old object is gone)
+      if (g->shadow_sets[k].key == made[0]) {
+        drop(g->shadow_sets[k]);
+        g->shadow_sets.erase(g->shadow_sets.begin() + static_cast<long>(k));
+      } else {
+        ++k;
+      }
     }
+    if (g->shadow_sets.size() >= dsopp_hip_window_group::kMaxShadowSets) {
+      drop(g->shadow_sets.front());
+      g->shadow_sets.erase(g->shadow_sets.begin());
+    }
+    g->shadow_sets.push_back({made[0], made});
     *out = made[0];
   });
 }
@@ -844,9 +868,12 @@ int dsopp_hip_window_group_refill_reference_depth_maps(dsopp_hip_window_group *g
   return guarded([&] {
     checkGroup(g);
     if (!maps) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
-    for (int s = 1; s < g->n; ++s)
-      if (!g->shadow_maps[static_cast<size_t>(s)]) fail(DSOPP_HIP_ERR_STATE, "refill needs maps made by dsopp_hip_window_group_create_reference_depth_maps of this group");
-    fanOut(*g, [&](int s, dsopp_hip_window *w) { return dsopp_hip_window_refill_reference_depth_maps(w, s ? g->shadow_maps[static_cast<size_t>(s)] : maps); });
+    const dsopp_hip_window_group::ShadowSet *set = nullptr;
+    for (const auto &c : g->shadow_sets)
+      if (c.key == maps) set = &c;
+    if (!set) fail(DSOPP_HIP_ERR_STATE, "refill needs maps made by dsopp_hip_window_group_create_reference_depth_maps of this group (one of its last %d calls)",
+                   static_cast<int>(dsopp_hip_window_group::kMaxShadowSets));
+    fanOut(*g, [&](int s, dsopp_hip_window *w) { return dsopp_hip_window_refill_reference_depth_maps(w, s ? set->of_shard[static_cast<size_t>(s)] : maps); });
   });
 }
 

@@ -87,3 +87,53 @@ def test_build_device_then_push_frame_immediately():
         return e
 
     assert run(False) == run(True)
+
+
+def test_pyramid_rewritten_while_a_window_borrows_it():
+    """A pyramid a keyframe was pushed with gets a new mask afterwards (dsopp_hip_pyramid_set_mask).  The linearising sweeps read the
+    texels, the residual-only sweeps the intensity plane derived from them: both must see the rewrite (round-3 advisor finding: the
+    plane was only rebuilt at the next topology change) — the window then agrees with one that was given the mask from the start."""
+    import numpy as np
+    from dsopp_amd import capi, synthetic as syn
+    win = syn.make_window(num_frames=3, num_points=210, width=320, height=240, seed=19)
+    H, W = win.frames[0].pixelinfo.shape[:2]
+    rng = np.random.default_rng(2)
+    mask = (rng.uniform(size=(H, W)) > 0.15).astype(np.uint8) * 255
+    intr = win.scene.intrinsics
+
+    def build(with_mask_from_start):
+        g = capi.HipWindow(capi.default_pba_options())
+        pyr = []
+        for i, f in enumerate(win.frames):
+            p = capi.Pyramid(W, H, 1)
+            p.set_level(0, f.pixelinfo)
+            if with_mask_from_start and i == 1:
+                p.set_mask(0, mask)
+            pyr.append(p)
+            g.push_frame(f.frame_id, f.timestamp, None, None, intr, syn.mat_to_params(f.T_w_c_init), f.exposure, f.affine_init, f.fixed, False, pyramid=p)
+            g.set_landmarks(f.frame_id, f.uv, f.idepth_init, f.patch, np.zeros(len(f.uv), dtype=np.uint8))
+            for j in range(i):
+                h = win.frames[j]
+                for (r, t) in ((h, f), (f, h)):
+                    g.set_connection(r.frame_id, t.frame_id, np.zeros(len(r.uv), dtype=np.uint8))
+        return g, pyr
+
+    ga, pa = build(True)
+    gb, pb = build(False)
+    gb.begin()
+    e_before, n_before = gb.calculate_energy()          # the unmasked state: sweeps have run, the intensity plane exists
+    pb[1].set_mask(0, mask)                              # ... and now the borrowed pyramid changes under the window
+    ga.begin()
+    gb.begin()
+    ea, na = ga.calculate_energy()
+    eb, nb = gb.calculate_energy()
+    assert nb == na and nb < n_before, (na, nb, n_before)
+    assert abs(ea - eb) <= 1e-12 * abs(ea)
+    ga.linearize()
+    gb.linearize()
+    for x, y in zip(ga.get_system(), gb.get_system()):
+        assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(x).max())
+    ga.close()
+    gb.close()
+    for p in pa + pb:
+        p.close()
