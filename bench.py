@@ -393,6 +393,7 @@ def main():
         extras["landmark_activation"] = run_landmark_activation_timing(capi, syn, args)
         extras["concurrent_windows"] = run_concurrent_windows(capi, syn, torch, win)
         extras["keyframe_step"] = run_keyframe_step_timing(capi, syn)
+        extras["tick_sequence"] = run_tick_sequences(torch, syn, args)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -995,6 +996,21 @@ def run_keyframe_step_timing(capi, syn):
     return {"workload": "7-frame window, 286 landmarks per keyframe, steady state with one marginalisation per keyframe",
             "push_frame_incl_fold_in_ms": float(med[0]), "landmarks_and_connections_ms": float(med[1]), "solve_ms": float(med[2]),
             "update_frame_read_back_ms": float(med[3]), "marginalisation_flags_ms": float(med[4]), "total_ms": float(med.sum())}
+
+
+def run_tick_sequences(torch, syn, args):
+    """BASELINE.json's second metric over tracked SEQUENCES (scripts/tick_sequence.py: MonocularTracker::tick through the C-ABI, 200 synthetic
+    frames, keyframes by the reference's flow rule, a 7-keyframe window with marginalisation), at the bundle adjustment's image size and at the
+    tracker configuration's, with the CPU port on a prefix of the same frames and both compared with the synthetic ground truth"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import tick_sequence
+    out = {}
+    for name, (w, h, levels, cpu_frames) in {"640x480": (640, 480, 4, 30), "1280x1024": (1280, 1024, 5, 16)}.items():
+        try:
+            out[name] = tick_sequence.run(torch, syn, w, h, levels, 200, cpu_frames, no_cpu=args.no_cpu)
+        except Exception as exc:  # noqa: BLE001 — an extra must not take the headline down
+            out[name] = {"error": repr(exc)}
+    return out
 
 
 def run_cpu_baseline(args, F, P, win, syn):

@@ -6,8 +6,10 @@
 
 #include "common.hpp"
 
+struct dsopp_hip_window;
 struct dsopp_hip_depth_maps {
-  dsopp_hip::StreamRef sr;  // borrowed from the window that produced the maps
+  dsopp_hip::StreamRef sr;  // borrowed from the window that produced the maps (reset to the device's default stream when that window goes first)
+  dsopp_hip_window *owner = nullptr;  // the producing window while it lives: it detaches its maps when it is destroyed
   int levels = 0;
   std::vector<int> width, height;
   // per level two row-major H x W planes: weighted idepth sum and weight (energy::problem::DepthMap::map, (x, y)-indexed there)

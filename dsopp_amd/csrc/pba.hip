@@ -160,6 +160,7 @@ struct dsopp_hip_window {
   std::vector<std::unique_ptr<HostFrame>> frame_pool;
   std::vector<std::unique_ptr<ResidualTable>> table_pool;
   std::vector<DeviceBuffer<double>> dm_tmp_id, dm_tmp_w;  // undilated reference depth maps (temporaries of createReferenceDepthMaps)
+  std::vector<dsopp_hip_depth_maps *> live_maps;          // maps this window produced and that still borrow its stream
   struct ActivationScratch {            // work buffers of dsopp_hip_window_activate_landmarks
     DeviceBuffer<ActKeyframe> keyframes;
     DeviceBuffer<ActPair> pairs;
@@ -1895,6 +1896,10 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
   w->frames.clear();
+  for (dsopp_hip_depth_maps *m : w->live_maps) {  // maps may outlive the window (the tracker holds them): they lose the borrowed stream
+    m->sr.stream = nullptr;
+    m->owner = nullptr;
+  }
   StreamRef sr = w->sr;
   delete w;
   sr.destroy();
@@ -2648,6 +2653,8 @@ int dsopp_hip_window_create_reference_depth_maps(dsopp_hip_window *w, int32_t le
       lh /= 2;
     }
     fillReferenceDepthMaps(w, maps.get());
+    maps->owner = w;
+    w->live_maps.push_back(maps.get());
     *out = maps.release();
   });
 }
@@ -2671,6 +2678,11 @@ void dsopp_hip_depth_maps_destroy(dsopp_hip_depth_maps *m) {
   if (!m) return;
   (void)hipSetDevice(m->sr.device);
   if (m->sr.stream) (void)hipStreamSynchronize(m->sr.stream);
+  else (void)hipDeviceSynchronize();
+  if (m->owner) {
+    auto &live = m->owner->live_maps;
+    live.erase(std::remove(live.begin(), live.end(), m), live.end());
+  }
   delete m;
 }
 
