@@ -394,6 +394,7 @@ def main():
         extras["concurrent_windows"] = run_concurrent_windows(capi, syn, torch, win)
         extras["keyframe_step"] = run_keyframe_step_timing(capi, syn)
         extras["tick_sequence"] = run_tick_sequences(torch, syn, args)
+        extras["dense_window"] = run_dense_window(capi, syn)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -996,6 +997,29 @@ def run_keyframe_step_timing(capi, syn):
     return {"workload": "7-frame window, 286 landmarks per keyframe, steady state with one marginalisation per keyframe",
             "push_frame_incl_fold_in_ms": float(med[0]), "landmarks_and_connections_ms": float(med[1]), "solve_ms": float(med[2]),
             "update_frame_read_back_ms": float(med[3]), "marginalisation_flags_ms": float(med[4]), "total_ms": float(med.sum())}
+
+
+def run_dense_window(capi, syn):
+    """the window shape of the reference's dense configuration (test/test_data/tummono/dense.yaml:35,42: 5000 desired points, up to 15
+    keyframes): K = 120, the 5-tiles-per-wave variant of the two-stage Schur kernel when the deterministic build is on"""
+    F, P = 15, 5000
+    win = syn.make_window(num_frames=F, num_points=P, width=640, height=480, seed=2)
+    out = {"workload": f"{F} keyframes, {P} points, 640x480, full clique (dense.yaml: number_of_desired_points 5000, maximum_size 15)"}
+    for name, det in (("default", False), ("deterministic", True)):
+        g = capi.HipWindow(capi.default_pba_options())
+        syn.load_window(g, win)
+        if det:
+            g.set_deterministic(True)
+        g.snapshot()
+        g.optimize_repeated(14)
+        t0 = time.perf_counter()
+        done, _ = g.optimize_repeated(140)
+        dt = time.perf_counter() - t0
+        g.restore()
+        out[name] = {"gn_iterations_per_s": done / dt, "us_per_iteration": dt / done * 1e6,
+                     "kernels_isolated_avg_us": {k: g.time_kernel(k, 50) for k in ("sweep_linearize", "sweep_energy", "schur", "assemble_solve")}}
+        g.close()
+    return out
 
 
 def run_tick_sequences(torch, syn, args):

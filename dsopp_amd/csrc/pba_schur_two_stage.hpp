@@ -154,11 +154,9 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
   const bool bd_in_pad = K < Kp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nt = Kp >> 4, n_tiles = nt * (nt + 1) / 2;
-  const int li = lane & 15, lk = lane >> 4;
   f64x4 acc[TPW];
   // LDS offsets of this wave's tiles (row block ti, column block tj), decoded once; wave-uniform, kept in scalar registers
   int off_a[TPW], off_b[TPW];
-  const int lane_off = lk * stride + li;
 #pragma unroll
   for (int q = 0; q < TPW; ++q) {
     acc[q] = f64x4{0, 0, 0, 0};
@@ -177,7 +175,13 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
   for (int chunk = first_chunk; chunk < last_chunk; ++chunk) {
     const SchurBlock &be = a.schur_table[chunk];
     const int r = be.r;
-    const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    // the thread index is opaque per chunk: what derives from it (row pointers, operand offsets) is recomputed with a few integer
+    // instructions instead of being kept across the loop — next to 4 / 5 resident accumulators those loop invariants went to scratch
+    int tid = static_cast<int>(threadIdx.x);
+    asm volatile("" : "+v"(tid));
+    const int l = tid >> 3, sub = tid & 7;
+    const int lane_off = ((tid & 63) >> 4) * stride + (tid & 15);
+    const int lk = (tid & 63) >> 4;
     const int i = be.offset + l;
     const unsigned conn = be.conn_mask & ~(1u << r);
     const size_t plane = ublkPlane(be.cap);
@@ -212,6 +216,9 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       for (int c = 0; c < kBlk; ++c) hr[c] = 0;
       double hdd = 0, bd = 0;
       double *row = hrow + l * stride;
+      // (not unrolled: two iterations in flight — windows of more than 8 keyframes — hold 20 row words each next to the resident MFMA
+      // accumulators, and the 4- / 5-tile variants spilled two of those accumulators around this phase)
+#pragma unroll 1
       for (int t = sub; t < F; t += 8) {
         if (!(take && ((conn >> t) & 1u))) {
           if (t != r) {  // (the chunk's own frame block is written by sub 0 below)
@@ -236,6 +243,9 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
 #pragma unroll
             for (int k = 0; k < 6; ++k) s += Tt[6 * k + c] * ht[k];
             hr[c] -= s;
+            // (4 / 5 resident accumulators per wave: without this the 36 LDS reads of the adjoint are all in flight at once — 72
+            // registers — and two accumulators went to scratch around this phase)
+            if (TPW >= 4) __builtin_amdgcn_sched_barrier(0);
           }
           hr[6] -= ht[6];
           hr[7] -= Tt[36] * ht[7];
@@ -286,10 +296,13 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       const double *pb = hrow + lane_off + off_b[q];
       // operands in two batches of 8 steps (24 words in flight): with all 16 steps preloaded the kernel needs 168 registers and
       // only ONE workgroup fits per compute unit; at <= 128 two fit, and the second hides the first one's memory round trips
-      constexpr int kHalf = kSchurLandmarks / 8;
+      // (windows of 13 .. 16 keyframes: 4 and 5 resident accumulators per wave — the batches shrink to 4 steps, 12 words in flight, so
+      // that the kernel keeps its 128 registers without scratch: it spilled 11 / 47 registers with batches of 8)
+      constexpr int kBatches = TPW >= 4 ? 4 : 2;
+      constexpr int kHalf = kSchurLandmarks / 4 / kBatches;
       f64x4 c4 = acc[q];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < kBatches; ++half) {
         double av[kHalf], bv[kHalf], wv[kHalf];
 #pragma unroll
         for (int s4 = 0; s4 < kHalf; ++s4) {
@@ -305,14 +318,14 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
       __builtin_amdgcn_sched_barrier(0);  // one tile's operands at a time: hoisting the next tile's LDS reads above costs the registers
     }
     TS_STAMP(4);
-    if (!bd_in_pad && static_cast<int>(threadIdx.x) < K) {
+    if (!bd_in_pad && tid < K) {
       double s = 0, s1 = 0, s2 = 0, s3 = 0;  // four partial sums, 16 LDS reads in flight per batch
 #pragma unroll 4
       for (int ll = 0; ll < kSchurLandmarks; ll += 4) {
-        s += wbd[ll] * hrow[ll * stride + threadIdx.x];
-        s1 += wbd[ll + 1] * hrow[(ll + 1) * stride + threadIdx.x];
-        s2 += wbd[ll + 2] * hrow[(ll + 2) * stride + threadIdx.x];
-        s3 += wbd[ll + 3] * hrow[(ll + 3) * stride + threadIdx.x];
+        s += wbd[ll] * hrow[ll * stride + tid];
+        s1 += wbd[ll + 1] * hrow[(ll + 1) * stride + tid];
+        s2 += wbd[ll + 2] * hrow[(ll + 2) * stride + tid];
+        s3 += wbd[ll + 3] * hrow[(ll + 3) * stride + tid];
       }
       bs_acc += (s + s1) + (s2 + s3);
     }
