@@ -59,7 +59,7 @@ SYMBOLS = [
     "dsopp_hip_window_reject_step", "dsopp_hip_window_update_point_statuses", "dsopp_hip_window_get_frame_state",
     "dsopp_hip_window_get_pose", "dsopp_hip_window_num_landmarks", "dsopp_hip_window_get_landmarks", "dsopp_hip_window_get_residuals",
     "dsopp_hip_window_get_marginalized", "dsopp_hip_window_get_covariance", "dsopp_hip_window_set_allreduce",
-    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_get_frame_update", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_aligner_set_lm_path", "dsopp_hip_estimate_depths", "dsopp_hip_immature_set_create", "dsopp_hip_immature_set_destroy", "dsopp_hip_immature_set_upload_state", "dsopp_hip_immature_set_download_state", "dsopp_hip_immature_set_estimate", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
+    "dsopp_hip_window_last_solve_ms", "dsopp_hip_window_optimize", "dsopp_hip_window_optimize_repeated", "dsopp_hip_window_get_frame_update", "dsopp_hip_window_create_reference_depth_maps", "dsopp_hip_depth_maps_destroy", "dsopp_hip_depth_maps_level_size", "dsopp_hip_depth_maps_get_level", "dsopp_hip_aligner_push_reference_depth_maps", "dsopp_hip_aligner_estimate_pose", "dsopp_hip_aligner_set_hypothesis_width", "dsopp_hip_aligner_set_lm_path", "dsopp_hip_estimate_depths", "dsopp_hip_immature_set_create", "dsopp_hip_immature_set_destroy", "dsopp_hip_immature_set_upload_state", "dsopp_hip_immature_set_download_state", "dsopp_hip_immature_set_estimate", "dsopp_hip_window_set_max_iterations", "dsopp_hip_window_set_lm_mode", "dsopp_hip_window_time_kernel", "dsopp_hip_window_snapshot", "dsopp_hip_window_restore",
     "dsopp_hip_window_set_profiling", "dsopp_hip_window_get_profile", "dsopp_hip_kernel_class_name", "dsopp_hip_aligner_create", "dsopp_hip_aligner_destroy", "dsopp_hip_aligner_reset",
     "dsopp_hip_aligner_push_reference_depth_map", "dsopp_hip_aligner_push_reference_points", "dsopp_hip_aligner_push_target",
     "dsopp_hip_aligner_push_known_pose", "dsopp_hip_aligner_solve", "dsopp_hip_aligner_num_points",
@@ -972,6 +972,10 @@ class HipAligner:
 
     def set_lm_path(self, path: int):
         _chk(lib().dsopp_hip_aligner_set_lm_path(self._h, int(path)))
+
+    def set_hypothesis_width(self, width: int):
+        """initialisations estimate_pose evaluates per launch: 0 automatic, 1 sequential, 2 .. 8 concurrent (one XCD each)"""
+        _chk(lib().dsopp_hip_aligner_set_hypothesis_width(self._h, int(width)))
 
     def push_known_pose(self, timestamp, T_w_agent):
         _chk(lib().dsopp_hip_aligner_push_known_pose(self._h, C.c_int64(int(timestamp)), _p(_f64(T_w_agent))))

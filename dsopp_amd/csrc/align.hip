@@ -722,6 +722,8 @@ constexpr unsigned kPyramidSentinelWord = 0x7FF85A5Au;
 constexpr unsigned long long kPyramidSentinel = (static_cast<unsigned long long>(kPyramidSentinelWord) << 32) | kPyramidSentinelWord;
 constexpr int kPyramidBuffers = 3;
 constexpr unsigned kPyramidFailed = 1u;
+constexpr int kPyramidHypotheses = 8;  // initialisations per launch: one per XCD
+constexpr size_t kPyramidSetDoubles = static_cast<size_t>(kPyramidBuffers) * kPyramidMaxWorkgroups * 48 + 1;  // one hypothesis: exchange buffers + failed flag
 
 struct AlignLevelDev {
   AlignFrameDev ref, tgt;
@@ -746,7 +748,7 @@ struct AlignPyramidResult {
   long long stamps[8];  // -DDSOPP_HIP_STAMPS: wall_clock64 at the phase boundaries of one pass (level 0, third pass) of workgroup 0
 };
 #ifdef DSOPP_HIP_STAMPS
-#define AP_STAMP(i) do { if (blk == 0 && tid == 0 && lvl == 0 && pass == 2) a.out->stamps[i] = wall_clock64(); } while (0)
+#define AP_STAMP(i) do { if (blk == 0 && tid == 0 && lvl == 0 && pass == 2) h_out->stamps[i] = wall_clock64(); } while (0)
 #else
 #define AP_STAMP(i) do { } while (0)
 #endif
@@ -756,13 +758,18 @@ struct AlignPyramidArgs {
   int n_levels;
   int max_iterations;
   double sigma_huber, affine_reg[2], function_tolerance, parameter_tolerance, decrease_on_accept, increase_on_reject, lambda0;
-  double T_tr0[12];
+  // Up to kPyramidHypotheses initialisations of estimatePose run in ONE launch, one per XCD: the workgroups with blockIdx % spread == h
+  // are the participants of hypothesis h (the dispatcher deals workgroups round-robin over the 8 XCDs), every hypothesis with its own
+  // exchange buffers, failed flag, buffer phase and result slot.  n_hyp == 1 is the single-initialisation launch (only every spread-th
+  // workgroup takes part).  The reference tries its initialisations one after the other (monocular_tracker.cpp:193-243); they do not
+  // depend on each other, so the host takes the lowest-index success of a batch and gets the sequential loop's result.
+  int n_hyp;
+  double T_tr0[kPyramidHypotheses][12];
   double ab0[2];
-  double *partials;        // [kPyramidBuffers][kPyramidMaxWorkgroups][kAlignPartial]
-  unsigned *failed;        // == kPyramidFailed once a workgroup gave up waiting (anything else: running); behind the partial buffers
-  AlignPyramidResult *out;
-  int start_phase;         // pass counter (mod 3) this launch continues from: which of the three buffers its first pass publishes into
-  int spread;              // launch = spread x participants; every spread-th workgroup takes part (8: one XCD, 1: no placement attempt)
+  double *partials;        // [n_hyp][kPyramidSetDoubles]: per hypothesis [kPyramidBuffers][kPyramidMaxWorkgroups][kAlignPartial] + the failed flag
+  AlignPyramidResult *out; // [n_hyp]
+  int start_phase[kPyramidHypotheses];  // pass counter (mod 3) the hypothesis' buffers continue from
+  int spread;              // launch = spread x participants per hypothesis (8: one XCD each, 1: no placement attempt — single hypothesis only)
 };
 
 using gu32 = __attribute__((address_space(1))) unsigned;
@@ -780,9 +787,15 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   // they really do is measured, not assumed: every participant publishes its XCC id in the first pass (agent-scope stores, valid
   // for any placement) and only when all ids agree do the later passes publish with plain stores, which stay in that L2 where the
   // L1-bypassing polls of the others find them without a trip over the fabric.
-  if (static_cast<int>(blockIdx.x) % a.spread != 0) return;
+  const int hyp = static_cast<int>(blockIdx.x) % a.spread;
+  if (hyp >= a.n_hyp) return;
   const int blk = static_cast<int>(blockIdx.x) / a.spread;
   const int G = static_cast<int>(gridDim.x) / a.spread;
+  // this hypothesis' exchange buffers, failed flag, result slot and buffer phase (locals: the kernel argument struct is never written)
+  double *const h_partials = a.partials + static_cast<size_t>(hyp) * kPyramidSetDoubles;
+  unsigned *const h_failed = reinterpret_cast<unsigned *>(h_partials + (kPyramidSetDoubles - 1));
+  AlignPyramidResult *const h_out = a.out + hyp;
+  const int h_start_phase = a.start_phase[hyp];
   unsigned xcc_id = 0;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
   xcc_id &= 0xFu;
@@ -792,7 +805,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   // current estimate (T_target_reference rows, affine brightness): in LDS, not in every thread's registers — 28 VGPRs less, and the
   // per-entry initialisation of the control block below needs no dynamically indexed private array (= scratch)
   __shared__ double s_T_cur[12], s_ab_cur[2];
-  if (tid < 12) s_T_cur[tid] = a.T_tr0[tid];
+  if (tid < 12) s_T_cur[tid] = a.T_tr0[hyp][tid];
   if (tid < 2) s_ab_cur[tid] = a.ab0[tid];
   if (tid == 0) s_failed = 0;
   int levels_done = 0, success = 1, lm_iterations = 0;
@@ -876,13 +889,13 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       // (the slot layout does not depend on G and the pass counter continues from the previous launch, so the buffers stay armed from
       // launch to launch and the host fills them only once: a workgroup re-arms its own slot and the slots blk + G, blk + 2 G, ...
       // no participant of THIS launch owns — a previous launch with more participants may have left sums there)
-      const unsigned buf_pass = static_cast<unsigned>(a.start_phase) + pass_global;
+      const unsigned buf_pass = static_cast<unsigned>(h_start_phase) + pass_global;
       if (tid < kAlignPartial)
         for (int slot = blk; slot < kPyramidMaxWorkgroups; slot += G)
-          publish(a.partials + (static_cast<size_t>((buf_pass + 1u) % kPyramidBuffers) * kPyramidMaxWorkgroups + slot) * kAlignPartial + tid, kPyramidSentinel);
+          publish(h_partials + (static_cast<size_t>((buf_pass + 1u) % kPyramidBuffers) * kPyramidMaxWorkgroups + slot) * kAlignPartial + tid, kPyramidSentinel);
       // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
       const int first = blk * kAlignThreads + tid;
-      double *dst = a.partials + (static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups + blk) * kAlignPartial;
+      double *dst = h_partials + (static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups + blk) * kAlignPartial;
       if (blk * kAlignThreads < L.n_points) {
         double acc[kAlignPartial];
         if (preloaded) {
@@ -941,7 +954,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       {
         constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
         const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
-        const double *src = a.partials + static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial + e;
+        const double *src = h_partials + static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial + e;
         if (grp < kGroups) {
           // all loads of this thread are issued before the first test: clamped indices + a 0 / 1 factor instead of predicated
           // loads (G <= 64: at most 13 per thread, one round trip per poll)
@@ -959,8 +972,8 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
 #pragma unroll
             for (int j = 0; j < kMaxPer; ++j) ready = ready && (w[j] != kPyramidSentinel);
             if (ready) break;
-            if (++spins > (1u << 20) || __hip_atomic_load((gu32 *)a.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPyramidFailed) {
-              __hip_atomic_store((gu32 *)a.failed, kPyramidFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++spins > (1u << 20) || __hip_atomic_load((gu32 *)h_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPyramidFailed) {
+              __hip_atomic_store((gu32 *)h_failed, kPyramidFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               s_failed = 1;
               break;
             }
@@ -980,7 +993,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         }
         __syncthreads();
         if (s_failed) {  // a workgroup never showed up (GPU shared with other work): the host falls back to launch-per-iteration
-          if (blk == 0 && tid == 0) a.out->failed = 1;
+          if (blk == 0 && tid == 0) h_out->failed = 1;
           return;
         }
         if (tid < kAlignPartial) {
@@ -1001,9 +1014,9 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     const double rmse = sqrt(sc.energy / static_cast<double>(sc.n_valid));  // NaN without a valid residual: fails the test below
     lm_iterations += sc.iteration;
     if (blk == 0 && tid == 0) {
-      a.out->rmse[lvl] = rmse;
-      a.out->iterations[lvl] = sc.iteration;
-      a.out->n_valid[lvl] = sc.n_valid;
+      h_out->rmse[lvl] = rmse;
+      h_out->iterations[lvl] = sc.iteration;
+      h_out->n_valid[lvl] = sc.n_valid;
     }
     if (!(rmse < L.rmse_limit)) {
       success = 0;
@@ -1032,15 +1045,15 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   }
   __syncthreads();
   if (blk == 0 && tid == 0) {
-    a.out->same_xcd = s_same_xcd;
-    a.out->end_phase = static_cast<int>((static_cast<unsigned>(a.start_phase) + pass_global) % kPyramidBuffers);
-    a.out->levels_done = levels_done;
-    a.out->success = success;
-    a.out->failed = 0;
-    a.out->lm_iterations = lm_iterations;
-    for (int i = 0; i < 12; ++i) a.out->T_tr[i] = s_T_cur[i];
-    a.out->ab[0] = s_ab_cur[0];
-    a.out->ab[1] = s_ab_cur[1];
+    h_out->same_xcd = s_same_xcd;
+    h_out->end_phase = static_cast<int>((static_cast<unsigned>(h_start_phase) + pass_global) % kPyramidBuffers);
+    h_out->levels_done = levels_done;
+    h_out->success = success;
+    h_out->failed = 0;
+    h_out->lm_iterations = lm_iterations;
+    for (int i = 0; i < 12; ++i) h_out->T_tr[i] = s_T_cur[i];
+    h_out->ab[0] = s_ab_cur[0];
+    h_out->ab[1] = s_ab_cur[1];
   }
 }
 
@@ -1070,7 +1083,10 @@ struct dsopp_hip_aligner {
 
   DeviceBuffer<AlignPyramidResult> d_pyr_out;
   AlignPyramidResult *h_pyr_out = nullptr;     // pinned
-  int pyr_phase = -1;  // buffer phase the next persistent launch starts with; -1: the exchange buffers have to be (re)armed by a fill first
+  int pyr_phase[kPyramidHypotheses] = {-1, -1, -1, -1, -1, -1, -1, -1};  // per hypothesis slot: buffer phase the next persistent launch starts
+                                                                          // with; -1: the slot's exchange buffers have to be (re)armed by a fill
+  int hypothesis_width = 0;  // initialisations per launch: 0 automatic (1 while tracking holds, 8 once a first try has failed), 1 .. 8 fixed
+  int last_tries = 0;        // tries of the previous estimate_pose (automatic width)
   bool pyramid_kernel_disabled = false;        // a bounded spin timed out once (GPU shared with other work): stay on the launch-per-iteration path
   bool have_rotation_prior = false;  // setRotationPrior, cleared by reset() (eigen_pose_alignment.cpp:254-263)
   double rotation_prior[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -1565,6 +1581,14 @@ int dsopp_hip_aligner_solve(dsopp_hip_aligner *a, dsopp_hip_align_result *result
 }
 
 
+int dsopp_hip_aligner_set_hypothesis_width(dsopp_hip_aligner *a, int32_t width) {
+  return guarded([&] {
+    if (!a) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null aligner");
+    if (width < 0 || width > kPyramidHypotheses) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "hypothesis width must be 0 (automatic) .. %d", kPyramidHypotheses);
+    a->hypothesis_width = width;
+  });
+}
+
 int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time, const double T_world_reference[7],
                                     const dsopp_hip_pyramid *reference_pyramid, const dsopp_hip_depth_maps *reference_depth_maps,
                                     double reference_exposure, const double reference_affine[2], int64_t target_time,
@@ -1604,17 +1628,17 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
   double T[7], ab[2], T_const[7] = {0, 0, 0, 1, 0, 0, 0}, ab_const[2] = {0, 0};
   bool success = false;
   int tries = 0, lm_iterations = 0;
-  for (int try_number = 0; !success && try_number < n_initializations; ++try_number) {
-    ++tries;
-    success = true;
-    std::memcpy(T, T_world_target_init + 7 * try_number, sizeof(T));
-    ab[0] = affine_init[0];
-    ab[1] = affine_init[1];
-    std::copy(rmse_last_pose_estimation, rmse_last_pose_estimation + levels, local_rmse.begin());
-    // ---- one persistent launch over all levels (alignPyramidKernel); the launch-per-iteration loop below is the fallback
-    // (lm_path 1, a known pose for this frame, or a spin time-out on a GPU shared with other work)
+  int try_number = 0;
+  while (!success && try_number < n_initializations) {
+    // ---- persistent launches over all levels (alignPyramidKernel), up to kPyramidHypotheses initialisations per launch; the
+    // launch-per-iteration loop below is the fallback (lm_path 1, a known pose for this frame, or a spin time-out on a GPU shared with
+    // other work).  Width of a batch: while tracking holds the first initialisation succeeds (previous motion), so it runs alone — one
+    // XCD, nothing wasted; once a first try has failed (this call or the previous one) the remaining initialisations go out 8 at a time.
     if (a->lm_path == 0 && !a->pyramid_kernel_disabled && a->known_poses.find(target_time) == a->known_poses.end()) {
-      int fast = 0;  // 1: the try was decided by the persistent launch
+      const int auto_width = (try_number == 0 && a->last_tries <= 1) ? 1 : kPyramidHypotheses;
+      const int width = a->hypothesis_width > 0 ? a->hypothesis_width : auto_width;
+      const int nb = std::min(width, n_initializations - try_number);
+      bool fast = false;  // the batch was decided by the persistent launch
       const int rc = guarded([&] {
         a->sr.use();
         hipStream_t st = a->sr.stream;
@@ -1641,7 +1665,8 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
           L.pid = pts.idepth.ptr;
           L.pint = pts.intensity.ptr;
           L.n_points = pts.n;
-          L.rmse_limit = kEnergyRatioThreshold * local_rmse[static_cast<size_t>(lvl)];
+          // (every try starts from the caller's rmse_last_pose_estimation: monocular_tracker.cpp:198)
+          L.rmse_limit = kEnergyRatioThreshold * rmse_last_pose_estimation[lvl];
           max_blocks = std::max(max_blocks, (pts.n + kAlignThreads - 1) / kAlignThreads);
         }
         const int G = std::min(kPyramidMaxWorkgroups, max_blocks);
@@ -1655,78 +1680,105 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         args.decrease_on_accept = 2.0;  // eigen_pose_alignment.cpp:304-305
         args.increase_on_reject = 2.0;
         args.lambda0 = 1.0 / a->opt.initial_trust_region_radius;
-        const Rigid T_tr = rigidMul(rigidInverse(rigidFromParams(T)), rigidFromParams(T_world_reference));  // eigen_pose_alignment.cpp:307-308
-        for (int i = 0; i < 3; ++i) {
-          for (int j = 0; j < 3; ++j) args.T_tr0[4 * i + j] = T_tr.R[3 * i + j];
-          args.T_tr0[4 * i + 3] = T_tr.t[i];
+        args.n_hyp = nb;
+        for (int h = 0; h < nb; ++h) {
+          const Rigid T_tr = rigidMul(rigidInverse(rigidFromParams(T_world_target_init + 7 * (try_number + h))),
+                                      rigidFromParams(T_world_reference));  // eigen_pose_alignment.cpp:307-308
+          for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) args.T_tr0[h][4 * i + j] = T_tr.R[3 * i + j];
+            args.T_tr0[h][4 * i + 3] = T_tr.t[i];
+          }
         }
-        args.ab0[0] = ab[0];
-        args.ab0[1] = ab[1];
-        const size_t n_partial = static_cast<size_t>(kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial;
-        a->d_pyr_partials.reserve(n_partial + 1, 0, st);  // + one word pair for the failed flag
-        a->d_pyr_out.reserve(1, 0, st);
-        if (!a->h_pyr_out) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_pyr_out), sizeof(AlignPyramidResult), hipHostMallocDefault));
+        args.ab0[0] = affine_init[0];
+        args.ab0[1] = affine_init[1];
+        static_assert(kAlignPartial == 48, "kPyramidSetDoubles");
+        a->d_pyr_partials.reserve(kPyramidHypotheses * kPyramidSetDoubles, 0, st);
+        if (!a->h_pyr_out)
+          HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_pyr_out), kPyramidHypotheses * sizeof(AlignPyramidResult), hipHostMallocDefault));
         args.partials = a->d_pyr_partials.ptr;
-        args.failed = reinterpret_cast<unsigned *>(a->d_pyr_partials.ptr + n_partial);
-        args.out = a->h_pyr_out;  // pinned host memory: the kernel leaves its result there itself (no copy kernel behind it)
-        // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill — before the first
-        // launch and after a failed one only; a launch leaves the buffers armed for its successor (the pass counter continues, the
-        // kernel re-arms by its rotation rule), which saves two fill kernels (10 us) per tracked frame
-        if (a->pyr_phase < 0) {
-          HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr), static_cast<int>(kPyramidSentinelWord), 2 * (n_partial + 1), st));
-          a->pyr_phase = 0;
+        args.out = a->h_pyr_out;  // pinned host memory: the kernel leaves its results there itself (no copy kernel behind it)
+        // every slot armed with the sentinel, the failed flag with the same (!= kPyramidFailed) pattern: one fill per hypothesis slot —
+        // before its first launch and after a failed one only; a launch leaves the buffers armed for its successor (the pass counter
+        // continues, the kernel re-arms by its rotation rule), which saves two fill kernels (10 us) per tracked frame
+        for (int h = 0; h < nb; ++h) {
+          if (a->pyr_phase[h] < 0) {
+            HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a->d_pyr_partials.ptr + static_cast<size_t>(h) * kPyramidSetDoubles),
+                                        static_cast<int>(kPyramidSentinelWord), 2 * kPyramidSetDoubles, st));
+            a->pyr_phase[h] = 0;
+          }
+          args.start_phase[h] = a->pyr_phase[h];
+          a->pyr_phase[h] = -1;  // (until this launch has reported how it left the buffers)
         }
-        args.start_phase = a->pyr_phase;
-        a->pyr_phase = -1;  // (until this launch has reported how it left the buffers)
         static const int spread_override = std::getenv("DSOPP_HIP_ALIGN_SPREAD") ? std::atoi(std::getenv("DSOPP_HIP_ALIGN_SPREAD")) : 0;  // tuning aid
-        args.spread = spread_override > 0 ? spread_override : 8;
+        args.spread = (nb == 1 && spread_override > 0) ? spread_override : 8;
         if (a->opt.dtype == DSOPP_HIP_F64)
           alignPyramidKernel<double><<<G * args.spread, kAlignThreads, 0, st>>>(args);
         else
           alignPyramidKernel<float><<<G * args.spread, kAlignThreads, 0, st>>>(args);
         HIP_CHECK(hipGetLastError());
         a->sr.sync();
-        const AlignPyramidResult &o = *a->h_pyr_out;
 #ifdef DSOPP_HIP_STAMPS
-        if (std::getenv("DSOPP_HIP_TRACE"))
+        if (std::getenv("DSOPP_HIP_TRACE")) {
+          const AlignPyramidResult &o = a->h_pyr_out[0];
           std::fprintf(stderr, "alignPyramid pass (level 0): decide %.2f  sweep %.2f  wg-reduce+store %.2f  arrive+wait %.2f  global sum %.2f us (G = %d, one XCD: %d)\n",
                        (o.stamps[1] - o.stamps[0]) / 100.0, (o.stamps[2] - o.stamps[1]) / 100.0, (o.stamps[3] - o.stamps[2]) / 100.0,
                        (o.stamps[4] - o.stamps[3]) / 100.0, (o.stamps[5] - o.stamps[4]) / 100.0, G, o.same_xcd);
+        }
 #endif
-        if (o.failed) {
-          a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
-          return;
-        }
-        a->pyr_phase = o.end_phase;  // the buffers are armed for a launch that continues the pass counter from here
-        fast = 1;
-        lm_iterations += o.lm_iterations;
-        success = o.success != 0;
-        const int accepted = o.success ? o.levels_done : o.levels_done - 1;  // the last level run failed its energy test
-        for (int k = 0; k < accepted; ++k) {
-          const int lvl = levels - 1 - k;
-          local_rmse[static_cast<size_t>(lvl)] = o.rmse[lvl];
-        }
-        Rigid Tfin;
-        for (int i = 0; i < 3; ++i) {
-          for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = o.T_tr[4 * i + j];
-          Tfin.t[i] = o.T_tr[4 * i + 3];
-        }
-        if (accepted > 0) {  // (no level accepted: the initialisation itself is what the reference keeps)
-          rigidToParams(rigidMul(rigidFromParams(T_world_reference), rigidInverse(Tfin)), T);
-          ab[0] = o.ab[0];
-          ab[1] = o.ab[1];
-        }
+        for (int h = 0; h < nb; ++h)
+          if (a->h_pyr_out[h].failed) {
+            a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else
+            return;
+          }
+        for (int h = 0; h < nb; ++h) a->pyr_phase[h] = a->h_pyr_out[h].end_phase;  // armed for a launch that continues the pass counter
+        fast = true;
       });
       if (rc != DSOPP_HIP_OK) return rc;
       if (fast) {
-        if (try_number == 0) {
-          std::memcpy(T_const, T, sizeof(T));
-          ab_const[0] = ab[0];
-          ab_const[1] = ab[1];
+        // the batch in the order of the sequential loop: the first success ends it
+        for (int h = 0; h < nb && !success; ++h) {
+          const AlignPyramidResult &o = a->h_pyr_out[h];
+          ++tries;
+          lm_iterations += o.lm_iterations;
+          std::memcpy(T, T_world_target_init + 7 * (try_number + h), sizeof(T));
+          ab[0] = affine_init[0];
+          ab[1] = affine_init[1];
+          const int accepted = o.success ? o.levels_done : o.levels_done - 1;  // the last level run failed its energy test
+          if (accepted > 0) {  // (no level accepted: the initialisation itself is what the reference keeps)
+            Rigid Tfin;
+            for (int i = 0; i < 3; ++i) {
+              for (int j = 0; j < 3; ++j) Tfin.R[3 * i + j] = o.T_tr[4 * i + j];
+              Tfin.t[i] = o.T_tr[4 * i + 3];
+            }
+            rigidToParams(rigidMul(rigidFromParams(T_world_reference), rigidInverse(Tfin)), T);
+            ab[0] = o.ab[0];
+            ab[1] = o.ab[1];
+          }
+          if (try_number + h == 0) {
+            std::memcpy(T_const, T, sizeof(T));
+            ab_const[0] = ab[0];
+            ab_const[1] = ab[1];
+          }
+          if (o.success) {
+            success = true;
+            std::copy(rmse_last_pose_estimation, rmse_last_pose_estimation + levels, local_rmse.begin());
+            for (int k = 0; k < accepted; ++k) {
+              const int lvl = levels - 1 - k;
+              local_rmse[static_cast<size_t>(lvl)] = o.rmse[lvl];
+            }
+          }
         }
+        try_number += nb;
         continue;
       }
     }
+    // ---- one initialisation, one launch per Levenberg-Marquardt iteration
+    ++tries;
+    success = true;
+    std::memcpy(T, T_world_target_init + 7 * try_number, sizeof(T));
+    ab[0] = affine_init[0];
+    ab[1] = affine_init[1];
+    std::copy(rmse_last_pose_estimation, rmse_last_pose_estimation + levels, local_rmse.begin());
     for (int lvl = levels - 1; success && lvl >= 0; --lvl) {
       const double s = static_cast<double>(1 << lvl);  // CameraCalibration::cameraModel(level), camera_calibration.cpp:66-70
       const double intr[4] = {intrinsics[0] / s, intrinsics[1] / s, intrinsics[2] / s, intrinsics[3] / s};
@@ -1753,7 +1805,9 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
       ab_const[0] = ab[0];
       ab_const[1] = ab[1];
     }
+    ++try_number;
   }
+  a->last_tries = tries;
   if (!success) {
     std::memcpy(T, T_const, sizeof(T));
     ab[0] = ab_const[0];

@@ -526,6 +526,13 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
                                     int32_t n_initializations, const double *T_world_target_init, const double affine_init[2],
                                     double *rmse_last_pose_estimation, double T_world_target[7], double affine_brightness[2],
                                     int32_t *success, int32_t *tries, int32_t *lm_iterations);
+/* Initialisations estimate_pose evaluates per launch.  The reference tries them one after the other until one passes its per-level
+ * energy gates (monocular_tracker.cpp:193-243); they are independent of each other, so up to 8 run concurrently — one per XCD of the
+ * device, each with its own exchange buffers — and the lowest-index success is taken: pose, `tries`, `lm_iterations` and the updated
+ * rmse_last_pose_estimation are those of the sequential loop.  0 (default): automatic — the first initialisation alone while
+ * tracking holds (it succeeds; nothing is computed in vain), 8 at a time as soon as a first try failed in this or the previous call
+ * (re-localisation: up to 113 initialisations); 1: strictly one per launch; 2 .. 8: that many per launch from the first one on. */
+int dsopp_hip_aligner_set_hypothesis_width(dsopp_hip_aligner *a, int32_t width);
 /* 0 (default): the whole LM loop of a solve runs in ONE launch of one workgroup when the reference has at most 16384 points
  * (a launch per iteration costs more than the iteration at that size); 1: always one launch per LM iteration (multi-workgroup).
  * Same state machine and arithmetic on both paths (parity cross-check in tests/test_gpu_tracker.py). */
