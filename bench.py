@@ -754,6 +754,37 @@ def run_tracker_timing(capi, syn, torch, frames=20, no_cpu=False, levels=5):
            "mean_square_optical_flow_ms_per_frame": flow_ms, "mean_square_optical_flow": float(flow[0]),
            "rmse_per_level": [float(x) for x in rl_final],
            "data": "synthetic 7-keyframe window + 1 new frame, target image resident in HBM"}
+    # re-localisation (monocular_tracker.cpp:136-176,193-243): the initialisations are tried until one passes the per-level energy gates —
+    # here every one but the last is far off (25 .. 45 degrees), with the gates a normally tracked frame leaves.  One per launch (the
+    # sequential loop) against eight per launch (one XCD each, dsopp_hip_aligner_set_hypothesis_width; the default switches to it once a
+    # first try has failed)
+    rng = np.random.default_rng(11)
+
+    def far():
+        ax = rng.normal(size=3)
+        return np.concatenate([rng.normal(0, 1.0, 3), ax / np.linalg.norm(ax) * rng.uniform(0.45, 0.8)])
+
+    hyp_out = {}
+    for n_hyp in (8, 113):
+        hyp = np.stack([syn.mat_to_params(new_frame.T_w_c_init @ syn.se3_exp(far())) for _ in range(n_hyp - 1)] + [T_init])
+        row = {}
+        for width, name in ((1, "one_per_launch_ms"), (8, "eight_per_launch_ms")):
+            a.set_hypothesis_width(width)
+            ts, r = [], None
+            for _ in range(3 if n_hyp > 8 and width == 1 else 7):
+                rl = rl_final.copy()
+                t0 = time.perf_counter()
+                r = a.estimate_pose(kf.timestamp, T_ref, pr, maps, 1.0, ab_ref, new_frame.timestamp, pt, 1.0, win.scene.intrinsics, hyp, np.zeros(2), rl)
+                ts.append(time.perf_counter() - t0)
+            row[name] = float(np.median(ts) * 1e3)
+            row.setdefault("tries", []).append(int(r["tries"]))
+            row.setdefault("success", []).append(bool(r["success"]))
+            row.setdefault("pose", []).append(r["T_w_target"])
+        row["identical_result"] = bool(np.array_equal(row["pose"][0], row["pose"][1]) and row["tries"][0] == row["tries"][1])
+        del row["pose"]
+        hyp_out[f"{n_hyp}_initialisations_last_one_good"] = row
+    a.set_hypothesis_width(0)
+    out["relocalisation"] = hyp_out
     if not no_cpu:
         # the same frame through the CPU port: pyramid of the new frame + the coarse-to-fine chain stepped level by level
         # (scan of the depth map, alignment) from the same initialisation, against the same (downloaded) depth maps
