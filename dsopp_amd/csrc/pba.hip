@@ -383,6 +383,7 @@ void syncTopology(W &w) {
   // measured: 7 KF / 20k points (120k items) 36.8 / 33.1 / 38.8 us at 2 / 4 / 6 groups; 12 KF / 50k points (550k items) 143 / 125 / 119 us
   const int groups = groups_override > 0 ? groups_override : (total_items >= 300000 ? 6 : (total_items >= 30000 ? 4 : 1));
   std::vector<int> pair_first(kMaxFrames * kMaxFrames, -1), pair_count(kMaxFrames * kMaxFrames, 0);
+  std::vector<std::vector<SweepBlock>> pair_blocks(kMaxFrames * kMaxFrames), pair_fine_blocks(kMaxFrames * kMaxFrames);
   for (int r = 0; r < F; ++r) {
     HostFrame &f = *w.frames[static_cast<size_t>(r)];
     FrameDev &d = fd[static_cast<size_t>(r)];
@@ -430,8 +431,8 @@ void syncTopology(W &w) {
       d.n_res[t] = rt.n;
       d.snap_status[t] = hbm(rt.snap_status.ptr);
       if (d.first_conn < 0) d.first_conn = t;
-      pair_first[static_cast<size_t>(r * kMaxFrames + t)] = static_cast<int>(sweep.size());
-      int cnt = 0;
+      std::vector<SweepBlock> &pair_sweep = pair_blocks[static_cast<size_t>(r * kMaxFrames + t)];
+      std::vector<SweepBlock> &pair_fine = pair_fine_blocks[static_cast<size_t>(r * kMaxFrames + t)];
       for (int off = 0; off < rt.n; off += kItemsPerBlock) {
         const bool coarse_entry = (off / kItemsPerBlock) % groups == 0;
         SweepBlock sb;
@@ -458,14 +459,12 @@ void syncTopology(W &w) {
         sb.fej_valid = hbm(rt.fej_valid.ptr);
         sb.cand = hbm(rt.cand.ptr);
         sb.n_groups = 1;
-        if (groups > 1) fine.push_back(sb);
+        if (groups > 1) pair_fine.push_back(sb);
         if (coarse_entry) {
           sb.n_groups = std::min(groups, (rt.n - off + kItemsPerBlock - 1) / kItemsPerBlock);
-          sweep.push_back(sb);
-          ++cnt;
+          pair_sweep.push_back(sb);
         }
       }
-      pair_count[static_cast<size_t>(r * kMaxFrames + t)] = cnt;
     }
     for (int off = 0; off < f.n; off += kSchurLandmarks) {
       SchurBlock sb;
@@ -491,6 +490,21 @@ void syncTopology(W &w) {
       schur.push_back(sb);
     }
   }
+  // Order of the sweep table: TARGET-major — all pairs that sample the same target image run back to back, so that an XCD's L2 (4 MB,
+  // against 9.8 MB of texels per 640 x 480 image) sees the second and later visits of a texel line while it may still hold it: the
+  // sweep is bound by the rate at which the fabric serves randomly placed 64-byte requests, and every L2 hit is one
+  // request less.  (Reference-major until round 4: consecutive pairs switched the image.)  DSOPP_HIP_SWEEP_ORDER=rt restores it (A/B).
+  static const bool reference_major = std::getenv("DSOPP_HIP_SWEEP_ORDER") != nullptr && std::string(std::getenv("DSOPP_HIP_SWEEP_ORDER")) == "rt";
+  for (int outer = 0; outer < F; ++outer)
+    for (int inner = 0; inner < F; ++inner) {
+      const int r = reference_major ? outer : inner, t = reference_major ? inner : outer;
+      const size_t pi = static_cast<size_t>(r * kMaxFrames + t);
+      if (pair_blocks[pi].empty()) continue;
+      pair_first[pi] = static_cast<int>(sweep.size());
+      pair_count[pi] = static_cast<int>(pair_blocks[pi].size());
+      sweep.insert(sweep.end(), pair_blocks[pi].begin(), pair_blocks[pi].end());
+      fine.insert(fine.end(), pair_fine_blocks[pi].begin(), pair_fine_blocks[pi].end());
+    }
   for (std::vector<SweepBlock> *tbl : {&sweep, &fine})
     for (SweepBlock &sb : *tbl) {
       const FrameDev &dr = fd[static_cast<size_t>(sb.r)], &dt = fd[static_cast<size_t>(sb.t)];
