@@ -555,7 +555,7 @@ class HipWindow:
 
 
 
-TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_LOCAL = 0, 1, 2
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_LOCAL, TRANSPORT_P2P = 0, 1, 2, 3
 
 
 class PyramidGroup:

@@ -34,6 +34,7 @@ namespace dsopp_hip {
 namespace {
 
 constexpr int kMaxShards = 16;
+constexpr int kBlkConst = DSOPP_HIP_BLOCK_SIZE;
 
 struct ShardBuffers {
   double *p[kMaxShards];
@@ -133,6 +134,146 @@ int localAllreduce(void *user, void *device_buffer, size_t count, void *stream) 
   if (!r.bar.wait()) return -2;
   if (i != 0 && hipStreamWaitEvent(st, r.ev_out, 0) != hipSuccess) r.failed.store(1);
   return r.failed.load() ? -1 : 0;
+}
+
+// ---- DSOPP_HIP_TRANSPORT_P2P: the one-shot all-reduce ----------------------------------------------------------------------------
+// The per-iteration collective is 15 .. 41 KB: a ring over xGMI (RCCL) pays its latency n - 1 times, the in-process reducer above a
+// host barrier.  Here every shard stores its partial sums straight into EVERY peer's receive area (xGMI is point to point: 7 direct
+// links per device, one write latency) and adds up what the others stored into its own — one kernel per shard, no host involvement:
+//   workgroup w of shard s:  push slice w of the buffer into recv[p][s] of every shard p  ->  system-scope release of flag[p][s][w]
+//                            ->  wait (system-scope acquire) for flag[s][q][w] of every shard q  ->  slice w of the sum, added in
+//                            shard order (deterministic, identical on every shard), back into the buffer.
+// Slice w of the result needs slice w of every source only, so the workgroups never meet.  Receive areas and flags are double
+// buffered by the collective's parity: a shard can be at most one collective ahead of the slowest (it needs everybody's pushes to
+// finish its own).  Flags carry the collective's number and are never reset.  The memory is fine-grained (coherent across devices
+// while kernels run).  Every spin is bounded: a time-out raises an error word in pinned memory that the group reports after the call.
+// Buffers larger than the receive area (the energies of the point statuses, the depth-map planes: once per solve / keyframe) take the
+// in-process reducer above.  Only executable on one device here (repeated ids): peers are then the device itself.
+constexpr int kP2PBlocks = 32, kP2PThreads = 256;
+constexpr size_t kP2PCapacity = 2 * (static_cast<size_t>(kBlkConst * DSOPP_HIP_MAX_FRAMES) * (kBlkConst * DSOPP_HIP_MAX_FRAMES) + kBlkConst * DSOPP_HIP_MAX_FRAMES) + 8 + 4 * 64;
+
+struct P2PArgs {
+  double *recv_of[kMaxShards];              // per shard: [2 parities][n sources][kP2PCapacity]
+  unsigned long long *flags_of[kMaxShards]; // per shard: [2 parities][n sources][kP2PBlocks]
+  double *buf_of[kMaxShards];               // the shards' buffers (distinct devices: only [shard] is used)
+  int *error;                               // pinned host words, one per shard
+  unsigned long long generation;
+  int shard, n;                             // shard < 0: ONE launch plays every shard, shard = blockIdx.y (all shards on one device)
+  unsigned count;
+};
+
+__global__ void __launch_bounds__(kP2PThreads) p2pAllreduceKernel(P2PArgs a) {
+  __shared__ int s_timeout;
+  const int w = blockIdx.x, tid = threadIdx.x;
+  // Shards on distinct devices launch one kernel each.  Shards that share a device cannot: kernels of different streams are not
+  // guaranteed to run concurrently (streams may share a hardware queue), so one waiting for the other can wait for ever — there the
+  // shards' workgroups are the rows of ONE launch (blockIdx.y), resident together, and run the same protocol.
+  const int shard = a.shard < 0 ? static_cast<int>(blockIdx.y) : a.shard;
+  double *const buf = a.buf_of[shard];
+  int *const error = a.error + shard;
+  const unsigned per = ((a.count + kP2PBlocks - 1) / kP2PBlocks + 1u) & ~1u;
+  const unsigned lo = min(a.count, w * per), hi = min(a.count, lo + per);
+  const size_t parity = a.generation & 1ull;
+  if (tid == 0) s_timeout = 0;
+  // push this workgroup's slice into every shard's receive area (its own included: one code path, sums in shard order)
+  for (int p = 0; p < a.n; ++p) {
+    double *dst = a.recv_of[p] + (parity * a.n + shard) * kP2PCapacity;
+    for (unsigned i = lo + tid; i < hi; i += kP2PThreads) dst[i] = buf[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < a.n)
+    __hip_atomic_store(a.flags_of[tid] + (parity * a.n + shard) * kP2PBlocks + w, a.generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // wait for the slice of every source
+  if (tid < a.n) {
+    const unsigned long long *f = a.flags_of[shard] + (parity * a.n + tid) * kP2PBlocks + w;
+    unsigned spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.generation) {
+      if (++spins > (1u << 22) || __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        s_timeout = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+  if (s_timeout) {
+    if (tid == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  __threadfence_system();  // (acquire side for the lanes that did not poll)
+  const double *mine = a.recv_of[shard] + parity * a.n * kP2PCapacity;
+  for (unsigned i = lo + tid; i < hi; i += kP2PThreads) {
+    double sum = 0;
+    for (int q = 0; q < a.n; ++q) sum += mine[static_cast<size_t>(q) * kP2PCapacity + i];
+    buf[i] = sum;
+  }
+}
+
+struct P2PReducer {
+  int n = 0;
+  std::vector<double *> recv;
+  std::vector<unsigned long long *> flags;
+  std::vector<unsigned long long> generation;  // per shard: collectives issued so far (all shards issue the same sequence)
+  int *error = nullptr;                        // pinned host memory, one word per shard
+  std::vector<int> device;
+  bool one_device = false;                     // every shard on the same device: one launch plays all shards (see the kernel)
+};
+
+struct P2PUser {
+  P2PReducer *p2p;
+  ShardUser *local;  // buffers beyond the receive area take the in-process reducer
+  int shard;
+};
+
+int p2pAllreduce(void *user, void *device_buffer, size_t count, void *stream) {
+  auto *u = static_cast<P2PUser *>(user);
+  if (count > kP2PCapacity) return localAllreduce(u->local, device_buffer, count, stream);
+  P2PReducer &r = *u->p2p;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  P2PArgs a;
+  for (int p = 0; p < r.n; ++p) {
+    a.recv_of[p] = r.recv[static_cast<size_t>(p)];
+    a.flags_of[p] = r.flags[static_cast<size_t>(p)];
+    a.buf_of[p] = nullptr;
+  }
+  a.error = r.error;
+  a.n = r.n;
+  a.count = static_cast<unsigned>(count);
+  if (!r.one_device) {
+    a.buf_of[u->shard] = static_cast<double *>(device_buffer);
+    a.generation = ++r.generation[static_cast<size_t>(u->shard)];
+    a.shard = u->shard;
+    p2pAllreduceKernel<<<kP2PBlocks, kP2PThreads, 0, st>>>(a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  // all shards on one device: event-ordered like the in-process reducer (ev_in -> host barrier -> shard 0 launches -> ev_out), but what
+  // shard 0 launches is the peer-to-peer kernel with one row of workgroups per shard
+  LocalReducer &lr = *u->local->red;
+  const int i = u->shard;
+  lr.slot[static_cast<size_t>(i)] = {static_cast<double *>(device_buffer), count, st};
+  if (hipEventRecord(lr.ev_in[static_cast<size_t>(i)], st) != hipSuccess) lr.failed.store(1);
+  if (!lr.bar.wait()) return -2;
+  if (i == 0) {
+    bool ok = true;
+    for (int j = 0; j < r.n; ++j) {
+      const LocalReducer::Slot &sl = lr.slot[static_cast<size_t>(j)];
+      ok = ok && sl.count == count && sl.buf != nullptr;
+      a.buf_of[j] = sl.buf;
+      if (j > 0 && hipStreamWaitEvent(st, lr.ev_in[static_cast<size_t>(j)], 0) != hipSuccess) ok = false;
+    }
+    if (ok) {
+      a.generation = ++r.generation[0];
+      a.shard = -1;
+      p2pAllreduceKernel<<<dim3(kP2PBlocks, static_cast<unsigned>(r.n)), kP2PThreads, 0, st>>>(a);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    if (hipEventRecord(lr.ev_out, st) != hipSuccess) ok = false;
+    if (!ok) lr.failed.store(1);
+  }
+  if (!lr.bar.wait()) return -2;
+  if (i != 0 && hipStreamWaitEvent(st, lr.ev_out, 0) != hipSuccess) lr.failed.store(1);
+  return lr.failed.load() ? -1 : 0;
 }
 
 /** one worker thread per shard; run() executes the same job on all of them and returns the per-shard status codes */
@@ -261,6 +402,8 @@ struct dsopp_hip_window_group {
   static constexpr size_t kMaxShadowSets = 4;
   LocalReducer reducer;
   std::vector<ShardUser> users;
+  P2PReducer p2p;
+  std::vector<P2PUser> p2p_users;
   ShardPool pool;
   bool pooled = false;               // calls go through the worker threads (n > 1, or DSOPP_HIP_GROUP_FORCE_POOL for a group of one)
   std::atomic<bool> poisoned{false};  // RCCL transport: a shard failed and the communicators were aborted — the group only waits to be destroyed
@@ -295,6 +438,13 @@ void fanOut(G &g, Body &&body) {
     return;
   }
   g.pool.run([&](int s) -> int { return body(s, g.win[static_cast<size_t>(s)]); });
+  if (g.p2p.error) {  // DSOPP_HIP_TRANSPORT_P2P: a bounded wait of the one-shot all-reduce ran out (raised by the kernel in pinned memory)
+    for (int s = 0; s < g.n; ++s)
+      if (g.p2p.error[s]) {
+        g.poisoned.store(true);
+        fail(DSOPP_HIP_ERR_HIP, "shard %d: the peer-to-peer all-reduce timed out waiting for another shard's partial sums (its results are invalid; destroy the group)", s);
+      }
+  }
 }
 
 void checkGroup(const G *g) {
@@ -310,7 +460,7 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
   return guarded([&] {
     if (!options || !device_ids || !out) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (n < 1 || n > kMaxShards) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "a window group holds 1 .. %d shards, %d requested", kMaxShards, n);
-    if (transport != DSOPP_HIP_TRANSPORT_AUTO && transport != DSOPP_HIP_TRANSPORT_RCCL && transport != DSOPP_HIP_TRANSPORT_LOCAL)
+    if (transport != DSOPP_HIP_TRANSPORT_AUTO && transport != DSOPP_HIP_TRANSPORT_RCCL && transport != DSOPP_HIP_TRANSPORT_LOCAL && transport != DSOPP_HIP_TRANSPORT_P2P)
       fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "unknown transport %d", transport);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) fail(DSOPP_HIP_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
@@ -385,7 +535,7 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
         };
       }
     }
-    if (n > 1 && transport == DSOPP_HIP_TRANSPORT_LOCAL) {
+    if (n > 1 && (transport == DSOPP_HIP_TRANSPORT_LOCAL || transport == DSOPP_HIP_TRANSPORT_P2P)) {
       LocalReducer &r = g->reducer;
       r.n = n;
       r.device = g->device;
@@ -404,13 +554,60 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
         (void)hipGetLastError();
       }
       HIP_CHECK(hipEventCreateWithFlags(&r.ev_out, hipEventDisableTiming));
+      const bool p2p = transport == DSOPP_HIP_TRANSPORT_P2P;
+      if (p2p) {
+        // every shard writes into every shard's receive area: peer access between all pairs of distinct devices
+        for (int i = 0; i < n; ++i) {
+          HIP_CHECK(hipSetDevice(g->device[static_cast<size_t>(i)]));
+          for (int j = 0; j < n; ++j) {
+            if (g->device[static_cast<size_t>(i)] == g->device[static_cast<size_t>(j)]) continue;
+            int can = 0;
+            HIP_CHECK(hipDeviceCanAccessPeer(&can, g->device[static_cast<size_t>(i)], g->device[static_cast<size_t>(j)]));
+            if (!can) fail(DSOPP_HIP_ERR_HIP, "device %d cannot access device %d: the peer-to-peer all-reduce needs peer access between all shards",
+                           g->device[static_cast<size_t>(i)], g->device[static_cast<size_t>(j)]);
+            const hipError_t e = hipDeviceEnablePeerAccess(g->device[static_cast<size_t>(j)], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e);
+            (void)hipGetLastError();
+          }
+        }
+        P2PReducer &q = g->p2p;
+        q.n = n;
+        q.device = g->device;
+        bool same = true;
+        for (int i = 1; i < n; ++i) same = same && g->device[static_cast<size_t>(i)] == g->device[0];
+        if (!same && !distinct)
+          fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the peer-to-peer transport takes shards on all-distinct devices, or all on one device (kernels of shards that share a "
+                                               "device cannot wait for each other)");
+        q.one_device = same;
+        q.recv.assign(static_cast<size_t>(n), nullptr);
+        q.flags.assign(static_cast<size_t>(n), nullptr);
+        q.generation.assign(static_cast<size_t>(n), 0);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&q.error), sizeof(int) * static_cast<size_t>(n), hipHostMallocDefault));
+        for (int i = 0; i < n; ++i) q.error[i] = 0;
+        g->p2p_users.resize(static_cast<size_t>(n));
+      }
       fanOut(*g, [&](int s, dsopp_hip_window *w) {
         if (hipEventCreateWithFlags(&r.ev_in[static_cast<size_t>(s)], hipEventDisableTiming) != hipSuccess) {
           lastError() = "hipEventCreate failed";
           return static_cast<int>(DSOPP_HIP_ERR_HIP);
         }
         g->users[static_cast<size_t>(s)] = {&r, s};
-        return dsopp_hip_window_set_allreduce(w, &localAllreduce, &g->users[static_cast<size_t>(s)], s, n);
+        if (!p2p) return dsopp_hip_window_set_allreduce(w, &localAllreduce, &g->users[static_cast<size_t>(s)], s, n);
+        // receive area and flags of this shard, on its device, fine-grained (coherent between devices while kernels run), zeroed
+        P2PReducer &q = g->p2p;
+        const size_t recv_bytes = 2 * static_cast<size_t>(n) * kP2PCapacity * sizeof(double);
+        const size_t flag_bytes = 2 * static_cast<size_t>(n) * kP2PBlocks * sizeof(unsigned long long);
+        void *rp = nullptr, *fp = nullptr;
+        if (hipExtMallocWithFlags(&rp, recv_bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+            hipExtMallocWithFlags(&fp, flag_bytes, hipDeviceMallocFinegrained) != hipSuccess || hipMemset(fp, 0, flag_bytes) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
+          lastError() = "allocation of the peer-to-peer receive area failed";
+          return static_cast<int>(DSOPP_HIP_ERR_HIP);
+        }
+        q.recv[static_cast<size_t>(s)] = static_cast<double *>(rp);
+        q.flags[static_cast<size_t>(s)] = static_cast<unsigned long long *>(fp);
+        g->p2p_users[static_cast<size_t>(s)] = {&q, &g->users[static_cast<size_t>(s)], s};
+        return dsopp_hip_window_set_allreduce(w, &p2pAllreduce, &g->p2p_users[static_cast<size_t>(s)], s, n);
       });
     }
     cleanup.armed = false;
@@ -427,10 +624,16 @@ void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g) {
     if (g->win[i]) dsopp_hip_window_destroy(g->win[i]);
     if (g->comm[i]) dsopp_hip_comm_destroy(g->comm[i]);
     if (static_cast<size_t>(s) < g->reducer.ev_in.size() && g->reducer.ev_in[i]) (void)hipEventDestroy(g->reducer.ev_in[i]);
+    if (i < g->p2p.recv.size()) {
+      if (g->p2p.recv[i]) (void)hipFree(g->p2p.recv[i]);
+      if (g->p2p.flags[i]) (void)hipFree(g->p2p.flags[i]);
+    }
     return DSOPP_HIP_OK;
   };
   try {
     g->poisoned.store(false);  // (the release job itself must run)
+    if (g->p2p.error)
+      for (int s = 0; s < g->n; ++s) g->p2p.error[s] = 0;
     if (!g->pool.threads.empty())
       g->pool.run(release);
     else
@@ -438,6 +641,7 @@ void dsopp_hip_window_group_destroy(dsopp_hip_window_group *g) {
   } catch (...) {
   }
   g->pool.stop();
+  if (g->p2p.error) (void)hipHostFree(g->p2p.error);
   if (g->reducer.ev_out) {
     (void)hipSetDevice(g->device[0]);
     (void)hipEventDestroy(g->reducer.ev_out);

@@ -229,9 +229,14 @@ int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm);
  * rank per device (all device ids distinct); LOCAL = an event-ordered sum kernel inside the process (peer access between the
  * devices; the only choice when shards share a device, e.g. to exercise the sharded path on a single GPU); AUTO = RCCL when the ids
  * are distinct (falling back to LOCAL when no communicator can be created, e.g. no librccl on the node — an explicit RCCL request
- * fails instead), else LOCAL.  dsopp_hip_window_group_size reports the transport in use.  A group of one shard is a plain window.
+ * fails instead), else LOCAL.  P2P = the one-shot all-reduce: every shard stores its partial sums (15 .. 41 KB per Gauss-Newton
+ * iteration) straight into every peer's receive area over the direct xGMI links and adds up what the others stored into its own — one
+ * kernel per shard and collective, no ring, no host barrier (fine-grained device memory, system-scope flags, every wait bounded: a
+ * time-out is reported as an error and leaves the group unusable); buffers beyond the receive area take the LOCAL reducer.  Never
+ * chosen by AUTO (so far only exercised with the shards on one device).
+ * dsopp_hip_window_group_size reports the transport in use.  A group of one shard is a plain window.
  * ---------------------------------------------------------------------------------------------------------------- */
-enum { DSOPP_HIP_TRANSPORT_AUTO = 0, DSOPP_HIP_TRANSPORT_RCCL = 1, DSOPP_HIP_TRANSPORT_LOCAL = 2 };
+enum { DSOPP_HIP_TRANSPORT_AUTO = 0, DSOPP_HIP_TRANSPORT_RCCL = 1, DSOPP_HIP_TRANSPORT_LOCAL = 2, DSOPP_HIP_TRANSPORT_P2P = 3 };
 typedef struct dsopp_hip_window_group dsopp_hip_window_group;
 typedef struct dsopp_hip_pyramid_group dsopp_hip_pyramid_group;
 typedef struct dsopp_hip_depth_maps dsopp_hip_depth_maps;

@@ -399,3 +399,57 @@ def test_group_of_one_through_the_worker_thread_and_rccl():
     env = dict(os.environ, DSOPP_HIP_GROUP_FORCE_POOL="1", PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", _FORCED_POOL_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "forced pool ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_P2P_SCRIPT = r"""
+import sys
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+shards = int(sys.argv[1])
+win = syn.make_window(num_frames=5, num_points=1100, width=320, height=240, seed=27)
+close = lambda a, b, rtol, atol: np.abs(np.asarray(a) - np.asarray(b)).max() <= atol + rtol * np.abs(np.asarray(b)).max()
+for lm_mode in (0, 2):
+    g1 = capi.HipWindow(capi.default_pba_options()); syn.load_window(g1, win)
+    gg = capi.HipWindowGroup(capi.default_pba_options(), devices=[0] * shards, transport=capi.TRANSPORT_P2P); syn.load_window(gg, win)
+    assert gg.transport == capi.TRANSPORT_P2P
+    g1.set_lm_mode(lm_mode); gg.set_lm_mode(lm_mode)
+    e1, it1, nv1 = g1.solve()
+    e2, it2, nv2 = gg.solve()
+    assert (it1, nv1) == (it2, nv2) and abs(e1 - e2) <= 1e-7 * abs(e1), (e1, e2, it1, it2)
+    for f in win.frames:
+        assert np.abs(g1.get_pose(f.frame_id)[0] - gg.get_pose(f.frame_id)[0]).max() <= 1e-7
+        l1, l2 = g1.get_landmarks(f.frame_id, False), gg.get_landmarks(f.frame_id, False)
+        assert close(l2["idepth"], l1["idepth"], 1e-7, 1e-12) and np.array_equal(l1["flags"], l2["flags"])
+    a, b = win.frames[1].frame_id, win.frames[3].frame_id
+    assert close(gg.get_covariance(a, b), g1.get_covariance(a, b), 1e-5, 0)
+    # reference depth maps: planes larger than the receive area go through the in-process reducer of the same group
+    m1, m2 = g1.create_reference_depth_maps(2), gg.create_reference_depth_maps(2)
+    for lvl in range(2):
+        (i1, w1), (i2, w2) = m1.get_level(lvl), m2.get_level(lvl)
+        assert np.array_equal(w1 > 0, w2 > 0) and close(i2, i1, 1e-9, 1e-12)
+    m1.close(); m2.close(); g1.close(); gg.close()
+# deterministic mode: two solves of two groups are bit-identical (sums in shard order)
+poses = []
+for _ in range(2):
+    gg = capi.HipWindowGroup(capi.default_pba_options(), devices=[0] * shards, transport=capi.TRANSPORT_P2P); syn.load_window(gg, win)
+    gg.set_deterministic(True); gg.solve()
+    poses.append(np.stack([gg.get_pose(f.frame_id)[0] for f in win.frames])); gg.close()
+assert np.array_equal(poses[0], poses[1])
+print("p2p ok")
+"""
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_peer_to_peer_transport_matches_single_window(shards):
+    """DSOPP_HIP_TRANSPORT_P2P: every shard stores its partial sums into every shard's receive area and sums its own in shard order —
+    flags instead of a host barrier, one kernel per shard and collective on distinct devices.  Kernels of shards that SHARE a device
+    cannot wait for each other (their streams may sit on one hardware queue: seen as a time-out — an error, not a hang — with one launch
+    per shard), so there ONE launch plays every shard (a row of workgroups each): the protocol — double-buffered receive areas,
+    generation-valued flags per slice, bounded system-scope waits, sums in shard order — is the one a multi-device group runs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", _P2P_SCRIPT, str(shards)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "p2p ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
