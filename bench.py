@@ -490,7 +490,7 @@ def run_window_group(job, args):
     out = None
     if job.rank == 0:
         devices = ",".join("0" if job.single_device else str(d) for d in range(job.world))
-        cmd = [sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devices, "--workload", "c3", "--blocks", "7"]
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devices, "--workload", "c3", "--blocks", "7", "--also", "p2p"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.group_timeout)
