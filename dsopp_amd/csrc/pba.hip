@@ -516,6 +516,37 @@ void syncTopology(W &w) {
       for (int k = 0; k < F; ++k)
         if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
     }
+  for (size_t b = 0; b < sweep.size(); ++b) sweep[b].partial_row = static_cast<int>(b);
+  for (size_t b = 0; b < fine.size(); ++b) fine[b].partial_row = static_cast<int>(b);
+  // EXPERIMENT (DSOPP_HIP_SWEEP_XCD_BANDS=1, off by default): launch order such that XCD x (= blockIdx % 8 under round-robin dispatch)
+  // sweeps the x-th eighth of every pair's landmarks.  With landmarks in a spatial order (rows of the image) an XCD then samples one
+  // band of a target image from all reference frames — 1.2 MB of texels, which its 4 MB L2 holds — instead of the whole image.
+  // Measures how much of the 2.6-fold re-use of texel lines across pairs an L2-aware order could turn into hits.
+  static const bool xcd_bands = std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS") != nullptr && std::atoi(std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS")) != 0;
+  if (xcd_bands && !sweep.empty()) {
+    std::vector<std::vector<int>> queue(8);
+    for (size_t b = 0; b < sweep.size(); ++b) {
+      const SweepBlock &sb = sweep[b];
+      const int band = std::min(7, static_cast<int>((static_cast<long long>(sb.offset) * 8) / std::max(1, sb.n_res)));
+      queue[static_cast<size_t>(band)].push_back(static_cast<int>(b));
+    }
+    size_t longest = 0;
+    for (const auto &q : queue) longest = std::max(longest, q.size());
+    std::vector<SweepBlock> launch;
+    int pad_row = static_cast<int>(sweep.size());
+    for (size_t k = 0; k < longest; ++k)
+      for (int x = 0; x < 8; ++x) {
+        if (k < queue[static_cast<size_t>(x)].size()) {
+          launch.push_back(sweep[static_cast<size_t>(queue[static_cast<size_t>(x)][k])]);
+        } else {  // a no-op entry keeps the XCD's turn (zero sums into a row of its own)
+          SweepBlock sb = sweep[0];
+          sb.n_groups = 0;
+          sb.partial_row = pad_row++;
+          launch.push_back(sb);
+        }
+      }
+    sweep.swap(launch);
+  }
   w.d_frames.reserve(kMaxFrames, 0, st);
   w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
   w.n_sweep_blocks = static_cast<int>(sweep.size());

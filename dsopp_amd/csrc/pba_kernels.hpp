@@ -860,7 +860,7 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
   }  // groups
   if (LIN) gramContract(gram_lds + (threadIdx.x >> 6) * 64 * kGramStride, gram);  // the last group's rows
   SWEEP_STAMP(4);
-  double *out = partials + static_cast<size_t>(blockIdx.x) * kPartial;
+  double *out = partials + static_cast<size_t>(be.partial_row) * kPartial;
   gramScalarsStore<LIN>(gram, sc, scalar_lds, out);
   SWEEP_STAMP(5);
   SWEEP_STAMP(6);

@@ -118,7 +118,8 @@ struct SweepBlock {
   // sweeps sample instead of the texels; itiles_t = 4 x 2 tiles per image row
   const hbm_void *iplane_t;
   int itiles_t;
-  int pad_t;
+  int partial_row;     // row of the sweep's per-workgroup sums this entry writes (= its index in the pair-contiguous numbering the pair
+                       // reductions walk; differs from the launch index only under the XCD-banded launch order, an experiment)
 };
 
 /** one thread block of the Schur kernel = a chunk of landmarks of one frame.  The descriptor repeats the frame's
