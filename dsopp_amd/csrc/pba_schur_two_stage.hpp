@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     }
     return;
   }
+
   // ---- Schur workgroup: chunks [first, last) of 64 landmarks each, tiles kept in registers across them
   const int Kp = (K + 15) & ~15;
   constexpr int stride = twoStageRowStride(TPW);
@@ -170,7 +171,16 @@ __global__ void __launch_bounds__(kSchurThreads, 4) schurTwoStageKernel(TwoStage
     off_b[q] = __builtin_amdgcn_readfirstlane(16 * (ti + rem));
   }
   double bs_acc = 0;  // b_schur entry threadIdx.x when the tiles have no spare column
-  const int first_chunk = blockIdx.x * a.chunks_per_wg, last_chunk = min(first_chunk + a.chunks_per_wg, a.n_chunks);
+  // chunks are dealt out evenly: with chunks_per_wg = 0 workgroup b takes n / W chunks, the first n mod W workgroups one more
+  int first_chunk, last_chunk;
+  if (a.chunks_per_wg > 0) {
+    first_chunk = blockIdx.x * a.chunks_per_wg;
+    last_chunk = min(first_chunk + a.chunks_per_wg, a.n_chunks);
+  } else {
+    const int base = a.n_chunks / a.n_schur_wgs, rem = a.n_chunks - base * a.n_schur_wgs, b = blockIdx.x;
+    first_chunk = b * base + min(b, rem);
+    last_chunk = first_chunk + base + (b < rem ? 1 : 0);
+  }
   int staged_r = -1;
   for (int chunk = first_chunk; chunk < last_chunk; ++chunk) {
     const SchurBlock &be = a.schur_table[chunk];

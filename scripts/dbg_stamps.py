@@ -7,7 +7,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 win = syn.make_window(F, P, 640, 480, seed=0)
 g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
-out = (C.c_longlong * 48)()
+out = (C.c_longlong * 64)()
 assert capi.lib().dsopp_hip_debug_solve_stamps(g._h, out) == 0, capi.lib().dsopp_hip_last_error()
 g.snapshot()
 for _ in range(3):
