@@ -536,8 +536,10 @@ def load_profile_kernel_avg_us(csv_name, needle):
 def profile_roofline(b_lin):
     out = {}
     for key, csv_name in (("isolated_launches", "c1_isolated_kernel_stats.csv"), ("in_loop", "c1_kernel_stats.csv")):
-        # newest round first; the template argument list of the sweep lost an argument in round 4
-        for alt, needle in ((os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, true, false>"),
+        # newest first: since the back-substitution moved into the solve launch the loop runs the plain linearisation variant; before
+        # that the BACKSUB variant (whose template argument list lost an argument in round 4)
+        for alt, needle in ((os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, false, false>"),
+                            (os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, true, false>"),
                             (os.path.join("r03", "c_" + csv_name), "sweepKernel<double, true, true, true, true, false, false>")):
             r = load_profile_kernel_avg_us(alt, needle)
             if r:

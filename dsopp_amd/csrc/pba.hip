@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "host_linalg.hpp"
 #include "pba_solve_kernels.hpp"
@@ -96,6 +97,8 @@ struct dsopp_hip_window {
     static const int override_chunks = std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS")) : 0;  // tuning aid
     return override_chunks > 0 ? override_chunks : twoStageMinChunks();
   }
+  unsigned *d_bs_flag = nullptr;  // hand-over word of the back-substitution inside the solve launch (pba_solve_combined.hpp)
+  unsigned bs_seq = 0, bs_ticket_base = 0;
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
@@ -964,19 +967,53 @@ void launchTwoStage(W &w, const LmControl *ctrl, int ublk_parity, double lambda,
 }
 
 /** K3 of the fused loop: priors + solve of the combined system launchReduceSchur(combined) left at the head of d_reduce */
+/** how many workgroups of the solve launch a device holds at once (its landmark workgroups wait for workgroup 0: all of them resident) */
+int solveResidentWorkgroups(W &w, bool wide) {
+  static std::map<std::pair<int, size_t>, int> cache;
+  static std::mutex mu;
+  const size_t smem = solveSmemBytes(w.K());
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(w.sr.device * 2 + (wide ? 1 : 0), smem);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int per_cu = 0, cus = 0;
+  if (wide)
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solveCombinedKernel<512>, 512, smem));
+  else
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, solveCombinedKernel<256>, 256, smem));
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.sr.device));
+  const int n = std::max(2, per_cu * cus);
+  cache[key] = n;
+  return n;
+}
+
 void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr,
-                         bool decide_from_groups = false) {
+                         bool decide_from_groups = false, bool backsub = false, int ublk_parity = 0) {
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<256>), w.sr.device, 150 * 1024);
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<512>), w.sr.device, 150 * 1024);
   SolveCombArgs a;
   if (decide_from) {
-    // landmark-sharded windows: decision + accept / reject as the prologue of this launch (workgroups 1 .. chunks: the landmarks)
+    // decision + accept / reject as the prologue of this launch (workgroups 1 ..: the landmarks), then calculateIdepths for the new step
     a.dec_in = decide_from;
     a.dec_scalars = w.d_reduce.ptr + w.combCount();  // the four sums travelled behind the combined system in the collective
     a.dec_table = w.d_schur_table.ptr;
-    a.dec_blocks = w.n_schur_blocks;
+    a.dec_chunks = w.n_schur_blocks;
+    // (landmark passes: 128 landmarks = two chunks at 512 threads, one chunk at 256 — pba_solve_combined.hpp)
+    const bool wide = w.F() > 8;
+    a.dec_blocks = std::min(wide ? (w.n_schur_blocks + 1) / 2 : w.n_schur_blocks, solveResidentWorkgroups(w, wide) - 1);
     a.dec_groups = decide_from_groups ? kScalarGroups : 0;
     a.dec_prm = *decide_prm;
+    if (backsub && a.dec_blocks > 0) {
+      if (!w.d_bs_flag) {
+        HIP_CHECK(hipMalloc(&w.d_bs_flag, 2 * sizeof(unsigned)));
+        HIP_CHECK(hipMemsetAsync(w.d_bs_flag, 0, 2 * sizeof(unsigned), w.sr.stream));
+      }
+      a.bs_flag = w.d_bs_flag;
+      a.bs_seq = ++w.bs_seq;
+      a.bs_parity = ublk_parity;
+      a.bs_ticket_base = w.bs_ticket_base;
+      w.bs_ticket_base += static_cast<unsigned>(1 + a.dec_blocks);  // every workgroup of the launch draws exactly one ticket
+    }
   }
   a.frames = w.d_frames.ptr;
   a.st = w.d_state.ptr;
@@ -1242,12 +1279,14 @@ void launchRestore(W &w) {
 /**
  * Same algorithm, three launches per Gauss-Newton iteration.  A linearisation sweep at the candidate state x + step
  * already contains the candidate's energy (NEW_EVALUATION_POINT) and, if the step is accepted, IS the next linearisation:
- *   round r:  K1  linearise at eps + step_r (step_0 = 0)  [+ calculateIdepths for step_r]
+ *   round r:  K1  linearise at eps + step_r (step_0 = 0)
  *             K2  pose-pose + Schur reduction into the combined system (lambda of the incoming control block: constant),
  *                 + one workgroup (64 on the two-stage path) that adds up K1's energy scalars
- *             K3  prologue: decide step_r from those sums, apply accept / reject (workgroups >= 1: the landmarks);
- *                 workgroup 0: solve -> step_{r+1}
- * (large windows: calculateIdepths as a kernel of its own in front of K1, K2 = partial systems + ordered sum, two launches)
+ *             K3  prologue: decide step_r from those sums, apply accept / reject (the landmark workgroups);
+ *                 the solving workgroup: solve -> step_{r+1}; the landmark workgroups: calculateIdepths for step_{r+1} as soon as it is
+ *                 published, under the solver's tail (round 4; until then a kernel of its own in front of K1 on large windows, fused into
+ *                 K1 on small ones: DSOPP_HIP_K3_BACKSUB=0)
+ * (large windows: K2 = partial systems + ordered sum, two launches)
  * max_iterations + 1 rounds, one host synchronisation.  A rejected step without force_accept costs one extra round (the
  * sweep re-linearises at the reverted state, which reproduces the system the reference keeps via linear_system_valid).
  * The Schur rows are double-buffered because K1 reads the previous round's rows while writing this round's.
@@ -1302,6 +1341,10 @@ void lmSolveFusedEnqueue(W &w) {
   // re-linearisation at the reverted state), so the budget doubles — rounds after the loop has ended are no-op launches
   const int rounds = (w.opt.force_accept ? w.opt.max_iterations : 2 * w.opt.max_iterations) + 1;
   bool result_written_by_kernel = false;
+  // calculateIdepths inside the solve launch (its landmark workgroups wait for the step under the factorisation): no back-substitution
+  // kernel in front of the sweeps of large windows, no Schur-row reads in the sweeps of small ones.  DSOPP_HIP_K3_BACKSUB=0: the round-3 flow
+  static const int k3_env = std::getenv("DSOPP_HIP_K3_BACKSUB") ? std::atoi(std::getenv("DSOPP_HIP_K3_BACKSUB")) : 1;
+  const bool k3_backsub = k3_env != 0 && w.opt.optimize_idepths && w.n_schur_blocks > 0;
   for (int r = 0; r < rounds; ++r) {
     LmControl *cin = ctrl + (r & 1), *cout = ctrl + ((r + 1) & 1);
     SweepExtras ex;
@@ -1313,7 +1356,13 @@ void lmSolveFusedEnqueue(W &w) {
     ex.write_fej = r == 0 && sweep_takes_fej;
     // the closing round only has to evaluate the last candidate (no linear system is built from it): residual-only sweep
     const bool large = w.n_schur_blocks > w.backsubSplitMinChunks();
-    if (large && r + 1 == rounds) {
+    if (k3_backsub) {
+      // calculateIdepths for this round's candidate ran in the solve launch that produced its step (launchSolveCombined): the sweep
+      // only reads the inverse-depth steps
+      ex.fused_lin_backsub = false;
+      ex.external_backsub = true;
+      launchSweep(w, /*lin=*/r + 1 < rounds, true, false, cin, false, 0.0, ex);
+    } else if (large && r + 1 == rounds) {
       // closing round of a large window: the same split (the residual-only sweep with the back-substitution fused in took 115 us
       // at 12 frames / 50 000 landmarks against 10 + 47 us as two kernels)
       launchBacksub(w, 0.0, cin, ex.ublk_read, /*gate_on_pending=*/true);
@@ -1382,7 +1431,7 @@ void lmSolveFusedEnqueue(W &w) {
       launchReduceSchur(w, false, cin, &fr, ReduceMode::kAccumulateOnly);
       decide_from_groups = w.allreduce != nullptr;  // (shards: the grouped tail, see launchReduceSchur)
     }
-    if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups);  // K3: decision prologue + solve
+    if (r + 1 < rounds) launchSolveCombined(w, 0.0, cout, cin, &fr.prm, decide_from_groups, k3_backsub, fr.ublk_parity);  // K3: decision prologue + solve (+ calculateIdepths)
   }
   LmControl *cfin = ctrl + (rounds & 1);
   HIP_CHECK(hipGetLastError());
@@ -1945,6 +1994,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->h_export) (void)hipHostFree(w->h_export);
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
+  if (w->d_bs_flag) (void)hipFree(w->d_bs_flag);
   w->frames.clear();
   for (dsopp_hip_depth_maps *m : w->live_maps) {  // maps may outlive the window (the tracker holds them): they lose the borrowed stream
     m->sr.stream = nullptr;
@@ -2825,13 +2875,16 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
         case DSOPP_HIP_KERNEL_SWEEP_LINEARIZE: launchSweep(*w, true, true, false); break;
         case DSOPP_HIP_KERNEL_SWEEP_ENERGY: launchSweep(*w, false, true, false); break;
         case DSOPP_HIP_KERNEL_SWEEP_LINEARIZE_LOOP: {
-          // exactly the launch of lmSolveFusedEnqueue's rounds >= 1: reads the Schur rows / pose step of the previous round,
-          // back-substitutes the inverse depths, linearises at the candidate state
+          // exactly the launch of lmSolveFusedEnqueue's rounds >= 1: linearises at the candidate state whose inverse-depth steps the
+          // solve launch in front of it left (DSOPP_HIP_K3_BACKSUB=0: the round-3 flow — the sweep reads the Schur rows / pose step of
+          // the previous round and back-substitutes itself)
+          static const int k3_env = std::getenv("DSOPP_HIP_K3_BACKSUB") ? std::atoi(std::getenv("DSOPP_HIP_K3_BACKSUB")) : 1;
           SweepExtras ex;
           ex.ublk_read = 0;
           ex.ublk_write = 1;
-          ex.fused_lin_backsub = true;
-          launchSweep(*w, true, true, false, nullptr, true, 1e-5, ex);
+          ex.fused_lin_backsub = k3_env == 0;
+          ex.external_backsub = k3_env != 0;
+          launchSweep(*w, true, true, false, nullptr, k3_env == 0, 1e-5, ex);
           break;
         }
         case DSOPP_HIP_KERNEL_SCHUR: {  // as the fused loop launches it (combined system), without the decision prologue

@@ -1,5 +1,7 @@
 // K3 of the fused Levenberg-Marquardt loop: priors + dense solve of the combined system the reduction kernel emits
-// (pba_solve_kernels.hpp: ReduceSchurArgs::comb), candidate pair constants, prior energy of the candidate — one workgroup.
+// (pba_solve_kernels.hpp: ReduceSchurArgs::comb), candidate pair constants, prior energy of the candidate — one workgroup; the
+// launch's other workgroups apply the LM decision to the landmarks and back-substitute the inverse depths for the new step while the
+// solving workgroup finishes (SolveCombArgs::bs_flag).
 //
 // Replaces, like assembleSolveKernel (which stays for the stage API / marginalisation / covariance paths that need the four
 // systems separately): evaluateLinearSystemPrior (problem.hpp:37-77), calculateStep (:342-361), NormalLinearSystem::solve
@@ -41,6 +43,20 @@ struct SolveCombArgs {
   int dec_blocks = 0;
   int dec_groups = 0;  // 0: dec_scalars holds the four sums; kScalarGroups: it holds that many group sums [g][4] (added here, fixed order)
   LmParams dec_prm;
+  // calculateIdepths for the step this launch solves for (hessian_block_evaluation.hpp:238-263), by the landmark workgroups: they
+  // request their landmarks' Schur rows while workgroup 0 factorises, wait for its step (bs_flag == bs_seq) and finish under its tail
+  // (pair constants, prior energy) — the back-substitution costs neither a launch nor a pass over the rows on the critical path.
+  // dec_chunks 64-landmark chunks are dealt out over the dec_blocks workgroups (all resident at once: sized by the host).
+  unsigned *bs_flag = nullptr;  // nullable = no back-substitution here; [0] hand-over word, [1] ticket counter
+  unsigned bs_seq = 0;
+  // Who solves is decided by arrival, not by block index: the first workgroup of the launch to draw a ticket ([1], counting on from
+  // bs_ticket_base) is "workgroup 0".  The waiting workgroups then wait for one that is certainly running — block 0 need not be: the
+  // XCDs dispatch their shares of a grid independently, and with another process's (or stream's) kernels holding XCD 0 the blocks
+  // 1, 2, ... were resident and waiting while block 0 was not (two ranks on one device deadlocked exactly so, with the other
+  // rank's collective waiting for this rank in turn).
+  unsigned bs_ticket_base = 0;
+  int bs_parity = 0;            // which half of the double-buffered Schur rows this round's linearisation wrote
+  int dec_chunks = 0;
 };
 #define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
@@ -82,7 +98,12 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   // Workgroup 0 requests everything that does not depend on the decision — pair constants, frame flags, right-hand side, the first
   // batch of the combined system — BEFORE it takes the decision: the decision's own loads, its LDS tree and its scalar chain then
   // run under these loads' round trip instead of in front of it (the other workgroups only apply the decision and leave).
-  const bool main_wg = blockIdx.x == 0;
+  const bool ticketed = a.bs_flag != nullptr;
+  unsigned my_ticket = 0;
+  if (ticketed && tid == 0) my_ticket = atomicAdd(a.bs_flag + 1, 1u) - a.bs_ticket_base;  // (in flight under everything requested below)
+  __shared__ unsigned s_vblock;
+  // with tickets every workgroup requests the solver's operands (it does not know its role yet; the others drop them)
+  bool main_wg = ticketed || blockIdx.x == 0;
   struct {
     int valid;
     Rigid T0;
@@ -90,29 +111,35 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   } pp;
   pp.valid = 0;
   const bool fast_refresh = a.fej != 0;
-  if (main_wg && fast_refresh && tid < F * F) {
-    const int r = tid / F, t = tid - F * (tid / F);
-    const PairConst &P = a.pc[r * kMaxFrames + t];
-    pp.valid = P.valid;
+  auto requestPairInputs = [&] {
+    if (fast_refresh && tid < F * F) {
+      const int r = tid / F, t = tid - F * (tid / F);
+      const PairConst &P = a.pc[r * kMaxFrames + t];
+      pp.valid = P.valid;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
-      pp.T0.t[i] = P.T0rel[4 * i + 3];
+        for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
+        pp.T0.t[i] = P.T0rel[4 * i + 3];
+      }
+      const FrameDev &fr = a.frames[r];
+      const FrameDev &ft = a.frames[t];
+      pp.fxr = fr.fx;
+      pp.fyr = fr.fy;
+      pp.cxr = fr.cx;
+      pp.cyr = fr.cy;
+      pp.fxt = ft.fx;
+      pp.fyt = ft.fy;
+      pp.cxt = ft.cx;
+      pp.cyt = ft.cy;
+      pp.exposure_r = fr.exposure;
+      pp.exposure_t = ft.exposure;
     }
-    const FrameDev &fr = a.frames[r];
-    const FrameDev &ft = a.frames[t];
-    pp.fxr = fr.fx;
-    pp.fyr = fr.fy;
-    pp.cxr = fr.cx;
-    pp.cyr = fr.cy;
-    pp.fxt = ft.fx;
-    pp.fyt = ft.fy;
-    pp.cxt = ft.cx;
-    pp.cyt = ft.cy;
-    pp.exposure_r = fr.exposure;
-    pp.exposure_t = ft.exposure;
-  }
+  };
+  // (with tickets the role is unknown here and these 22 doubles would be live across the landmark workgroups' register-hungry branch:
+  // the compiler spilled them at the head and reloaded them in front of the pair refresh; the solver requests them once it knows
+  // what it is — they are not needed before the kernel's tail)
+  if (!ticketed && main_wg) requestPairInputs();
   double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < THREADS)
   int fixed_c = 0, tomarg_c = 0;
   if (main_wg && tid < K) {
@@ -186,12 +213,12 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       t[2] = a.dec_scalars[2];
       t[3] = a.dec_scalars[3];
     }
-    if (blockIdx.x == 0 && tid < K) {  // (frame states: read and written by workgroup 0 only)
+    if (main_wg && tid < K) {  // (frame states: read and written by workgroup 0 only)
       dec_eps = a.st->eps[tid >> 3][tid & 7];
       dec_step = a.st->step[tid >> 3][tid & 7];
     }
     if (!cin.active) {  // the loop has ended: the control block is handed on unchanged
-      if (blockIdx.x == 0 && tid == 0) *a.ctrl = cin;
+      if (tid == 0 && (ticketed ? my_ticket == 0 : blockIdx.x == 0)) *a.ctrl = cin;
       return;
     }
     if (tid == 0) {
@@ -201,35 +228,142 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       s_dec_out = c;
       s_dec_accept = accept;
       s_dec_proceed = proceed;
+      s_vblock = ticketed ? my_ticket : blockIdx.x;
     }
     ldsBarrier();
     dec_accept = s_dec_accept;
-    if (blockIdx.x > 0) {
-      // acceptStep / rejectStep of the landmarks of one chunk (problem.hpp:364-402): 8 threads per landmark, thread `sub` owns the
-      // targets sub and sub + 8; 32 landmarks per pass of the 256 threads
-      if (!cin.pending) return;
-      const SchurBlock &be = a.dec_table[blockIdx.x - 1];
-      for (int l = tid >> 3; l < kSchurLandmarks; l += THREADS / 8) {
-        const int sub = tid & 7, i = be.offset + l;
-        if (i >= be.n) continue;
+    const unsigned vblock = s_vblock;
+    main_wg = vblock == 0;
+    if (vblock > 0) {
+      // ---- landmark workgroups.  4 lanes per landmark (lane `sub` owns the frame slots sub, sub + 4, ...), THREADS / 4 landmarks per
+      // pass = CPP chunks of 64; workgroup b takes the passes b - 1, b - 1 + W, ...
+      constexpr int LP = THREADS / 4, CPP = LP / kSchurLandmarks;
+      static_assert(CPP >= 1, "a pass covers whole chunks");
+      const int W = gridDim.x - 1, n_pass = (a.dec_chunks + CPP - 1) / CPP;
+      const int sub = tid & 3, grp = tid >> 2, l = grp & (kSchurLandmarks - 1), chunk_in_pass = grp / kSchurLandmarks;
+      if (cin.pending) {
+        // acceptStep / rejectStep of the landmarks (problem.hpp:364-402)
+        for (int p = static_cast<int>(vblock) - 1; p < n_pass; p += W) {
+          const int chunk = p * CPP + chunk_in_pass;
+          if (chunk >= a.dec_chunks) continue;
+          const SchurBlock &be = a.dec_table[chunk];
+          const int i = be.offset + l;
+          if (i >= be.n) continue;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int t2 = sub + 8 * h;
-          if (t2 < F && be.status[t2] != nullptr && i < be.n_res[t2]) {
-            if (dec_accept)
-              be.status[t2][i] = be.cand[t2][i];
-            else
-              be.cand[t2][i] = be.status[t2][i];
+          for (int h = 0; h < 4; ++h) {
+            const int t2 = sub + 4 * h;
+            if (t2 < F && be.status[t2] != nullptr && i < be.n_res[t2]) {
+              if (dec_accept)
+                be.status[t2][i] = be.cand[t2][i];
+              else
+                be.cand[t2][i] = be.status[t2][i];
+            }
+          }
+          if (sub == 0) {
+            if (dec_accept) be.idepth[i] += be.idepth_step[i];
+            be.idepth_step[i] = 0;
           }
         }
-        if (sub == 0) {
-          if (dec_accept) be.idepth[i] += be.idepth_step[i];
-          be.idepth_step[i] = 0;
+      }
+      // what workgroup 0 does with this decision: no step -> nothing to substitute
+      if (!a.bs_flag || !s_dec_proceed || s_dec_out.relin) return;
+      // (a) the rows of the first kPre passes are requested now and wait in registers (12 frames / 50 000 landmarks: 255 workgroups x
+      // 2 passes x 128 landmarks hold all of them)
+      auto backSubstitute = [&](auto ns_tag) {
+      constexpr int NS = decltype(ns_tag)::value;  // frame slots per lane: 2 up to 8 frames, 3 up to 12, 4 up to 16
+      constexpr int kPre = THREADS >= 512 ? (NS >= 4 ? 1 : 2) : 4;  // (13 - 16 frames: one pass in registers, the compiler spilled with two)
+      double rows[kPre][NS][kBlk], bdv[kPre], ihv[kPre];
+      hbm_f64 *dstp[kPre];
+    #pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        dstp[u] = nullptr;
+        bdv[u] = ihv[u] = 0;
+    #pragma unroll
+        for (int q = 0; q < NS; ++q)
+    #pragma unroll
+          for (int c = 0; c < kBlk; ++c) rows[u][q][c] = 0;
+      }
+      auto fetch = [&](int p, double (&rw)[NS][kBlk], double &bd, double &ih, hbm_f64 *&dst) {
+        dst = nullptr;
+        const int chunk = p * CPP + chunk_in_pass;
+        if (chunk >= a.dec_chunks) return;
+        const SchurBlock &be = a.dec_table[chunk];
+        const int i = be.offset + l;
+        if (i >= be.n) return;
+        const uint8_t flg = be.flags[i];
+        if (flg & (kFlagMarginalized | kFlagIllConditioned)) return;
+        const size_t plane = ublkPlane(be.cap);
+        const hbm_f64 *base = be.ublk + static_cast<size_t>(a.bs_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
+    #pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int t = sub + 4 * q;
+          if (t < F && (t == be.r || ((be.conn_mask >> t) & 1u))) {
+    #pragma unroll
+            for (int c = 0; c < kBlk; ++c) rw[q][c] = base[t * plane + c];
+          }
+        }
+        bd = be.b_d[i];
+        ih = be.inv_hdd[i];
+        dst = be.idepth_step + i;
+      };
+    #pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const int p = static_cast<int>(vblock) - 1 + u * W;
+        if (p < n_pass) fetch(p, rows[u], bdv[u], ihv[u], dstp[u]);
+      }
+      // (b) wait for the solving workgroup's step.  It drew its ticket before this one and waits for nobody; the bound only turns an
+      // accident into a loud failure instead of a hang
+      if (tid == 0) {
+        const long long t0 = wall_clock64();
+        // (relaxed polls: an acquire per poll would invalidate this XCD's non-coherent L2 lines a few million times a second)
+        while (__hip_atomic_load(a.bs_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.bs_seq) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - t0 > 200000000ll) __builtin_trap();  // 2 s
         }
       }
+      __syncthreads();
+      // the step through LDS (this workgroup's share of the launch's dynamic allocation is otherwise unused): every lane reads its
+      // slots' eight values per pass instead of keeping NS x 8 more doubles in registers next to the rows
+      double *stp = reinterpret_cast<double *>(smem_raw);  // [kBlk * kMaxFrames], zero beyond K
+      if (tid < kBlk * kMaxFrames) stp[tid] = tid < K ? __hip_atomic_load(a.step + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      __syncthreads();
+      const double damp = 1.0 / (1.0 + s_dec_out.lambda);
+      auto finish = [&](const double (&rw)[NS][kBlk], double bd, double ih, hbm_f64 *dst) {
+        double d = 0;
+    #pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const double *sq = stp + kBlk * (sub + 4 * q);
+    #pragma unroll
+          for (int c = 0; c < kBlk; ++c) d += rw[q][c] * sq[c];
+        }
+        d += dppMove<0xB1>(d);  // the landmark's four lanes: quad_perm [1,0,3,2], [2,3,0,1]
+        d += dppMove<0x4E>(d);
+        if (sub == 0 && dst) *dst = -((bd - d) * damp * ih);
+      };
+    #pragma unroll
+      for (int u = 0; u < kPre; ++u) finish(rows[u], bdv[u], ihv[u], dstp[u]);
+      // (c) passes beyond what the registers hold (very large windows): fetched behind the step
+      for (int p = static_cast<int>(vblock) - 1 + kPre * W; p < n_pass; p += W) {
+        double rw[NS][kBlk], bd = 0, ih = 0;
+        hbm_f64 *dst = nullptr;
+    #pragma unroll
+        for (int q = 0; q < NS; ++q)
+    #pragma unroll
+          for (int c = 0; c < kBlk; ++c) rw[q][c] = 0;
+        fetch(p, rw, bd, ih, dst);
+        finish(rw, bd, ih, dst);
+      }
+      };
+      if (THREADS < 512)
+        backSubstitute(std::integral_constant<int, 2>{});
+      else if (F <= 12)
+        backSubstitute(std::integral_constant<int, 3>{});
+      else
+        backSubstitute(std::integral_constant<int, 4>{});
       return;
     }
     // workgroup 0: the frame states and the outgoing control block, then the solve at the decided state
+    if (ticketed) requestPairInputs();
     if (cin.pending && tid < K) {
       if (dec_accept) {
         dec_eps += dec_step;
@@ -502,8 +636,20 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   if (tid < K) {
     const double x = xs[tid];
     stpl[tid] = -x;
-    a.step[tid] = x;
+    // (device-scope stores: written through to where the other XCDs read, no cache-wide write-back needed to hand the step over)
+    if (a.bs_flag)
+      __hip_atomic_store(a.step + tid, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      a.step[tid] = x;
     a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
+  }
+  if (a.bs_flag) {
+    // the landmark workgroups of this launch wait for the step (back-substitution, above).  Its stores are device-scope and have been
+    // acknowledged behind the barrier (vmcnt 0), so the hand-over word is one more such store — a release fence here would write the
+    // whole L2 back (the landmark workgroups have just dirtied it: + 5 us before the word became visible).  The last wave publishes:
+    // it has nothing else to do
+    __syncthreads();
+    if (tid == THREADS - 64) __hip_atomic_store(a.bs_flag, a.bs_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   SC_STAMP(3);
   // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312) and the frame part of the

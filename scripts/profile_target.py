@@ -2,9 +2,9 @@
 is what DESIGN.md's per-kernel figures are recomputed from.
    c1         the bench's C1 loop (7 KF / 2000 points): 140 GN iterations
    c1_isolated  the roofline kernel alone, as bench.py times it: 200 back-to-back launches of the in-loop linearisation sweep
-              (sweepKernel<double, LIN, FEJ, HUBER, BACKSUB>) on the C1 window — the only launches of that instantiation in the
-              process, so the csv's average for it IS the figure `roofline.avg_launch_us` quotes (in the c1 csv the same kernel
-              runs inside the loop, between dependent launches, and averages ~10 % longer)
+              (sweepKernel<double, LIN, FEJ, HUBER, BACKSUB = false>: since the back-substitution moved into the solve launch the loop
+              runs the plain linearisation variant) on the C1 window — so the csv's average for it IS the figure
+              `roofline.avg_launch_us` quotes (in the c1 csv the same kernel runs inside the loop, between dependent launches)
    large      12 KF / 50 000 points on one GPU: 3 LM solves + isolated kernel launches
    large_loop the same window, fused loop only (5 solves)
    c3_loop    7 KF / 20 000 points, fused loop only
