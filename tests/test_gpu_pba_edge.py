@@ -473,3 +473,48 @@ def test_large_window_two_stage_is_bit_reproducible():
         out.append((e, it, nv, np.concatenate([np.concatenate(g.get_frame_state(f.frame_id)) for f in win.frames])))
     assert out[0][:3] == out[1][:3] and np.array_equal(out[0][3], out[1][3])
     g.close()
+
+
+_K3_BACKSUB_SCRIPT = r"""
+import sys
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+out = {}
+for name, (F, P, W, H, seed) in {"small": (5, 600, 320, 240, 3), "wide": (10, 1500, 320, 240, 5), "large": (7, 14000, 640, 480, 7)}.items():
+    win = syn.make_window(num_frames=F, num_points=P, width=W, height=H, seed=seed)
+    g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
+    e, it, nv = g.solve()
+    poses = np.concatenate([np.concatenate(g.get_pose(f.frame_id)) for f in win.frames])
+    idepths = np.concatenate([g.get_landmarks(f.frame_id, with_hpib=False)["idepth"] for f in win.frames])
+    # the same window again through a batch of back-to-back solves (every solve launch draws its own tickets / sequence number)
+    g.snapshot(); g.restore()
+    n, e_rep = g.optimize_repeated(21)
+    out[name] = (e, it, nv, poses, idepths, n, e_rep)
+    g.close()
+np.savez(sys.argv[1], **{f"{k}_{i}": np.asarray(v) for k, t in out.items() for i, v in enumerate(t)})
+print("k3 flow ok")
+"""
+
+
+def test_idepth_back_substitution_inside_the_solve_launch_equals_the_kernel_flow(tmp_path):
+    """calculateIdepths by the landmark workgroups of the solve launch (default) against the round-3 flow (DSOPP_HIP_K3_BACKSUB=0, read
+    once per process: a back-substitution kernel on large windows, fused into the sweep on small ones) — 256- and 512-thread solve
+    kernels, atomic and two-stage Schur builds: same iterations and residual counts, energies / poses / inverse depths to rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flow in ("1", "0"):
+        path = str(tmp_path / f"flow{flow}.npz")
+        env = dict(os.environ, DSOPP_HIP_K3_BACKSUB=flow, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _K3_BACKSUB_SCRIPT, path], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "k3 flow ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        res[flow] = np.load(path)
+    a, b = res["1"], res["0"]
+    for name in ("small", "wide", "large"):
+        assert int(a[f"{name}_1"]) == int(b[f"{name}_1"]) and int(a[f"{name}_2"]) == int(b[f"{name}_2"]), name
+        assert abs(float(a[f"{name}_0"]) - float(b[f"{name}_0"])) <= 1e-9 * abs(float(b[f"{name}_0"])), name
+        assert np.abs(a[f"{name}_3"] - b[f"{name}_3"]).max() <= 1e-9, name
+        assert np.abs(a[f"{name}_4"] - b[f"{name}_4"]).max() <= 1e-8 * max(1.0, np.abs(b[f"{name}_4"]).max()), name
+        assert int(a[f"{name}_5"]) == int(b[f"{name}_5"]) and abs(float(a[f"{name}_6"]) - float(b[f"{name}_6"])) <= 1e-9 * abs(float(b[f"{name}_6"])), name
