@@ -97,7 +97,7 @@ struct dsopp_hip_window {
     static const int override_chunks = std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_BACKSUB_SPLIT_MIN_CHUNKS")) : 0;  // tuning aid
     return override_chunks > 0 ? override_chunks : twoStageMinChunks();
   }
-  unsigned *d_bs_flag = nullptr;  // hand-over word of the back-substitution inside the solve launch (pba_solve_combined.hpp)
+  unsigned *d_bs_flag = nullptr;  // ticket counter + hand-over buffers of the back-substitution inside the solve launch (pba_solve_combined.hpp)
   unsigned bs_seq = 0, bs_ticket_base = 0;
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
@@ -1005,11 +1005,22 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
     a.dec_prm = *decide_prm;
     if (backsub && a.dec_blocks > 0) {
       if (!w.d_bs_flag) {
-        HIP_CHECK(hipMalloc(&w.d_bs_flag, 2 * sizeof(unsigned)));
-        HIP_CHECK(hipMemsetAsync(w.d_bs_flag, 0, 2 * sizeof(unsigned), w.sr.stream));
+        // [ticket counter | pad] + two hand-over buffers of kBlk * kMaxFrames doubles, both armed
+        constexpr size_t kHand = static_cast<size_t>(kBlk) * kMaxFrames;
+        HIP_CHECK(hipMalloc(&w.d_bs_flag, 16 + 2 * kHand * sizeof(double)));
+        std::vector<double> arm(2 * kHand, kHandOverSentinel());
+        HIP_CHECK(hipMemsetAsync(w.d_bs_flag, 0, 16, w.sr.stream));
+        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(w.d_bs_flag) + 16, arm.data(), arm.size() * sizeof(double), hipMemcpyHostToDevice, w.sr.stream));
+        HIP_CHECK(hipStreamSynchronize(w.sr.stream));  // (`arm` is a pageable host buffer)
       }
-      a.bs_flag = w.d_bs_flag;
-      a.bs_seq = ++w.bs_seq;
+      {
+        constexpr size_t kHand = static_cast<size_t>(kBlk) * kMaxFrames;
+        double *hand = reinterpret_cast<double *>(reinterpret_cast<char *>(w.d_bs_flag) + 16);
+        const unsigned n = w.bs_seq++;
+        a.bs_ticket = w.d_bs_flag;
+        a.bs_hand = hand + (n & 1u) * kHand;
+        a.bs_hand_next = hand + ((n + 1) & 1u) * kHand;
+      }
       a.bs_parity = ublk_parity;
       a.bs_ticket_base = w.bs_ticket_base;
       w.bs_ticket_base += static_cast<unsigned>(1 + a.dec_blocks);  // every workgroup of the launch draws exactly one ticket

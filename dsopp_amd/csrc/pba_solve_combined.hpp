@@ -1,7 +1,7 @@
 // K3 of the fused Levenberg-Marquardt loop: priors + dense solve of the combined system the reduction kernel emits
 // (pba_solve_kernels.hpp: ReduceSchurArgs::comb), candidate pair constants, prior energy of the candidate — one workgroup; the
 // launch's other workgroups apply the LM decision to the landmarks and back-substitute the inverse depths for the new step while the
-// solving workgroup finishes (SolveCombArgs::bs_flag).
+// solving workgroup finishes (SolveCombArgs::bs_ticket).
 //
 // Replaces, like assembleSolveKernel (which stays for the stage API / marginalisation / covariance paths that need the four
 // systems separately): evaluateLinearSystemPrior (problem.hpp:37-77), calculateStep (:342-361), NormalLinearSystem::solve
@@ -44,20 +44,33 @@ struct SolveCombArgs {
   int dec_groups = 0;  // 0: dec_scalars holds the four sums; kScalarGroups: it holds that many group sums [g][4] (added here, fixed order)
   LmParams dec_prm;
   // calculateIdepths for the step this launch solves for (hessian_block_evaluation.hpp:238-263), by the landmark workgroups: they
-  // request their landmarks' Schur rows while workgroup 0 factorises, wait for its step (bs_flag == bs_seq) and finish under its tail
+  // request their landmarks' Schur rows while workgroup 0 factorises, wait for its step and finish under its tail
   // (pair constants, prior energy) — the back-substitution costs neither a launch nor a pass over the rows on the critical path.
   // dec_chunks 64-landmark chunks are dealt out over the dec_blocks workgroups (all resident at once: sized by the host).
-  unsigned *bs_flag = nullptr;  // nullable = no back-substitution here; [0] hand-over word, [1] ticket counter
-  unsigned bs_seq = 0;
-  // Who solves is decided by arrival, not by block index: the first workgroup of the launch to draw a ticket ([1], counting on from
+  // Hand-over: the step travels through one of two buffers whose slots hold a NaN pattern no step can take until the solver stores
+  // into them (device scope): a value that is not the sentinel IS the step — the waiters poll the values themselves, one read from
+  // memory instead of a flag and then the data.  Every launch re-arms the OTHER buffer (nobody reads it before the next launch).
+  unsigned *bs_ticket = nullptr;   // nullable = no back-substitution here; the ticket counter (below)
+  double *bs_hand = nullptr;       // [kBlk * kMaxFrames] this launch's hand-over slots (armed by the previous launch)
+  double *bs_hand_next = nullptr;  // the other buffer: armed here
+  int bs_parity = 0;            // which half of the double-buffered Schur rows this round's linearisation wrote
+  int dec_chunks = 0;
+  // Who solves is decided by arrival, not by block index: the first workgroup of the launch to draw a ticket (counting on from
   // bs_ticket_base) is "workgroup 0".  The waiting workgroups then wait for one that is certainly running — block 0 need not be: the
   // XCDs dispatch their shares of a grid independently, and with another process's (or stream's) kernels holding XCD 0 the blocks
   // 1, 2, ... were resident and waiting while block 0 was not (two ranks on one device deadlocked exactly so, with the other
   // rank's collective waiting for this rank in turn).
   unsigned bs_ticket_base = 0;
-  int bs_parity = 0;            // which half of the double-buffered Schur rows this round's linearisation wrote
-  int dec_chunks = 0;
 };
+/** what an armed hand-over slot holds: a quiet NaN with a payload no arithmetic produces */
+__host__ __device__ inline double kHandOverSentinel() {
+  union {
+    unsigned long long u;
+    double d;
+  } c;
+  c.u = 0x7FF8D50FF00DBEEFull;
+  return c.d;
+}
 #define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
 /** block index b of the packed lower triangle -> (bi, bj), bj <= bi */
@@ -98,9 +111,10 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   // Workgroup 0 requests everything that does not depend on the decision — pair constants, frame flags, right-hand side, the first
   // batch of the combined system — BEFORE it takes the decision: the decision's own loads, its LDS tree and its scalar chain then
   // run under these loads' round trip instead of in front of it (the other workgroups only apply the decision and leave).
-  const bool ticketed = a.bs_flag != nullptr;
+  const bool ticketed = a.bs_ticket != nullptr;
   unsigned my_ticket = 0;
-  if (ticketed && tid == 0) my_ticket = atomicAdd(a.bs_flag + 1, 1u) - a.bs_ticket_base;  // (in flight under everything requested below)
+  if (ticketed && tid == 0) my_ticket = atomicAdd(a.bs_ticket, 1u) - a.bs_ticket_base;  // (in flight under everything requested below)
+  if (ticketed && tid < kBlk * kMaxFrames) a.bs_hand_next[tid] = kHandOverSentinel();  // (every workgroup: the same value; read by the next launch)
   __shared__ unsigned s_vblock;
   // with tickets every workgroup requests the solver's operands (it does not know its role yet; the others drop them)
   bool main_wg = ticketed || blockIdx.x == 0;
@@ -266,7 +280,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         }
       }
       // what workgroup 0 does with this decision: no step -> nothing to substitute
-      if (!a.bs_flag || !s_dec_proceed || s_dec_out.relin) return;
+      if (!ticketed || !s_dec_proceed || s_dec_out.relin) return;
       // (a) the rows of the first kPre passes are requested now and wait in registers (12 frames / 50 000 landmarks: 255 workgroups x
       // 2 passes x 128 landmarks hold all of them)
       auto backSubstitute = [&](auto ns_tag) {
@@ -311,21 +325,24 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         const int p = static_cast<int>(vblock) - 1 + u * W;
         if (p < n_pass) fetch(p, rows[u], bdv[u], ihv[u], dstp[u]);
       }
-      // (b) wait for the solving workgroup's step.  It drew its ticket before this one and waits for nobody; the bound only turns an
-      // accident into a loud failure instead of a hang
-      if (tid == 0) {
-        const long long t0 = wall_clock64();
-        // (relaxed polls: an acquire per poll would invalidate this XCD's non-coherent L2 lines a few million times a second)
-        while (__hip_atomic_load(a.bs_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.bs_seq) {
-          __builtin_amdgcn_s_sleep(8);
-          if (wall_clock64() - t0 > 200000000ll) __builtin_trap();  // 2 s
-        }
-      }
-      __syncthreads();
-      // the step through LDS (this workgroup's share of the launch's dynamic allocation is otherwise unused): every lane reads its
-      // slots' eight values per pass instead of keeping NS x 8 more doubles in registers next to the rows
+      // (b) wait for the solving workgroup's step: thread k polls slot k until it holds a value.  The solver drew its ticket before
+      // this workgroup and waits for nobody; the bound only turns an accident into a loud failure instead of a hang.  The step goes
+      // through LDS (this workgroup's share of the launch's dynamic allocation is otherwise unused): every lane reads its slots' eight
+      // values per pass instead of keeping NS x 8 more doubles in registers next to the rows
       double *stp = reinterpret_cast<double *>(smem_raw);  // [kBlk * kMaxFrames], zero beyond K
-      if (tid < kBlk * kMaxFrames) stp[tid] = tid < K ? __hip_atomic_load(a.step + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      if (tid < kBlk * kMaxFrames) {
+        double v = 0;
+        if (tid < K) {
+          const long long t0 = wall_clock64();
+          for (;;) {
+            v = __hip_atomic_load(a.bs_hand + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__double_as_longlong(v) != __double_as_longlong(kHandOverSentinel())) break;
+            __builtin_amdgcn_s_sleep(24);  // (255 workgroups poll the same 12 lines: a poll every ~0.7 us keeps that queue short)
+            if (wall_clock64() - t0 > 200000000ll) __builtin_trap();  // 2 s
+          }
+        }
+        stp[tid] = v;
+      }
       __syncthreads();
       const double damp = 1.0 / (1.0 + s_dec_out.lambda);
       auto finish = [&](const double (&rw)[NS][kBlk], double bd, double ih, hbm_f64 *dst) {
@@ -636,20 +653,10 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   if (tid < K) {
     const double x = xs[tid];
     stpl[tid] = -x;
-    // (device-scope stores: written through to where the other XCDs read, no cache-wide write-back needed to hand the step over)
-    if (a.bs_flag)
-      __hip_atomic_store(a.step + tid, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      a.step[tid] = x;
+    // (a device-scope store: written through to where the other XCDs read — no flag, no fence: the slot's sentinel gives way to the value)
+    if (a.bs_hand) __hip_atomic_store(a.bs_hand + tid, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the waiting workgroups' copy
+    a.step[tid] = x;
     a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
-  }
-  if (a.bs_flag) {
-    // the landmark workgroups of this launch wait for the step (back-substitution, above).  Its stores are device-scope and have been
-    // acknowledged behind the barrier (vmcnt 0), so the hand-over word is one more such store — a release fence here would write the
-    // whole L2 back (the landmark workgroups have just dirtied it: + 5 us before the word became visible).  The last wave publishes:
-    // it has nothing else to do
-    __syncthreads();
-    if (tid == THREADS - 64) __hip_atomic_store(a.bs_flag, a.bs_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   SC_STAMP(3);
   // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312) and the frame part of the
