@@ -433,7 +433,7 @@ def main():
                        "frames": F, "points_per_gpu": P, "total_points": total_points,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
                        "exchange": job.transport, "ranks": world},
-            "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN, FEJ, HUBER, BACKSUB>: the in-loop variant)",
+            "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN = true, FEJ, HUBER, BACKSUB = false>: the linearisation sweep as the LM loop launches it)",
                          "achieved": (b_lin / (in_loop["avg_us"] * 1e-6) / 1e9) if in_loop else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": in_loop["frac"] if in_loop else frac_events,
                          "frac_source": (f"{in_loop['source']}: average duration of the kernel inside the bench loop under rocprofv3 --kernel-trace --stats "

@@ -285,7 +285,11 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       // 2 passes x 128 landmarks hold all of them)
       auto backSubstitute = [&](auto ns_tag) {
       constexpr int NS = decltype(ns_tag)::value;  // frame slots per lane: 2 up to 8 frames, 3 up to 12, 4 up to 16
-      constexpr int kPre = THREADS >= 512 ? (NS >= 4 ? 1 : 2) : 4;  // (13 - 16 frames: one pass in registers, the compiler spilled with two)
+      // passes whose rows wait in registers: 2 x 128 landmarks at 512 threads (1 at 13 - 16 frames: the compiler spilled with two),
+      // 2 x 64 at 256 threads — with 4 the 256-thread kernel needed 255 VGPRs + 38 AGPRs and its solving path slowed down (the
+      // factorisation 8.2 -> 8.8 us at 7 frames: accumulator-register moves in the pivot loop); with 2 it is 217 VGPRs, two workgroups
+      // per compute unit, and every window up to 8 frames / 65 000 landmarks still has all rows prefetched
+      constexpr int kPre = THREADS >= 512 ? (NS >= 4 ? 1 : 2) : 2;
       double rows[kPre][NS][kBlk], bdv[kPre], ihv[kPre];
       hbm_f64 *dstp[kPre];
     #pragma unroll
