@@ -368,7 +368,7 @@ struct CombineArgs {
   int F, n_schur_wgs;
 };
 
-constexpr int kCombineEntries = 32, kCombineSlices = 16;  // a workgroup of 512 threads: 32 entries x 16 slices of the partial systems
+constexpr int kCombineEntries = 32, kCombineSlices = 32;  // a workgroup of 1024 threads: 32 entries x 32 slices of the partial systems (512 partial systems = ONE round of 16 loads per thread; with 16 slices two)
 
 /** pair-block part of entry (row R, col C), R >= C, of the combined system (without the damping of the diagonal).  Slots of
  *  unconnected pairs hold zeros (stage 1), so every slot is added, in frame order, with all loads in flight together. */
