@@ -211,8 +211,10 @@ BASE_MOTION = np.array([0.08, 0.01, 0.02, 0.004, 0.012, 0.003])
 
 def make_window(num_frames: int = 7, num_points: int = 2000, width: int = 640, height: int = 480, seed: int = 0,
                 pose_noise: bool = True, idepth_noise: float = 2e-3, affine_jitter: bool = False,
-                min_gradient: float = 4.0, quantize: bool = True) -> SyntheticWindow:
-    """C1 of SURVEY.md §8d by default: 7 keyframes, 2000 active points, 640x480, full clique."""
+                min_gradient: float = 4.0, quantize: bool = True, order: str = None) -> SyntheticWindow:
+    """C1 of SURVEY.md §8d by default: 7 keyframes, 2000 active points, 640x480, full clique.
+    `order`: order of a frame's landmarks — "random" (default: the order the pixels were drawn in), "raster" (row-major by pixel),
+    "tileN" (N x N-pixel tiles in raster order, raster inside a tile: what a grid-cell feature extractor yields)."""
     scene = Scene.make(width, height, seed)
     rng = np.random.default_rng(seed + 1)
     frames = []
@@ -242,7 +244,7 @@ def make_window(num_frames: int = 7, num_points: int = 2000, width: int = 640, h
             ok = grad[cand[:, 1], cand[:, 0]] > min_gradient
             uv = np.concatenate([uv, cand[ok].astype(np.float64)])
         uv = uv[:n]
-        order = os.environ.get("DSOPP_SYN_ORDER", "random")  # experiment: order of the landmarks within a frame
+        order = order or os.environ.get("DSOPP_SYN_ORDER", "random")  # (environment: experiments on unmodified callers)
         if order == "clump":  # experiment: every landmark inside one 48 x 48 window (cache-resident gather)
             uv = np.stack([200 + (uv[:, 0] % 48), 200 + (uv[:, 1] % 48)], axis=1)
         if order == "raster":

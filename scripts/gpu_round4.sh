@@ -9,12 +9,12 @@ if [ "$1" != "quick" ]; then
   timeout 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; grep -E "passed|failed|error" $O/pytest_gpu.log | tail -2
 fi
 # rocprofv3 --kernel-trace --stats per workload
-for what in c1 c1_isolated large large_loop c3_loop tracker depth activation; do
+for what in c1 c1_isolated large large_loop large_loop_tile32 c3_loop tracker depth activation; do
   d=/tmp/prof_$what; rm -rf $d
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o prof -- python $GRAFT_REPO_ROOT/scripts/profile_target.py $what > $GRAFT_REPO_ROOT/$O/$what.log 2>&1)
   f=$(find $d -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $O/${what}_kernel_stats.csv || echo "no stats for $what"
-  if [ "$what" = c1 ] || [ "$what" = large_loop ] || [ "$what" = c3_loop ]; then
+  if [ "$what" = c1 ] || [ "$what" = large_loop ] || [ "$what" = large_loop_tile32 ] || [ "$what" = c3_loop ]; then
     t=$(find $d -name '*kernel_trace.csv' | head -1)
     [ -n "$t" ] && python scripts/one_solve_timeline.py "$t" > $O/${what}_one_solve_timeline.csv
   fi

@@ -8,6 +8,7 @@ is what DESIGN.md's per-kernel figures are recomputed from.
    large      12 KF / 50 000 points on one GPU: 3 LM solves + isolated kernel launches
    large_loop the same window, fused loop only (5 solves)
    c3_loop    7 KF / 20 000 points, fused loop only
+   large_loop_tile32  as large_loop, every frame's landmarks in 32 x 32-pixel tiles in raster order (a grid-cell extractor's order)
    tracker    C2: 1280x1024, 5 levels, 20 frames of pyramid + estimatePose
    depth      7 x 2000 immature landmarks against one 640x480 frame
    activation 6 x (286 active + 1500 immature) landmarks against a new keyframe"""
@@ -58,6 +59,15 @@ elif what == "c3_loop":
 elif what == "large_loop":
     # only the fused loop (for a kernel-by-kernel timeline of one solve at this size: scripts/one_solve_timeline.py)
     win = syn.make_window(12, 50000, 640, 480, seed=1)
+    g = capi.HipWindow(capi.default_pba_options())
+    syn.load_window(g, win)
+    g.snapshot()
+    g.optimize_repeated(7)
+    g.optimize_repeated(28)
+    g.close()
+elif what == "large_loop_tile32":
+    # the large window with spatially ordered landmarks (32 x 32-pixel tiles in raster order): fused loop only
+    win = syn.make_window(12, 50000, 640, 480, seed=1, order="tile32")
     g = capi.HipWindow(capi.default_pba_options())
     syn.load_window(g, win)
     g.snapshot()
