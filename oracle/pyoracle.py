@@ -198,7 +198,7 @@ class OracleWindow:
         self._chk(lib().orc_window_get_pose(self._h, int(frame_id), _p(T), _p(ab)))
         return T, ab
 
-    def get_landmarks(self, frame_id):
+    def get_landmarks(self, frame_id, with_hpib=True):  # (with_hpib: signature parity with the HIP wrapper; the rows are always returned)
         n = self._chk(lib().orc_window_num_landmarks(self._h, int(frame_id)))
         K = self.K
         out = dict(idepth=np.zeros(n), idepth_step=np.zeros(n), inv_hdd=np.zeros(n), b_d=np.zeros(n),

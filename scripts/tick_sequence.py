@@ -182,11 +182,13 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
     min_distance = 2.0
     rmse_ref = -1.0
 
+    # the window's keyframe poses only change in a solve: read once per keyframe (as the tracker's frame objects hold them), not per frame
+    kf_pose = {kf.id: win.get_pose(kf.id) for kf in alive}
     for k in range(first_kf_gap + 1, n_frames):
         t0 = time.perf_counter()
         f = make_frame(k)
         ref = alive[-1]
-        T_ref, ab_ref = win.get_pose(ref.id)
+        T_ref, ab_ref = kf_pose[ref.id]
         if hip:
             hyp = capi.initialization_poses(est[k - 2], est[k - 1], T_ref)
             res = aligner.estimate_pose(ref.ts, T_ref, ref.frame["pyr"], maps, 1.0, ab_ref, f["ts"], f["pyr"], 1.0, intr, hyp, affine_prev, rmse_last)
@@ -217,8 +219,8 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
             flow = po.mean_square_optical_flow(maps[0][0], maps[0][1], intr, syn.mat_to_params(T_t_r))
             flow_nr = po.mean_square_optical_flow(maps[0][0], maps[0][1], intr, syn.mat_to_params(T_nr))
         # estimateDepths: every keyframe's immature landmarks against the new frame
-        rel = [syn.mat_to_params(np.linalg.inv(syn.params_to_mat(T_new)) @ syn.params_to_mat(win.get_pose(kf.id)[0])) for kf in alive]
-        abs_kf = [win.get_pose(kf.id)[1] for kf in alive]
+        rel = [syn.mat_to_params(np.linalg.inv(syn.params_to_mat(T_new)) @ syn.params_to_mat(kf_pose[kf.id][0])) for kf in alive]
+        abs_kf = [kf_pose[kf.id][1] for kf in alive]
         if hip:
             capi.estimate_depths_batched([kf.dset for kf in alive], f["pyr"], 0, intr, np.stack(rel), np.ones(len(alive)), np.stack(abs_kf), 1.0, affine_prev)
             alive[0].dset.sync()
@@ -263,13 +265,16 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
             proj = kf.imm["projection"][act]
             kf.uv = np.concatenate([kf.uv, proj])
             kf.patch = np.concatenate([kf.patch, kf.imm["patch"][act]])
-            cur = win.get_landmarks(kf.id) if hip else win.get_landmarks(kf.id)
-            n_old = len(cur["idepth"])
-            old = {h.id: win.get_residuals(kf.id, h.id)["status"] for h in alive if h is not kf}
+            # (flags + inverse depths only, in one transfer on the HIP side: dsopp_hip_window_get_frame_update — not the n x K Schur rows)
+            cur = win.get_frame_update(kf.id, []) if hip else win.get_landmarks(kf.id)
             win.set_landmarks(kf.id, kf.uv, np.concatenate([cur["idepth"], idp[act]]), kf.patch,
                               np.concatenate([cur["flags"] & 3, np.zeros(int(act.sum()), dtype=np.uint8)]))
-            for hid, st_old in old.items():
-                win.set_connection(kf.id, hid, np.concatenate([st_old[:n_old], np.zeros(len(kf.uv) - n_old, dtype=np.uint8)]))
+            # set_connection APPENDS the entries [current size, n) of a residual list (photometric_bundle_adjustment.cpp:109-123): the new
+            # landmarks start as kOk = 0, what is passed for the existing ones is not read — no need to fetch their statuses first
+            fresh = np.zeros(len(kf.uv), dtype=np.uint8)
+            for h in alive:
+                if h is not kf:
+                    win.set_connection(kf.id, h.id, fresh)
         push_keyframe(new, est[k], affine_prev, False)
         win.solve()
         stats["solves"] += 1
@@ -277,7 +282,7 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
         if len(alive) > max_keyframes:
             victim = alive[1]
             for kf in alive:
-                cur = win.get_landmarks(kf.id)
+                cur = win.get_frame_update(kf.id, []) if hip else win.get_landmarks(kf.id)
                 flags = cur["flags"] & 3
                 if kf is victim:
                     flags = flags | 1
@@ -292,6 +297,7 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
         else:
             maps = cpu_depth_maps()
         rmse_last = np.full(levels, 1e10)
+        kf_pose = {kf.id: win.get_pose(kf.id) for kf in alive}
         t_keyframe.append(time.perf_counter() - t1 - t_candidates)
         kf_ids.append(k)
 
