@@ -42,3 +42,25 @@ def test_host_mirror_solves_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_synthetic_window_landmark_orders():
+    """synthetic.make_window(order=...): the same landmarks, listed randomly (default), row-major, or tile by tile (what the bench's
+    `spatially_ordered_landmarks` line and profiles/r04/large_loop_tile32_* use)"""
+    import numpy as np
+    from dsopp_amd import synthetic as syn
+    a = syn.make_window(3, 300, 320, 240, seed=1)
+    r = syn.make_window(3, 300, 320, 240, seed=1, order="raster")
+    t = syn.make_window(3, 300, 320, 240, seed=1, order="tile32")
+    for fa, fr, ft in zip(a.frames, r.frames, t.frames):
+        key = lambda uv: sorted(map(tuple, uv.tolist()))
+        assert key(fa.uv) == key(fr.uv) == key(ft.uv)
+        assert np.all(np.diff(fr.uv[:, 1] * 10000 + fr.uv[:, 0]) > 0)                                  # row-major
+        tile = (ft.uv[:, 1] // 32) * 100000 + (ft.uv[:, 0] // 32)
+        assert np.all(np.diff(tile) >= 0)                                                              # tiles in raster order
+        same = np.diff(tile) == 0
+        assert np.all(np.diff(ft.uv[:, 1] * 10000 + ft.uv[:, 0])[same] > 0)                            # raster inside a tile
+        # the per-landmark data travelled with the permutation
+        ia = {tuple(uv): (d, tuple(p)) for uv, d, p in zip(fa.uv.tolist(), fa.idepth_gt, fa.patch.tolist())}
+        for uv, d, p in zip(ft.uv.tolist(), ft.idepth_gt, ft.patch.tolist()):
+            assert ia[tuple(uv)] == (d, tuple(p))
