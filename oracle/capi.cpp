@@ -581,4 +581,38 @@ int orc_relative_transformation_uncertainty(const double T_w_1[7], const double 
   return 0;
 }
 
+/* The restated third-party arithmetic on its own (Eigen LDLT / completeOrthogonalDecomposition().pseudoInverse(), the bilinear
+ * sampler of pixel_map.hpp:20-40), so that tests/test_oracle_thirdparty.py can hold each against a third-party implementation
+ * (scipy / numpy) instead of against a second statement by the same author */
+int orc_ldlt_solve(int n, const double *A, const double *b, double *x) {
+  Mat m(n, n);
+  std::memcpy(m.a.data(), A, sizeof(double) * static_cast<size_t>(n) * n);
+  Vec r = ldltSolve(m, Vec(b, b + n));
+  std::memcpy(x, r.data(), sizeof(double) * static_cast<size_t>(n));
+  return 0;
+}
+int orc_pinv_cod(int n, const double *H, double *out) {
+  Mat m(n, n);
+  std::memcpy(m.a.data(), H, sizeof(double) * static_cast<size_t>(n) * n);
+  Mat r = pseudoInverseCOD(m);
+  std::memcpy(out, r.a.data(), sizeof(double) * r.a.size());
+  return 0;
+}
+int orc_interpolate_linear(int width, int height, const double *pixelinfo, int n, const double *x, const double *y, double *out3) {
+  PixelMapView map;
+  map.data = pixelinfo;
+  map.width = width;
+  map.height = height;
+  for (int i = 0; i < n; ++i) interpolateLinear3(map, x[i], y[i], out3 + 3 * i);
+  return 0;
+}
+int orc_mask_valid(int width, int height, const uint8_t *mask, int n, const double *x, const double *y, uint8_t *out) {
+  MaskView m;
+  m.data = mask;
+  m.width = width;
+  m.height = height;
+  for (int i = 0; i < n; ++i) out[i] = m.valid(x[i], y[i]) ? 1 : 0;
+  return 0;
+}
+
 }  // extern "C"

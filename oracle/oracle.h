@@ -163,6 +163,13 @@ int orc_pinv_drop(int n, const double *H, int nullspaces, double *out);
 /* covariance of the relative pose of two frames from the blocks of their joint covariance — se3_motion.hpp:151-158 */
 int orc_relative_transformation_uncertainty(const double T_w_1[7], const double T_w_2[7], const double *sigma_11, const double *sigma_22,
                                             const double *sigma_12, double *out36);
+/* third-party restatements on their own (tests/test_oracle_thirdparty.py): Eigen::LDLT solve (normal_linear_system.cpp:57),
+ * completeOrthogonalDecomposition().pseudoInverse() (:35-37), PixelMap bilinear sampler (pixel_map.hpp:20-40), CameraMask lookup at the
+ * rounded position (camera_mask.hpp:64-66) */
+int orc_ldlt_solve(int n, const double *A, const double *b, double *x);
+int orc_pinv_cod(int n, const double *H, double *out);
+int orc_interpolate_linear(int width, int height, const double *pixelinfo, int n, const double *x, const double *y, double *out3);
+int orc_mask_valid(int width, int height, const uint8_t *mask, int n, const double *x, const double *y, uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -477,3 +477,39 @@ def relative_transformation_uncertainty(T_w_1, T_w_2, sigma_11, sigma_22, sigma_
     out = np.zeros((6, 6))
     lib().orc_relative_transformation_uncertainty(_p(_f64(T_w_1)), _p(_f64(T_w_2)), _p(_f64(sigma_11)), _p(_f64(sigma_22)), _p(_f64(sigma_12)), _p(out))
     return out
+
+
+def ldlt_solve(A, b):
+    """Eigen::LDLT (pivoted) as the oracle restates it, on its own (oracle/linalg.hpp: ldltSolve)"""
+    n = len(b)
+    x = np.zeros(n)
+    lib().orc_ldlt_solve(n, _p(_f64(A)), _p(_f64(b)), _p(x))
+    return x
+
+
+def pinv_cod(H):
+    """completeOrthogonalDecomposition().pseudoInverse() of a symmetric matrix as the oracle restates it"""
+    n = H.shape[0]
+    out = np.zeros((n, n))
+    lib().orc_pinv_cod(n, _p(_f64(H)), _p(out))
+    return out
+
+
+def interpolate_linear(pixelinfo, x, y):
+    """PixelMap<1>::Evaluate -> interpolateLinear<true,1> (pixel_map.hpp:20-40) at n positions: (n, 3) = (I, Ix, Iy)"""
+    pix = _f64(pixelinfo)
+    H, W = pix.shape[:2]
+    x, y = _f64(x), _f64(y)
+    out = np.zeros((len(x), 3))
+    lib().orc_interpolate_linear(W, H, _p(pix), len(x), _p(x), _p(y), _p(out))
+    return out
+
+
+def mask_valid(mask, x, y):
+    """CameraMask::valid at the rounded position with the border check (camera_mask.hpp:48-89)"""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    H, W = m.shape
+    x, y = _f64(x), _f64(y)
+    out = np.zeros(len(x), dtype=np.uint8)
+    lib().orc_mask_valid(W, H, _p(m, np.uint8), len(x), _p(x), _p(y), _p(out, np.uint8))
+    return out.astype(bool)
