@@ -493,7 +493,8 @@ def run_window_group(job, args):
         cmd = [sys.executable, os.path.join(ROOT, "scripts", "group_bench.py"), "--devices", devices, "--workload", "c3", "--blocks", "7", "--also", "p2p"]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.group_timeout)
+            # (the one-shot peer-to-peer all-reduce across distinct devices is an opt-in experiment of the library: this measurement opts in)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.group_timeout, env=dict(os.environ, DSOPP_HIP_P2P_EXPERIMENTAL="1"))
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode == 0 and lines:
                 out = json.loads(lines[-1])

@@ -9,6 +9,7 @@
 // librccl is a 0.5 GB library: it is loaded lazily with dlopen on the first dsopp_hip_comm_* call, so a single-GPU process
 // never maps it.  Inside a process that already holds an RCCL (PyTorch ships one with the same SONAME) the loaded instance
 // is reused.
+#include <atomic>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -21,7 +22,11 @@ struct dsopp_hip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   bool owned = true;
-  bool aborted = false;  // dsopp_hip_comm_abort: the handle only waits to be destroyed
+  // dsopp_hip_comm_abort (called from the failing shard's worker thread while other workers may be inside nativeAllreduce): the handle
+  // only waits to be destroyed.  The flag is atomic and `comm` is never nulled by abort, so a worker that tested the flag just before the
+  // abort hands ncclAllReduce the aborted handle (RCCL's own abort flag makes that call fail) rather than a null pointer.  No mutex
+  // around the two: the abort exists to release workers that are BLOCKED inside RCCL, which would hold it.
+  std::atomic<bool> aborted{false};
 };
 
 namespace dsopp_hip {
@@ -151,21 +156,19 @@ int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out) {
 int dsopp_hip_comm_abort(dsopp_hip_comm *c) {
   return guarded([&] {
     if (!c) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null communicator");
-    if (c->aborted) return;
-    c->aborted = true;
+    if (c->aborted.exchange(true)) return;
     // ncclCommAbort releases the kernels of collectives the OTHER ranks already enqueued and that would wait for this rank for ever
     // (a rank that failed between two collectives never enqueues its side); afterwards the communicator can only be destroyed
     if (c->owned && c->comm && rccl().CommAbort) {
       (void)hipSetDevice(c->device);
-      (void)rccl().CommAbort(c->comm);
-      c->comm = nullptr;
+      (void)rccl().CommAbort(c->comm);  // (ncclCommAbort frees the communicator's resources: destroy skips ncclCommDestroy)
     }
   });
 }
 
 void dsopp_hip_comm_destroy(dsopp_hip_comm *c) {
   if (!c) return;
-  if (c->owned && c->comm) {
+  if (c->owned && c->comm && !c->aborted) {
     (void)hipSetDevice(c->device);
     try {
       (void)rccl().CommDestroy(c->comm);

@@ -99,6 +99,7 @@ struct dsopp_hip_window {
   }
   unsigned *d_bs_flag = nullptr;  // ticket counter + hand-over buffers of the back-substitution inside the solve launch (pba_solve_combined.hpp)
   unsigned bs_seq = 0, bs_ticket_base = 0;
+  int *h_bs_fault = nullptr;  // pinned: raised by a landmark workgroup of the solve launch whose bounded wait for the step ran out (checkSolveLaunchFault)
   long long *dbg_stamps = nullptr;
   long long *dbg_sweep = nullptr;
   bool dbg_sweep_lin = true;
@@ -1012,18 +1013,20 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
         HIP_CHECK(hipMemsetAsync(w.d_bs_flag, 0, 16, w.sr.stream));
         HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(w.d_bs_flag) + 16, arm.data(), arm.size() * sizeof(double), hipMemcpyHostToDevice, w.sr.stream));
         HIP_CHECK(hipStreamSynchronize(w.sr.stream));  // (`arm` is a pageable host buffer)
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&w.h_bs_fault), sizeof(int), hipHostMallocDefault));
+        *w.h_bs_fault = 0;
       }
       {
         constexpr size_t kHand = static_cast<size_t>(kBlk) * kMaxFrames;
         double *hand = reinterpret_cast<double *>(reinterpret_cast<char *>(w.d_bs_flag) + 16);
-        const unsigned n = w.bs_seq++;
+        const unsigned n = w.bs_seq;
         a.bs_ticket = w.d_bs_flag;
         a.bs_hand = hand + (n & 1u) * kHand;
         a.bs_hand_next = hand + ((n + 1) & 1u) * kHand;
       }
       a.bs_parity = ublk_parity;
-      a.bs_ticket_base = w.bs_ticket_base;
-      w.bs_ticket_base += static_cast<unsigned>(1 + a.dec_blocks);  // every workgroup of the launch draws exactly one ticket
+      a.bs_ticket_base = w.bs_ticket_base;  // (both mirrors advance behind the launch, once it is known to have been accepted)
+      a.bs_fault = w.h_bs_fault;
     }
   }
   a.frames = w.d_frames.ptr;
@@ -1050,11 +1053,36 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
                 else
                   solveCombinedKernel<256><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(a);
               });
+  HIP_CHECK(hipGetLastError());
+  if (a.bs_ticket) {
+    // the launch was accepted: every one of its workgroups draws exactly one ticket and arms the other hand-over buffer.  (Advancing
+    // these before the launch was known to exist left every later launch without a ticket 0 — all workgroups waiting for a solver
+    // that is none of them — after a single failed launch.)
+    w.bs_seq++;
+    w.bs_ticket_base += static_cast<unsigned>(1 + a.dec_blocks);
+  }
   if (!w.fej()) {
     // no first-estimate Jacobians: all pair constants follow the candidate state eps + step the solve just wrote
     pairSetupKernel<<<1, kMaxFrames * kMaxFrames, 0, w.sr.stream>>>(w.d_frames.ptr, w.d_state.ptr, w.d_pc.ptr, w.F(), 0, nullptr);
+    HIP_CHECK(hipGetLastError());
   }
-  HIP_CHECK(hipGetLastError());
+}
+
+/** behind a synchronisation of a fused solve: did a landmark workgroup of a solve launch give up waiting for the step?  Then the inverse
+ *  depths of that round were not back-substituted and the solve's result is not the algorithm's: the hand-over state is rebuilt and the
+ *  call fails (the window stays usable). */
+void checkSolveLaunchFault(W &w) {
+  if (!w.h_bs_fault || !*w.h_bs_fault) return;
+  *w.h_bs_fault = 0;
+  constexpr size_t kHand = static_cast<size_t>(kBlk) * kMaxFrames;
+  std::vector<double> arm(2 * kHand, kHandOverSentinel());
+  HIP_CHECK(hipMemsetAsync(w.d_bs_flag, 0, 16, w.sr.stream));
+  HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(w.d_bs_flag) + 16, arm.data(), arm.size() * sizeof(double), hipMemcpyHostToDevice, w.sr.stream));
+  HIP_CHECK(hipStreamSynchronize(w.sr.stream));
+  w.bs_seq = 0;
+  w.bs_ticket_base = 0;
+  fail(DSOPP_HIP_ERR_HIP, "a solve launch's landmark workgroups waited 2 s for the pose step (device shared with a kernel that never yields?): "
+                          "the inverse depths of that iteration were not updated, the solve is void");
 }
 
 void launchBacksub(W &w, double lambda, const LmControl *ctrl, int ublk_parity = 0, bool gate_on_pending = false) {
@@ -1465,6 +1493,7 @@ void lmSolveFusedFinish(W &w, double &energy_out, int &iterations, int &n_valid_
   hipStream_t st = w.sr.stream;
   const LmControl *cfin = w.fused_final_ctrl;
   w.sr.sync();  // the only host synchronisation of the solve (unless the last step was rejected, below)
+  checkSolveLaunchFault(w);
   if (w.h_ctrl->need_final_setup) {
     // closing problem.calculateEnergy() at the final state: the last sweep already evaluated it unless the last step was
     // rejected — then the pair constants are rebuilt and a residual sweep re-evaluates energies / candidate statuses
@@ -2006,6 +2035,7 @@ void dsopp_hip_window_destroy(dsopp_hip_window *w) {
   if (w->stage.base) (void)hipHostFree(w->stage.base);
   if (w->h_update) (void)hipHostFree(w->h_update);
   if (w->d_bs_flag) (void)hipFree(w->d_bs_flag);
+  if (w->h_bs_fault) (void)hipHostFree(w->h_bs_fault);
   w->frames.clear();
   for (dsopp_hip_depth_maps *m : w->live_maps) {  // maps may outlive the window (the tracker holds them): they lose the borrowed stream
     m->sr.stream = nullptr;
@@ -2430,6 +2460,7 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
       prefetchFrameUpdates(*w);
       if (w->opt.estimate_uncertainty) estimateUncertaintyHost(*w, want_state);
       w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
+      checkSolveLaunchFault(*w);
       e = w->h_ctrl->energy;
       it = w->h_ctrl->iteration;
       nv = w->h_ctrl->n_valid;
@@ -2996,6 +3027,7 @@ void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, doubl
       w.result_device = nullptr;
       HIP_CHECK(hipMemcpyAsync(w.h_results, w.d_results.ptr, static_cast<size_t>(n) * sizeof(LmControl), hipMemcpyDeviceToHost, st));
       w.sr.sync();
+      checkSolveLaunchFault(w);
       for (int k = 0; k < n; ++k) {
         const LmControl &r = w.h_results[k];
         if (r.iteration <= 0) stalled = true;  // no progress: leave (iterations_done < target)

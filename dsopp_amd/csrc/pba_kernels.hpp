@@ -858,7 +858,8 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     }
   }
   }  // groups
-  if (LIN) gramContract(gram_lds + (threadIdx.x >> 6) * 64 * kGramStride, gram);  // the last group's rows
+  // the last group's rows (a padding entry of the XCD-banded launch order has no group: nothing was published, its sums stay zero)
+  if (LIN && be.n_groups > 0) gramContract(gram_lds + (threadIdx.x >> 6) * 64 * kGramStride, gram);
   SWEEP_STAMP(4);
   double *out = partials + static_cast<size_t>(be.partial_row) * kPartial;
   gramScalarsStore<LIN>(gram, sc, scalar_lds, out);

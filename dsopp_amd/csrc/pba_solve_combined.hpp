@@ -61,6 +61,11 @@ struct SolveCombArgs {
   // 1, 2, ... were resident and waiting while block 0 was not (two ranks on one device deadlocked exactly so, with the other
   // rank's collective waiting for this rank in turn).
   unsigned bs_ticket_base = 0;
+  // Where a landmark workgroup whose bounded wait for the step ran out says so: one int in pinned host memory (0 = fine).  The workgroup
+  // then leaves its landmarks' idepth_step untouched and returns; the host finds the word set at the solve's synchronisation and fails
+  // the solve with DSOPP_HIP_ERR_HIP.  (Until round 5 the waiter trapped, which takes the whole HIP context — every window, aligner and
+  // group of the process — down with it.)
+  int *bs_fault = nullptr;
 };
 /** what an armed hand-over slot holds: a quiet NaN with a payload no arithmetic produces */
 __host__ __device__ inline double kHandOverSentinel() {
@@ -334,6 +339,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       // through LDS (this workgroup's share of the launch's dynamic allocation is otherwise unused): every lane reads its slots' eight
       // values per pass instead of keeping NS x 8 more doubles in registers next to the rows
       double *stp = reinterpret_cast<double *>(smem_raw);  // [kBlk * kMaxFrames], zero beyond K
+      __shared__ int s_timed_out;
+      if (tid == 0) s_timed_out = 0;
+      ldsBarrier();
       if (tid < kBlk * kMaxFrames) {
         double v = 0;
         if (tid < K) {
@@ -342,12 +350,17 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
             v = __hip_atomic_load(a.bs_hand + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__double_as_longlong(v) != __double_as_longlong(kHandOverSentinel())) break;
             __builtin_amdgcn_s_sleep(24);  // (255 workgroups poll the same 12 lines: a poll every ~0.7 us keeps that queue short)
-            if (wall_clock64() - t0 > 200000000ll) __builtin_trap();  // 2 s
+            if (wall_clock64() - t0 > 200000000ll) {  // 2 s: report and leave (SolveCombArgs::bs_fault)
+              s_timed_out = 1;
+              if (a.bs_fault) __hip_atomic_store(a.bs_fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
           }
         }
         stp[tid] = v;
       }
       __syncthreads();
+      if (s_timed_out) return;  // (uniform: read after the barrier)
       const double damp = 1.0 / (1.0 + s_dec_out.lambda);
       auto finish = [&](const double (&rw)[NS][kBlk], double bd, double ih, hbm_f64 *dst) {
         double d = 0;

@@ -578,6 +578,13 @@ int dsopp_hip_window_group_create(const dsopp_hip_options *options, const int32_
         if (!same && !distinct)
           fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "the peer-to-peer transport takes shards on all-distinct devices, or all on one device (kernels of shards that share a "
                                                "device cannot wait for each other)");
+        // The distinct-device branch (one kernel per shard, remote xGMI stores into fine-grained receive areas, generation-valued
+        // flags) has never executed: no box this library was built on had two GPUs.  Until one has, it is an opt-in experiment —
+        // an explicit request without the opt-in is refused instead of running untested synchronisation in a caller's process.
+        static const bool p2p_experimental = std::getenv("DSOPP_HIP_P2P_EXPERIMENTAL") != nullptr && std::atoi(std::getenv("DSOPP_HIP_P2P_EXPERIMENTAL")) != 0;
+        if (!same && !p2p_experimental)
+          fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "DSOPP_HIP_TRANSPORT_P2P across distinct devices is experimental (never run on a multi-GPU node): set "
+                                               "DSOPP_HIP_P2P_EXPERIMENTAL=1 to opt in, or use DSOPP_HIP_TRANSPORT_RCCL / _LOCAL");
         q.one_device = same;
         q.recv.assign(static_cast<size_t>(n), nullptr);
         q.flags.assign(static_cast<size_t>(n), nullptr);

@@ -280,3 +280,18 @@ def load_window(backend, win: SyntheticWindow, statuses=None):
                     st = np.zeros(len(r.uv), dtype=np.uint8)
                 backend.set_connection(r.frame_id, t.frame_id, st)
     return backend
+
+
+# ImmatureLandmarkStatus (src/track/landmarks/include/track/landmarks/immature_tracking_landmark.hpp) as the C-ABI encodes it
+IMMATURE_STATUS = dict(good=0, out_of_boundary=1, outlier=2, skipped=3, ill_conditioned=4, uninitialized=5, delete=6)
+
+
+def new_immature_landmarks(uv, direction, patch, gradient):
+    """struct-of-arrays ImmatureTrackingLandmark set with the constructor defaults (immature_tracking_landmark.hpp:93-106): the plain
+    data both the device sets (capi.ImmatureSet) and the CPU checker take — no arithmetic, so it lives with the generators"""
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).copy()  # noqa: E731
+    n = len(uv)
+    return dict(projection=f64(uv), direction=f64(direction), patch=f64(patch), gradient=f64(gradient),
+                idepth_min=np.zeros(n), idepth_max=np.full(n, 1.0 / 0.001), uniqueness=np.full(n, np.finfo(np.float64).max),
+                search_pixel_interval=np.full(n, np.finfo(np.float64).max), status=np.full(n, IMMATURE_STATUS["uninitialized"], dtype=np.uint8),
+                traced=np.zeros(n, dtype=np.uint8))

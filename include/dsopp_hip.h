@@ -233,7 +233,9 @@ int dsopp_hip_window_set_comm(dsopp_hip_window *w, dsopp_hip_comm *comm);
  * iteration) straight into every peer's receive area over the direct xGMI links and adds up what the others stored into its own — one
  * kernel per shard and collective, no ring, no host barrier (fine-grained device memory, system-scope flags, every wait bounded: a
  * time-out is reported as an error and leaves the group unusable); buffers beyond the receive area take the LOCAL reducer.  Never
- * chosen by AUTO (so far only exercised with the shards on one device).
+ * chosen by AUTO.  EXPERIMENTAL across distinct devices: that branch has never run on a multi-GPU node, so a P2P request with distinct
+ * device ids is refused (DSOPP_HIP_ERR_INVALID_ARGUMENT) unless the process sets DSOPP_HIP_P2P_EXPERIMENTAL=1; with all shards on one
+ * device (what the one-GPU tests execute) it needs no opt-in.
  * dsopp_hip_window_group_size reports the transport in use.  A group of one shard is a plain window.
  * ---------------------------------------------------------------------------------------------------------------- */
 enum { DSOPP_HIP_TRANSPORT_AUTO = 0, DSOPP_HIP_TRANSPORT_RCCL = 1, DSOPP_HIP_TRANSPORT_LOCAL = 2, DSOPP_HIP_TRANSPORT_P2P = 3 };

@@ -260,16 +260,8 @@ def points_from_depth_map(pixelinfo, idepth_sum, weight):
     return u[:n].copy(), v[:n].copy(), d[:n].copy(), inten[:n].copy()
 
 
-IMMATURE_STATUS = dict(good=0, out_of_boundary=1, outlier=2, skipped=3, ill_conditioned=4, uninitialized=5, delete=6)
-
-
-def new_immature_landmarks(uv, direction, patch, gradient):
-    """struct-of-arrays ImmatureTrackingLandmark set with the constructor defaults (immature_tracking_landmark.hpp:93-106)"""
-    n = len(uv)
-    return dict(projection=_f64(uv).copy(), direction=_f64(direction).copy(), patch=_f64(patch).copy(), gradient=_f64(gradient).copy(),
-                idepth_min=np.zeros(n), idepth_max=np.full(n, 1.0 / 0.001), uniqueness=np.full(n, np.finfo(np.float64).max),
-                search_pixel_interval=np.full(n, np.finfo(np.float64).max), status=np.full(n, IMMATURE_STATUS["uninitialized"], dtype=np.uint8),
-                traced=np.zeros(n, dtype=np.uint8))
+# (the status codes and the constructor-default struct of arrays are plain data: they live with the generators, re-exported here)
+from dsopp_amd.synthetic import IMMATURE_STATUS, new_immature_landmarks  # noqa: E402,F401
 
 
 def estimate_depths(lms, target_pixelinfo, mask, intrinsics, T_target_reference, reference_exposure=1.0, reference_affine=(0, 0),

@@ -98,12 +98,14 @@ class _Keyframe:
 def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_boot, n_immature, desired_points, max_keyframes, kf_factor, seed=7,
                  first_kf_gap=3, max_frames=None, threads=None):
     """backend: "hip" (dsopp_amd.capi) or "cpu" (oracle.pyoracle).  Returns timings per frame / per keyframe and the estimated poses."""
-    from oracle import pyoracle as po
     hip = backend == "hip"
     if hip:
-        from dsopp_amd import capi
-    elif threads:
-        po.set_threads(threads)
+        from dsopp_amd import capi  # (the HIP leg never imports the CPU checker)
+        po = None
+    else:
+        from oracle import pyoracle as po
+        if threads:
+            po.set_threads(threads)
     W, H = scene.width, scene.height
     intr = scene.intrinsics
     rng = np.random.default_rng(seed)
@@ -132,7 +134,7 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
         ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
         grad = np.stack([info0[vi, ui, 1], info0[vi, ui, 2]], axis=1)
         direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
-        kf.imm = po.new_immature_landmarks(uv, direction, _patch(f["u8"].astype(np.float64), uv, syn.PATTERN), grad)
+        kf.imm = syn.new_immature_landmarks(uv, direction, _patch(f["u8"].astype(np.float64), uv, syn.PATTERN), grad)
         kf.dset = capi.ImmatureSet(kf.imm) if hip else None
         return kf
 

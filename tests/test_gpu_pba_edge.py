@@ -480,7 +480,8 @@ import sys
 import numpy as np
 from dsopp_amd import capi, synthetic as syn
 out = {}
-for name, (F, P, W, H, seed) in {"small": (5, 600, 320, 240, 3), "wide": (10, 1500, 320, 240, 5), "large": (7, 14000, 640, 480, 7)}.items():
+for name, (F, P, W, H, seed) in {"small": (5, 600, 320, 240, 3), "wide": (10, 1500, 320, 240, 5), "large": (7, 14000, 640, 480, 7),
+                                   "fourteen": (14, 1800, 320, 240, 9)}.items():  # (13 - 16 keyframes: four frame slots per lane, ONE prefetched pass)
     win = syn.make_window(num_frames=F, num_points=P, width=W, height=H, seed=seed)
     g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
     e, it, nv = g.solve()
@@ -512,7 +513,7 @@ def test_idepth_back_substitution_inside_the_solve_launch_equals_the_kernel_flow
         assert r.returncode == 0 and "k3 flow ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         res[flow] = np.load(path)
     a, b = res["1"], res["0"]
-    for name in ("small", "wide", "large"):
+    for name in ("small", "wide", "large", "fourteen"):
         assert int(a[f"{name}_1"]) == int(b[f"{name}_1"]) and int(a[f"{name}_2"]) == int(b[f"{name}_2"]), name
         assert abs(float(a[f"{name}_0"]) - float(b[f"{name}_0"])) <= 1e-9 * abs(float(b[f"{name}_0"])), name
         assert np.abs(a[f"{name}_3"] - b[f"{name}_3"]).max() <= 1e-9, name

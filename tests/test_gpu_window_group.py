@@ -453,3 +453,47 @@ def test_peer_to_peer_transport_matches_single_window(shards):
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", _P2P_SCRIPT, str(shards)], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "p2p ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_P2P_MULTI_DEVICE_SCRIPT = r"""
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+n = min(capi.device_count(), 4)
+win = syn.make_window(num_frames=5, num_points=1100, width=320, height=240, seed=29)
+res = {}
+for name, transport in (("local", capi.TRANSPORT_LOCAL), ("p2p", capi.TRANSPORT_P2P)):
+    gg = capi.HipWindowGroup(capi.default_pba_options(), devices=list(range(n)), transport=transport); syn.load_window(gg, win)
+    assert gg.transport == transport
+    gg.set_deterministic(True)
+    e, it, nv = gg.solve()
+    res[name] = (e, it, nv, np.stack([gg.get_pose(f.frame_id)[0] for f in win.frames]),
+                 np.concatenate([gg.get_landmarks(f.frame_id, False)["idepth"] for f in win.frames]))
+    gg.close()
+a, b = res["local"], res["p2p"]
+assert a[:3] == b[:3], (a[:3], b[:3])
+assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])  # both sum in shard order: bitwise
+print("p2p multi-device ok", n)
+"""
+
+
+def _device_count():
+    from dsopp_amd import capi
+    return capi.device_count()
+
+
+@pytest.mark.skipif("_device_count() < 2", reason="needs two GPUs: the distinct-device branch of the peer-to-peer all-reduce")
+def test_peer_to_peer_transport_on_distinct_devices_is_opt_in_and_matches_local():
+    """Across distinct devices DSOPP_HIP_TRANSPORT_P2P is refused without DSOPP_HIP_P2P_EXPERIMENTAL=1 (that branch — one kernel per shard,
+    remote stores over xGMI, generation-valued flags — has never run where this library was built); with the opt-in it has to reproduce
+    the in-process reducer bit for bit in deterministic mode (both add the shards' partial sums in shard order)."""
+    import os
+    import subprocess
+    import sys
+    from dsopp_amd import capi
+    with pytest.raises(capi.HipError) as ei:
+        capi.HipWindowGroup(capi.default_pba_options(), devices=[0, 1], transport=capi.TRANSPORT_P2P)
+    assert "experimental" in str(ei.value).lower()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, DSOPP_HIP_P2P_EXPERIMENTAL="1")
+    r = subprocess.run([sys.executable, "-c", _P2P_MULTI_DEVICE_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "p2p multi-device ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
