@@ -77,7 +77,7 @@ struct dsopp_hip_window {
   DeviceBuffer<SchurBlock> d_schur_table;
   DeviceBuffer<int> d_pair_first, d_pair_count;
   // d_reduce = [Hpp K*K | bpp K | Hsc K*K | bsc K] (no priors): everything a multi-GPU run must sum across ranks, contiguous
-  DeviceBuffer<double> d_partials, d_reduce, d_Hpp, d_bpp, d_Hm, d_bm, d_step, d_scalars, d_gather;
+  DeviceBuffer<double> d_partials, d_reduce, d_Hpp, d_bpp, d_Hm, d_Hm_packed, d_bm, d_step, d_scalars, d_gather;
   bool marg_nonzero = false;
   // two-stage (atomic-free, order-deterministic) build of the combined system: pba_schur_two_stage.hpp
   DeviceBuffer<double> d_schur_partials, d_pair_out;
@@ -614,6 +614,18 @@ void uploadMarginal(W &w) {
   for (double v : w.bm) w.marg_nonzero = w.marg_nonzero || v != 0;
   w.d_Hm.upload(w.Hm.data(), static_cast<size_t>(K) * K, 0, w.sr.stream);
   w.d_bm.upload(w.bm.data(), static_cast<size_t>(K), 0, w.sr.stream);
+  // ... and the matrix in the combined system's own layout (8 x 8 blocks of the lower triangle, row-major inside: combBlockIndex), which
+  // the fused loop's solve launch adds while it loads the system (SolveCombArgs::HmPacked)
+  const int F = w.F();
+  std::vector<double> packed(static_cast<size_t>(combBlockCount(F)) * 64);
+  for (int bi = 0; bi < F; ++bi)
+    for (int bj = 0; bj <= bi; ++bj)
+      for (int i = 0; i < kBlk; ++i)
+        for (int j = 0; j < kBlk; ++j)
+          packed[static_cast<size_t>(combBlockIndex(bi, bj)) * 64 + static_cast<size_t>(i * kBlk + j)] =
+              w.Hm[static_cast<size_t>(kBlk * bi + i) * K + static_cast<size_t>(kBlk * bj + j)];
+  w.d_Hm_packed.reserve(static_cast<size_t>(combBlockCount(kMaxFrames)) * 64, 0, w.sr.stream);
+  w.d_Hm_packed.upload(packed.data(), packed.size(), 0, w.sr.stream);
   w.sr.sync();
   w.marg_dirty = false;
 }
@@ -1034,6 +1046,7 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
   a.pc = w.d_pc.ptr;
   a.comb = w.d_reduce.ptr;
   a.Hm = w.d_Hm.ptr;
+  a.HmPacked = w.d_Hm_packed.ptr;
   a.bm = w.d_bm.ptr;
   a.step = w.d_step.ptr;
   a.ctrl = ctrl;

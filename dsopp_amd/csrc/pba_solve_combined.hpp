@@ -23,6 +23,11 @@ struct SolveCombArgs {
   PairConst *pc;
   const double *comb;  // combBlockCount(F) * 64 block entries, then K right-hand-side entries
   const double *Hm, *bm;  // marginal prior
+  // the marginal prior's matrix once more in the layout of `comb` (block-packed lower triangle, packed by the host with the prior:
+  // pba.hip uploadMarginal): the load phase adds it entry by entry at the SAME offsets as the combined system — no per-entry block
+  // decode (a square root and a dozen integer instructions per entry) and no second set of addresses in the prologue, whose register
+  // pressure had the 512-thread kernel spill freshly loaded values (and wait for them) in front of the decision
+  const double *HmPacked = nullptr;
   double *step;        // out: K
   LmControl *ctrl;     // nullable (isolated timing launches pass lambda explicitly)
   double lambda;
@@ -172,16 +177,22 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   }
   // the prior energy of the candidate (kernel tail) is evaluated by the threads 64 .. 64 + K - 1, i.e. on other waves than the
   // pair-constant refresh it runs beside; their operands are requested here with everything else
+  // (requested behind the factorisation — requestTailInputs below —: fetched here they were live, or spilled, across the whole solve)
   const int pc = tid - 64;
   const bool prior_thread = main_wg && pc >= 0 && pc < K;
   double ab0_p = 0, bm_p = 0;
-  if (prior_thread) {
-    ab0_p = a.st->ab0[pc >> 3][(pc & 7) < 6 ? 0 : (pc & 7) - 6];
-    if (a.use_marginal) bm_p = a.bm[pc];
-  }
+  auto requestTailInputs = [&] {
+    if (prior_thread) {
+      ab0_p = a.st->ab0[pc >> 3][(pc & 7) < 6 ? 0 : (pc & 7) - 6];
+      if (a.use_marginal) bm_p = a.bm[pc];
+    }
+  };
+  if (!ticketed) requestTailInputs();
   // the block-packed lower triangle: entry e = tid + 256 u, coalesced.  kBatch loads are in flight per thread.
   const int n_entries = combBlockCount(F) * 64;
-  constexpr int kBatch = 8;
+  // (512 threads: 6 per batch cover the 4992 entries of 12 frames in two rounds and the 8704 of 16 frames in three, as 8 would, with
+  // eight registers fewer held across the decision)
+  constexpr int kBatch = THREADS >= 512 ? 6 : 8;
   double hv[kBatch], hm[kBatch];
   auto loadBatch = [&](int base) {
 #pragma unroll
@@ -192,12 +203,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     }
     if (a.use_marginal) {
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        const int e = min(base + tid + THREADS * u, n_entries - 1);
-        int bi, bj;
-        combBlockDecode(e >> 6, bi, bj);
-        hm[u] = a.Hm[(8 * bi + ((e >> 3) & 7)) * K + 8 * bj + (e & 7)];
-      }
+      for (int u = 0; u < kBatch; ++u) hm[u] = a.HmPacked[min(base + tid + THREADS * u, n_entries - 1)];
     }
   };
   if (main_wg) loadBatch(0);
@@ -319,7 +325,8 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         const hbm_f64 *base = be.ublk + static_cast<size_t>(a.bs_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
     #pragma unroll
         for (int q = 0; q < NS; ++q) {
-          const int t = sub + 4 * q;
+          int t = sub + 4 * q;
+          asm volatile("" : "+v"(t));  // (opaque: otherwise the per-slot masks 1 << t are hoisted out of the pass loop and held — two of them spilled)
           if (t < F && (t == be.r || ((be.conn_mask >> t) & 1u))) {
     #pragma unroll
             for (int c = 0; c < kBlk; ++c) rw[q][c] = base[t * plane + c];
@@ -595,6 +602,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     __syncthreads();
   }
   SC_STAMP(2);
+  // what only the kernel's tail reads (pair-constant refresh, prior energy of the candidate) is requested HERE, to land under the
+  // back-substitution: requested at the head, these 24 doubles per thread were held — or spilled and reloaded — across the factorisation
+  if (ticketed) requestTailInputs();
   // ---- back substitution x = L^-T y (y = row K of L), column-oriented on one wave: lane j carries y_j (and y_{j+64});
   // going down from k = K-1, x_k = y_k / L_kk is broadcast with v_readlane and every lane j < k takes y_j -= L_kj x_k.
   // 4-7 instructions per unknown, no LDS round trip or barrier inside the chain (L_kj is prefetched a frame block ahead).

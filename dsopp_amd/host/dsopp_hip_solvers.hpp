@@ -406,6 +406,15 @@ class HipPhotometricBundleAdjustment {
   std::map<time_point, int32_t> times_;
 };
 
+/** what MonocularTracker::estimatePose leaves behind (monocular_tracker.cpp:179-245): the new frame's pose and affine brightness,
+ *  whether an initialisation passed the per-level rmse gates, how many were tried and the LM iterations spent */
+struct PoseEstimate {
+  Motion t_world_target;
+  Vector2 affine_brightness;
+  bool success;
+  int tries, lm_iterations;
+};
+
 /** mirror of EigenPoseAlignment<SE3, PinholeCamera, 1, PixelMap, 1, true> backed by HIP kernels */
 class HipPoseAlignment {
  public:
@@ -459,6 +468,31 @@ class HipPoseAlignment {
     check(dsopp_hip_aligner_solve(a_, &last_));
     return last_.rmse;
   }
+  /** estimatePose of the tracker (monocular_tracker.cpp:179-245) as ONE call: for every initialisation in turn, coarse to fine over the
+   *  levels of the target pyramid { reset; pushFrame(keyframe, depth map of the level); pushFrame(target, current estimate); solve; gate on
+   *  2.5 x rmse_last_pose_estimation[level] } — the loop the tracker runs over this object, executed by one persistent launch per frame
+   *  (up to 8 initialisations per launch once a first one has failed).  `rmse_last_pose_estimation` (one entry per level) is updated
+   *  as the reference updates it. */
+  PoseEstimate estimatePose(time_point reference_time, const Motion &t_world_reference, const DevicePyramid &reference_pyramids,
+                            const DeviceDepthMaps &reference_depth_maps, double reference_exposure_time, const Vector2 &reference_affine_brightness,
+                            time_point target_time, const DevicePyramid &target_pyramids, double target_exposure_time, const PinholeModel &model,
+                            const std::vector<Motion> &initializations, const Vector2 &affine_brightness_init,
+                            std::vector<double> &rmse_last_pose_estimation) {
+    const double intr[4] = {model.fx, model.fy, model.cx, model.cy};
+    std::vector<double> inits(7 * initializations.size());
+    for (size_t i = 0; i < initializations.size(); ++i) std::copy(initializations[i].begin(), initializations[i].end(), inits.begin() + 7 * static_cast<long>(i));
+    PoseEstimate out{};
+    int32_t success = 0, tries = 0, its = 0;
+    check(dsopp_hip_aligner_estimate_pose(a_, reference_time, t_world_reference.data(), reference_pyramids.handle(), reference_depth_maps.handle(),
+                                          reference_exposure_time, reference_affine_brightness.data(), target_time, target_pyramids.handle(),
+                                          target_exposure_time, intr, static_cast<int32_t>(initializations.size()), inits.data(),
+                                          affine_brightness_init.data(), rmse_last_pose_estimation.data(), out.t_world_target.data(),
+                                          out.affine_brightness.data(), &success, &tries, &its));
+    out.success = success != 0;
+    out.tries = tries;
+    out.lm_iterations = its;
+    return out;
+  }
   Motion getPose(time_point) const {
     Motion T;
     for (int i = 0; i < 7; ++i) T[static_cast<size_t>(i)] = last_.T_world_target[i];
@@ -508,6 +542,8 @@ class DeviceImmatureSet {
     check(dsopp_hip_immature_set_estimate(s_, target_frame.handle(), 0, intr, t_t_r.data(), reference_exposure_time, reference_affine_brightness.data(),
                                           target_exposure_time, target_affine_brightness.data(), sigma_huber_loss));
   }
+  /** wait for the estimator launches enqueued on the set's stream (a download with no outputs) */
+  void synchronize() const { check(dsopp_hip_immature_set_download_state(s_, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)); }
   void upload(const std::vector<ImmatureLandmarkView> &landmarks) {
     std::vector<double> imin(n_), imax(n_), uniq(n_), spi(n_);
     std::vector<uint8_t> status(n_), traced(n_);

@@ -133,6 +133,39 @@ class Scene:
             t += a * np.cos(2 * np.pi * (ku * u0 + kv * v0) + ph)
         return t
 
+    def render_torch(self, T_w_c: np.ndarray, a: float, b: float, device: str):
+        """render() with the per-pixel loops on a torch device (float64): a 1280x1024 frame takes milliseconds instead of ~5 s.  The
+        bench's full-resolution windows use it; cos / exp may differ from NumPy's in the last bit, so parity tests (which compare two
+        backends on ONE window) may use either, but golden fixtures are made with render()."""
+        import torch
+        W, H = self.width, self.height
+        f64 = dict(dtype=torch.float64, device=device)
+        vv, uu = torch.meshgrid(torch.arange(H, **f64), torch.arange(W, **f64), indexing="ij")
+        rx, ry = (uu - self.cx) / self.fx, (vv - self.cy) / self.fy
+        R, t = T_w_c[:3, :3], T_w_c[:3, 3]
+
+        def project(d):
+            X = R[0, 0] * rx * d + R[0, 1] * ry * d + R[0, 2] * d + t[0]
+            Y = R[1, 0] * rx * d + R[1, 1] * ry * d + R[1, 2] * d + t[1]
+            Z = R[2, 0] * rx * d + R[2, 1] * ry * d + R[2, 2] * d + t[2]
+            return self.fx * X / Z + self.cx, self.fy * Y / Z + self.cy, Z
+
+        def depth0(u0, v0):
+            z = torch.full_like(u0, 6.0)
+            for amp, fu, fv, ph in zip(self.depth_amp, self.depth_fu, self.depth_fv, self.depth_ph):
+                z += amp * torch.cos(2 * np.pi * (fu * u0 / self.width + fv * v0 / self.height) + ph)
+            return z
+
+        d = torch.full((H, W), 6.0, **f64)
+        for _ in range(12):
+            u0, v0, Z = project(d)
+            d = d * depth0(u0, v0) / Z
+        u0, v0, _ = project(d)
+        tex = torch.full_like(u0, 127.5)
+        for amp, ku, kv, ph in zip(self.tex_amp, self.tex_ku, self.tex_kv, self.tex_ph):
+            tex += amp * torch.cos(2 * np.pi * (ku * u0 + kv * v0) + ph)
+        return (float(np.exp(a)) * tex + b).cpu().numpy(), d.cpu().numpy()
+
     def render(self, T_w_c: np.ndarray, a: float = 0.0, b: float = 0.0):
         """Returns (radiance image float64 HxW = exp(a)*texture + b, z-depth map HxW) for camera pose T_w_c."""
         W, H = self.width, self.height
@@ -211,10 +244,11 @@ BASE_MOTION = np.array([0.08, 0.01, 0.02, 0.004, 0.012, 0.003])
 
 def make_window(num_frames: int = 7, num_points: int = 2000, width: int = 640, height: int = 480, seed: int = 0,
                 pose_noise: bool = True, idepth_noise: float = 2e-3, affine_jitter: bool = False,
-                min_gradient: float = 4.0, quantize: bool = True, order: str = None) -> SyntheticWindow:
+                min_gradient: float = 4.0, quantize: bool = True, order: str = None, render_device: str = None) -> SyntheticWindow:
     """C1 of SURVEY.md §8d by default: 7 keyframes, 2000 active points, 640x480, full clique.
     `order`: order of a frame's landmarks — "random" (default: the order the pixels were drawn in), "raster" (row-major by pixel),
-    "tileN" (N x N-pixel tiles in raster order, raster inside a tile: what a grid-cell feature extractor yields)."""
+    "tileN" (N x N-pixel tiles in raster order, raster inside a tile: what a grid-cell feature extractor yields).
+    `render_device`: render the frames with torch on that device (Scene.render_torch) — full-resolution bench windows."""
     scene = Scene.make(width, height, seed)
     rng = np.random.default_rng(seed + 1)
     frames = []
@@ -222,7 +256,7 @@ def make_window(num_frames: int = 7, num_points: int = 2000, width: int = 640, h
     for i in range(num_frames):
         T_gt = se3_exp(i * BASE_MOTION)
         a, b = (rng.uniform(-0.05, 0.05), rng.uniform(-5, 5)) if (affine_jitter and i > 0) else (0.0, 0.0)
-        img, depth = scene.render(T_gt, a, b)
+        img, depth = scene.render_torch(T_gt, a, b, render_device) if render_device else scene.render(T_gt, a, b)
         if quantize:
             u8 = np.clip(np.rint(img), 0, 255).astype(np.uint8)
             plane = u8.astype(np.float64)

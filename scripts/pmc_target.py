@@ -8,7 +8,7 @@
                      footprint: 2 x 2 texels per lane at a random (odd or even) column, second row one image row below
   2. back-to-back launches of the bundle-adjustment kernels on the C1 window and on the 12-KF / 50 000-point window
      (the same launches bench.py times).
-Usage: pmc_target.py [c1|large]"""
+Usage: pmc_target.py [c1|large|fullres|fullres_f32]"""
 import ctypes as C
 import os
 import sys
@@ -61,9 +61,13 @@ del buf
 # ---- the kernels
 if which == "c1":
     win = syn.make_window(7, 2000, 640, 480, seed=0)
+elif which.startswith("fullres"):
+    # 12 KF / 50 000 points on 1280 x 1024 images (the resolution the reference's dense configuration runs at, dense.yaml:21-22): 503 MB of
+    # f64 texels — beyond the 256 MiB Infinity Cache, so the counters see DRAM traffic (fullres_f32: 16-byte texels)
+    win = syn.make_window(12, 50000, 1280, 1024, seed=1, render_device="cuda")
 else:
     win = syn.make_window(12, 50000, 640, 480, seed=1)
-g = capi.HipWindow(capi.default_pba_options())
+g = capi.HipWindow(capi.default_pba_options(dtype=capi.F32) if which.endswith("_f32") else capi.default_pba_options())
 syn.load_window(g, win)
 g.snapshot()
 g.restore()

@@ -2,7 +2,7 @@
 SEPARATE rocprofv3 --pmc passes (they do not fit one pass), no trace domains besides --kernel-trace, and calibrations on
 known byte counts in the same pass: a 512 MiB streaming copy AND texel gathers with the access shape of the sweeps
 (scripts/pmc_target.py).  Writes gpurun_out/pmc_traffic.json (+ the raw counter csv files under gpurun_out/pmc/).
-Run on the GPU box:  python scripts/pmc_traffic.py [c1|large]"""
+Run on the GPU box:  python scripts/pmc_traffic.py [c1|large|fullres|fullres_f32]"""
 import csv
 import glob
 import json
@@ -50,9 +50,10 @@ def main():
     res = {}
     copy_bytes = 128 * 1024 * 1024 * 4
     # (the loop's sweep is the plain linearisation variant since the back-substitution moved into the solve launch: one kernel, two labels)
-    labels = (("sweep_linearize", "sweepKernel<double, true, true, true, false"),
-              ("sweep_linearize_loop", "sweepKernel<double, true, true, true, false"),
-              ("sweep_energy", "sweepKernel<double, false, true, true, false"),
+    S = "float" if WHICH.endswith("_f32") else "double"
+    labels = (("sweep_linearize", f"sweepKernel<{S}, true, true, true, false"),
+              ("sweep_linearize_loop", f"sweepKernel<{S}, true, true, true, false"),
+              ("sweep_energy", f"sweepKernel<{S}, false, true, true, false"),
               ("schur", "reduceSchurKernel"), ("assemble_solve", "assembleSolveKernel"))
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         rows = run_pass(counter)
@@ -92,7 +93,8 @@ def main():
     iso = res["FETCH_SIZE"]["gather"].get("isolated", {})
     gather_bpc = iso.get("bytes_per_count_if_seg64") or 1024.0
     out = {"source": f"rocprofv3 --kernel-trace --pmc <C> -- python scripts/pmc_target.py {WHICH} (one pass per counter)",
-           "workload": "C1: 7 KF / 2000 points / 640x480" if WHICH == "c1" else "12 KF / 50 000 points / 640x480",
+           "workload": {"c1": "C1: 7 KF / 2000 points / 640x480", "fullres": "12 KF / 50 000 points / 1280x1024, f64 texels (503 MB)",
+                        "fullres_f32": "12 KF / 50 000 points / 1280x1024, f32 texels (252 MB)"}.get(WHICH, "12 KF / 50 000 points / 640x480"),
            "note": "bytes = counter x bytes_per_count.  Streaming calibration: 512 MiB elementwise copy (MI355X_MICROARCH.md: FETCH_SIZE "
                    "under-reports wide streaming reads 2x on gfx950).  Gather calibration: texel gathers of known geometry in the same pass; "
                    "the sweeps' fetches are converted with the unit the isolated gather pins (~993 B per count: one 64-byte request per texel access), the small dense kernels with the streaming unit.",
@@ -107,7 +109,7 @@ def main():
         out["per_launch_bytes"][label] = {"fetch": f, "write": w, "total": f + w,
                                           "fetch_if_streaming_calibration": res["FETCH_SIZE"]["kernels"][label]["counter_avg"] * res["FETCH_SIZE"]["bytes_per_count"]}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    name = "pmc_traffic.json" if WHICH == "c1" else "pmc_traffic_large.json"
+    name = {"c1": "pmc_traffic.json", "large": "pmc_traffic_large.json"}.get(WHICH, f"pmc_traffic_{WHICH}.json")
     with open(os.path.join(ROOT, "gpurun_out", name), "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out["per_launch_bytes"], indent=1))

@@ -89,6 +89,68 @@ def _pixelinfo0(u8):
     return info
 
 
+def candidate_pixels(seed, k, u8, n):
+    """the stand-in for the feature extractor: n random high-gradient pixels of frame k.  A generator of its own per frame, so that every
+    driver of the sequence (this one on either backend, dsopp_amd/host/tick_sequence.cpp through the exported file) sees the same
+    candidates whichever frames it turns into keyframes"""
+    return _pick_pixels(np.random.default_rng([seed, 7, k]), _pixelinfo0(u8), n)
+
+
+def bootstrap_keyframe(seed, k, u8, depth, pose_gt, n_boot, syn):
+    """active landmarks near the truth + a slightly perturbed pose for one of the two bootstrap keyframes (the reference's initializer is
+    outside the hot path)"""
+    rng = np.random.default_rng([seed, 11, k])
+    uv = _pick_pixels(rng, _pixelinfo0(u8), n_boot)
+    ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
+    idepth = 1.0 / depth[vi, ui] * (1 + rng.uniform(-2e-3, 2e-3, n_boot))
+    T0 = pose_gt if k == 0 else pose_gt @ syn.se3_exp(np.concatenate([rng.normal(0, 5e-3, 3), rng.normal(0, 1e-3, 3)]))
+    return uv, idepth, syn.mat_to_params(T0)
+
+
+def export_sequence(path, frames_u8, depths, poses_gt, scene, syn, *, levels, n_boot, n_immature, desired_points, max_keyframes, kf_factor, seed=7,
+                    first_kf_gap=3):
+    """the sequence as dsopp_amd/host/tick_sequence.cpp reads it (little endian): "DSOPTICK" | 9 x int32 (W, H, levels, frames, n_boot,
+    n_immature, desired_points, max_keyframes, first_kf_gap) | kf_factor f64 | intrinsics 4 x f64 | frames x (H x W) u8 | frames x pose
+    7 x f64 | 2 x (boot uv, boot idepth, boot pose) | frames x (n_immature x 2) f64 candidate pixels"""
+    n = len(frames_u8)
+    with open(path, "wb") as fh:
+        fh.write(b"DSOPTICK")
+        fh.write(np.array([scene.width, scene.height, levels, n, n_boot, n_immature, desired_points, max_keyframes, first_kf_gap], dtype="<i4").tobytes())
+        fh.write(np.array([kf_factor], dtype="<f8").tobytes())
+        fh.write(np.asarray(scene.intrinsics, dtype="<f8").tobytes())
+        for im in frames_u8:
+            fh.write(np.ascontiguousarray(im, dtype=np.uint8).tobytes())
+        for T in poses_gt:
+            fh.write(np.asarray(syn.mat_to_params(T), dtype="<f8").tobytes())
+        for k in (0, first_kf_gap):
+            uv, idepth, T0 = bootstrap_keyframe(seed, k, frames_u8[k], depths[k], poses_gt[k], n_boot, syn)
+            fh.write(np.ascontiguousarray(uv, dtype="<f8").tobytes() + np.ascontiguousarray(idepth, dtype="<f8").tobytes() + np.asarray(T0, dtype="<f8").tobytes())
+        for k in range(n):
+            fh.write(np.ascontiguousarray(candidate_pixels(seed, k, frames_u8[k], n_immature), dtype="<f8").tobytes())
+
+
+def run_native(path, exe=None, timeout=600):
+    """builds (g++, seconds) and runs the C++ driver on an exported sequence: (its JSON line, {frame: pose})"""
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "dsopp_amd", "lib")
+    tmp = tempfile.mkdtemp(prefix="dsopp_tick_")
+    exe = exe or os.path.join(tmp, "tick_sequence")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "dsopp_amd", "host", "tick_sequence.cpp"), f"-L{lib}", "-ldsopp_hip",
+                               f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    poses_path = os.path.join(tmp, "poses.txt")
+    r = subprocess.run([exe, path, poses_path], capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        raise RuntimeError(f"native tick sequence failed ({r.returncode}): {r.stdout[-500:]} {r.stderr[-1500:]}")
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    poses = {}
+    for ln in open(poses_path):
+        v = ln.split()
+        poses[int(v[0])] = np.array([float(x) for x in v[1:]])
+    return json.loads(line), poses
+
+
 class _Keyframe:
     def __init__(self, fid, ts):
         self.id, self.ts = fid, ts
@@ -108,7 +170,6 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
             po.set_threads(threads)
     W, H = scene.width, scene.height
     intr = scene.intrinsics
-    rng = np.random.default_rng(seed)
     n_frames = len(frames_u8) if max_frames is None else min(max_frames, len(frames_u8))
     win = capi.HipWindow(capi.default_pba_options()) if hip else po.OracleWindow(po.default_pba_options())
     aligner = capi.HipAligner(capi.default_align_options()) if hip else None
@@ -130,7 +191,7 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
         kf = _Keyframe(f["k"], f["ts"])
         kf.frame = f
         info0 = _pixelinfo0(f["u8"])
-        uv = _pick_pixels(rng, info0, n_immature)
+        uv = candidate_pixels(seed, f["k"], f["u8"], n_immature)
         ui, vi = uv[:, 0].astype(int), uv[:, 1].astype(int)
         grad = np.stack([info0[vi, ui, 1], info0[vi, ui, 2]], axis=1)
         direction = np.stack([(uv[:, 0] - intr[2]) / intr[0], (uv[:, 1] - intr[3]) / intr[1], np.ones(len(uv))], axis=1)
@@ -167,13 +228,9 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
         f = make_frame(k)
         boot[k] = f
         kf = new_keyframe(f)
-        info0 = _pixelinfo0(f["u8"])
-        kf.uv = _pick_pixels(rng, info0, n_boot)
-        ui, vi = kf.uv[:, 0].astype(int), kf.uv[:, 1].astype(int)
-        kf.idepth = 1.0 / depths[k][vi, ui] * (1 + rng.uniform(-2e-3, 2e-3, n_boot))
+        kf.uv, kf.idepth, T0 = bootstrap_keyframe(seed, k, f["u8"], depths[k], poses_gt[k], n_boot, syn)
         kf.patch = _patch(f["u8"].astype(np.float64), kf.uv, syn.PATTERN)
-        T0 = poses_gt[k] if k == 0 else poses_gt[k] @ syn.se3_exp(np.concatenate([rng.normal(0, 5e-3, 3), rng.normal(0, 1e-3, 3)]))
-        push_keyframe(kf, syn.mat_to_params(T0), np.zeros(2), k == 0)
+        push_keyframe(kf, T0, np.zeros(2), k == 0)
     win.solve()
     maps = win.create_reference_depth_maps(levels) if hip else cpu_depth_maps()
     for k in range(first_kf_gap + 1):
@@ -326,7 +383,7 @@ def run_sequence(backend, frames_u8, depths, poses_gt, scene, syn, *, levels, n_
 
 
 def run(torch, syn, width=640, height=480, levels=4, frames=200, cpu_frames=30, step=0.2, n_boot=1000, n_immature=1500, desired_points=2000,
-        max_keyframes=7, kf_factor=None, cpu_threads=None, no_cpu=False):
+        max_keyframes=7, kf_factor=None, cpu_threads=None, no_cpu=False, native=True):
     """the bench's entry point: renders the sequence, runs the HIP tracker over all of it and the CPU port over its first `cpu_frames` frames"""
     scene = syn.Scene.make(width, height, 41)
     poses = [syn.se3_exp(step * k * syn.BASE_MOTION) for k in range(frames)]
@@ -342,6 +399,23 @@ def run(torch, syn, width=640, height=480, levels=4, frames=200, cpu_frames=30, 
            "not_in_the_per_frame_time": "rendering, candidate-pixel selection (feature extractor), marginalisation strategy"}
     hip, est_hip = run_sequence("hip", u8, depths, poses, scene, syn, **kw)
     out["hip"] = hip
+    if native:
+        # the same sequence, the same calls, from C++ (dsopp_amd/host/tick_sequence.cpp over the host mirror): no interpreter, no NumPy
+        # marshalling between the C-ABI calls — what the reference's MonocularTracker::tick would pay for this backend
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(prefix="dsopp_seq_"), "sequence.bin")
+        try:
+            export_sequence(path, u8, depths, poses, scene, syn, **kw)
+            nat, est_nat = run_native(path)
+            common = sorted(set(est_hip) & set(est_nat))
+            nat["pose_difference_to_the_python_driven_run_max"] = float(max(np.abs(est_hip[k] - est_nat[k]).max() for k in common))
+            nat["frames_compared"] = len(common)
+            out["native"] = nat
+        except Exception as exc:  # noqa: BLE001 — reported, never fatal for the bench line
+            out["native"] = {"error": repr(exc)[:600]}
+        finally:
+            if os.path.exists(path):
+                os.remove(path)
     if not no_cpu and cpu_frames > 0:
         import multiprocessing
         threads = cpu_threads or max(1, min(multiprocessing.cpu_count(), 8) - 1)    # the reference's pool: min(hw, 8) - 1 (dsopp_main.cpp:114-119)

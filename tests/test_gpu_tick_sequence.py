@@ -241,3 +241,22 @@ def test_tick_sequence():
             assert np.abs(ids - want[lvl][0]).max() <= 1e-5 * max(1.0, np.abs(want[lvl][0]).max()), (k, lvl)
         rmse_last = np.full(L, 1e10)   # new reference keyframe
     assert stats["tracked"] == N_FRAMES - KF_EVERY - 1 and stats["solves"] == 3 and stats["activated"] > 100 and stats["marginalised"] >= 1, stats
+
+
+def test_native_sequence_driver_reproduces_the_python_driven_run():
+    """dsopp_amd/host/tick_sequence.cpp — MonocularTracker::tick (monocular_tracker.cpp:425-525) in C++ over the host mirror — on an
+    exported 60-frame sequence: same keyframes, same activations, poses equal to the Python-driven HIP run of scripts/tick_sequence.py
+    (both make the same C-ABI calls on the same inputs; the native one adds the reference's updateFrame / updateLocalFrame traffic)."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import tick_sequence
+    out = tick_sequence.run(torch, syn, width=320, height=240, levels=3, frames=60, cpu_frames=0, n_boot=500, n_immature=700, desired_points=900,
+                            max_keyframes=5, no_cpu=True, native=True)
+    nat = out["native"]
+    assert "error" not in nat, nat
+    assert nat["frames"] == out["hip"]["frames"] and nat["keyframes"] == out["hip"]["keyframes"] and nat["keyframes"] >= 6
+    assert nat["activated"] == out["hip"]["activated"] and nat["marginalised"] == out["hip"]["marginalised"] and nat["marginalised"] >= 1
+    assert nat["frames_compared"] >= 55 and nat["pose_difference_to_the_python_driven_run_max"] <= 1e-9

@@ -27,6 +27,18 @@ def test_host_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
     assert r.returncode == 2 and "no CPU fallback" in r.stdout
 
 
+def test_native_sequence_driver_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """dsopp_amd/host/tick_sequence.cpp (MonocularTracker::tick over the host mirror) builds with plain g++ -Werror against the C-ABI"""
+    from dsopp_amd import capi
+    exe = str(tmp_path / "tick_sequence")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "dsopp_amd", "host", "tick_sequence.cpp"),
+                           f"-L{LIBDIR}", "-ldsopp_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", exe])
+    if capi.device_count() > 0:
+        pytest.skip("GPU present: tests/test_gpu_tick_sequence.py runs it")
+    r = subprocess.run([exe, "/nonexistent"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stdout
+
+
 def test_reference_adapters_pass_the_lint():
     """the reference-side adapters cannot be compiled here (no Eigen / Sophus / glog / OpenCV); scripts/adapter_lint.py checks what can be
     checked without a compiler: every C-ABI call exists with the declared arity, every include resolves in the reference tree and
