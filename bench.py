@@ -418,6 +418,7 @@ def main():
             "warmup": args.warmup,  # as given; a warm-up shorter than one LM solve (7 iterations) is rounded up to one:
             "warmup_effective": warmup,
             "ms_per_step": ms_per_step,
+            "timed_region_s": block_s,   # the median timed block: `steps` iterations between two barrier + synchronize pairs
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -433,7 +434,9 @@ def main():
                                    "production LM settings", "name": args.workload,
                        "frames": F, "points_per_gpu": P, "total_points": total_points,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
-                       "exchange": job.transport, "ranks": world},
+                       "exchange": job.transport, "ranks": world,
+                       # the launcher's world size above; what the communicator itself counts (ncclCommCount) when the native one is in use
+                       "ranks_comm": job.comm.size() if job.comm is not None else None},
             "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN = true, FEJ, HUBER, BACKSUB = false>: the linearisation sweep as the LM loop launches it)",
                          "achieved": (b_lin / (in_loop["avg_us"] * 1e-6) / 1e9) if in_loop else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": in_loop["frac"] if in_loop else frac_events,
@@ -535,17 +538,30 @@ def load_profile_kernel_avg_us(csv_name, needle):
     return None
 
 
+def _committed_at(rel_path):
+    """commit and date a tracked profile file was last written at (None outside a git checkout, e.g. on the GPU box): a reader can see how
+    old the figure `roofline.frac` is priced with is — the kernel may have changed since"""
+    import subprocess
+    try:
+        r = subprocess.run(["git", "log", "-1", "--format=%h %cI", "--", rel_path], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        return r.stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def profile_roofline(b_lin):
     out = {}
     for key, csv_name in (("isolated_launches", "c1_isolated_kernel_stats.csv"), ("in_loop", "c1_kernel_stats.csv")):
         # newest first: since the back-substitution moved into the solve launch the loop runs the plain linearisation variant; before
         # that the BACKSUB variant (whose template argument list lost an argument in round 4)
-        for alt, needle in ((os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, false, false>"),
+        for alt, needle in ((os.path.join("r05", csv_name), "sweepKernel<double, true, true, true, false, false>"),
+                            (os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, false, false>"),
                             (os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, true, false>"),
                             (os.path.join("r03", "c_" + csv_name), "sweepKernel<double, true, true, true, true, false, false>")):
             r = load_profile_kernel_avg_us(alt, needle)
             if r:
-                out[key] = {"source": f"profiles/{alt}", "avg_us": r[0], "calls": r[1], "frac": b_lin / (r[0] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                out[key] = {"source": f"profiles/{alt}", "avg_us": r[0], "calls": r[1], "frac": b_lin / (r[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "committed_at": _committed_at(os.path.join("profiles", alt))}
                 break
     return out or None
 

@@ -243,6 +243,12 @@ class Comm:
         _chk(lib().dsopp_hip_comm_create(buf, int(rank), int(world_size), int(device), C.byref(self._h)))
         self.rank, self.world_size = int(rank), int(world_size)
 
+    def size(self) -> int:
+        """ranks of the communicator as RCCL itself reports them (ncclCommCount, read when the communicator was created)"""
+        r, n = C.c_int(), C.c_int()
+        _chk(lib().dsopp_hip_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return n.value
+
     def allreduce(self, device_ptr: int, count: int, stream: int = 0):
         _chk(lib().dsopp_hip_comm_allreduce(self._h, C.c_void_p(device_ptr), C.c_size_t(count), C.c_void_p(stream or 0)))
 

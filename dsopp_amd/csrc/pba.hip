@@ -49,6 +49,16 @@ struct HostFrame {
   int snap_n = 0;
   std::map<int, std::unique_ptr<ResidualTable>> residuals;  // by target frame id
   std::map<int, std::array<double, 36>> covariance;
+  // Internal order of the landmarks.  The C-ABI speaks the CALLER's indices; on the device every appended batch of
+  // landmarks is held sorted by 32 x 32-pixel tile of its projection (raster inside a tile): neighbouring items of a sweep workgroup then
+  // sample neighbouring texels, i.e. share 64-byte granules — the sweep is bound by the rate of those requests.  Invariant that keeps the
+  // residual tables' prefix meaning ("landmark i has a residual in target t iff i < n_res[t]"): for every entry e of batch_end the device
+  // indices [0, e) hold exactly the caller indices [0, e).  A connection that ends INSIDE a batch splits it (splitBatchAt).
+  std::vector<int> to_internal, to_caller;  // caller index <-> device index; empty = identity (order kept: DSOPP_HIP_LANDMARK_ORDER=caller)
+  std::vector<int> batch_end;
+  DeviceBuffer<int> d_to_internal;          // the caller -> device map on the device (export kernels un-permute there)
+  bool permuted() const { return !to_internal.empty(); }
+  int internalOf(int caller) const { return to_internal.empty() ? caller : to_internal[static_cast<size_t>(caller)]; }
 };
 
 }  // namespace
@@ -263,6 +273,94 @@ void collectTimings(W &w) {
     w.event_pool.push_back(t.b);
   }
   w.timed.clear();
+}
+
+/** does the device hold the landmarks in its own (spatial) order?  DSOPP_HIP_LANDMARK_ORDER=caller keeps the caller's (A/B aid) */
+bool sortLandmarksInternally() {
+  static const bool keep = std::getenv("DSOPP_HIP_LANDMARK_ORDER") != nullptr && std::string(std::getenv("DSOPP_HIP_LANDMARK_ORDER")) == "caller";
+  return !keep;
+}
+
+/** rows of `row_bytes` bytes gathered from absolute row indices: dst[k] = src[rows[k]] (the rare re-ordering of a landmark batch) */
+__global__ void gatherRowsKernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const int *__restrict__ rows, int count, int row_bytes) {
+  const long long e = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= static_cast<long long>(count) * row_bytes) return;
+  const int k = static_cast<int>(e / row_bytes), b = static_cast<int>(e % row_bytes);
+  dst[e] = src[static_cast<size_t>(rows[k]) * row_bytes + b];
+}
+
+/**
+ * A residual list of frame `f` is about to end at caller index n, INSIDE a batch the device holds in its own order: the batch is split —
+ * the landmarks with caller index < n move in front of the others (each part keeps its order) — so that device indices [0, n) again hold
+ * exactly the caller indices [0, n), which is what `i < n_res[t]` means in every kernel.  Every per-landmark array of the frame and of its
+ * residual tables is re-ordered on the device.  Rare: the tracker's lists always end where a batch ends (LocalFrame::update appends
+ * landmarks and their residuals together, local_frame.hpp:484-521); ragged test windows come through here.
+ */
+void splitBatchAt(W &w, HostFrame &f, int n) {
+  if (!f.permuted() || n <= 0 || n >= f.n) return;
+  int b0 = 0, b1 = f.n;
+  for (int e : f.batch_end) {
+    if (e == n) return;  // already a boundary
+    if (e < n) b0 = std::max(b0, e);
+    if (e > n) b1 = std::min(b1, e);
+  }
+  const int count = b1 - b0;
+  std::vector<int> new_to_old;  // absolute device rows
+  new_to_old.reserve(static_cast<size_t>(count));
+  for (int p = b0; p < b1; ++p)
+    if (f.to_caller[static_cast<size_t>(p)] < n) new_to_old.push_back(p);
+  for (int p = b0; p < b1; ++p)
+    if (f.to_caller[static_cast<size_t>(p)] >= n) new_to_old.push_back(p);
+  hipStream_t st = w.sr.stream;
+  DeviceBuffer<int> d_rows;
+  DeviceBuffer<uint8_t> tmp;
+  d_rows.reserve(static_cast<size_t>(count), 0, st);
+  d_rows.upload(new_to_old.data(), new_to_old.size(), 0, st);
+  auto permute = [&](void *base, size_t row_bytes) {
+    if (!base) return;
+    const size_t bytes = static_cast<size_t>(count) * row_bytes;
+    tmp.reserve(bytes, 0, st);
+    gatherRowsKernel<<<static_cast<unsigned>((bytes + 255) / 256), 256, 0, st>>>(static_cast<const uint8_t *>(base), tmp.ptr, d_rows.ptr, count,
+                                                                                 static_cast<int>(row_bytes));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(base) + static_cast<size_t>(b0) * row_bytes, tmp.ptr, bytes, hipMemcpyDeviceToDevice, st));
+  };
+  permute(f.uv.ptr, 2 * sizeof(double));
+  permute(f.idepth.ptr, sizeof(double));
+  permute(f.idepth_step.ptr, sizeof(double));
+  permute(f.idepth_fej.ptr, sizeof(double));
+  permute(f.patch.ptr, kPat * sizeof(double));
+  permute(f.inv_hdd.ptr, sizeof(double));
+  permute(f.b_d.ptr, sizeof(double));
+  permute(f.relative_baseline.ptr, sizeof(double));
+  permute(f.n_inliers.ptr, sizeof(int32_t));
+  permute(f.dflags.ptr, 1);
+  if (f.ublk.ptr)
+    for (int pl = 0; pl < 2 * kMaxFrames; ++pl) permute(f.ublk.ptr + static_cast<size_t>(pl) * ublkPlane(f.cap), kUblk * sizeof(double));
+  for (auto &kv : f.residuals) {
+    ResidualTable &rt = *kv.second;
+    if (rt.n < b1) continue;  // (ends at or before b0: every list ends on a boundary)
+    permute(rt.status.ptr, 1);
+    permute(rt.cand.ptr, 1);
+    permute(rt.fej_valid.ptr, 1);
+    permute(rt.energy.ptr, sizeof(double));
+  }
+  // the device-side snapshot was taken in the old order: it is void (dsopp_hip_window_restore reports the missing snapshot)
+  f.snap_n = 0;
+  for (auto &kv : f.residuals) kv.second->snap_n = 0;
+  w.snap_valid = false;
+  HIP_CHECK(hipStreamSynchronize(st));  // (d_rows / tmp go out of scope)
+  const std::vector<int> old_to_caller(f.to_caller.begin() + b0, f.to_caller.begin() + b1);
+  for (int k = 0; k < count; ++k) {
+    const int c = old_to_caller[static_cast<size_t>(new_to_old[static_cast<size_t>(k)] - b0)];
+    f.to_caller[static_cast<size_t>(b0 + k)] = c;
+    f.to_internal[static_cast<size_t>(c)] = b0 + k;
+  }
+  f.batch_end.push_back(n);
+  f.d_to_internal.upload(f.to_internal.data(), f.to_internal.size(), 0, st);
+  HIP_CHECK(hipStreamSynchronize(st));
+  w.linearized = false;
+  w.export_valid = false;
 }
 
 void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
@@ -1707,7 +1805,9 @@ void updatePointStatuses(W &w) {
       if (!(flags[static_cast<size_t>(r)][static_cast<size_t>(i)] & kFlagMarginalized)) cur[static_cast<size_t>(i)] = inliers[static_cast<size_t>(r)][static_cast<size_t>(i)];
     f.n_inliers.upload(cur.data(), cur.size(), 0, st);
     w.sr.sync();
-    f.flags = flags[static_cast<size_t>(r)];
+    // (the host mirror is indexed as the caller lists the landmarks, the device arrays in the device's order)
+    f.flags.resize(static_cast<size_t>(f.n));
+    for (int c = 0; c < f.n; ++c) f.flags[static_cast<size_t>(c)] = flags[static_cast<size_t>(r)][static_cast<size_t>(f.internalOf(c))];
   }
   w.sr.sync();
 }
@@ -2082,6 +2182,9 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
       f->n = 0;
       f->snap_n = 0;
       f->flags.clear();
+      f->to_internal.clear();
+      f->to_caller.clear();
+      f->batch_end.clear();
       f->to_marginalize = false;
     } else {
       f = std::make_unique<HostFrame>();
@@ -2144,9 +2247,45 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     }
     for (int i = old; i < n_total; ++i)
       f.flags[static_cast<size_t>(i)] = static_cast<uint8_t>(((flags[i] & 1) ? kFlagMarginalized : 0) | ((flags[i] & 2) ? kFlagOutlier : 0));
+    // the new batch in the device's order: by 32 x 32-pixel tile (rows of tiles, then tiles), raster inside a tile — what a grid-cell
+    // feature extractor yields, and the order in which the sweep's neighbouring items share texel granules (HostFrame::to_internal)
+    const size_t add = static_cast<size_t>(n_total - old);
+    if (add && (f.permuted() || (old == 0 && sortLandmarksInternally()))) {
+      std::vector<int> order(add);
+      for (size_t k = 0; k < add; ++k) order[k] = old + static_cast<int>(k);
+      auto key = [&](int c) {
+        const long long u = static_cast<long long>(uv[2 * c]), v = static_cast<long long>(uv[2 * c + 1]);
+        return (((v >> 5) * 65536 + (u >> 5)) * 32 + (v & 31)) * 32 + (u & 31);
+      };
+      // (ties — two landmarks on one pixel — are broken by their content, so that the device order, and with it every sum of the
+      // deterministic build, depends on the SET of landmarks only, not on the order the caller lists them in)
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const long long ka = key(a), kb = key(b);
+        if (ka != kb) return ka < kb;
+        if (idepth[a] != idepth[b]) return idepth[a] < idepth[b];
+        return std::lexicographical_compare(patch + static_cast<size_t>(kPat) * a, patch + static_cast<size_t>(kPat) * (a + 1),
+                                            patch + static_cast<size_t>(kPat) * b, patch + static_cast<size_t>(kPat) * (b + 1));
+      });
+      f.to_internal.resize(static_cast<size_t>(n_total));
+      f.to_caller.resize(static_cast<size_t>(n_total));
+      for (size_t k = 0; k < add; ++k) {
+        f.to_internal[static_cast<size_t>(order[k])] = old + static_cast<int>(k);
+        f.to_caller[static_cast<size_t>(old) + k] = order[k];
+      }
+      f.d_to_internal.reserve(static_cast<size_t>(std::max(f.cap, n_total)), static_cast<size_t>(old), st);
+      uploadStaged(*w, f.d_to_internal, f.to_internal.data() + old, add, static_cast<size_t>(old));
+    }
+    if (add) f.batch_end.push_back(n_total);
+    const bool permuted = f.permuted();
     if (n_total) {
       w->d_flag_stage.reserve(static_cast<size_t>(n_total), 0, st);
-      uploadStaged(*w, w->d_flag_stage, f.flags.data(), static_cast<size_t>(n_total), 0);
+      if (permuted) {
+        std::vector<uint8_t> staged(static_cast<size_t>(n_total));
+        for (int p = 0; p < n_total; ++p) staged[static_cast<size_t>(p)] = f.flags[static_cast<size_t>(f.to_caller[static_cast<size_t>(p)])];
+        uploadStaged(*w, w->d_flag_stage, staged.data(), staged.size(), 0);
+      } else {
+        uploadStaged(*w, w->d_flag_stage, f.flags.data(), static_cast<size_t>(n_total), 0);
+      }
       if (n_total > old) {
         const NewLandmarkArrays na{f.idepth_step.ptr, f.idepth_fej.ptr, f.inv_hdd.ptr, f.b_d.ptr, f.relative_baseline.ptr, f.n_inliers.ptr};
         mergeFlagsInitLandmarksKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total, na);
@@ -2156,8 +2295,19 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       HIP_CHECK(hipGetLastError());
     }
     for (int i = old; i < n_total; ++i) f.flags[static_cast<size_t>(i)] &= kFlagMarginalized;  // the mirror keeps host-decided bits only
-    const size_t add = static_cast<size_t>(n_total - old);
-    if (add) {
+    if (add && permuted) {
+      std::vector<double> s_uv(2 * add), s_id(add), s_patch(static_cast<size_t>(kPat) * add);
+      for (size_t k = 0; k < add; ++k) {
+        const size_t c = static_cast<size_t>(f.to_caller[static_cast<size_t>(old) + k]);
+        s_uv[2 * k] = uv[2 * c];
+        s_uv[2 * k + 1] = uv[2 * c + 1];
+        s_id[k] = idepth[c];
+        std::memcpy(&s_patch[static_cast<size_t>(kPat) * k], patch + static_cast<size_t>(kPat) * c, kPat * sizeof(double));
+      }
+      uploadStaged(*w, f.uv, s_uv.data(), 2 * add, 2 * static_cast<size_t>(old));
+      uploadStaged(*w, f.idepth, s_id.data(), add, static_cast<size_t>(old));
+      uploadStaged(*w, f.patch, s_patch.data(), kPat * add, kPat * static_cast<size_t>(old));
+    } else if (add) {
       uploadStaged(*w, f.uv, uv + 2 * old, 2 * add, 2 * static_cast<size_t>(old));
       uploadStaged(*w, f.idepth, idepth + old, add, static_cast<size_t>(old));
       uploadStaged(*w, f.patch, patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old));
@@ -2196,7 +2346,15 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     rt.energy.reserve(cap, keep, st);
     if (n > rt.n) {
       const size_t add = static_cast<size_t>(n - rt.n);
-      uploadStaged(*w, rt.status, statuses + rt.n, add, keep);
+      if (f.permuted()) {
+        // the list grows by the caller's landmarks [rt.n, n): they must be the device's [rt.n, n) as well (splitBatchAt), in the device's order
+        splitBatchAt(*w, f, n);
+        std::vector<uint8_t> staged(add);
+        for (size_t k = 0; k < add; ++k) staged[k] = statuses[f.to_caller[keep + k]];
+        uploadStaged(*w, rt.status, staged.data(), add, keep);
+      } else {
+        uploadStaged(*w, rt.status, statuses + rt.n, add, keep);
+      }
       initConnectionKernel<<<static_cast<unsigned>((add + 255) / 256), 256, 0, st>>>(rt.status.ptr, rt.cand.ptr, rt.fej_valid.ptr, rt.energy.ptr,
                                                                                     static_cast<int>(keep), static_cast<int>(add));
       HIP_CHECK(hipGetLastError());
@@ -2385,6 +2543,7 @@ void prefetchFrameUpdates(dsopp_hip_window &w) {
     a.relative_baseline = f.relative_baseline.ptr;
     a.n_inliers = f.n_inliers.ptr;
     a.flags = f.dflags.ptr;
+    a.to_internal = f.permuted() ? f.d_to_internal.ptr : nullptr;
     a.n = f.n;
     a.n_targets = static_cast<int>(e.target_ids.size());
     for (int t = 0; t < a.n_targets; ++t) a.status[t] = f.residuals[e.target_ids[static_cast<size_t>(t)]]->status.ptr;
@@ -2563,14 +2722,30 @@ int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double
     if (n_inliers) f.n_inliers.download(n_inliers, n, 0, st);
     if (flags_out) f.dflags.download(flags_out, n, 0, st);
     w->sr.sync();
+    if (f.permuted()) {  // device order -> the caller's (HostFrame::to_internal)
+      auto unpermute = [&](auto *a) {
+        if (!a) return;
+        std::vector<std::remove_reference_t<decltype(*a)>> tmp(a, a + n);
+        for (size_t c = 0; c < n; ++c) a[c] = tmp[static_cast<size_t>(f.to_internal[c])];
+      };
+      unpermute(idepth);
+      unpermute(idepth_step);
+      unpermute(inv_hessian_idepth);
+      unpermute(b_idepth);
+      unpermute(relative_baseline);
+      unpermute(n_inliers);
+      unpermute(flags_out);
+    }
     if (hpib && n) {
       const int F = w->F(), K = w->K();
       std::vector<double> blk(static_cast<size_t>(f.cap) * kUblk);
       for (int t = 0; t < F; ++t) {
         f.ublk.download(blk.data(), n * kUblk, static_cast<size_t>(t) * ublkPlane(f.cap), st);
         w->sr.sync();
-        for (size_t i = 0; i < n; ++i)
-          for (int a = 0; a < kBlk; ++a) hpib[i * K + static_cast<size_t>(kBlk * t + a)] = blk[i * kUblk + static_cast<size_t>(a)];
+        for (size_t i = 0; i < n; ++i) {
+          const size_t p = static_cast<size_t>(f.internalOf(static_cast<int>(i)));
+          for (int a = 0; a < kBlk; ++a) hpib[i * K + static_cast<size_t>(kBlk * t + a)] = blk[p * kUblk + static_cast<size_t>(a)];
+        }
       }
     }
   });
@@ -2614,6 +2789,7 @@ int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, dou
     a.relative_baseline = f.relative_baseline.ptr;
     a.n_inliers = f.n_inliers.ptr;
     a.flags = f.dflags.ptr;
+    a.to_internal = f.permuted() ? f.d_to_internal.ptr : nullptr;
     a.n = f.n;
     a.n_targets = n_targets;
     for (int t = 0; t < n_targets; ++t) {
@@ -2660,6 +2836,23 @@ int dsopp_hip_window_get_residuals(dsopp_hip_window *w, int32_t reference_id, in
     ResidualTable &rt = *it->second;
     if (n > rt.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection holds %d residuals, %d requested", rt.n, n);
     hipStream_t st = w->sr.stream;
+    if (f.permuted()) {
+      // the caller's first n landmarks sit anywhere among the device's first rt.n (n need not end a batch): whole list, then picked
+      const size_t m = static_cast<size_t>(rt.n);
+      std::vector<uint8_t> s_st(status ? m : 0), s_ca(candidate ? m : 0);
+      std::vector<double> s_en(energy ? m : 0);
+      if (status) rt.status.download(s_st.data(), m, 0, st);
+      if (candidate) rt.cand.download(s_ca.data(), m, 0, st);
+      if (energy) rt.energy.download(s_en.data(), m, 0, st);
+      w->sr.sync();
+      for (int i = 0; i < n; ++i) {
+        const size_t p = static_cast<size_t>(f.to_internal[static_cast<size_t>(i)]);
+        if (status) status[i] = s_st[p];
+        if (candidate) candidate[i] = s_ca[p];
+        if (energy) energy[i] = s_en[p];
+      }
+      return;
+    }
     if (status) rt.status.download(status, static_cast<size_t>(n), 0, st);
     if (candidate) rt.cand.download(candidate, static_cast<size_t>(n), 0, st);
     if (energy) rt.energy.download(energy, static_cast<size_t>(n), 0, st);

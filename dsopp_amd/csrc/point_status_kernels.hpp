@@ -269,19 +269,24 @@ struct FrameExportArgs {
   const int32_t *n_inliers;
   const uint8_t *flags;
   const uint8_t *status[kMaxFrames];
+  const int *to_internal;  // nullable: caller index -> device index of the frame's landmarks (the export is in the caller's order)
   int n, n_targets;
   double *out_d;   // 4 n doubles
   uint8_t *out_b;  // (1 + n_targets) n bytes
 };
+__device__ __forceinline__ void exportLandmark(const FrameExportArgs &a, int i) {
+  const int p = a.to_internal ? a.to_internal[i] : i;
+  a.out_d[i] = a.idepth[p];
+  a.out_d[a.n + i] = a.inv_hdd[p];
+  a.out_d[2 * a.n + i] = a.relative_baseline[p];
+  a.out_d[3 * a.n + i] = static_cast<double>(a.n_inliers[p]);
+  a.out_b[i] = a.flags[p];
+  for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][p] : DSOPP_HIP_STATUS_UNKNOWN;
+}
 __global__ void exportFrameKernel(FrameExportArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  a.out_d[i] = a.idepth[i];
-  a.out_d[a.n + i] = a.inv_hdd[i];
-  a.out_d[2 * a.n + i] = a.relative_baseline[i];
-  a.out_d[3 * a.n + i] = static_cast<double>(a.n_inliers[i]);
-  a.out_b[i] = a.flags[i];
-  for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][i] : DSOPP_HIP_STATUS_UNKNOWN;
+  exportLandmark(a, i);
 }
 
 /** all keyframes of the window in one launch (blockIdx.y = entry): seven 3 us kernels were bound by the host's enqueue rate */
@@ -294,12 +299,7 @@ __global__ void exportFramesKernel(FrameExportBatch b) {
   const FrameExportArgs &a = b.f[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  a.out_d[i] = a.idepth[i];
-  a.out_d[a.n + i] = a.inv_hdd[i];
-  a.out_d[2 * a.n + i] = a.relative_baseline[i];
-  a.out_d[3 * a.n + i] = static_cast<double>(a.n_inliers[i]);
-  a.out_b[i] = a.flags[i];
-  for (int t = 0; t < a.n_targets; ++t) a.out_b[static_cast<size_t>(1 + t) * a.n + i] = a.status[t] ? a.status[t][i] : DSOPP_HIP_STATUS_UNKNOWN;
+  exportLandmark(a, i);
 }
 
 /** relinearizeSystem — :310-316: the newest frame's linearisation point moves to its current estimate */

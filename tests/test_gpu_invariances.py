@@ -101,3 +101,27 @@ def test_landmark_permutation(c1, base):
     assert (r["it"], r["nv"]) == (base["it"], base["nv"]) and abs(r["e"] - base["e"]) <= 1e-8 * base["e"]
     for A, B in zip(r["poses"], base["poses"]):
         assert np.abs(A - B).max() <= 1e-8
+
+
+def test_landmark_permutation_is_bitwise_in_the_deterministic_build(c1):
+    """The device holds every batch of landmarks in its OWN order (32 x 32-pixel tiles, raster inside; ties by content — pba.hip:
+    HostFrame::to_internal), so with the order-deterministic build (dsopp_hip_window_set_deterministic) the caller's order changes
+    nothing at all: energies, poses and every landmark's inverse depth are bit-identical, and the getters answer in the caller's order."""
+    rng = np.random.default_rng(2)
+    perm = [rng.permutation(len(f.uv)) for f in c1.frames]
+    res = []
+    for p in (None, perm):
+        g = _load(c1, perm=p)
+        g.set_deterministic(True)
+        r = _solve(g, c1)
+        r["idepth"] = [g.get_landmarks(f.frame_id, False)["idepth"] for f in c1.frames]
+        r["energy01"] = g.get_residuals(c1.frames[0].frame_id, c1.frames[1].frame_id)["energy"]
+        g.close()
+        res.append(r)
+    a, b = res
+    assert (a["e0"], a["n0"], a["e"], a["it"], a["nv"]) == (b["e0"], b["n0"], b["e"], b["it"], b["nv"])
+    for A, B in zip(a["poses"], b["poses"]):
+        assert np.array_equal(A, B)
+    for i, (da, db) in enumerate(zip(a["idepth"], b["idepth"])):
+        assert np.array_equal(da[perm[i]], db)   # landmark j of the permuted listing is landmark perm[j] of the original one
+    assert np.array_equal(a["energy01"][perm[0]], b["energy01"])

@@ -519,3 +519,46 @@ def test_idepth_back_substitution_inside_the_solve_launch_equals_the_kernel_flow
         assert np.abs(a[f"{name}_3"] - b[f"{name}_3"]).max() <= 1e-9, name
         assert np.abs(a[f"{name}_4"] - b[f"{name}_4"]).max() <= 1e-8 * max(1.0, np.abs(b[f"{name}_4"]).max()), name
         assert int(a[f"{name}_5"]) == int(b[f"{name}_5"]) and abs(float(a[f"{name}_6"]) - float(b[f"{name}_6"])) <= 1e-9 * abs(float(b[f"{name}_6"])), name
+
+
+def test_residual_list_that_ends_inside_a_landmark_batch():
+    """The device keeps every appended batch of landmarks in its own spatial order (pba.hip: HostFrame::to_internal) under the invariant
+    that the device's first n landmarks are the caller's first n wherever a residual list ends.  Here lists end INSIDE a batch (60 and
+    then 130 of 200 landmarks), landmarks are appended in a second batch and the lists are completed afterwards: every step re-orders
+    or extends the device arrays (splitBatchAt), and the finished window must solve exactly like the oracle's, with every getter
+    answering in the caller's order."""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    win = syn.make_window(num_frames=4, num_points=4 * 260, width=320, height=240, seed=43)
+    rng = np.random.default_rng(7)
+    statuses = {}
+    for a in win.frames:
+        for b in win.frames:
+            if a.frame_id != b.frame_id:
+                st = np.zeros(len(a.uv), dtype=np.uint8)
+                bad = rng.random(len(a.uv)) < 0.1
+                st[bad] = rng.integers(1, 4, int(bad.sum()))
+                statuses[(a.frame_id, b.frame_id)] = st
+    o = _load(po.OracleWindow(po.default_pba_options()), win, statuses=statuses)
+    g = capi.HipWindow(capi.default_pba_options())
+    intr = win.scene.intrinsics
+    first = 200  # landmarks of the first batch; the rest arrive later
+    for f in win.frames:
+        g.push_frame(f.frame_id, f.timestamp, f.pixelinfo, None, intr, syn.mat_to_params(f.T_w_c_init), f.exposure, f.affine_init, f.fixed, False)
+        g.set_landmarks(f.frame_id, f.uv[:first], f.idepth_init[:first], f.patch[:first], np.zeros(first, dtype=np.uint8))
+    cuts = (60, 130)
+    for a in win.frames:
+        for k, b in enumerate(x for x in win.frames if x.frame_id != a.frame_id):
+            g.set_connection(a.frame_id, b.frame_id, statuses[(a.frame_id, b.frame_id)][:cuts[k % 2]])   # ends inside the batch
+    for f in win.frames:
+        n = len(f.uv)
+        g.set_landmarks(f.frame_id, f.uv, f.idepth_init, f.patch, np.zeros(n, dtype=np.uint8))            # second batch appended
+    for a in win.frames:
+        for b in win.frames:
+            if a.frame_id != b.frame_id:
+                g.set_connection(a.frame_id, b.frame_id, statuses[(a.frame_id, b.frame_id)])                # lists completed
+    # before anything runs: the residual statuses come back in the caller's order
+    a, b = win.frames[1], win.frames[2]
+    assert np.array_equal(g.get_residuals(a.frame_id, b.frame_id)["status"], statuses[(a.frame_id, b.frame_id)])
+    _compare_solve(o, g, win)
+    g.close()
