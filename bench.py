@@ -1008,8 +1008,47 @@ def run_concurrent_windows(capi, syn, torch, win, counts=(1, 2, 4, 8), solves=60
         out[str(n)] = its / dt
         for g in gs:
             g.close()
+    # ... and with one host thread PER window (each runs its window's pipelined solves, as the headline loop does): the single enqueueing
+    # thread above is bound by its own launch rate (~3 us per launch, 25 launches per solve); with a thread each the cap is the number of
+    # hardware queues HIP maps the streams onto (GPU_MAX_HW_QUEUES, 4 by default: kernels of one queue run in order, so windows that
+    # share a queue take turns) — profiles/r05/concurrent_windows_rates.txt
+    import threading
+    threaded = {}
+    for n in counts:
+        streams = [torch.cuda.Stream() for _ in range(n)]
+        gs = []
+        for st in streams:
+            g = capi.HipWindow(capi.default_pba_options(), stream=st.cuda_stream)
+            syn.load_window(g, win)
+            g.snapshot()
+            g.optimize_repeated(14)
+            gs.append(g)
+        torch.cuda.synchronize()
+        barrier = threading.Barrier(n + 1)
+        done = [0] * n
+
+        def worker(i):
+            barrier.wait()
+            done[i], _ = gs[i].optimize_repeated(7 * solves)
+            barrier.wait()
+
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(n)]
+        for t in ts:
+            t.start()
+        barrier.wait()
+        t0 = time.perf_counter()
+        barrier.wait()
+        dt = time.perf_counter() - t0
+        for t in ts:
+            t.join()
+        threaded[str(n)] = sum(done) / dt
+        for g in gs:
+            g.close()
     return {"workload": "n independent C1 windows, one stream each, one host thread (async enqueue, then wait)",
-            "gn_iterations_per_s_by_window_count": out}
+            "gn_iterations_per_s_by_window_count": out,
+            "one_host_thread_per_window": {"gn_iterations_per_s_by_window_count": threaded,
+                                           "what": "each window's solves enqueued by its own thread (dsopp_hip_window_optimize_repeated): the aggregate "
+                                                   "rate follows the number of hardware queues in use (4 by default), see profiles/r05/concurrent_windows_rates.txt"}}
 
 
 def run_keyframe_step_timing(capi, syn):

@@ -171,13 +171,24 @@ int main(int argc, char **argv) {
     HipPhotometricBundleAdjustment pba(pba_opt, /*estimate_uncertainty=*/true, /*force_accept=*/true);
     HipPoseAlignment aligner(align_opt);
     HipLandmarksActivator<true> activator(20.0, static_cast<size_t>(seq.desired_points));
-    std::vector<std::unique_ptr<Keyframe>> alive, retired;
+    std::vector<std::unique_ptr<Keyframe>> alive, retired, retired_before;
     std::vector<Motion> est(static_cast<size_t>(seq.n_frames));
     std::vector<char> have(static_cast<size_t>(seq.n_frames), 0);
     std::vector<double> t_frame, t_keyframe;
+    double phase[5] = {0, 0, 0, 0, 0};  // per frame: pyramid object, pyramid build, estimatePose (+ hypotheses), optical flow, depth estimation
+    double kphase[6] = {0, 0, 0, 0, 0, 0};  // per keyframe: activation + appends, pushFrame, solve, updateFrame x window, marginalisation, depth maps
     int activated = 0, marginalised = 0, solves = 0, tries_max = 0;
     long lm_iterations = 0;
 
+    // Device pyramids are recycled: allocating the five levels of a frame afresh (and freeing them, a device-wide synchronisation)
+    // measured 2.2 ms per frame in this process — more than everything the frame computes.
+    std::vector<std::unique_ptr<DevicePyramid>> pyramid_pool;
+    auto takePyramid = [&] {
+      if (pyramid_pool.empty()) return std::make_unique<DevicePyramid>(W, H, levels);
+      auto p = std::move(pyramid_pool.back());
+      pyramid_pool.pop_back();
+      return p;
+    };
     auto image = [&](int k) -> const std::vector<uint8_t> & { return seq.images[static_cast<size_t>(k)]; };
     auto patchAt = [&](int k, double u, double v, std::array<double, 8> &patch) {
       const int ui = static_cast<int>(u), vi = static_cast<int>(v);
@@ -249,14 +260,17 @@ int main(int argc, char **argv) {
 
     for (int k = seq.first_kf_gap + 1; k < seq.n_frames; ++k) {
       const double t0 = now();
-      auto pyr = std::make_unique<DevicePyramid>(W, H, levels);
+      auto pyr = takePyramid();
+      const double t_a = now();
       pyr->build(image(k).data());
+      const double t_b = now();
       Keyframe &ref = *alive.back();
       const Motion T_ref = ref.view.t_world_agent;
       const Vector2 ab_ref = ref.view.affine_brightness;
       const std::vector<Motion> hyp = initializationPoses(&est[static_cast<size_t>(k - 2)], &est[static_cast<size_t>(k - 1)], &T_ref);
       const PoseEstimate pe = aligner.estimatePose(ref.view.timestamp, T_ref, *ref.pyramid, maps, 1.0, ab_ref, 1000 * (static_cast<int64_t>(k) + 1), *pyr, 1.0,
                                                    model, hyp, affine_prev, rmse_last);
+      const double t_c = now();
       if (!pe.success) throw std::runtime_error("frame " + std::to_string(k) + ": tracking lost");
       const Motion T_new = pe.t_world_target;
       est[static_cast<size_t>(k)] = T_new, have[static_cast<size_t>(k)] = 1;
@@ -270,6 +284,7 @@ int main(int argc, char **argv) {
       Mat34 t_nr = t_t_r;
       for (int i = 0; i < 9; ++i) t_nr.R[i] = (i % 4 == 0) ? 1.0 : 0.0;
       const std::vector<double> flow = maps.meanSquareOpticalFlow(0, {fromMat(t_t_r), fromMat(t_nr)}, model);
+      const double t_d = now();
       // estimateDepths: every keyframe's immature landmarks against the new frame, one launch (:74-102)
       {
         std::vector<DeviceImmatureSet *> sets;
@@ -288,8 +303,13 @@ int main(int argc, char **argv) {
       // keyframe decision: mean_square_optical_flow_and_rmse_keyframe_strategy.cpp:14-48 (exposures are 1 in this sequence)
       if (rmse_ref < 0) rmse_ref = rmse0;
       const bool need_kf = seq.kf_factor * (4.5 * flow[0] + 9.0 * flow[1] + 2.0 * std::abs(affine_prev[0] - ab_ref[0])) > 1.0 || rmse0 / rmse_ref > 4.0;
-      t_frame.push_back(now() - t0);
-      if (!need_kf) continue;
+      const double t_e = now();
+      t_frame.push_back(t_e - t0);
+      phase[0] += t_a - t0, phase[1] += t_b - t_a, phase[2] += t_c - t_b, phase[3] += t_d - t_c, phase[4] += t_e - t_d;
+      if (!need_kf) {
+        pyramid_pool.push_back(std::move(pyr));  // the frame's images go back to the pool (a tracker keeps a ring of them)
+        continue;
+      }
 
       // ================= new keyframe (:471-525) =================
       rmse_ref = -1;
@@ -327,20 +347,25 @@ int main(int argc, char **argv) {
         for (auto &kv : kf.view.reprojection_statuses) kv.second.resize(kf.view.active_landmarks.size(), DSOPP_HIP_STATUS_OK);
         pba.updateLocalFrame(kf.view);
       }
+      const double t2 = now();
       pushKeyframe(std::move(fresh), T_new, affine_prev, false);
-      retired.clear();  // (frames marginalised at the previous keyframe have been folded by this pushFrame: their images may go)
+      // the keyframe marginalised at the previous keyframe is folded into the prior now: its connections leave the frames (until here the
+      // landmarks activated above still got their residual towards it, as LocalFrame::update gives them one in every connection)
+      for (auto &gone : retired_before)
+        for (auto &kf : alive) kf->view.reprojection_statuses.erase(gone->view.keyframe_id);
+      const double t3 = now();
       pba.solve(1);  // refinePoses
       ++solves;
+      const double t4 = now();
       for (auto &kf : alive) pba.updateFrame(kf->view);  // poses, affine brightness, inverse depths, statuses, covariances back into the frames
       est[static_cast<size_t>(k)] = alive.back()->view.t_world_agent;
+      const double t5 = now();
       if (static_cast<int>(alive.size()) > seq.max_keyframes) {
         // marginalisation strategy (outside the hot path): the oldest free keyframe leaves; its landmarks are flagged, every frame is updated
         Keyframe &victim = *alive[1];
         for (LandmarkView &lm : victim.view.active_landmarks) lm.is_marginalized = true;
         victim.view.is_marginalized = true;
         for (auto &kf : alive) pba.updateLocalFrame(kf->view);
-        for (auto &kf : alive)
-          if (kf.get() != &victim) kf->view.reprojection_statuses.erase(victim.view.keyframe_id);
         // The solver keeps the marginalised frame — and BORROWS its image — until the next pushFrame folds it into the prior
         // (eigen_photometric_bundle_adjustment.cpp:119-141): its pyramid must outlive that call, as the keyframe's PixelMap does in the
         // reference (unloadMarginalizedResources runs behind the bundle adjustment, monocular_tracker.cpp:504)
@@ -348,9 +373,17 @@ int main(int argc, char **argv) {
         alive.erase(alive.begin() + 1);
         ++marginalised;
       }
+      const double t6 = now();
       pba.createReferenceDepthMaps(maps);  // refill of the tracker's map object
       std::fill(rmse_last.begin(), rmse_last.end(), 1e10);
-      t_keyframe.push_back(now() - t1);
+      const double t7 = now();
+      t_keyframe.push_back(t7 - t1);
+      kphase[0] += t2 - t1, kphase[1] += t3 - t2, kphase[2] += t4 - t3, kphase[3] += t5 - t4, kphase[4] += t6 - t5, kphase[5] += t7 - t6;
+      // frames marginalised at the PREVIOUS keyframe were folded into the prior by this keyframe's pushFrame: their resources go now
+      // (images back to the pool; unloadMarginalizedResources, monocular_tracker.cpp:504) — device memory management, not tracker time
+      for (auto &old_kf : retired_before) pyramid_pool.push_back(std::move(old_kf->pyramid));
+      retired_before.clear();
+      retired_before.swap(retired);
     }
 
     // ---- report
@@ -384,10 +417,18 @@ int main(int argc, char **argv) {
                 "\"ms_per_frame_mean\": %.4f, \"ms_per_frame_median\": %.4f, \"ms_per_frame_p95\": %.4f, \"ms_per_keyframe_mean\": %.4f, "
                 "\"ms_per_keyframe_p95\": %.4f, \"ms_per_frame_including_keyframe_work\": %.4f, \"lm_iterations_per_frame\": %.2f, "
                 "\"hypotheses_tried_max\": %d, \"activated\": %d, \"marginalised\": %d, \"solves\": %d, \"window_landmarks_end\": %zu, "
-                "\"translation_error_final\": %.6g}\n",
+                "\"translation_error_final\": %.6g, \"ms_per_frame_by_phase\": {\"pyramid_object\": %.4f, \"pyramid_build\": %.4f, \"estimate_pose\": %.4f, "
+                "\"optical_flow\": %.4f, \"depth_estimation\": %.4f}, \"ms_per_keyframe_by_phase\": {\"activation_and_appends\": %.4f, \"push_frame\": %.4f, "
+                "\"solve\": %.4f, \"update_frames\": %.4f, \"marginalisation\": %.4f, \"depth_maps\": %.4f}}\n",
                 t_frame.size(), t_keyframe.size(), 1e3 * sum_f / std::max<size_t>(1, t_frame.size()), 1e3 * stat(t_frame, 0.5), 1e3 * stat(t_frame, 0.95),
                 1e3 * sum_k / std::max<size_t>(1, t_keyframe.size()), 1e3 * stat(t_keyframe, 0.95), 1e3 * (sum_f + sum_k) / std::max<size_t>(1, t_frame.size()),
-                static_cast<double>(lm_iterations) / std::max<size_t>(1, t_frame.size()), tries_max, activated, marginalised, solves, window_landmarks, final_err);
+                static_cast<double>(lm_iterations) / std::max<size_t>(1, t_frame.size()), tries_max, activated, marginalised, solves, window_landmarks, final_err,
+                1e3 * phase[0] / std::max<size_t>(1, t_frame.size()), 1e3 * phase[1] / std::max<size_t>(1, t_frame.size()),
+                1e3 * phase[2] / std::max<size_t>(1, t_frame.size()), 1e3 * phase[3] / std::max<size_t>(1, t_frame.size()),
+                1e3 * phase[4] / std::max<size_t>(1, t_frame.size()), 1e3 * kphase[0] / std::max<size_t>(1, t_keyframe.size()),
+                1e3 * kphase[1] / std::max<size_t>(1, t_keyframe.size()), 1e3 * kphase[2] / std::max<size_t>(1, t_keyframe.size()),
+                1e3 * kphase[3] / std::max<size_t>(1, t_keyframe.size()), 1e3 * kphase[4] / std::max<size_t>(1, t_keyframe.size()),
+                1e3 * kphase[5] / std::max<size_t>(1, t_keyframe.size()));
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "tick_sequence: %s\n", e.what());

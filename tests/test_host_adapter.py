@@ -48,6 +48,21 @@ def test_reference_adapters_pass_the_lint():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_adapter_include_closure_list_is_current():
+    """INTEGRATION.md §5a lists what stands between the reference adapters and a compiler (the third-party headers the two base classes
+    reach); re-derived here from the reference tree, where it exists"""
+    import sys
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference tree on this machine")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "adapter_include_closure.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("| `")]
+    assert len(rows) >= 10
+    for ln in rows:
+        assert ln in doc, ln
+
+
 @pytest.mark.gpu
 def test_host_mirror_solves_on_gpu(tmp_path):
     exe = _build(tmp_path)
