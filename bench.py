@@ -584,7 +584,7 @@ def load_pmc_traffic(F, P, args):
     """per-launch HBM bytes of the in-loop linearisation sweep from the committed counter run (profiles/, newest round first)"""
     if (F, P, args.width, args.height, args.dtype, args.workload) != (7, 2000, 640, 480, "f64", "c1"):
         return None, None
-    for name in (os.path.join("r04", "pmc_traffic_c1.json"), os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in (os.path.join("r05", "pmc_traffic_c1.json"), os.path.join("r04", "pmc_traffic_c1.json"), os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_file = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_file):
             continue

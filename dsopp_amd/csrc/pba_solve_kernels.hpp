@@ -398,11 +398,34 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   long long rs_dbg[2] = {0, 0};
   // (inside the fused loop the LM decision for the pending candidate is the prologue of the SOLVE launch behind this one — it needs
   // the sums of all of the sweep's energy scalars, which the extra workgroup below produces while the others build the system)
-  if (a.ctrl && (!a.ctrl->active || a.ctrl->linear_system_valid)) return;
+  // every control-block word this launch needs is requested BEFORE the first one is tested: three dependent scalar round trips
+  // (active -> linear_system_valid -> lambda) become one.  Damping of the system being built: the incoming control block (the PBA's
+  // LM keeps lambda constant, eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
+  int c_active = 1, c_lsv = 0;
+  double comb_lam = a.comb_lambda;
+  if (a.ctrl) {
+    c_active = a.ctrl->active;
+    c_lsv = a.ctrl->linear_system_valid;
+    comb_lam = a.ctrl->lambda;
+  }
+  // ... and with them the head of this workgroup's Schur descriptor (the pair / scalar workgroups behind the Schur blocks fetch the
+  // last one and ignore it): the descriptor's address depends on the launch arguments only, so it need not wait for the test
+  struct SchurHead {
+    int r, offset, n, cap;
+  } hd = {0, 0, 0, 0};
+  unsigned hd_conn = 0;
+  decltype(SchurBlock::ublk) hd_ublk = nullptr;
+  decltype(SchurBlock::flags) hd_flags = nullptr;
+  if (a.n_schur_blocks > 0) {
+    const SchurBlock &d = a.schur_table[min(static_cast<int>(blockIdx.x), a.n_schur_blocks - 1)];
+    hd = {d.r, d.offset, d.n, d.cap};
+    hd_conn = d.conn_mask;
+    hd_ublk = d.ublk;
+    hd_flags = d.flags;
+  }
+  asm volatile("" ::"s"(hd.r), "s"(hd_conn), "s"(hd_ublk), "s"(hd_flags), "s"(c_active), "s"(c_lsv));
+  if (!c_active || c_lsv) return;
   const int F = a.F, K = kBlk * F;
-  // damping of the system being built: the incoming control block (the PBA's LM keeps lambda constant,
-  // eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
-  const double comb_lam = a.ctrl ? a.ctrl->lambda : a.comb_lambda;
   if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {
     // ---- landmark-sharded windows: one extra workgroup sums the sweep's 4 energy scalars (fixed order) into the tail of
     // the reduction buffer, so that they travel in the same collective as the systems (no separate kernel for it)
@@ -498,8 +521,8 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   double *hrow = reinterpret_cast<double *>(smem_raw);  // [kSchurLandmarks][stride]
   double *wgt = hrow + kSchurLandmarks * stride;        // inv per landmark (0 = excluded)
   double *wbd = wgt + kSchurLandmarks;                  // inv * bd
-  const SchurBlock &be = a.schur_table[blockIdx.x];
-  const int r = be.r;
+  const SchurBlock &be = a.schur_table[blockIdx.x];  // (head: hd, fetched above)
+  const int r = hd.r;
   const bool bd_in_pad = K < Kp;  // H_schur^T W b_d as one more column of the SYRK when the tiles have a spare column
   if (kStamps && a.dbg && threadIdx.x == 0 && blockIdx.x == 1) { a.dbg[0] = rs_t0; a.dbg[6] = rs_dbg[0]; a.dbg[7] = rs_dbg[1]; }
   RS_STAMP(1);
@@ -507,20 +530,20 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   // of the landmark flags and of this thread's share of the per-target constants T = blockdiag(Adj, 1, s0) are issued
   // before the LDS rows are cleared so that their latency overlaps.
   const int l = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  const int i = be.offset + l;
-  const unsigned conn = be.conn_mask & ~(1u << r);
-  const size_t plane = ublkPlane(be.cap);
-  const double *ubase = be.ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
+  const int i = hd.offset + l;
+  const unsigned conn = hd_conn & ~(1u << r);
+  const size_t plane = ublkPlane(hd.cap);
+  const double *ubase = hd_ublk + static_cast<size_t>(a.ublk_parity) * kMaxFrames * plane + static_cast<size_t>(i) * kUblk;
   bool take = false;
   uint8_t flg = 0;
-  if (i < be.n) {
-    flg = be.flags[i];
+  if (i < hd.n) {
+    flg = hd_flags[i];
     take = a.for_marginalized ? (flg & kFlagToMarginalize) != 0 : (flg & kFlagMarginalized) == 0;
   }
   double ht[kUblk];
 #pragma unroll
   for (int c = 0; c < kUblk; ++c) ht[c] = 0;
-  const bool first = i < be.n && sub < F && ((conn >> sub) & 1u);
+  const bool first = i < hd.n && sub < F && ((conn >> sub) & 1u);
   if (first) {
     const double *src = ubase + sub * plane;
 #pragma unroll
