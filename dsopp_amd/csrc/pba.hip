@@ -2253,9 +2253,28 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     if (add && (f.permuted() || (old == 0 && sortLandmarksInternally()))) {
       std::vector<int> order(add);
       for (size_t k = 0; k < add; ++k) order[k] = old + static_cast<int>(k);
+      // (experiment switches, defaults = what is described above: DSOPP_HIP_LANDMARK_TILE = log2 of the tile edge, DSOPP_HIP_LANDMARK_INNER =
+      // raster | morton | snake (rows of a tile alternate direction, tile rows alternate direction))
+      static const int tb = std::getenv("DSOPP_HIP_LANDMARK_TILE") ? std::max(2, std::min(8, std::atoi(std::getenv("DSOPP_HIP_LANDMARK_TILE")))) : 5;
+      static const int inner = [] {
+        const char *e = std::getenv("DSOPP_HIP_LANDMARK_INNER");
+        return !e ? 0 : (std::string(e) == "morton" ? 1 : (std::string(e) == "snake" ? 2 : 0));
+      }();
       auto key = [&](int c) {
         const long long u = static_cast<long long>(uv[2 * c]), v = static_cast<long long>(uv[2 * c + 1]);
-        return (((v >> 5) * 65536 + (u >> 5)) * 32 + (v & 31)) * 32 + (u & 31);
+        const long long m = (1ll << tb) - 1;
+        long long tu = u >> tb, tv = v >> tb, iu = u & m, iv = v & m, in;
+        if (inner == 1) {
+          in = 0;
+          for (int b = 0; b < tb; ++b) in |= ((iu >> b) & 1) << (2 * b) | ((iv >> b) & 1) << (2 * b + 1);
+        } else {
+          if (inner == 2) {
+            if (tv & 1) tu = 65535 - tu;
+            if (iv & 1) iu = m - iu;
+          }
+          in = (iv << tb) + iu;
+        }
+        return ((tv * 65536 + tu) << (2 * tb)) + in;
       };
       // (ties — two landmarks on one pixel — are broken by their content, so that the device order, and with it every sum of the
       // deterministic build, depends on the SET of landmarks only, not on the order the caller lists them in)

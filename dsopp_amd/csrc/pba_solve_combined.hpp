@@ -753,7 +753,20 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   // (without first-estimate Jacobians every pair constant moves with the state: the host launches pairSetupKernel behind this
   // kernel, as it does behind assembleSolveKernel)
   SC_STAMP(4);
-  if (a.ctrl) {
+  if (a.ctrl && K <= 64) {
+    // windows of up to 8 keyframes: the K prior threads are ONE wave (wave 1), which sums and writes the control block on its own while
+    // wave 0 is still refreshing pair constants — no barrier, nothing behind the refresh on the workgroup's critical path
+    // (bitwise the sums of the general form below: the other waves contribute exact zeros)
+    part = waveSum(part);
+    nstate = waveSum(nstate);
+    nstep = waveSum(nstep);
+    if (tid == 64) {
+      a.ctrl->cand_prior = a.energy_marginalized + part;
+      a.ctrl->frame_state_sq = nstate;
+      a.ctrl->frame_step_sq = nstep;
+      a.ctrl->pending = 1;
+    }
+  } else if (a.ctrl) {
     part = waveSum(part);
     nstate = waveSum(nstate);
     nstep = waveSum(nstep);
