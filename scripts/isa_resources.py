@@ -113,10 +113,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--filter", default=None, help="substring of the demangled kernel name")
+    ap.add_argument("--lib", default="lib", help="directory under dsopp_amd/ holding the object files")
     args = ap.parse_args()
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
-        for obj in sorted(glob.glob(os.path.join(ROOT, "dsopp_amd", "lib", "*.o"))):
+        for obj in sorted(glob.glob(os.path.join(ROOT, "dsopp_amd", args.lib, "*.o"))):
             co = code_object(obj, tmp)
             if not co:
                 continue

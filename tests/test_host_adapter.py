@@ -72,8 +72,8 @@ def test_host_mirror_solves_on_gpu(tmp_path):
 
 
 def test_synthetic_window_landmark_orders():
-    """synthetic.make_window(order=...): the same landmarks, listed randomly (default), row-major, or tile by tile (what the bench's
-    `spatially_ordered_landmarks` line and profiles/r04/large_loop_tile32_* use)"""
+    """synthetic.make_window(order=...): the same landmarks, listed randomly (default), row-major, or tile by tile (what the round-4 bench's
+    `spatially_ordered_landmarks` line and profiles/r04/large_loop_tile32_* used; since round 5 the library sorts behind the C-ABI)"""
     import numpy as np
     from dsopp_amd import synthetic as syn
     a = syn.make_window(3, 300, 320, 240, seed=1)
