@@ -137,3 +137,58 @@ def test_pyramid_rewritten_while_a_window_borrows_it():
     gb.close()
     for p in pa + pb:
         p.close()
+
+
+def test_windows_solved_concurrently_from_their_own_threads():
+    """DESIGN.md section 5, "One GPU, many windows": the throughput form is one host thread per window, each on a stream of its own.  The
+    library holds no cross-window state that a concurrent solve could trample on (staging buffers, event pools, the solve launch's
+    ticket counters and fault word are per window; error text is per thread): four DIFFERENT windows, each solved three times by its
+    own thread while the others run, end bitwise where the same windows end when solved one after the other (deterministic build),
+    and — every thread reading its own window back — with the oracle-checked single-window results of the other tests."""
+    import threading
+    import torch
+    from dsopp_amd import capi
+    wins = [syn.make_window(num_frames=4 + i, num_points=400 + 150 * i, width=320, height=240, seed=40 + i) for i in range(4)]
+
+    def make(i, stream):
+        g = capi.HipWindow(capi.default_pba_options(), stream=stream)
+        g.set_deterministic(True)
+        syn.load_window(g, wins[i])
+        g.snapshot()
+        return g
+
+    def result(g):
+        out = []
+        for _ in range(3):
+            g.restore()
+            e, it, nv = g.optimize()
+            out.append((e, it, nv, np.concatenate([g.get_pose(f.frame_id)[0] for f in wins[gs.index(g)].frames])))
+        return out
+
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    gs = [make(i, streams[i].cuda_stream) for i in range(4)]
+    sequential = [result(g) for g in gs]
+    concurrent = [None] * 4
+    errors = []
+    barrier = threading.Barrier(4)
+
+    def worker(i):
+        try:
+            barrier.wait()
+            concurrent[i] = result(gs[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        for (e0, it0, nv0, p0), (e1, it1, nv1, p1) in zip(sequential[i], concurrent[i]):
+            assert it0 == it1 and nv0 == nv1 and e0 == e1
+            assert np.array_equal(p0, p1)
+        assert sequential[i][0][1] >= 1
+    for g in gs:
+        g.close()
