@@ -469,7 +469,12 @@ __device__ __forceinline__ void gramScalarsStore(const f64x4 &acc, const double 
  * memory round trip deep per stage instead of eight.
  */
 template <typename S, bool LIN, bool FEJ, bool HUBER, bool BACKSUB = false, bool WFEJ = false>
-__global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
+#ifdef DSOPP_HIP_EXPERIMENT_SWEEP_WAVES  // experiment: force an occupancy (waves per SIMD) on the sweeps, whatever it spills
+__global__ void __launch_bounds__(kSweepThreads, DSOPP_HIP_EXPERIMENT_SWEEP_WAVES) sweepKernel(
+#else
+__global__ void __launch_bounds__(kSweepThreads) sweepKernel(
+#endif
+const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
                                                              SweepParams prm) {
   // LIN: the exchange buffer of the Gram accumulation (gramAccumulate: one row of kGramStride doubles per pattern pixel);
@@ -533,6 +538,15 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(const FrameDev *__r
     w.u = static_cast<S>(g_uv[2 * j]);
     w.v = static_cast<S>(g_uv[2 * j + 1]);
     w.idepth_d = g_idepth[j];
+#ifdef DSOPP_HIP_EXPERIMENT_FEW_ITEM_WORDS  // timing only (wrong results): 5 item-word loads per group instead of 10
+    w.idepth_step_d = w.idepth_d * 1e-9;
+    w.status = g_status[j];
+    w.cand = w.status;
+    w.patch_k = static_cast<S>(g_patch[kPat * j + k]);
+    w.fej_bit = 1;
+    w.idepth_fej_d = w.idepth_d;
+    return w;
+#endif
     w.idepth_step_d = g_idepth_step[j];
     w.status = g_status[j];
     w.cand = g_cand[j];
