@@ -2,10 +2,13 @@
 # Builds the HIP library for gfx950 in-tree: dsopp_amd/lib/libdsopp_hip.so (+ libdsopp_hip_tools.so: counter-calibration kernels)
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${DSOPP_HIP_OUT:-$HERE/../lib}"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function ${DSOPP_HIP_EXTRA_FLAGS:-}"
+# -amdgpu-kernarg-preload-count=16: the dispatcher hands the first 16 argument words to every wave in scalar registers (gfx940+), so a
+# kernel whose first loads depend on its leading pointer arguments alone starts them in its first cycles instead of behind an
+# argument fetch (the sweep, reduction and solve launches are laid out for this: profiles/r05/prologue_kernel_stats.txt)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${DSOPP_HIP_EXTRA_FLAGS:-}"
 pids=()
 for src in pyramid pba align depth_estimation comm calibration window_group; do
   if [ -f "$HERE/$src.hip" ]; then

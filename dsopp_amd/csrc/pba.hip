@@ -828,33 +828,33 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   timedLaunch(w, lin ? DSOPP_HIP_KERNEL_SWEEP_LINEARIZE : DSOPP_HIP_KERNEL_SWEEP_ENERGY, [&] {
     if (opening) {
       // opening linearisation of a fused solve: first-estimate snapshot taken by the sweep itself, no back-substitution
-      sweepKernel<S, true, true, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+      sweepKernel<S, true, true, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     } else if (lin && ex.fused_lin_backsub) {
       // fused LM loop: linearisation at the candidate state = its energy evaluation + calculateIdepths in one pass
       if (w.fej())
-        sweepKernel<S, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
       else
-        sweepKernel<S, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     } else if (!lin && backsub) {
       if (w.fej())
-        sweepKernel<S, false, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, false, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
       else
-        sweepKernel<S, false, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, false, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     } else if (!lin) {
       if (w.fej())
-        sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, false, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
       else
-        sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, false, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     } else if (w.fej()) {
       if (huber)
-        sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, true, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
       else
-        sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, true, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     } else {
       if (huber)
-        sweepKernel<S, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, false, true><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
       else
-        sweepKernel<S, true, false, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm);
+        sweepKernel<S, true, false, false><<<grid, block, 0, st>>>(fr, pc, tb, pa, prm.ctrl, prm.run_flag, prm);
     }
   });
   HIP_CHECK(hipGetLastError());
@@ -952,7 +952,8 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   }
   timedLaunch(w, DSOPP_HIP_KERNEL_SCHUR, [&] {
     // both systems are accumulated with atomics into d_reduce, which the preceding linearisation sweep zeroed
-    reduceSchurKernel<<<a.n_schur_blocks + F * F + (a.scalars_out ? 1 : 0), kSchurThreads, std::max(schurSmemBytes(K), decide_smem), st>>>(a);
+    reduceSchurKernel<<<a.n_schur_blocks + F * F + (a.scalars_out ? 1 : 0), kSchurThreads, std::max(schurSmemBytes(K), decide_smem), st>>>(
+        a.ctrl, a.schur_table, a.pc, a.partials, a.pair_first_block, a.pair_num_blocks, a.n_schur_blocks, a.F, a);
   });
   HIP_CHECK(hipGetLastError());
   // multi-GPU: landmarks are sharded, so both systems are partial sums: one collective over one contiguous buffer
@@ -1160,9 +1161,11 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
   timedLaunch(w, DSOPP_HIP_KERNEL_ASSEMBLE_SOLVE,
               [&] {
                 if (w.F() > 8)
-                  solveCombinedKernel<512><<<1 + a.dec_blocks, 512, solveSmemBytes(w.K()), w.sr.stream>>>(a);
+                  solveCombinedKernel<512><<<1 + a.dec_blocks, 512, solveSmemBytes(w.K()), w.sr.stream>>>(
+                      a.bs_ticket, a.bs_hand_next, a.dec_in, a.dec_scalars, a.comb, a.frames, a.st, a.F, a);
                 else
-                  solveCombinedKernel<256><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(a);
+                  solveCombinedKernel<256><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(
+                      a.bs_ticket, a.bs_hand_next, a.dec_in, a.dec_scalars, a.comb, a.frames, a.st, a.F, a);
               });
   HIP_CHECK(hipGetLastError());
   if (a.bs_ticket) {

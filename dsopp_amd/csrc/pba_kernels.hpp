@@ -476,23 +476,42 @@ __global__ void __launch_bounds__(kSweepThreads) sweepKernel(
 #endif
 const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
                                                              const SweepBlock *__restrict__ table, double *__restrict__ partials,
+                                                             // (= prm.ctrl, prm.run_flag once more, as pointer arguments of their own: the
+                                                             // first 16 argument words are preloaded into scalar registers by the dispatcher
+                                                             // — build.sh: -amdgpu-kernarg-preload-count — and members of a by-value struct
+                                                             // are not; with them the prologue's burst below starts at the wave's first cycle)
+                                                             const LmControl *ctrl_arg, const int *run_flag_arg,
                                                              SweepParams prm) {
   // LIN: the exchange buffer of the Gram accumulation (gramAccumulate: one row of kGramStride doubles per pattern pixel);
   // the four energy scalars (+ sum of weights) cross the workgroup through kSweepScalars doubles per wave
   __shared__ __attribute__((aligned(16))) double gram_lds[LIN ? kSweepThreads * kGramStride : 2];
   __shared__ double scalar_lds[(kSweepThreads / 64) * (64 + kSweepScalars)];
   // ---- round trip 1: block descriptor + LM control block (scalar loads, all requested before any of them is tested)
+  // The whole descriptor, the control block's words and the run flag leave in ONE burst of scalar loads with one wait behind it: the
+  // control block and the flag are read through a pointer that is valid either way (the table itself stands in for an absent one) and
+  // every word is pinned below.  Until round 5 the compiler's own placement was descriptor head -> wait -> control block -> wait ->
+  // run flag -> wait -> rest of the descriptor + remaining arguments -> wait: four scalar round trips in front of the first item word.
   const SweepBlock be = table[blockIdx.x];
-  int c_active = 1, c_lsv = 0, c_pending = 1, run = 1;
-  double lam = prm.lambda;
-  if (prm.ctrl) {
-    c_active = prm.ctrl->active;
-    c_lsv = prm.ctrl->linear_system_valid;
-    c_pending = prm.ctrl->pending;
-    lam = prm.ctrl->lambda;
+  const LmControl DSOPP_CONSTANT *ctrl_or_any =
+      ctrl_arg ? (const LmControl DSOPP_CONSTANT *)ctrl_arg : (const LmControl DSOPP_CONSTANT *)(const void DSOPP_CONSTANT *)table;
+  const int DSOPP_CONSTANT *flag_or_any = run_flag_arg ? (const int DSOPP_CONSTANT *)run_flag_arg : (const int DSOPP_CONSTANT *)(const void DSOPP_CONSTANT *)table;
+  int c_active = ctrl_or_any->active, c_lsv = ctrl_or_any->linear_system_valid, c_pending = ctrl_or_any->pending, run = *flag_or_any;
+  double lam = ctrl_or_any->lambda;
+  asm volatile("" ::"s"(be.r), "s"(be.t), "s"(be.offset), "s"(be.n_res), "s"(be.cap), "s"(be.owns_landmark_sums), "s"(be.width_r), "s"(be.height_r),
+               "s"(be.width_t), "s"(be.height_t), "s"(be.conn_mask), "s"(be.n_groups), "s"(be.uv), "s"(be.idepth), "s"(be.patch), "s"(be.idepth_fej),
+               "s"(be.b_d), "s"(be.inv_hdd), "s"(be.idepth_step), "s"(be.ublk), "s"(be.energy), "s"(be.flags), "s"(be.status), "s"(be.fej_valid),
+               "s"(be.cand), "s"(be.texels_t), "s"(be.iplane_t), "s"(be.itiles_t), "s"(be.partial_row));
+  asm volatile("" : "+s"(c_active), "+s"(c_lsv), "+s"(c_pending), "+s"(run), "+s"(lam));
+  // (the argument words beyond the preloaded ones ride in the same burst instead of being fetched one by one where they are first used)
+  asm volatile("" ::"s"(prm.sigma_huber), "s"(prm.for_marginalized), "s"(prm.use_fej_flag), "s"(prm.clear_buf), "s"(prm.clear_count), "s"(prm.step),
+               "s"(prm.lambda), "s"(prm.F), "s"(prm.ublk_read), "s"(prm.ublk_write), "s"(prm.gate_on_pending), "s"(prm.external_backsub), "s"(prm.dbg));
+  if (!ctrl_arg) {
+    c_active = 1;
+    c_lsv = 0;
+    c_pending = 1;
+    lam = prm.lambda;
   }
-  if (prm.run_flag) run = *prm.run_flag;
-  asm volatile("" ::"s"(be.offset), "s"(c_active), "s"(run));
+  if (!run_flag_arg) run = 1;
   // device-driven LM: skip when the loop has ended (or, for the linearisation, when the last step was rejected and the
   // linear system is still valid — levenberg_marquardt_algorithm.hpp:88-90)
   if (!run || !c_active || (LIN && c_lsv)) return;

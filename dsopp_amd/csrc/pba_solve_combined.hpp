@@ -96,10 +96,15 @@ __device__ __forceinline__ void combBlockDecode(int b, int &bi, int &bj) {
  *  columns of a 9..16-frame system is longer than the panel wave's factor step with three waves (12 frames: Cholesky 20 us), and the
  *  combined system arrives in two rounds of batched loads instead of three.  Every matrix entry is produced by one thread with a
  *  fixed summation order, so the two instantiations give bit-identical results. */
+/** (the leading arguments repeat members of `a`: the dispatcher preloads the first 16 argument words into scalar registers — build.sh:
+ *  -amdgpu-kernarg-preload-count — but not the members of a by-value struct.  With them the ticket and the solver's first operand loads
+ *  leave in the wave's first cycles, beside the rest of the argument block instead of behind it.) */
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs a) {
+__global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_ticket_p, double *bs_hand_next_p, const LmControl *dec_in_p,
+                                                                  const double *dec_scalars_p, const double *comb_p, const FrameDev *frames_p,
+                                                                  WindowState *st_p, int F_p, SolveCombArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int F = a.F, K = kBlk * F;
+  const int F = F_p, K = kBlk * F;
   const int N = K + 1;   // augmented with the right-hand side row
   const int ld = N + 1;
   double *A = reinterpret_cast<double *>(smem_raw);  // N x ld (lower triangle used)
@@ -111,20 +116,35 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   double *ab0l = stpl + K;                           // 2 F: affine brightness at the linearisation point
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  const long long sc_t_entry = (kStamps && a.dbg_stamps) ? wall_clock64() : 0;  // (tuning aid: the solving workgroup's first cycle)
 
   // ---- everything is requested before anything waits: the kernel start costs one memory round trip
   int c_active = 1, c_relin = 0;
   double lam = a.lambda;
-  const bool decides = a.dec_in != nullptr;
+  const bool decides = dec_in_p != nullptr;
   double dec_eps = 0, dec_step = 0;
   int dec_accept = 0;
   // Workgroup 0 requests everything that does not depend on the decision — pair constants, frame flags, right-hand side, the first
   // batch of the combined system — BEFORE it takes the decision: the decision's own loads, its LDS tree and its scalar chain then
   // run under these loads' round trip instead of in front of it (the other workgroups only apply the decision and leave).
-  const bool ticketed = a.bs_ticket != nullptr;
-  unsigned my_ticket = 0;
-  if (ticketed && tid == 0) my_ticket = atomicAdd(a.bs_ticket, 1u) - a.bs_ticket_base;  // (in flight under everything requested below)
-  if (ticketed && tid < kBlk * kMaxFrames) a.bs_hand_next[tid] = kHandOverSentinel();  // (every workgroup: the same value; read by the next launch)
+  const bool ticketed = bs_ticket_p != nullptr;
+  // The ticket is drawn here and NOT looked at before the decision below: the returned value stays in its register, un-waited-for, under
+  // everything requested in between.  (Until round 5 the base was subtracted right here — the compiler then waits for the atomic's
+  // return, a device-scope round trip of 1 - 2 us, in front of every operand load of the solver.)
+  unsigned ticket_raw = 0;
+  if (ticketed && tid == 0) {
+    // (the address is made opaque: for a wave-uniform address the compiler rewrites the add as a wave scan whose v_readfirstlane
+    // consumes — and waits for — the returned value on the spot)
+    auto tp = glb(bs_ticket_p);
+    asm volatile("" : "+v"(tp));
+    ticket_raw = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (ticketed && tid < kBlk * kMaxFrames) bs_hand_next_p[tid] = kHandOverSentinel();  // (every workgroup: the same value; read by the next launch)
+  // Every other argument word the kernel's head reads is requested in ONE burst of scalar loads with one wait: left to itself the
+  // compiler fetches each member where it is first used — a dozen s_load / s_waitcnt pairs in a row in front of the operand loads,
+  // four of them on argument lines no wave of the launch had touched yet.
+  asm volatile("" ::"s"(a.pc), "s"(a.Hm), "s"(a.bm), "s"(a.HmPacked), "s"(a.step), "s"(a.ctrl), "s"(a.fej), "s"(a.use_marginal), "s"(a.dec_table),
+               "s"(a.dec_blocks), "s"(a.dec_groups), "s"(a.bs_hand), "s"(a.bs_parity), "s"(a.dec_chunks), "s"(a.bs_ticket_base));
   __shared__ unsigned s_vblock;
   // with tickets every workgroup requests the solver's operands (it does not know its role yet; the others drop them)
   bool main_wg = ticketed || blockIdx.x == 0;
@@ -146,8 +166,8 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         for (int j = 0; j < 3; ++j) pp.T0.R[3 * i + j] = P.T0rel[4 * i + j];
         pp.T0.t[i] = P.T0rel[4 * i + 3];
       }
-      const FrameDev &fr = a.frames[r];
-      const FrameDev &ft = a.frames[t];
+      const FrameDev &fr = frames_p[r];
+      const FrameDev &ft = frames_p[t];
       pp.fxr = fr.fx;
       pp.fyr = fr.fy;
       pp.cxr = fr.cx;
@@ -168,11 +188,11 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   int fixed_c = 0, tomarg_c = 0;
   if (main_wg && tid < K) {
     const int f = tid >> 3, i = tid & 7;
-    if (!decides) eps_c = a.st->eps[f][i];
-    fixed_c = a.frames[f].fixed;
-    tomarg_c = a.frames[f].to_marginalize;
-    ab0_c = a.st->ab0[f][i < 6 ? 0 : i - 6];
-    rhs_c = a.comb[combBlockCount(F) * 64 + tid];
+    if (!decides) eps_c = st_p->eps[f][i];
+    fixed_c = frames_p[f].fixed;
+    tomarg_c = frames_p[f].to_marginalize;
+    ab0_c = st_p->ab0[f][i < 6 ? 0 : i - 6];
+    rhs_c = comb_p[combBlockCount(F) * 64 + tid];
     if (a.use_marginal) bm_c = a.bm[tid];
   }
   // the prior energy of the candidate (kernel tail) is evaluated by the threads 64 .. 64 + K - 1, i.e. on other waves than the
@@ -183,7 +203,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   double ab0_p = 0, bm_p = 0;
   auto requestTailInputs = [&] {
     if (prior_thread) {
-      ab0_p = a.st->ab0[pc >> 3][(pc & 7) < 6 ? 0 : (pc & 7) - 6];
+      ab0_p = st_p->ab0[pc >> 3][(pc & 7) < 6 ? 0 : (pc & 7) - 6];
       if (a.use_marginal) bm_p = a.bm[pc];
     }
   };
@@ -198,7 +218,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int e = base + tid + THREADS * u;
-      hv[u] = a.comb[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
+      hv[u] = comb_p[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
       hm[u] = 0;
     }
     if (a.use_marginal) {
@@ -210,7 +230,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   if (decides) {
     __shared__ LmControl s_dec_out;
     __shared__ int s_dec_accept, s_dec_proceed;
-    const LmControl cin = *a.dec_in;
+    const LmControl cin = *dec_in_p;
     double t[4] = {0, 0, 0, 0};
     if (a.dec_groups) {
       // 64 group sums per scalar -> 8 sums of 8 -> one (fixed order: identical in every workgroup and from run to run)
@@ -219,7 +239,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         const int e = tid >> 3, j = tid & 7;
         double sacc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sacc += a.dec_scalars[4 * (8 * j + k) + e];
+        for (int k = 0; k < 8; ++k) sacc += dec_scalars_p[4 * (8 * j + k) + e];
         s_grp[e * 8 + j] = sacc;
       }
       ldsBarrier();
@@ -233,17 +253,17 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
         }
       }
     } else {
-      t[0] = a.dec_scalars[0];
-      t[1] = a.dec_scalars[1];
-      t[2] = a.dec_scalars[2];
-      t[3] = a.dec_scalars[3];
+      t[0] = dec_scalars_p[0];
+      t[1] = dec_scalars_p[1];
+      t[2] = dec_scalars_p[2];
+      t[3] = dec_scalars_p[3];
     }
     if (main_wg && tid < K) {  // (frame states: read and written by workgroup 0 only)
-      dec_eps = a.st->eps[tid >> 3][tid & 7];
-      dec_step = a.st->step[tid >> 3][tid & 7];
+      dec_eps = st_p->eps[tid >> 3][tid & 7];
+      dec_step = st_p->step[tid >> 3][tid & 7];
     }
     if (!cin.active) {  // the loop has ended: the control block is handed on unchanged
-      if (tid == 0 && (ticketed ? my_ticket == 0 : blockIdx.x == 0)) *a.ctrl = cin;
+      if (tid == 0 && (ticketed ? ticket_raw == a.bs_ticket_base : blockIdx.x == 0)) *a.ctrl = cin;
       return;
     }
     if (tid == 0) {
@@ -253,7 +273,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
       s_dec_out = c;
       s_dec_accept = accept;
       s_dec_proceed = proceed;
-      s_vblock = ticketed ? my_ticket : blockIdx.x;
+      s_vblock = ticketed ? ticket_raw - a.bs_ticket_base : blockIdx.x;
     }
     ldsBarrier();
     dec_accept = s_dec_accept;
@@ -408,9 +428,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     if (cin.pending && tid < K) {
       if (dec_accept) {
         dec_eps += dec_step;
-        a.st->eps[tid >> 3][tid & 7] = dec_eps;
+        st_p->eps[tid >> 3][tid & 7] = dec_eps;
       }
-      a.st->step[tid >> 3][tid & 7] = 0;
+      st_p->step[tid >> 3][tid & 7] = 0;
     }
     if (tid == 0) *a.ctrl = s_dec_out;
     if (!s_dec_proceed) return;
@@ -424,6 +444,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
   }
   if (decides) eps_c = dec_eps;  // (decided here: the accepted state is already in registers)
   SC_STAMP(0);
+  if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[7] = sc_t_entry;
   // opaque to the optimiser: stops it from testing these loaded flags (and waiting for them) above the loads
   asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(pp.valid), "+v"(c_active), "+v"(c_relin));
   int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness (evaluateLinearSystemPrior, problem.hpp:39-62)
@@ -683,7 +704,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(SolveCombArgs 
     // (a device-scope store: written through to where the other XCDs read — no flag, no fence: the slot's sentinel gives way to the value)
     if (a.bs_hand) __hip_atomic_store(a.bs_hand + tid, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the waiting workgroups' copy
     a.step[tid] = x;
-    a.st->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
+    st_p->step[tid >> 3][tid & 7] = -x;  // problem.hpp:353-357
   }
   SC_STAMP(3);
   // prior + marginal energy at the candidate state x = eps + step (calculateEnergy, problem.hpp:293-312) and the frame part of the

@@ -392,8 +392,21 @@ __device__ inline bool fusedDecideApply(const ReduceSchurArgs &a, double *lds, l
  *    deterministic sum of the sweep's per-block partials (G, q), the derived blocks T^T G T, G T, T^T q, and their
  *    scatter into H_pp / b_pp (H_rr += T^T G T, H_tt += G, H_rt = -(G T)^T, H_tr = -G T, b_r += T^T q, b_t -= q).
  */
-__global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurArgs a) {
+/** (the leading arguments repeat members of `a`: the dispatcher preloads the first 16 argument words into scalar registers —
+ *  build.sh: -amdgpu-kernarg-preload-count — but not the members of a by-value struct.  With them the control block and the descriptor
+ *  are requested in the wave's first cycles, beside the rest of the argument block instead of behind it.) */
+__global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmControl *ctrl_p, const SchurBlock *table_p, const PairConst *pc_p,
+                                                                   const double *partials_p, const int *pair_first_p, const int *pair_num_p,
+                                                                   int n_schur_blocks_p, int F_p, ReduceSchurArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  a.ctrl = ctrl_p;
+  a.schur_table = table_p;
+  a.pc = pc_p;
+  a.partials = partials_p;
+  a.pair_first_block = pair_first_p;
+  a.pair_num_blocks = pair_num_p;
+  a.n_schur_blocks = n_schur_blocks_p;
+  a.F = F_p;
   const long long rs_t0 = (kStamps && a.dbg) ? wall_clock64() : 0;
   long long rs_dbg[2] = {0, 0};
   // (inside the fused loop the LM decision for the pending candidate is the prologue of the SOLVE launch behind this one — it needs
@@ -401,13 +414,13 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   // every control-block word this launch needs is requested BEFORE the first one is tested: three dependent scalar round trips
   // (active -> linear_system_valid -> lambda) become one.  Damping of the system being built: the incoming control block (the PBA's
   // LM keeps lambda constant, eigen_photometric_bundle_adjustment.cpp:74-75), or the launch argument
-  int c_active = 1, c_lsv = 0;
-  double comb_lam = a.comb_lambda;
-  if (a.ctrl) {
-    c_active = a.ctrl->active;
-    c_lsv = a.ctrl->linear_system_valid;
-    comb_lam = a.ctrl->lambda;
-  }
+  // Both are read through pointers that are valid whatever the launch passes (the argument block itself stands in for an absent control
+  // block / an empty table), so that there is no branch in front of the loads: control block, descriptor head and the remaining
+  // argument words leave together and are waited for once.
+  const void DSOPP_CONSTANT *any_words = (const void DSOPP_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
+  const LmControl DSOPP_CONSTANT *cp = ctrl_p ? (const LmControl DSOPP_CONSTANT *)ctrl_p : (const LmControl DSOPP_CONSTANT *)any_words;
+  int c_active = cp->active, c_lsv = cp->linear_system_valid;
+  double comb_lam = cp->lambda;
   // ... and with them the head of this workgroup's Schur descriptor (the pair / scalar workgroups behind the Schur blocks fetch the
   // last one and ignore it): the descriptor's address depends on the launch arguments only, so it need not wait for the test
   struct SchurHead {
@@ -416,14 +429,32 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(ReduceSchurAr
   unsigned hd_conn = 0;
   decltype(SchurBlock::ublk) hd_ublk = nullptr;
   decltype(SchurBlock::flags) hd_flags = nullptr;
-  if (a.n_schur_blocks > 0) {
-    const SchurBlock &d = a.schur_table[min(static_cast<int>(blockIdx.x), a.n_schur_blocks - 1)];
+  {
+    const SchurBlock DSOPP_CONSTANT *dp =
+        n_schur_blocks_p > 0 ? (const SchurBlock DSOPP_CONSTANT *)table_p + min(static_cast<int>(blockIdx.x), n_schur_blocks_p - 1)
+                             : (const SchurBlock DSOPP_CONSTANT *)any_words;
+    const SchurBlock DSOPP_CONSTANT &d = *dp;
     hd = {d.r, d.offset, d.n, d.cap};
     hd_conn = d.conn_mask;
     hd_ublk = d.ublk;
     hd_flags = d.flags;
   }
-  asm volatile("" ::"s"(hd.r), "s"(hd_conn), "s"(hd_ublk), "s"(hd_flags), "s"(c_active), "s"(c_lsv));
+  // the other argument words the kernel's head reads: one burst, in flight with the control block and the descriptor
+  asm volatile("" ::"s"(a.frames), "s"(a.Hpp), "s"(a.bpp), "s"(a.Hsc), "s"(a.bsc), "s"(a.for_marginalized), "s"(a.ublk_parity), "s"(a.ctrl_out),
+               "s"(a.st), "s"(a.scalars), "s"(a.n_sweep_blocks), "s"(a.scalars_out), "s"(a.scalars_out_groups), "s"(a.comb), "s"(a.comb_lambda));
+  asm volatile("" : "+s"(hd.r), "+s"(hd.offset), "+s"(hd.n), "+s"(hd.cap), "+s"(hd_conn), "+s"(hd_ublk), "+s"(hd_flags), "+s"(c_active), "+s"(c_lsv),
+               "+s"(comb_lam));
+  if (!ctrl_p) {
+    c_active = 1;
+    c_lsv = 0;
+    comb_lam = a.comb_lambda;
+  }
+  if (n_schur_blocks_p <= 0) {
+    hd = {0, 0, 0, 0};
+    hd_conn = 0;
+    hd_ublk = nullptr;
+    hd_flags = nullptr;
+  }
   if (!c_active || c_lsv) return;
   const int F = a.F, K = kBlk * F;
   if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {

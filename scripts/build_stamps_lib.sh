@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$HERE/dsopp_amd/lib_stamps"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -DDSOPP_HIP_STAMPS"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -DDSOPP_HIP_STAMPS ${DSOPP_HIP_EXTRA_FLAGS:-}"
 pids=()
 for src in pyramid pba align depth_estimation comm window_group; do
   $HIPCC $FLAGS -c "$HERE/dsopp_amd/csrc/$src.hip" -o "$OUT/$src.o" &

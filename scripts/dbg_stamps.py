@@ -14,7 +14,7 @@ for _ in range(3):
     g.restore(); g.optimize()
 capi.lib().dsopp_hip_debug_solve_stamps(g._h, out)
 st = np.array(list(out), dtype=np.int64) / 100.0   # wall_clock64 ticks at 100 MHz -> us
-print(f"solve: loads+assemble {st[1]-st[0]:.2f}  cholesky {st[2]-st[1]:.2f}  back-substitution {st[6]-st[2]:.2f}  step out {st[3]-st[6]:.2f}  pair refresh {st[4]-st[3]:.2f}  prior energy {st[5]-st[4]:.2f}  "
+print(f"solve: entry -> operands + decision {st[0]-st[7]:.2f}  loads+assemble {st[1]-st[0]:.2f}  cholesky {st[2]-st[1]:.2f}  back-substitution {st[6]-st[2]:.2f}  step out {st[3]-st[6]:.2f}  pair refresh {st[4]-st[3]:.2f}  prior energy {st[5]-st[4]:.2f}  "
       f"total {st[5]-st[0]:.2f}")
 rs = st[24:]
 print("reduceSchur (wg 1) stamps us:", np.round(rs[:8] - rs[0], 2))
