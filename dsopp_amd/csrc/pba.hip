@@ -131,6 +131,11 @@ struct dsopp_hip_window {
   size_t reduceCount() const { return 2 * (static_cast<size_t>(K()) * K() + K()); }
   /** fused LM loop: the combined block-packed system [blocks | rhs] at the head of d_reduce (pba_solve_kernels.hpp: ReduceSchurArgs::comb) */
   size_t combCount() const { return static_cast<size_t>(combBlockCount(F())) * 64 + static_cast<size_t>(K()); }
+  // copies of the combined system the reduction launch spreads its atomics over (ReduceSchurArgs::comb_copies); > 1 only while the fused
+  // loop of an unsharded window of up to 8 keyframes on the atomics path is being enqueued
+  int comb_copies_active = 1;
+  size_t combCopyFirst() const { return (combCount() + 4 * kScalarGroups + 8 + 1) & ~static_cast<size_t>(1); }
+  size_t combCopyStride() const { return (combCount() + 1) & ~static_cast<size_t>(1); }
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
   bool state_dirty = true;   // host mirror newer than device
@@ -677,7 +682,7 @@ void syncTopology(W &w) {
   w.d_bpp.reserve(KK, 0, st);
   // + tail: the sweep's energy scalars sit behind the combined system (4 sums, or 4 x kScalarGroups group sums) and ride in the same
   // collective on landmark-sharded windows
-  w.d_reduce.reserve(2 * (KK * KK + KK) + 8 + 4 * kScalarGroups, 0, st);
+  w.d_reduce.reserve(2 * (KK * KK + KK) + 8 + 4 * kScalarGroups + 16 + static_cast<size_t>(kMaxCombCopies - 1) * (static_cast<size_t>(combBlockCount(kMaxFrames)) * 64 + KK + 2), 0, st);
   w.d_Hm.reserve(KK * KK, 0, st);
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
@@ -808,6 +813,8 @@ void launchSweepTyped(W &w, bool lin, bool huber, bool for_marg, const LmControl
   prm.ctrl = ctrl;
   prm.clear_buf = lin ? w.d_reduce.ptr : nullptr;
   prm.clear_count = static_cast<int>(ex.combined ? w.combCount() + 4 : w.reduceCount());
+  if (ex.combined && w.comb_copies_active > 1)  // (the copies lie behind the scalar groups' slots: everything up to the last one)
+    prm.clear_count = static_cast<int>(w.combCopyFirst() + (w.comb_copies_active - 1) * w.combCopyStride());
   prm.step = w.d_step.ptr;
   prm.lambda = lambda;
   prm.F = w.F();
@@ -930,6 +937,11 @@ void launchReduceSchur(W &w, bool for_marg, const LmControl *ctrl, const FusedRe
   const size_t reduce_count = combined ? w.combCount() : w.reduceCount();
   a.comb = combined ? w.d_reduce.ptr : nullptr;
   a.comb_lambda = fused ? fused->comb_lambda : 0.0;
+  if (combined && mode == ReduceMode::kAccumulateOnly && w.comb_copies_active > 1) {
+    a.comb_copies = w.comb_copies_active;
+    a.comb_copy_first = static_cast<int>(w.combCopyFirst());
+    a.comb_copy_stride = static_cast<int>(w.combCopyStride());
+  }
   a.scalars = mode == ReduceMode::kDecideOnly ? w.d_reduce.ptr + reduce_count : w.d_scalars.ptr;
   a.n_sweep_blocks = w.n_sweep_blocks;
   a.total_blocks = a.n_schur_blocks + F * F;
@@ -1102,6 +1114,7 @@ int solveResidentWorkgroups(W &w, bool wide) {
 void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *decide_from = nullptr, const LmParams *decide_prm = nullptr,
                          bool decide_from_groups = false, bool backsub = false, int ublk_parity = 0) {
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<256>), w.sr.device, 150 * 1024);
+  ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<256, kMaxCombCopies>), w.sr.device, 150 * 1024);
   ensureDynamicLds(reinterpret_cast<const void *>(solveCombinedKernel<512>), w.sr.device, 150 * 1024);
   SolveCombArgs a;
   if (decide_from) {
@@ -1144,6 +1157,11 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
   a.st = w.d_state.ptr;
   a.pc = w.d_pc.ptr;
   a.comb = w.d_reduce.ptr;
+  if (w.comb_copies_active > 1) {
+    a.comb_copies = w.comb_copies_active;
+    a.comb_copy_first = static_cast<int>(w.combCopyFirst());
+    a.comb_copy_stride = static_cast<int>(w.combCopyStride());
+  }
   a.Hm = w.d_Hm.ptr;
   a.HmPacked = w.d_Hm_packed.ptr;
   a.bm = w.d_bm.ptr;
@@ -1162,6 +1180,9 @@ void launchSolveCombined(W &w, double lambda, LmControl *ctrl, const LmControl *
               [&] {
                 if (w.F() > 8)
                   solveCombinedKernel<512><<<1 + a.dec_blocks, 512, solveSmemBytes(w.K()), w.sr.stream>>>(
+                      a.bs_ticket, a.bs_hand_next, a.dec_in, a.dec_scalars, a.comb, a.frames, a.st, a.F, a);
+                else if (a.comb_copies > 1)
+                  solveCombinedKernel<256, kMaxCombCopies><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(
                       a.bs_ticket, a.bs_hand_next, a.dec_in, a.dec_scalars, a.comb, a.frames, a.st, a.F, a);
                 else
                   solveCombinedKernel<256><<<1 + a.dec_blocks, 256, solveSmemBytes(w.K()), w.sr.stream>>>(
@@ -1498,6 +1519,17 @@ void lmSolveFusedEnqueue(W &w) {
   // kernel in front of the sweeps of large windows, no Schur-row reads in the sweeps of small ones.  DSOPP_HIP_K3_BACKSUB=0: the round-3 flow
   static const int k3_env = std::getenv("DSOPP_HIP_K3_BACKSUB") ? std::atoi(std::getenv("DSOPP_HIP_K3_BACKSUB")) : 1;
   const bool k3_backsub = k3_env != 0 && w.opt.optimize_idepths && w.n_schur_blocks > 0;
+  // atomics path of an unsharded window of up to 8 keyframes: the reduction launch accumulates into several copies of the combined system
+  // and the solve launch adds them while loading (the queue of same-address f64 atomics is that launch's tail).  DSOPP_HIP_COMB_COPIES=1: off
+  static const int comb_copies_env = std::getenv("DSOPP_HIP_COMB_COPIES") ? std::atoi(std::getenv("DSOPP_HIP_COMB_COPIES")) : 4;
+  static const int comb_copies_min_chunks = std::getenv("DSOPP_HIP_COMB_COPIES_MIN_CHUNKS") ? std::atoi(std::getenv("DSOPP_HIP_COMB_COPIES_MIN_CHUNKS")) : 80;
+  w.comb_copies_active = (!w.twoStage() && !w.allreduce && w.F() <= 7 && w.n_schur_blocks >= comb_copies_min_chunks)
+                             ? std::max(1, std::min(comb_copies_env, kMaxCombCopies))
+                             : 1;
+  struct CopiesReset {
+    W &w;
+    ~CopiesReset() { w.comb_copies_active = 1; }
+  } copies_reset{w};
   for (int r = 0; r < rounds; ++r) {
     LmControl *cin = ctrl + (r & 1), *cout = ctrl + ((r + 1) & 1);
     SweepExtras ex;

@@ -22,6 +22,10 @@ struct SolveCombArgs {
   WindowState *st;
   PairConst *pc;
   const double *comb;  // combBlockCount(F) * 64 block entries, then K right-hand-side entries
+  // the reduction launch spread its atomics over comb_copies copies of the system (ReduceSchurArgs::comb_copies): copy c > 0 starts
+  // comb_copy_first + (c - 1) * comb_copy_stride doubles behind `comb`; the load phase adds them entry by entry (fixed order)
+  int comb_copies = 1;
+  int comb_copy_first = 0, comb_copy_stride = 0;
   const double *Hm, *bm;  // marginal prior
   // the marginal prior's matrix once more in the layout of `comb` (block-packed lower triangle, packed by the host with the prior:
   // pba.hip uploadMarginal): the load phase adds it entry by entry at the SAME offsets as the combined system — no per-entry block
@@ -81,6 +85,7 @@ __host__ __device__ inline double kHandOverSentinel() {
   c.u = 0x7FF8D50FF00DBEEFull;
   return c.d;
 }
+constexpr int kMaxCombCopies = 4;
 #define SC_STAMP(i) do { if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[i] = wall_clock64(); } while (0)
 
 /** block index b of the packed lower triangle -> (bi, bj), bj <= bi */
@@ -99,7 +104,8 @@ __device__ __forceinline__ void combBlockDecode(int b, int &bi, int &bj) {
 /** (the leading arguments repeat members of `a`: the dispatcher preloads the first 16 argument words into scalar registers — build.sh:
  *  -amdgpu-kernarg-preload-count — but not the members of a by-value struct.  With them the ticket and the solver's first operand loads
  *  leave in the wave's first cycles, beside the rest of the argument block instead of behind it.) */
-template <int THREADS>
+/** COPIES: 1, or kMaxCombCopies for a system the reduction launch accumulated in several copies (SolveCombArgs::comb_copies of them are live) */
+template <int THREADS, int COPIES = 1>
 __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_ticket_p, double *bs_hand_next_p, const LmControl *dec_in_p,
                                                                   const double *dec_scalars_p, const double *comb_p, const FrameDev *frames_p,
                                                                   WindowState *st_p, int F_p, SolveCombArgs a) {
@@ -140,11 +146,41 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     ticket_raw = __hip_atomic_fetch_add(tp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (ticketed && tid < kBlk * kMaxFrames) bs_hand_next_p[tid] = kHandOverSentinel();  // (every workgroup: the same value; read by the next launch)
+  // The decision's inputs — the incoming control block and the sweep's four sums — as SCALAR loads, requested in the launch's first
+  // cycles (both addresses are preloaded arguments): scalar loads return on their own counter, so the decision below runs as soon as these
+  // 30 words are here, under the flight of the solver's vector operands instead of behind it.  (Until round 5 they were vector loads issued
+  // behind ~300 instructions of address arithmetic, and the four sums were fetched only after the control block had been tested.)
+  // Absent control block (isolated timing launches): the argument block stands in, the values are not used.
+  const void DSOPP_CONSTANT *any_words = (const void DSOPP_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
+  const LmControl DSOPP_CONSTANT *cin_src = dec_in_p ? (const LmControl DSOPP_CONSTANT *)dec_in_p : (const LmControl DSOPP_CONSTANT *)any_words;
+  LmControl cin;
+  cin.lambda = cin_src->lambda;
+  cin.energy = cin_src->energy;
+  cin.cand_prior = cin_src->cand_prior;
+  cin.idepth_sq = cin_src->idepth_sq;
+  cin.frame_state_sq = cin_src->frame_state_sq;
+  cin.frame_step_sq = cin_src->frame_step_sq;
+  cin.n_valid = cin_src->n_valid;
+  cin.converged = cin_src->converged;
+  cin.active = cin_src->active;
+  cin.linear_system_valid = cin_src->linear_system_valid;
+  cin.iteration = cin_src->iteration;
+  cin.need_final_setup = cin_src->need_final_setup;
+  cin.pending = cin_src->pending;
+  cin.relin = cin_src->relin;
+  const double DSOPP_CONSTANT *t_src = dec_scalars_p ? (const double DSOPP_CONSTANT *)dec_scalars_p : (const double DSOPP_CONSTANT *)any_words;
+  double t_early[4] = {t_src[0], t_src[1], t_src[2], t_src[3]};
   // Every other argument word the kernel's head reads is requested in ONE burst of scalar loads with one wait: left to itself the
   // compiler fetches each member where it is first used — a dozen s_load / s_waitcnt pairs in a row in front of the operand loads,
   // four of them on argument lines no wave of the launch had touched yet.
-  asm volatile("" ::"s"(a.pc), "s"(a.Hm), "s"(a.bm), "s"(a.HmPacked), "s"(a.step), "s"(a.ctrl), "s"(a.fej), "s"(a.use_marginal), "s"(a.dec_table),
-               "s"(a.dec_blocks), "s"(a.dec_groups), "s"(a.bs_hand), "s"(a.bs_parity), "s"(a.dec_chunks), "s"(a.bs_ticket_base));
+  // (the decision's inputs ride in the same burst and the same wait: pinned, because loads from the constant address space may otherwise
+  // be sunk to their uses behind the branches below)
+  asm volatile("" : "+s"(cin.lambda), "+s"(cin.energy), "+s"(cin.cand_prior), "+s"(cin.idepth_sq), "+s"(cin.frame_state_sq), "+s"(cin.frame_step_sq),
+               "+s"(cin.n_valid), "+s"(cin.converged), "+s"(cin.active), "+s"(cin.linear_system_valid), "+s"(cin.iteration),
+               "+s"(cin.need_final_setup), "+s"(cin.pending), "+s"(cin.relin), "+s"(t_early[0]), "+s"(t_early[1]), "+s"(t_early[2]), "+s"(t_early[3])
+               : "s"(a.pc), "s"(a.Hm), "s"(a.bm), "s"(a.HmPacked), "s"(a.step), "s"(a.ctrl), "s"(a.fej), "s"(a.use_marginal), "s"(a.dec_table),
+               "s"(a.dec_blocks), "s"(a.dec_groups), "s"(a.bs_hand), "s"(a.bs_parity), "s"(a.dec_chunks), "s"(a.bs_ticket_base), "s"(a.comb_copies),
+               "s"(a.comb_copy_first), "s"(a.comb_copy_stride));
   __shared__ unsigned s_vblock;
   // with tickets every workgroup requests the solver's operands (it does not know its role yet; the others drop them)
   bool main_wg = ticketed || blockIdx.x == 0;
@@ -189,10 +225,20 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   if (main_wg && tid < K) {
     const int f = tid >> 3, i = tid & 7;
     if (!decides) eps_c = st_p->eps[f][i];
+    if (decides) {
+      // the frame states the decision moves (read and written by the solving workgroup only): requested here with everything else — behind
+      // the control block's arrival, where they used to be requested, their round trip was 0.7 us of waiting behind the decision
+      dec_eps = st_p->eps[f][i];
+      dec_step = st_p->step[f][i];
+    }
     fixed_c = frames_p[f].fixed;
     tomarg_c = frames_p[f].to_marginalize;
     ab0_c = st_p->ab0[f][i < 6 ? 0 : i - 6];
     rhs_c = comb_p[combBlockCount(F) * 64 + tid];
+    if (COPIES > 1) {
+      for (int cp = 1; cp < a.comb_copies; ++cp)
+        rhs_c += comb_p[a.comb_copy_first + static_cast<size_t>(cp - 1) * a.comb_copy_stride + combBlockCount(F) * 64 + tid];
+    }
     if (a.use_marginal) bm_c = a.bm[tid];
   }
   // the prior energy of the candidate (kernel tail) is evaluated by the threads 64 .. 64 + K - 1, i.e. on other waves than the
@@ -221,6 +267,24 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       hv[u] = comb_p[min(e, n_entries - 1)];  // clamped, unconditional (a select around a load makes hipcc branch per element)
       hm[u] = 0;
     }
+    // (the other copies of a system accumulated in several: all requested before the first is added)
+    if (COPIES > 1) {  // (a kernel of its own: the plain one carries neither the test nor the registers)
+      double hc[COPIES > 1 ? COPIES - 1 : 1][kBatch];
+#pragma unroll
+      for (int cp = 1; cp < COPIES; ++cp) {
+        const double *cpy = comb_p + a.comb_copy_first + static_cast<size_t>(cp - 1) * a.comb_copy_stride;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) hc[cp - 1][u] = 0;
+        if (cp < a.comb_copies) {
+#pragma unroll
+          for (int u = 0; u < kBatch; ++u) hc[cp - 1][u] = cpy[min(base + tid + THREADS * u, n_entries - 1)];
+        }
+      }
+#pragma unroll
+      for (int cp = 1; cp < COPIES; ++cp)
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) hv[u] += hc[cp - 1][u];
+    }
     if (a.use_marginal) {
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) hm[u] = a.HmPacked[min(base + tid + THREADS * u, n_entries - 1)];
@@ -230,16 +294,22 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   if (decides) {
     __shared__ LmControl s_dec_out;
     __shared__ int s_dec_accept, s_dec_proceed;
-    const LmControl cin = *dec_in_p;
     double t[4] = {0, 0, 0, 0};
     if (a.dec_groups) {
       // 64 group sums per scalar -> 8 sums of 8 -> one (fixed order: identical in every workgroup and from run to run)
       __shared__ double s_grp[4 * 8];
       if (tid < 32) {
         const int e = tid >> 3, j = tid & 7;
+        // (all eight requested before the first is added: written as one running sum the compiler issued them one by one, each behind
+        // the previous one's arrival — seven memory round trips in front of every decision of a two-stage / sharded window)
+        const auto gsrc = glb(dec_scalars_p);
+        double gv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gv[k] = gsrc[4 * (8 * j + k) + e];
+        asm volatile("" : "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]), "+v"(gv[4]), "+v"(gv[5]), "+v"(gv[6]), "+v"(gv[7]));
         double sacc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sacc += dec_scalars_p[4 * (8 * j + k) + e];
+        for (int k = 0; k < 8; ++k) sacc += gv[k];
         s_grp[e * 8 + j] = sacc;
       }
       ldsBarrier();
@@ -253,19 +323,16 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
         }
       }
     } else {
-      t[0] = dec_scalars_p[0];
-      t[1] = dec_scalars_p[1];
-      t[2] = dec_scalars_p[2];
-      t[3] = dec_scalars_p[3];
-    }
-    if (main_wg && tid < K) {  // (frame states: read and written by workgroup 0 only)
-      dec_eps = st_p->eps[tid >> 3][tid & 7];
-      dec_step = st_p->step[tid >> 3][tid & 7];
+      t[0] = t_early[0];
+      t[1] = t_early[1];
+      t[2] = t_early[2];
+      t[3] = t_early[3];
     }
     if (!cin.active) {  // the loop has ended: the control block is handed on unchanged
       if (tid == 0 && (ticketed ? ticket_raw == a.bs_ticket_base : blockIdx.x == 0)) *a.ctrl = cin;
       return;
     }
+    SC_STAMP(8);
     if (tid == 0) {
       LmControl c;
       int accept = 0, proceed = 0;
@@ -276,6 +343,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       s_vblock = ticketed ? ticket_raw - a.bs_ticket_base : blockIdx.x;
     }
     ldsBarrier();
+    SC_STAMP(9);
     dec_accept = s_dec_accept;
     const unsigned vblock = s_vblock;
     main_wg = vblock == 0;
@@ -446,7 +514,10 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   SC_STAMP(0);
   if (kStamps && a.dbg_stamps && tid == 0) a.dbg_stamps[7] = sc_t_entry;
   // opaque to the optimiser: stops it from testing these loaded flags (and waiting for them) above the loads
-  asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(pp.valid), "+v"(c_active), "+v"(c_relin));
+  // (with tickets the pair inputs were requested a moment ago, behind the decision: they must NOT be waited for here — they are needed at
+  // the kernel's tail and land under the assembly and the factorisation)
+  asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(c_active), "+v"(c_relin));
+  if (!ticketed) asm volatile("" : "+v"(pp.valid));
   int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness (evaluateLinearSystemPrior, problem.hpp:39-62)
   double pd_c = 0;
   if (tid < K) {
@@ -457,26 +528,48 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     Linv[tid] = pd_c;  // prior diagonal, parked in the Linv area until the factorisation starts
     if ((tid & 7) >= 6) ab0l[2 * (tid >> 3) + (tid & 7) - 6] = ab0_c;
   }
-  __syncthreads();  // keeps every load above; prior diagonal / eps visible
+  // (an LDS-only barrier: __syncthreads() also waits for every outstanding global access — here the pair inputs just requested and the
+  // stores of the decided frame states and the control block, a memory round trip of about 1 us in front of the assembly)
+  ldsBarrier();  // keeps every load above; prior diagonal / eps visible
+  SC_STAMP(10);
   if (!c_active || c_relin) return;
   const double *prior_diag = Linv;
+  // Where entry e = base + tid + THREADS * u goes: its block index (e >> 6) is the same for the whole wave (THREADS and base are multiples
+  // of 64) and advances by THREADS / 64 per u; the position inside the block depends on the lane alone.  The block's row and column are
+  // therefore walked in scalar registers, one decode per batch (until round 5: a float square root and two dozen vector instructions per
+  // entry — 1.2 of the 1.9 us between the decision and the factorisation at 7 frames).
+  const int in_row = (tid >> 3) & 7, in_col = tid & 7;
   auto storeBatch = [&](int base) {
+    int blk = __builtin_amdgcn_readfirstlane((base + tid) >> 6);
+    int bi, bj;
+    combBlockDecode(blk, bi, bj);
+    bi = __builtin_amdgcn_readfirstlane(bi);
+    bj = __builtin_amdgcn_readfirstlane(bj);
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       const int e = base + tid + THREADS * u;
-      if (e >= n_entries) continue;
-      int bi, bj;
-      combBlockDecode(e >> 6, bi, bj);
-      const int row = 8 * bi + ((e >> 3) & 7), col = 8 * bj + (e & 7);
-      if (col > row) continue;  // upper half of a diagonal block
-      double v = hv[u] + hm[u];
-      if (row == col) {
-        v += prior_diag[row] * (1.0 + lam);  // the prior's diagonal takes the damping too (problem.hpp:347-349)
-        // The reference solves the Jacobi-scaled system p H p, p = 1/sqrt(diag + 10) (normal_linear_system.cpp:10-16,52-59).  A
-        // Cholesky factorisation is invariant under symmetric diagonal scaling, so only the zero-pivot guard refers to it
-        pv[row] = v + 10.0;
+      if (blk < n_entries / 64) {  // (wave-uniform: n_entries is a multiple of 64)
+        const int row = 8 * bi + in_row, col = 8 * bj + in_col;
+        const bool diag_blk = bi == bj;
+        if (!(diag_blk && in_col > in_row)) {  // (upper half of a diagonal block: not stored)
+          double v = hv[u] + hm[u];
+          if (diag_blk && in_row == in_col) {
+            v += prior_diag[row] * (1.0 + lam);  // the prior's diagonal takes the damping too (problem.hpp:347-349)
+            // The reference solves the Jacobi-scaled system p H p, p = 1/sqrt(diag + 10) (normal_linear_system.cpp:10-16,52-59).  A
+            // Cholesky factorisation is invariant under symmetric diagonal scaling, so only the zero-pivot guard refers to it
+            pv[row] = v + 10.0;
+          }
+          A[row * ld + col] = v;
+        }
       }
-      A[row * ld + col] = v;
+      (void)e;
+      // next block of this wave: THREADS / 64 further along the packed lower triangle
+      blk += THREADS / 64;
+      bj += THREADS / 64;
+      while (bj > bi) {
+        bj -= bi + 1;
+        ++bi;
+      }
     }
   };
   storeBatch(0);
@@ -484,6 +577,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     loadBatch(base);
     storeBatch(base);
   }
+  SC_STAMP(11);
   if (tid < K) {
     double v = rhs_c;
     if (prior_kind == 1)
@@ -498,7 +592,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     A[K * ld + tid] = v;
   }
   if (tid == 0) A[K * ld + K] = 0;
-  __syncthreads();
+  ldsBarrier();
   SC_STAMP(1);
 
   // (Measured alternatives, all slower on this part — scripts/probes/bcast_probe.hip, dbg_stamps.py: a single barrier per block
@@ -584,7 +678,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     }
   };
   if (wave == 0) factorAndPanel(0);
-  __syncthreads();
+  ldsBarrier();
   for (int kb = 0; kb < F; ++kb) {
     const int k0 = kb * kBlk, k1 = k0 + kBlk, k2 = k1 + kBlk;
     if (kb + 1 < F) {
@@ -600,7 +694,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
         A[row * ld + col] -= sacc;
       }
     }
-    __syncthreads();
+    ldsBarrier();
     if (wave == 0) {
       if (kb + 1 < F) factorAndPanel(kb + 1);
     } else {
@@ -620,7 +714,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
         }
       }
     }
-    __syncthreads();
+    ldsBarrier();
   }
   SC_STAMP(2);
   // what only the kernel's tail reads (pair-constant refresh, prior energy of the candidate) is requested HERE, to land under the

@@ -116,6 +116,13 @@ struct ReduceSchurArgs {
   // as combBlockCount(F) 8 x 8 blocks (bi >= bj) of 64 doubles, followed by b = b_pp - b_schur / (1 + lambda) (K doubles): the solve
   // kernel then loads 14 KB instead of two K x K matrices, and a sharded window all-reduces 14 KB instead of 51 KB
   double *comb;
+  // comb_copies > 1 (single-GPU windows of the fused loop): workgroup b accumulates into copy b mod comb_copies — the first at `comb`,
+  // the others comb_copy_stride doubles apart from comb + comb_copy_first — and the solve launch adds the copies while it loads them.
+  // An f64 atomic add is carried out at the memory side, one after the other per address (~85 ns each: profiles/r05/atomic_fanin_probe.txt);
+  // every entry of the 7-frame system receives one from each of the 35 landmark workgroups, and their queue — not the arithmetic — is the
+  // last 2 - 3 us of the launch.
+  int comb_copies = 1;
+  int comb_copy_first = 0, comb_copy_stride = 0;
   double comb_lambda;  // lambda when neither control block is given (isolated timing launches)
   LmParams prm;
   long long *dbg;  // nullable tuning aid
@@ -441,7 +448,8 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
   }
   // the other argument words the kernel's head reads: one burst, in flight with the control block and the descriptor
   asm volatile("" ::"s"(a.frames), "s"(a.Hpp), "s"(a.bpp), "s"(a.Hsc), "s"(a.bsc), "s"(a.for_marginalized), "s"(a.ublk_parity), "s"(a.ctrl_out),
-               "s"(a.st), "s"(a.scalars), "s"(a.n_sweep_blocks), "s"(a.scalars_out), "s"(a.scalars_out_groups), "s"(a.comb), "s"(a.comb_lambda));
+               "s"(a.st), "s"(a.scalars), "s"(a.n_sweep_blocks), "s"(a.scalars_out), "s"(a.scalars_out_groups), "s"(a.comb), "s"(a.comb_lambda), "s"(a.comb_copies),
+               "s"(a.comb_copy_first), "s"(a.comb_copy_stride));
   asm volatile("" : "+s"(hd.r), "+s"(hd.offset), "+s"(hd.n), "+s"(hd.cap), "+s"(hd_conn), "+s"(hd_ublk), "+s"(hd_flags), "+s"(c_active), "+s"(c_lsv),
                "+s"(comb_lam));
   if (!ctrl_p) {
@@ -457,6 +465,10 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
   }
   if (!c_active || c_lsv) return;
   const int F = a.F, K = kBlk * F;
+  // this workgroup's copy of the combined system (ReduceSchurArgs::comb_copies)
+  double *const comb_w = (a.comb && a.comb_copies > 1 && (blockIdx.x % a.comb_copies) != 0)
+                             ? a.comb + a.comb_copy_first + static_cast<size_t>(blockIdx.x % a.comb_copies - 1) * a.comb_copy_stride
+                             : a.comb;
   if (a.scalars_out && static_cast<int>(blockIdx.x) == a.n_schur_blocks + F * F) {
     // ---- landmark-sharded windows: one extra workgroup sums the sweep's 4 energy scalars (fixed order) into the tail of
     // the reduction buffer, so that they travel in the same collective as the systems (no separate kernel for it)
@@ -522,14 +534,14 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
       // combined system: diagonal entries carry the (1 + lambda) of calculateStep; of the two off-diagonal blocks
       // H_rt = -(G T)^T and H_tr = -G T only the one below the diagonal is kept
       const double dl = i == j ? 1.0 + comb_lam : 1.0;
-      atomicAdd(&a.comb[combBlockIndex(r, r) * 64 + lane], dl * drv[lane]);
-      atomicAdd(&a.comb[combBlockIndex(t, t) * 64 + lane], dl * lds[symIdx(i, j)]);
+      atomicAdd(&comb_w[combBlockIndex(r, r) * 64 + lane], dl * drv[lane]);
+      atomicAdd(&comb_w[combBlockIndex(t, t) * 64 + lane], dl * lds[symIdx(i, j)]);
       if (r > t)
-        atomicAdd(&a.comb[combBlockIndex(r, t) * 64 + lane], -drv[64 + 8 * j + i]);
+        atomicAdd(&comb_w[combBlockIndex(r, t) * 64 + lane], -drv[64 + 8 * j + i]);
       else
-        atomicAdd(&a.comb[combBlockIndex(t, r) * 64 + lane], -drv[64 + lane]);
+        atomicAdd(&comb_w[combBlockIndex(t, r) * 64 + lane], -drv[64 + lane]);
       if (lane < 8) {
-        double *rhs = a.comb + combBlockCount(F) * 64;
+        double *rhs = comb_w + combBlockCount(F) * 64;
         atomicAdd(&rhs[kBlk * r + lane], drv[128 + lane]);
         atomicAdd(&rhs[kBlk * t + lane], -lds[36 + lane]);
       }
@@ -702,8 +714,8 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
         if (a.comb) {
           // symmetric: the upper-triangular tile entry (row, col) lands at (col, row) of the lower-packed combined system
           const double sv = v * comb_sc;
-          if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.comb[combIndex(col, row)], sv);
-          if (bd_in_pad && row < K && col == K && v != 0) atomicAdd(&a.comb[combBlockCount(F) * 64 + row], sv);
+          if (row < K && col < K && col >= row && v != 0) atomicAdd(&comb_w[combIndex(col, row)], sv);
+          if (bd_in_pad && row < K && col == K && v != 0) atomicAdd(&comb_w[combBlockCount(F) * 64 + row], sv);
           continue;
         }
         if (row < K && col < K && col >= row && v != 0) atomicAdd(&a.Hsc[row * K + col], v);
@@ -717,7 +729,7 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
       for (int ll = 0; ll < kSchurLandmarks; ++ll) s += wbd[ll] * hrow[ll * stride + c];
       if (s != 0) {
         if (a.comb)
-          atomicAdd(&a.comb[combBlockCount(F) * 64 + c], s * comb_sc);
+          atomicAdd(&comb_w[combBlockCount(F) * 64 + c], s * comb_sc);
         else
           atomicAdd(&a.bsc[c], s);
       }

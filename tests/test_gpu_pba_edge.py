@@ -521,6 +521,53 @@ def test_idepth_back_substitution_inside_the_solve_launch_equals_the_kernel_flow
         assert int(a[f"{name}_5"]) == int(b[f"{name}_5"]) and abs(float(a[f"{name}_6"]) - float(b[f"{name}_6"])) <= 1e-9 * abs(float(b[f"{name}_6"])), name
 
 
+_COMB_COPIES_SCRIPT = r"""
+import sys
+import numpy as np
+from dsopp_amd import capi, synthetic as syn
+out = {}
+for name, (F, P, W, H, seed) in {"small": (5, 600, 320, 240, 3), "seven": (7, 2000, 320, 240, 11), "mid": (7, 6000, 640, 480, 7)}.items():
+    win = syn.make_window(num_frames=F, num_points=P, width=W, height=H, seed=seed)
+    g = capi.HipWindow(capi.default_pba_options()); syn.load_window(g, win)
+    e, it, nv = g.solve()
+    poses = np.concatenate([np.concatenate(g.get_pose(f.frame_id)) for f in win.frames])
+    idepths = np.concatenate([g.get_landmarks(f.frame_id, with_hpib=False)["idepth"] for f in win.frames])
+    g.snapshot(); g.restore()
+    n, e_rep = g.optimize_repeated(14)
+    out[name] = (e, it, nv, poses, idepths, n, e_rep)
+    g.close()
+np.savez(sys.argv[1], **{f"{k}_{i}": np.asarray(v) for k, t in out.items() for i, v in enumerate(t)})
+print("comb copies ok")
+"""
+
+
+def test_combined_system_accumulated_in_several_copies_equals_the_single_copy(tmp_path):
+    """The reduction launch of an unsharded window on the atomics path may spread its f64 atomics over several copies of the combined
+    system, which the solve launch adds while loading (pba.hip: comb_copies_active; by default from 80 chunks of 64 landmarks up to the
+    two-stage threshold, at most 7 keyframes).  Forced on for every window (DSOPP_HIP_COMB_COPIES_MIN_CHUNKS=1, read once per process)
+    with 4 and with 2 copies against the single copy: same iterations and residual counts, energies / poses / inverse depths to rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for copies in ("1", "2", "4"):
+        path = str(tmp_path / f"copies{copies}.npz")
+        env = dict(os.environ, DSOPP_HIP_COMB_COPIES=copies, DSOPP_HIP_COMB_COPIES_MIN_CHUNKS="1", PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _COMB_COPIES_SCRIPT, path], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "comb copies ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        res[copies] = np.load(path)
+    b = res["1"]
+    for copies in ("2", "4"):
+        a = res[copies]
+        for name in ("small", "seven", "mid"):
+            assert int(a[f"{name}_1"]) == int(b[f"{name}_1"]) and int(a[f"{name}_2"]) == int(b[f"{name}_2"]), (copies, name)
+            assert abs(float(a[f"{name}_0"]) - float(b[f"{name}_0"])) <= 1e-9 * abs(float(b[f"{name}_0"])), (copies, name)
+            assert np.abs(a[f"{name}_3"] - b[f"{name}_3"]).max() <= 1e-9, (copies, name)
+            assert np.abs(a[f"{name}_4"] - b[f"{name}_4"]).max() <= 1e-8 * max(1.0, np.abs(b[f"{name}_4"]).max()), (copies, name)
+            assert int(a[f"{name}_5"]) == int(b[f"{name}_5"]) and abs(float(a[f"{name}_6"]) - float(b[f"{name}_6"])) <= 1e-9 * abs(float(b[f"{name}_6"])), (copies, name)
+
+
 def test_residual_list_that_ends_inside_a_landmark_batch():
     """The device keeps every appended batch of landmarks in its own spatial order (pba.hip: HostFrame::to_internal) under the invariant
     that the device's first n landmarks are the caller's first n wherever a residual list ends.  Here lists end INSIDE a batch (60 and
