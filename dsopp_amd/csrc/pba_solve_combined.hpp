@@ -629,17 +629,22 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
     int e = 0;
-#pragma unroll
-    for (int k = 0; k < kBlk; ++k) {
-      const double d = readLane(c[k], k);
-      // inv = 1/sqrt(d) from the hardware estimate + two Newton steps; pivots whose Jacobi-scaled value d / (diag + 10) is
-      // below 1e-30 are treated as zero, as a rank-revealing factorisation would
-      const bool okp = d > guard[k];
-      // (v_rsq_f64 seed, 2^-23 relative, straight on the f64 pivot: the f32 seed cost two conversions on the dependent chain)
+    // inverse square root of a pivot: the hardware estimate (v_rsq_f64, 2^-23 relative, straight on the f64 value: an f32 seed costs two
+    // conversions on the dependent chain) + two Newton steps
+    auto rsqrtRefined = [](double d) {
       const double hd = 0.5 * d;
       double inv = __builtin_amdgcn_rsq(d);
       inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
       inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
+      return inv;
+    };
+#ifndef DSOPP_HIP_PAIRED_PIVOTS
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) {
+      const double d = readLane(c[k], k);
+      // pivots whose Jacobi-scaled value d / (diag + 10) is below 1e-30 are treated as zero, as a rank-revealing factorisation would
+      const bool okp = d > guard[k];
+      double inv = rsqrtRefined(d);
       inv = okp ? inv : 0.0;
       invd[k] = inv;
       const double l = c[k] * inv;  // lane k: sqrt(d); lanes i > k: l_ik
@@ -651,6 +656,55 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
         c[j] -= l * ljk;
       }
     }
+#else
+    // (-DDSOPP_HIP_PAIRED_PIVOTS: built, parity-green, measured and NOT the default — round 5.)  Pivots eliminated in PAIRS, on the
+    // assumption that the panel wave's time is the dependent chain pivot -> 1/sqrt (estimate + two Newton steps: 7 dependent operations)
+    // -> column -> broadcast -> update -> next pivot.  It is not: the wave issues an instruction every ~4.7 cycles (a v_readlane ~8)
+    // whether or not it depends on the previous one (scripts/probes/clock_probe.hip: 4.70 cycles per dependent f64 fma at 2.33 - 2.40
+    // GHz), and this form has more instructions (the extra broadcast of b, a cc - b^2, the selects): stamps, factor + panel summed over the 7
+    // block steps of a 7-frame window 7.8 - 8.3 us against 6.8 - 7.0 us; the solve launch in the loop 19.45 against 18.29 us
+    // (profiles/r05/paired_pivots_ab.txt).  For the pivots k, k + 1 both inverse square roots can be started
+    // from values that are known at the same time: with a = c_kk, b = c_(k+1)k, cc = c_(k+1)(k+1) the second pivot is
+    // d2 = cc - b^2 / a = (a cc - b^2) / a, so 1/sqrt(d2) = sqrt(a) / sqrt(a cc - b^2) = (a / sqrt(a)) * rsqrt(a cc - b^2): the two
+    // refinements run side by side and the chain is walked four times per block instead of eight.  The updates themselves are those of
+    // the pivot-by-pivot loop, in the same order (l_(k+1)k = b / sqrt(a) is formed from the broadcast b instead of being broadcast).
+    // Zero-pivot guards as before: a pivot whose Jacobi-scaled value d / (diag + 10) is below 1e-30 is treated as zero; for the second
+    // one the test d2 > g reads a cc - b^2 > g a, and behind a zero first pivot (nothing is eliminated) d2 = cc.
+    double ljm[kBlk][kBlk];  // l_jk of the diagonal block (uniform), for the rows beyond 64
+#pragma unroll
+    for (int k = 0; k < kBlk; k += 2) {
+      const double a0 = readLane(c[k], k), b0 = readLane(c[k], k + 1), cc0 = readLane(c[k + 1], k + 1);
+      const bool ok1 = a0 > guard[k];
+      const double s0 = fma(a0, cc0, -(b0 * b0));
+      const bool ok2 = ok1 ? s0 > guard[k + 1] * a0 : cc0 > guard[k + 1];
+      double inv1 = rsqrtRefined(a0);
+      double r2 = rsqrtRefined(ok1 ? s0 : cc0);
+      inv1 = ok1 ? inv1 : 0.0;
+      double inv2 = ok1 ? r2 * (a0 * inv1) : r2;
+      inv2 = ok2 ? inv2 : 0.0;
+      invd[k] = inv1;
+      invd[k + 1] = inv2;
+      const double l0 = c[k] * inv1;       // lane k: sqrt(a); lanes i > k: l_ik
+      const double l10 = b0 * inv1;        // l_(k+1)k (uniform)
+      ljm[k][k + 1] = l10;
+      c[k] = l0;
+      c[k + 1] -= l0 * l10;
+      const double l1 = c[k + 1] * inv2;   // lane k + 1: sqrt(d2); lanes i > k + 1: l_i(k+1)
+      c[k + 1] = l1;
+#pragma unroll
+      for (int j = k + 2; j < kBlk; ++j) {
+        const double lj0 = readLane(l0, j), lj1 = readLane(l1, j);
+        ljm[k][j] = lj0;
+        ljm[k + 1][j] = lj1;
+        c[j] -= l0 * lj0;
+        c[j] -= l1 * lj1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k)
+#pragma unroll
+      for (int j = k + 1; j < kBlk; ++j) lj[e++] = ljm[k][j];
+#endif
     if (valid) {
       double *dst = A + row * ld + k0;
 #pragma unroll
@@ -677,8 +731,19 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];  // diagonal of the inverse; completed below
     }
   };
+  // (tuning aid, stamps build: where the panel wave's time goes over the block steps — slots 12 column update, 13 its barrier, 14 factor +
+  // panel, 15 the barrier behind it)
+  long long cs_acc[4] = {0, 0, 0, 0}, cs_t = (kStamps && a.dbg_stamps) ? wall_clock64() : 0;
+  auto csMark = [&](int slot) {
+    if (kStamps && a.dbg_stamps) {
+      const long long now = wall_clock64();
+      cs_acc[slot] += now - cs_t;
+      cs_t = now;
+    }
+  };
   if (wave == 0) factorAndPanel(0);
   ldsBarrier();
+  csMark(2);
   for (int kb = 0; kb < F; ++kb) {
     const int k0 = kb * kBlk, k1 = k0 + kBlk, k2 = k1 + kBlk;
     if (kb + 1 < F) {
@@ -694,9 +759,12 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
         A[row * ld + col] -= sacc;
       }
     }
+    csMark(0);
     ldsBarrier();
+    csMark(1);
     if (wave == 0) {
       if (kb + 1 < F) factorAndPanel(kb + 1);
+      csMark(2);
     } else {
       // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (the other waves as a 12 x 16 / 28 x 16 tile)
       const int t = tid - 64, tr = t >> 4, tc = t & 15;
@@ -715,6 +783,10 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       }
     }
     ldsBarrier();
+    csMark(3);
+  }
+  if (kStamps && a.dbg_stamps && tid == 0) {
+    for (int q = 0; q < 4; ++q) a.dbg_stamps[12 + q] = cs_acc[q];
   }
   SC_STAMP(2);
   // what only the kernel's tail reads (pair-constant refresh, prior energy of the candidate) is requested HERE, to land under the

@@ -18,6 +18,7 @@ print(f"solve: entry -> operands + decision {st[0]-st[7]:.2f}  loads+assemble {s
       f"total {st[5]-st[0]:.2f}")
 rs = st[24:]
 print(f"solve head: entry -> control block here {st[8]-st[7]:.2f} -> decided {st[9]-st[8]:.2f} -> states stored (stamp 0) {st[0]-st[9]:.2f} -> first barrier {st[10]-st[0]:.2f} -> system stored {st[11]-st[10]:.2f} -> rhs + barrier {st[1]-st[11]:.2f}")
+print(f"cholesky, panel wave, summed over the block steps: column update {st[12]:.2f}  barrier {st[13]:.2f}  factor + panel {st[14]:.2f}  barrier behind it {st[15]:.2f}")
 print("reduceSchur (wg 1) stamps us:", np.round(rs[:8] - rs[0], 2))
 ts = st[32:40]
 print("schurTwoStage (wg 1, first chunk) stamps us:", np.round(ts - ts[0], 2), "(0 chunk start, 1 rows cleared + flags, 2 phase 1 done, 3 barrier, 4 MFMA done, 5 b_schur done, 6 all chunks done, 7 partial written)")
