@@ -539,30 +539,37 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   // therefore walked in scalar registers, one decode per batch (until round 5: a float square root and two dozen vector instructions per
   // entry — 1.2 of the 1.9 us between the decision and the factorisation at 7 frames).
   const int in_row = (tid >> 3) & 7, in_col = tid & 7;
+  // (an entry's LDS address = the block's offset — scalar — + the thread's offset inside a block — computed once; the divergent tests for the
+  // diagonal and the upper triangle exist only in diagonal blocks, behind a scalar branch.  The first scalar-walk version still spent ~45
+  // instructions per entry — row x ld as a vector integer multiply, two exec-mask regions — i.e. 1 us per batch of 8 on an
+  // instruction-bound workgroup.)
+  double *const A_thr = A + in_row * ld + in_col;
   auto storeBatch = [&](int base) {
     int blk = __builtin_amdgcn_readfirstlane((base + tid) >> 6);
     int bi, bj;
     combBlockDecode(blk, bi, bj);
     bi = __builtin_amdgcn_readfirstlane(bi);
     bj = __builtin_amdgcn_readfirstlane(bj);
+    const int n_blocks = n_entries >> 6;
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      const int e = base + tid + THREADS * u;
-      if (blk < n_entries / 64) {  // (wave-uniform: n_entries is a multiple of 64)
-        const int row = 8 * bi + in_row, col = 8 * bj + in_col;
-        const bool diag_blk = bi == bj;
-        if (!(diag_blk && in_col > in_row)) {  // (upper half of a diagonal block: not stored)
-          double v = hv[u] + hm[u];
-          if (diag_blk && in_row == in_col) {
-            v += prior_diag[row] * (1.0 + lam);  // the prior's diagonal takes the damping too (problem.hpp:347-349)
+      if (blk < n_blocks) {  // (wave-uniform)
+        const int blk_off = __builtin_amdgcn_readfirstlane(8 * bi * ld + 8 * bj);
+        const double v = hv[u] + hm[u];
+        if (bi != bj) {  // (wave-uniform)
+          A_thr[blk_off] = v;
+        } else if (in_col <= in_row) {  // diagonal block: the lower triangle is stored, the diagonal takes the prior and feeds the guard
+          double vd = v;
+          if (in_row == in_col) {
+            const int row = 8 * bi + in_row;
+            vd += prior_diag[row] * (1.0 + lam);  // the prior's diagonal takes the damping too (problem.hpp:347-349)
             // The reference solves the Jacobi-scaled system p H p, p = 1/sqrt(diag + 10) (normal_linear_system.cpp:10-16,52-59).  A
             // Cholesky factorisation is invariant under symmetric diagonal scaling, so only the zero-pivot guard refers to it
-            pv[row] = v + 10.0;
+            pv[row] = vd + 10.0;
           }
-          A[row * ld + col] = v;
+          A_thr[blk_off] = vd;
         }
       }
-      (void)e;
       // next block of this wave: THREADS / 64 further along the packed lower triangle
       blk += THREADS / 64;
       bj += THREADS / 64;
