@@ -951,14 +951,18 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     // windows of up to 8 keyframes: the K prior threads are ONE wave (wave 1), which sums and writes the control block on its own while
     // wave 0 is still refreshing pair constants — no barrier, nothing behind the refresh on the workgroup's critical path
     // (bitwise the sums of the general form below: the other waves contribute exact zeros)
-    part = waveSum(part);
-    nstate = waveSum(nstate);
-    nstep = waveSum(nstep);
-    if (tid == 64) {
-      a.ctrl->cand_prior = a.energy_marginalized + part;
-      a.ctrl->frame_state_sq = nstate;
-      a.ctrl->frame_step_sq = nstep;
-      a.ctrl->pending = 1;
+    // (wave 1 alone: the other waves hold exact zeros — and wave 0, which has just finished the pair constants, would spend another
+    // 0.45 us of the launch's tail on three wave sums of zeros: it is the last wave to finish)
+    if (wave == 1) {
+      part = waveSum(part);
+      nstate = waveSum(nstate);
+      nstep = waveSum(nstep);
+      if (tid == 64) {
+        a.ctrl->cand_prior = a.energy_marginalized + part;
+        a.ctrl->frame_state_sq = nstate;
+        a.ctrl->frame_step_sq = nstep;
+        a.ctrl->pending = 1;
+      }
     }
   } else if (a.ctrl) {
     part = waveSum(part);
