@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       }
       st_p->step[tid >> 3][tid & 7] = 0;
     }
-    if (tid == 0) *a.ctrl = s_dec_out;
+    if (tid == 64) *a.ctrl = s_dec_out;  // (a lane of wave 1, which has nothing else to do here: wave 0 stores the decided states and requests the pair inputs)
     if (!s_dec_proceed) return;
     c_active = 1;
     c_relin = s_dec_out.relin;
