@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
                "+s"(cin.need_final_setup), "+s"(cin.pending), "+s"(cin.relin), "+s"(t_early[0]), "+s"(t_early[1]), "+s"(t_early[2]), "+s"(t_early[3])
                : "s"(a.pc), "s"(a.Hm), "s"(a.bm), "s"(a.HmPacked), "s"(a.step), "s"(a.ctrl), "s"(a.fej), "s"(a.use_marginal), "s"(a.dec_table),
                "s"(a.dec_blocks), "s"(a.dec_groups), "s"(a.bs_hand), "s"(a.bs_parity), "s"(a.dec_chunks), "s"(a.bs_ticket_base), "s"(a.comb_copies),
-               "s"(a.comb_copy_first), "s"(a.comb_copy_stride));
+               "s"(a.comb_copy_first), "s"(a.comb_copy_stride), "s"(a.lambda), "s"(a.affine_reg[0]), "s"(a.affine_reg[1]), "s"(a.fixed_reg),
+               "s"(a.energy_marginalized));
   __shared__ unsigned s_vblock;
   // with tickets every workgroup requests the solver's operands (it does not know its role yet; the others drop them)
   bool main_wg = ticketed || blockIdx.x == 0;
@@ -219,7 +220,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   // (with tickets the role is unknown here and these 22 doubles would be live across the landmark workgroups' register-hungry branch:
   // the compiler spilled them at the head and reloaded them in front of the pair refresh; the solver requests them once it knows
   // what it is — they are not needed before the kernel's tail)
-  if (!ticketed && main_wg) requestPairInputs();
+  // (requested at ONE place, behind the decision — below: with a second request here for the launches without tickets the two sets of loaded
+  // values met in different registers where the paths join, and the copies that unify them wait for the loads: a full memory round trip
+  // in front of the assembly, on every launch)
   double eps_c = 0, ab0_c = 0, rhs_c = 0, bm_c = 0;  // this thread's entry c = tid (K <= 128 < THREADS)
   int fixed_c = 0, tomarg_c = 0;
   if (main_wg && tid < K) {
@@ -492,7 +495,6 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       return;
     }
     // workgroup 0: the frame states and the outgoing control block, then the solve at the decided state
-    if (ticketed) requestPairInputs();
     if (cin.pending && tid < K) {
       if (dec_accept) {
         dec_eps += dec_step;
@@ -517,12 +519,11 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   // (with tickets the pair inputs were requested a moment ago, behind the decision: they must NOT be waited for here — they are needed at
   // the kernel's tail and land under the assembly and the factorisation)
   asm volatile("" : "+v"(fixed_c), "+v"(tomarg_c), "+v"(c_active), "+v"(c_relin));
-  if (!ticketed) asm volatile("" : "+v"(pp.valid));
   int prior_kind = 0;  // 0 none, 1 fixed frame, 2 affine brightness (evaluateLinearSystemPrior, problem.hpp:39-62)
   double pd_c = 0;
   if (tid < K) {
     if (!tomarg_c) prior_kind = fixed_c ? 1 : ((tid & 7) >= 6 ? 2 : 0);
-    pd_c = prior_kind == 1 ? a.fixed_reg : (prior_kind == 2 ? a.affine_reg[(tid & 7) - 6] : 0.0);
+    pd_c = prior_kind == 1 ? a.fixed_reg : (prior_kind == 2 ? ((tid & 7) == 6 ? a.affine_reg[0] : a.affine_reg[1]) : 0.0);  // (no dynamic index: that is a vector load of the argument block)
     xs[tid] = eps_c;
     epsl[tid] = eps_c;
     Linv[tid] = pd_c;  // prior diagonal, parked in the Linv area until the factorisation starts
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     if (prior_kind == 1)
       v += a.fixed_reg * eps_c;
     else if (prior_kind == 2)
-      v += a.affine_reg[(tid & 7) - 6] * (ab0_c + eps_c);
+      v += ((tid & 7) == 6 ? a.affine_reg[0] : a.affine_reg[1]) * (ab0_c + eps_c);
     if (a.use_marginal) {
       double s = 0;
       for (int k = 0; k < K; ++k) s += a.Hm[tid * K + k] * xs[k];
@@ -601,6 +602,12 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   if (tid == 0) A[K * ld + K] = 0;
   ldsBarrier();
   SC_STAMP(1);
+  // The pair inputs (needed at the kernel's tail) are requested HERE: the factorisation and the back-substitution below touch LDS only, so
+  // nothing waits for these loads before the tail.  Requested in the head — at either of the two places they have been — something always
+  // did: the copies that unify two request sites' registers where the paths join, the test of P.valid (which the compiler evaluates as soon
+  // as the word is loaded unless it is pinned at its use), a kernel-argument array read through a vector load with vmcnt(0) behind it —
+  // each a memory round trip on the solving workgroup's path.
+  if (main_wg) requestPairInputs();
 
   // (Measured alternatives, all slower on this part — scripts/probes/bcast_probe.hip, dbg_stamps.py: a single barrier per block
   // step with the panel wave applying the previous panel to its own column: 10.2 us against 9.2 us for the 7-frame window; L D L^T
@@ -894,7 +901,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     }
     if ((pc & 7) >= 6) {
       const double ab = ab0_p + xc;
-      part += 0.5 * ab * a.affine_reg[(pc & 7) - 6] * ab;
+      part += 0.5 * ab * ((pc & 7) == 6 ? a.affine_reg[0] : a.affine_reg[1]) * ab;
     }
     nstate = epsl[pc] * epsl[pc] + ((pc & 7) >= 6 ? ab0_p * ab0_p : 0.0);
     nstep = stpl[pc] * stpl[pc];
@@ -912,6 +919,7 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       E[tid] = rigidExp(xi);
     }
     ldsBarrier();
+    asm volatile("" : "+v"(pp.valid));  // (tested here, not where it was loaded)
     if (tid < F * F && pp.valid) {
       const int r = tid / F, t = tid - F * (tid / F);
       PairConst &P = a.pc[r * kMaxFrames + t];
