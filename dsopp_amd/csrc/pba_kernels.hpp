@@ -795,6 +795,7 @@ const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
     }
   }
   if (!evaluate) energy = 0;
+  SWEEP_STAMP(10);
 
   if (LIN) {
     double gj[kBlk + 2];  // w * g (8), then hdd, bd contributions
@@ -844,7 +845,9 @@ const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
       gj[8] = wgt * jdd * jdd;
       gj[9] = wgt * jdd * rk;
     }
+    SWEEP_STAMP(11);
     gramPublish(ga, gb, gram_rows);
+    SWEEP_STAMP(12);
     // per-item Schur quantities: sum over the 8 pixels; h_p block of target t is w * J_t^T J_d = -u
     // (hessian_block_evaluation.hpp:207-208), zero for invalid residuals (:190-192).  Transposed butterfly: in every step a lane
     // keeps one value of a pair and hands the other to its partner, so the 8 totals end up one per lane (lane k holds entry
@@ -875,6 +878,7 @@ const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
       }
     }
   }
+  SWEEP_STAMP(13);
   // NEW_EVALUATION_POINT bookkeeping (lane 0 of the item)
   if (active && k == 0) {
     g_energy[i] = energy;
@@ -892,6 +896,7 @@ const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
   }
   }  // groups
   // the last group's rows (a padding entry of the XCD-banded launch order has no group: nothing was published, its sums stay zero)
+  SWEEP_STAMP(14);
   if (LIN && be.n_groups > 0) gramContract(gram_lds + (threadIdx.x >> 6) * 64 * kGramStride, gram);
   SWEEP_STAMP(4);
   double *out = partials + static_cast<size_t>(be.partial_row) * kPartial;
