@@ -402,8 +402,8 @@ def main():
         cpu_baseline = run_cpu_baseline(args, F, P, win, syn)
 
     if rank == 0:
-        # `roofline.frac` is priced with the rocprofv3 figure of the kernel AS THE LOOP RUNS IT (committed kernel_stats csv of the same
-        # command under profiles/): the event-bracketed back-to-back launches measured above are the live cross-check (`frac_events`)
+        # the committed rocprofv3 figure of the kernel AS THE LOOP RUNS IT (kernel_stats csv of the same command under profiles/) rides
+        # along as `frac_profile`; `roofline.frac` itself is the event-bracketed measurement of this run
         prof_roof = profile_roofline(b_lin) if (F, P_local, args.dtype) == (7, 2000, "f64") else None
         in_loop = (prof_roof or {}).get("in_loop")
         frac_events = achieved / HBM_PEAK_GBS
@@ -437,12 +437,15 @@ def main():
                        "exchange": job.transport, "ranks": world,
                        # the launcher's world size above; what the communicator itself counts (ncclCommCount) when the native one is in use
                        "ranks_comm": job.comm.size() if job.comm is not None else None},
-            "roofline": {"bound": "hbm", "kernel": "sweep_linearize_loop (sweepKernel<S, LIN = true, FEJ, HUBER, BACKSUB = false>: the linearisation sweep as the LM loop launches it)",
-                         "achieved": (b_lin / (in_loop["avg_us"] * 1e-6) / 1e9) if in_loop else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": in_loop["frac"] if in_loop else frac_events,
-                         "frac_source": (f"{in_loop['source']}: average duration of the kernel inside the bench loop under rocprofv3 --kernel-trace --stats "
-                                         f"({in_loop['calls']} launches)") if in_loop else "HIP events of this run (no committed kernel_stats csv found)",
-                         "frac_events": frac_events, "achieved_events": achieved,
+            # `frac` / `achieved` / `avg_launch_us` are THIS run's measurement: HIP events on the library's stream around 200 back-to-back
+            # launches of the kernel as the loop configures it.  `frac_profile` is the committed rocprofv3 --kernel-trace --stats average of
+            # the kernel inside the bench loop (profiles/, file and commit named) — the cross-check, never the headline figure.
+            "roofline": {"bound": "hbm", "kernel": "sweepKernel<double,LIN,FEJ,HUBER> (linearisation sweep as the LM loop launches it)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac_events,
+                         "frac_source": "HIP events of this run on the library's stream, 200 back-to-back launches",
+                         "frac_profile": in_loop["frac"] if in_loop else None,
+                         "profile_source": in_loop["source"] if in_loop else None,
+                         "profile_commit": in_loop["committed_at"] if in_loop else None,
                          "traffic": traffic, "traffic_detail": traffic_detail,
                          "algorithmic_bytes_per_launch": b_lin, "avg_launch_us": lin_avg_s * 1e6,
                          "mfma": load_mfma_utilisation(),
@@ -474,9 +477,67 @@ def main():
         if cpu_baseline is not None:
             line["cpu_baseline"] = cpu_baseline
             line["speedup_vs_cpu_port"] = line["value"] / cpu_baseline["value"]
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        headline, extras_path = emit(line)
+        os.write(json_fd, (json.dumps(headline, separators=(",", ":")) + "\n").encode())
     g.close()
     job.close()
+
+
+HEADLINE_MAX_BYTES = 4096   # the driver keeps an 8 KB tail of stdout: the ONE stdout line must fit it with room to spare
+
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_s", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "speedup", "speedup_vs_cpu_port")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us",
+                 "frac_source", "frac_profile", "profile_source", "profile_commit", "iteration_frac")
+
+
+def make_headline(line):
+    """The compact form of the result that goes to stdout: the driver's contract keys + roofline + cpu_baseline and nothing else.  Everything
+    the run measured beside the headline (stage table, tracker, tick sequences, large windows, ...) stays in `line`, which emit() writes to
+    bench_extras.json.  Raises when the result would not fit HEADLINE_MAX_BYTES: a line the driver cannot parse is worth nothing."""
+    head = {k: line[k] for k in HEADLINE_KEYS if k in line}
+    cfg = line.get("config") or {}
+    head["config"] = {k: cfg[k] for k in ("workload", "name", "frames", "points_per_gpu", "total_points", "parallelism", "exchange", "ranks") if k in cfg}
+    roof = line.get("roofline") or {}
+    head["roofline"] = {k: roof[k] for k in ROOFLINE_KEYS if k in roof}
+    if "same_workload_1gpu" in line:
+        head["same_workload_1gpu"] = line["same_workload_1gpu"].get("value")
+    cpu = line.get("cpu_baseline")
+    if cpu is not None:
+        head["cpu_baseline"] = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cpu}
+        head["cpu_baseline"]["sample"] = str(head["cpu_baseline"].get("sample", ""))[:400]
+    # BASELINE.json's second metric, when the run measured it (N = 1 with extras): frame-tracking ms / frame at 1280x1024
+    trk = {}
+    for key, name in (("tracker", "5_levels"), ("tracker_4_levels", "4_levels")):
+        if isinstance(line.get(key), dict) and "ms_per_frame" in line[key]:
+            trk[name] = line[key]["ms_per_frame"]
+    if trk:
+        head["frame_tracking_ms_per_frame_1280x1024"] = trk
+    if "extras_file" in line:
+        head["extras_file"] = line["extras_file"]
+    text = json.dumps(head, separators=(",", ":"))
+    if len(text) > HEADLINE_MAX_BYTES:
+        raise RuntimeError(f"bench headline is {len(text)} bytes (> {HEADLINE_MAX_BYTES}): trim it, the driver keeps an 8 KB tail only")
+    return head
+
+
+def emit(line):
+    """writes the full result to bench_extras.json (repo root; also gpurun_out/ when that exists, so that it travels back from a GPU box) and to
+    stderr, and returns (headline, path)"""
+    line["extras_file"] = "bench_extras.json"
+    head = make_headline(line)
+    full = json.dumps(line, indent=1)
+    path = os.path.join(ROOT, "bench_extras.json")
+    for p in (path, os.path.join(ROOT, "gpurun_out", "bench_extras.json")):
+        try:
+            if os.path.isdir(os.path.dirname(p)):
+                with open(p, "w") as fh:
+                    fh.write(full + "\n")
+        except OSError as exc:
+            print(f"[bench] could not write {p}: {exc}", file=sys.stderr)
+    print("[bench] full result (also in bench_extras.json):", file=sys.stderr)
+    print(json.dumps(line), file=sys.stderr)
+    return head, path
 
 
 def run_window_group(job, args):
@@ -522,6 +583,17 @@ def run_window_group(job, args):
     return out
 
 
+PROFILE_ROUNDS = ("r06", "r05", "r04")   # newest first: a figure read from profiles/ always names the file (and its commit) it came from
+
+
+def newest_profile(name):
+    """relative path (under profiles/) of the newest round's copy of `name`, or None"""
+    for rnd in PROFILE_ROUNDS:
+        if os.path.exists(os.path.join(ROOT, "profiles", rnd, name)):
+            return os.path.join(rnd, name)
+    return None
+
+
 def load_profile_kernel_avg_us(csv_name, needle):
     """average duration (us) of the kernel whose name contains `needle` in a committed rocprofv3 kernel_stats csv under profiles/"""
     import csv
@@ -542,6 +614,11 @@ def _committed_at(rel_path):
     """commit and date a tracked profile file was last written at (None outside a git checkout, e.g. on the GPU box): a reader can see how
     old the figure `roofline.frac` is priced with is — the kernel may have changed since"""
     import subprocess
+    # the profile scripts stamp the commit of the build they measured next to their output (there is no .git on the GPU box)
+    stamp = os.path.join(ROOT, os.path.dirname(rel_path), "BUILD_COMMIT.txt")
+    if os.path.exists(stamp):
+        with open(stamp) as fh:
+            return fh.read().strip() or None
     try:
         r = subprocess.run(["git", "log", "-1", "--format=%h %cI", "--", rel_path], cwd=ROOT, capture_output=True, text=True, timeout=10)
         return r.stdout.strip() or None
@@ -554,7 +631,8 @@ def profile_roofline(b_lin):
     for key, csv_name in (("isolated_launches", "c1_isolated_kernel_stats.csv"), ("in_loop", "c1_kernel_stats.csv")):
         # newest first: since the back-substitution moved into the solve launch the loop runs the plain linearisation variant; before
         # that the BACKSUB variant (whose template argument list lost an argument in round 4)
-        for alt, needle in ((os.path.join("r05", csv_name), "sweepKernel<double, true, true, true, false, false>"),
+        for alt, needle in ((os.path.join("r06", csv_name), "sweepKernel<double, true, true, true, false, false>"),
+                            (os.path.join("r05", csv_name), "sweepKernel<double, true, true, true, false, false>"),
                             (os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, false, false>"),
                             (os.path.join("r04", csv_name), "sweepKernel<double, true, true, true, true, false>"),
                             (os.path.join("r03", "c_" + csv_name), "sweepKernel<double, true, true, true, true, false, false>")):
@@ -570,11 +648,14 @@ def load_mfma_utilisation():
     """f64 matrix-core figures of the kernels that use them, from the committed SQ counter passes (scripts/mfma_utilisation.py ->
     profiles/r04/mfma_utilisation.json): instruction counts, busy cycles of the matrix pipe against the kernel's cycles, achieved
     TFLOP/s against AMD's 78.6 TFLOP/s fp64-matrix figure for MI355X (MI355X_MICROARCH.md lists no fp64 row)"""
-    path = os.path.join(ROOT, "profiles", "r04", "mfma_utilisation.json")
+    rel = newest_profile("mfma_utilisation.json")
+    if rel is None:
+        return None
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, "profiles", rel)) as fh:
             d = json.load(fh)
-        d["source"] = "profiles/r04/mfma_utilisation.json"
+        d["source"] = f"profiles/{rel}"
+        d["committed_at"] = _committed_at(os.path.join("profiles", rel))
         return d
     except (OSError, ValueError):
         return None
@@ -584,7 +665,7 @@ def load_pmc_traffic(F, P, args):
     """per-launch HBM bytes of the in-loop linearisation sweep from the committed counter run (profiles/, newest round first)"""
     if (F, P, args.width, args.height, args.dtype, args.workload) != (7, 2000, 640, 480, "f64", "c1"):
         return None, None
-    for name in (os.path.join("r05", "pmc_traffic_c1.json"), os.path.join("r04", "pmc_traffic_c1.json"), os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in (os.path.join("r06", "pmc_traffic_c1.json"), os.path.join("r05", "pmc_traffic_c1.json"), os.path.join("r04", "pmc_traffic_c1.json"), os.path.join("r03", "pmc_traffic_c1.json"), "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         pmc_file = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pmc_file):
             continue
@@ -703,7 +784,7 @@ def run_large_window_roofline(capi, syn, dtype, s_bytes):
     # The generator lists a frame's landmarks in the order random pixels were drawn in; since round 5 the library keeps its own order on the
     # device (every appended batch sorted into 32 x 32-pixel tiles), so this IS the spatially ordered sweep the round-4 line
     # reported as an extra.  The loop's own sweep launches (rocprofv3 timeline of one solve, committed):
-    rel = os.path.join("r05", "large_loop_one_solve_timeline.csv")
+    rel = newest_profile("large_loop_one_solve_timeline.csv") or os.path.join("r05", "large_loop_one_solve_timeline.csv")
     try:
         durs = []
         with open(os.path.join(ROOT, "profiles", rel)) as fh:
