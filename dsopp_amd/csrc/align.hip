@@ -398,12 +398,11 @@ struct AlignSweepCtx {
   double sigma;
 };
 
+/** per-pass constants from the candidate pose and the reference camera's reciprocal intrinsics (per-level constants of the persistent
+ *  kernel: four f64 divisions less per pass) */
 template <typename S>
-__device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const AlignFrameDev &ref, const AlignFrameDev &tgt, const AlignControl &sc,
-                                                const AlignParams &prm) {
-  const double *T = sc.cand_T;
-  // ArrayReprojector ctor — camera_reproject.hpp:235-260
-  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
+__device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const AlignFrameDev &ref, const AlignFrameDev &tgt, const double *T, double cand_ab0,
+                                                double cand_ab1, double sigma, double ifx, double ify, double k02, double k12, double s_ratio) {
   double Ud[12];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -420,8 +419,8 @@ __device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const Align
     x.M[4 + j] = S(tgt.fy * Ud[4 + j] + tgt.cy * Ud[8 + j]);
     x.M[8 + j] = S(Ud[8 + j]);
   }
-  const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
-  x.s_ratio = tgt.exposure / ref.exposure;
+  const double tab0 = tgt.ab0[0] + cand_ab0, tab1 = tgt.ab0[1] + cand_ab1;
+  x.s_ratio = s_ratio;
   x.s_arg = tab0 - ref.ab0[0];
   x.b_t = S(tab1);
   x.b_r = S(ref.ab0[1]);
@@ -433,13 +432,23 @@ __device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const Align
   x.fyt = S(tgt.fy);
   x.img = static_cast<const Texel<S> *>(tgt.texels);
   x.W = tgt.width;
-  x.sigma = prm.sigma_huber;
+  x.sigma = sigma;
 }
 
-/** one reference point: residual, Huber weight, Jacobian row and its contribution to H (36 upper) | b (8) | energy | n_valid.
- *  Everything is predicated instead of branching: an invalid point reads a safe texel and contributes with weight zero. */
 template <typename S>
-__device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, S idepth, S iref, bool present, double (&acc)[kAlignPartial]) {
+__device__ __forceinline__ void alignSweepSetup(AlignSweepCtx<S> &x, const AlignFrameDev &ref, const AlignFrameDev &tgt, const AlignControl &sc,
+                                                const AlignParams &prm) {
+  const double *T = sc.cand_T;
+  // ArrayReprojector ctor — camera_reproject.hpp:235-260
+  const double ifx = 1.0 / ref.fx, ify = 1.0 / ref.fy, k02 = -ref.cx / ref.fx, k12 = -ref.cy / ref.fy;
+  alignSweepSetup<S>(x, ref, tgt, T, sc.cand_ab[0], sc.cand_ab[1], prm.sigma_huber, ifx, ify, k02, k12, tgt.exposure / ref.exposure);
+}
+
+/** one reference point: residual r, Huber weight, Jacobian row d[8], energy term and validity (1 / 0).
+ *  Everything is predicated instead of branching: an invalid point reads a safe texel and comes back with weight zero. */
+template <typename S>
+__device__ __forceinline__ void alignPointEval(const AlignSweepCtx<S> &x, S u, S v, S idepth, S iref, bool present, double (&d)[8], double &r_out,
+                                               double &wgt_out, double &energy_out, double &valid_out) {
   const S *M = x.M, *U = x.U;
   // reproject (checked) — camera_reproject.hpp:270-293
   bool good = present && validIdepth(idepth) && insideROI(u, v, x.Wr, x.Hr);
@@ -452,7 +461,7 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   const S tu = good ? ta : S(4), tv = good ? tb : S(4);
   const int ix = static_cast<int>(tu), iy = static_cast<int>(tv);
   const Texel<S> *p = x.img + static_cast<size_t>(iy) * x.W + ix;
-  const Texel<S> t00 = p[0], t10 = p[1], t01 = p[x.W], t11 = p[x.W + 1];
+  const Texel<S> t00 = loadTexel(p), t10 = loadTexel(p + 1), t01 = loadTexel(p + x.W), t11 = loadTexel(p + x.W + 1);
   const S s_scale = S(x.s_ratio * exp(x.s_arg));  // (behind the loads: ~50 instructions that do not depend on them)
   const S dx = tu - static_cast<S>(ix), dy = tv - static_cast<S>(iy), dxdy = dx * dy;
   const int rx = static_cast<int>(floor(tu + S(0.5))) - ix, ry = static_cast<int>(floor(tv + S(0.5))) - iy;
@@ -467,16 +476,16 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   const double r2 = r * r, sig = x.sigma;
   const bool lin = r2 > sig * sig;
   const double nrm = fabs(r);
-  const double wgt = valid ? (lin ? sig / nrm : 1.0) : 0.0;
-  acc[44] += valid ? (lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2) : 0.0;
-  acc[45] += valid ? 1.0 : 0.0;
+  r_out = r;
+  wgt_out = valid ? (lin ? sig / nrm : 1.0) : 0.0;
+  energy_out = valid ? (lin ? sig * nrm - 0.5 * sig * sig : 0.5 * r2) : 0.0;
+  valid_out = valid ? 1.0 : 0.0;
   // Jacobian row at the same state (non-checking reprojector, camera_reproject.hpp:339-365; eigen_pose_alignment.cpp:158-172)
   const S X = U[0] * u + U[1] * v + (U[2] + U[3] * idepth);
   const S Y = U[4] * u + U[5] * v + (U[6] + U[7] * idepth);
   const S Z = U[8] * u + U[9] * v + (U[10] + U[11] * idepth);
   const S rho = valid ? alignRcp(Z) : S(0), b0 = X * rho, b1 = Y * rho, nid = idepth * rho;
   const S fxt = x.fxt, fyt = x.fyt, b0b1 = b0 * b1;
-  double d[8];
   d[0] = -static_cast<double>(sIx * (fxt * nid));
   d[1] = -static_cast<double>(sIy * (fyt * nid));
   d[2] = -static_cast<double>(sIx * (fxt * (-nid * b0)) + sIy * (fyt * (-nid * b1)));
@@ -485,6 +494,16 @@ __device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, 
   d[5] = -static_cast<double>(sIx * (fxt * (-b1)) + sIy * (fyt * b0));
   d[6] = -static_cast<double>(right);
   d[7] = -1.0;
+}
+
+/** ... and its contribution to this thread's H (36 upper) | b (8) | energy | n_valid (the launch-per-iteration and single-workgroup
+ *  kernels: per-thread accumulators, workgroup reduction through an LDS transpose) */
+template <typename S>
+__device__ __forceinline__ void alignPoint(const AlignSweepCtx<S> &x, S u, S v, S idepth, S iref, bool present, double (&acc)[kAlignPartial]) {
+  double d[8], r, wgt, en, vl;
+  alignPointEval<S>(x, u, v, idepth, iref, present, d, r, wgt, en, vl);
+  acc[44] += en;
+  acc[45] += vl;
   int e = 0;
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
@@ -745,10 +764,13 @@ struct AlignPyramidResult {
   int n_valid[DSOPP_HIP_MAX_LEVELS];
   double T_tr[12];   // T_target_reference after the last accepted level ([R | t] rows)
   double ab[2];      // target affine brightness after the last accepted level
-  long long stamps[8];  // -DDSOPP_HIP_STAMPS: wall_clock64 at the phase boundaries of one pass (level 0, third pass) of workgroup 0
+  long long stamps[16];  // -DDSOPP_HIP_STAMPS: wall_clock64 at the phase boundaries of one pass (level 0, third pass) of workgroup 0
 };
 #ifdef DSOPP_HIP_STAMPS
 #define AP_STAMP(i) do { if (blk == 0 && tid == 0 && lvl == 0 && pass == 2) h_out->stamps[i] = wall_clock64(); } while (0)
+#elif defined(DSOPP_HIP_MARKS)
+// ISA reading aid (scripts/isa_phase_count.py): a comment line in the assembly at every phase boundary
+#define AP_STAMP(i) asm volatile("; ##AP_MARK " #i)
 #else
 #define AP_STAMP(i) do { } while (0)
 #endif
@@ -758,6 +780,7 @@ struct AlignPyramidArgs {
   int n_levels;
   int max_iterations;
   double sigma_huber, affine_reg[2], function_tolerance, parameter_tolerance, decrease_on_accept, increase_on_reject, lambda0;
+  double inv_decrease;  // 1 / decrease_on_accept, exact (a power of two): the control step multiplies
   // Up to kPyramidHypotheses initialisations of estimatePose run in ONE launch, one per XCD: the workgroups with blockIdx % spread == h
   // are the participants of hypothesis h (the dispatcher deals workgroups round-robin over the 8 XCDs), every hypothesis with its own
   // exchange buffers, failed flag, buffer phase and result slot.  n_hyp == 1 is the single-initialisation launch (only every spread-th
@@ -769,19 +792,194 @@ struct AlignPyramidArgs {
   double *partials;        // [n_hyp][kPyramidSetDoubles]: per hypothesis [kPyramidBuffers][kPyramidMaxWorkgroups][kAlignPartial] + the failed flag
   AlignPyramidResult *out; // [n_hyp]
   int start_phase[kPyramidHypotheses];  // pass counter (mod 3) the hypothesis' buffers continue from
+  int debug_poison_lds;    // -DDSOPP_HIP_STAMPS only: fill the LDS block with NaN at kernel start (a read of uninitialised LDS then shows in every call)
+  double *debug_sums;      // -DDSOPP_HIP_STAMPS only: [pass][workgroup][2] totals (energy, H00) every workgroup derived, hypothesis 0 (exchange check)
   int spread;              // launch = spread x participants per hypothesis (8: one XCD each, 1: no placement attempt — single hypothesis only)
 };
 
 using gu32 = __attribute__((address_space(1))) unsigned;
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 
+// Workgroup sums of the persistent kernel: the f64 matrix cores add up the points of a wave.  Every lane hands the row of its point to
+// the wave through LDS — A row [w d0 .. w d7 | energy | valid], B row [d0 .. d7 | r | 1] — and sixteen v_mfma_f64_16x16x4_f64
+// (four points each) leave  D[i][j] = sum w d_i d_j (i, j < 8),  D[i][8] = sum w d_i r,  D[8][9] = sum energy,  D[9][9] = n_valid  in
+// 4 registers per lane: no 48 f64 accumulators per lane (96 VGPRs: the kernel spilled and the workgroup reduction moved 2 x 98 KB
+// through LDS per pass, 1.2 us), and the wave's sum needs no shuffle tree.
+constexpr int kRowStride = 18;                       // doubles per published row (10 used; 144 B: b128 stores of 64 lanes spread over all banks)
+constexpr int kWaveRows = 2 * 64 * kRowStride;       // A rows, then B rows of one wave
+constexpr int kAlignWaves = kAlignThreads / 64;
+using af64x4 = __attribute__((ext_vector_type(4))) double;
+
+__device__ __forceinline__ void alignPublishRow(double *wave_rows, const double (&d)[8], double r, double wgt, double en, double vl) {
+  const int lane = threadIdx.x & 63;
+  double2 *ra = reinterpret_cast<double2 *>(wave_rows + lane * kRowStride);
+  double2 *rb = reinterpret_cast<double2 *>(wave_rows + 64 * kRowStride + lane * kRowStride);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    ra[c] = double2{wgt * d[2 * c], wgt * d[2 * c + 1]};
+    rb[c] = double2{d[2 * c], d[2 * c + 1]};
+  }
+  ra[4] = double2{en, vl};
+  rb[4] = double2{r, 1.0};
+}
+
+/** acc0 / acc1 += the products of the 64 published points (even / odd steps: two independent accumulation chains) */
+__device__ __forceinline__ void alignContract(const double *wave_rows, af64x4 &acc0, af64x4 &acc1) {
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // operand lane l = (m = l & 15, k = l >> 4) of step t reads entry m of point 4 t + k (entries 10 .. 15 feed result entries nobody reads)
+  const double *src = wave_rows + (lane >> 4) * kRowStride + (lane & 15);
+  double av[16], bv[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    av[t] = src[4 * t * kRowStride];
+    bv[t] = src[64 * kRowStride + 4 * t * kRowStride];
+  }
+  asm volatile("" ::: "memory");  // (all operands are requested before the first matrix instruction waits for one)
+#pragma unroll
+  for (int t = 0; t < 16; t += 2) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t + 1], bv[t + 1], acc1, 0, 0, 0);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+/** where result register v of this lane goes in the packed sums (H upper 36 | b 8 | energy | n_valid), -1: nowhere.
+ *  Result layout of the instruction: register v of lane l = entry (row (l >> 4) + 4 v, column l & 15). */
+__device__ __forceinline__ int alignPackedIndex(int lane, int v) {
+  const int i = (lane >> 4) + 4 * v, j = lane & 15;
+  if (i < 8) {
+    if (j < 8) return j >= i ? i * 8 - i * (i - 1) / 2 + (j - i) : -1;
+    return j == 8 ? 36 + i : -1;
+  }
+  if (j == 9) return i == 8 ? 44 : (i == 9 ? 45 : -1);
+  return -1;
+}
+
+/**
+ * The LM control step of the persistent kernel: alignDecideWave's state machine and arithmetic (levenberg_marquardt_algorithm.hpp:77-128,
+ * eigen_pose_alignment.cpp:101-104,174-212) in the form one wave executes fastest — one instruction per ~4.7 cycles whatever it does, so
+ * the step costs what its instruction count says:
+ *   * `tot` arrives with the affine prior already folded into its four entries, and the accepted state's system is kept in the same packed
+ *     form (`acc_sys`): the solve reads ONE of the two through a selected pointer — one instance of the factorisation instead of two, no
+ *     expanded 8 x 8 copies (H / H_used are not results of estimatePose);
+ *   * decisions are selects, not branches (the branchy form spent a third of its instructions on register copies at the joins);
+ *   * no f64 division: lambda / decrease_on_accept is a multiplication by the exact reciprocal of a power of two (checked by the host), and
+ *     |e - e'| / e < tol is decided by |e - e'| < tol e outside a 1e-12 band around the threshold (inside it: the division).
+ * All 64 lanes run it redundantly; lane 0 stores.
+ */
+__device__ __forceinline__ void pyramidDecide(AlignControl &c, const double *tot, double *acc_sys, double tgt_ab0, double tgt_ab1, double reg0, double reg1,
+                                              double function_tolerance, double parameter_tolerance, double inv_decrease, double increase, int max_iterations) {
+  const int lane = threadIdx.x & 63;
+  // ---- loads
+  const double cand_ab0 = c.cand_ab[0], cand_ab1 = c.cand_ab[1];
+  double ab_eps0 = c.ab_eps[0], ab_eps1 = c.ab_eps[1];
+  double energy = c.energy, lambda = c.lambda;
+  int n_valid = c.n_valid, converged = c.converged, iteration = c.iteration;
+  const bool first = c.have_candidate == 0;
+  double stepv[8], Ttr[12], candT[12];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) stepv[a] = c.step[a];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    Ttr[a] = c.T_tr[a];
+    candT[a] = c.cand_T[a];
+  }
+  const double red_energy = tot[44], red_n = tot[45];
+  const double sys_new = lane < 44 ? tot[lane] : 0.0;
+  // ---- decision (uniform)
+  const double tab0 = tgt_ab0 + cand_ab0, tab1 = tgt_ab1 + cand_ab1;
+  const double e_eval = red_energy + 0.5 * (tab0 * reg0 * tab0 + tab1 * reg1 * tab1);
+  const int n_eval = static_cast<int>(red_n + 0.5);
+  const bool has = n_eval != 0, better = e_eval < energy;
+  const double diff = fabs(energy - e_eval), thr = function_tolerance * energy;
+  bool conv_f = diff < thr * (1.0 - 1e-12);
+  if (!conv_f && !(diff > thr * (1.0 + 1e-12))) conv_f = diff / energy < function_tolerance;  // on the threshold (or not a number): the reference's own expression
+  const double a0 = tgt_ab0 + ab_eps0, a1 = tgt_ab1 + ab_eps1;
+  double step_sq = 0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) step_sq += stepv[a] * stepv[a];
+  const bool conv_p = step_sq < parameter_tolerance * ((a0 * a0 + a1 * a1) + parameter_tolerance);
+  const bool accept = !first && has && better;   // acceptStep (eigen_pose_alignment.cpp:208-212)
+  const bool take = first || accept;             // the evaluated state's system becomes the accepted state's
+  iteration += first ? 0 : 1;
+  converged = (!first && has && (conv_f || (better && conv_p))) ? 1 : converged;
+  lambda = accept ? lambda * inv_decrease : ((!first && has) ? lambda * increase : lambda);  // rejectStep: the accepted state and its system stay
+  energy = take ? e_eval : energy;
+  n_valid = take ? n_eval : n_valid;
+  int active = first ? ((max_iterations > 0 && n_eval > 0) ? 1 : 0) : ((has && !converged && iteration < max_iterations) ? 1 : 0);
+#pragma unroll
+  for (int a = 0; a < 12; ++a) Ttr[a] = accept ? candT[a] : Ttr[a];
+  ab_eps0 = accept ? cand_ab0 : ab_eps0;
+  ab_eps1 = accept ? cand_ab1 : ab_eps1;
+  // ---- calculateStep (eigen_pose_alignment.cpp:194-206): (H + lambda diag(H)) step = b from the packed sums of the accepted state
+  // (a pointer the compiler cannot see through: left to itself it reads BOTH systems and selects entry by entry)
+  using LdsDouble = const __attribute__((address_space(3))) double;
+  LdsDouble *src = take ? (LdsDouble *)tot : (LdsDouble *)acc_sys;
+  asm volatile("" : "+v"(src));
+  double stepn[8];
+  solve8Impl([&](int i, int j) { return src[j * 8 - j * (j - 1) / 2 + (i - j)]; }, [&](int i) { return src[36 + i]; }, lambda, stepn);
+  if (take && lane < 44) acc_sys[lane] = sys_new;  // (behind the solve's reads: nothing waits for it)
+  const Rigid E = rigidExp(stepn);
+  double Em[12], candTn[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Em[4 * i + j] = E.R[3 * i + j];
+    Em[4 * i + 3] = E.t[i];
+  }
+  mat34Compose(Em, Ttr, candTn);
+  // ---- one batch of stores (lane 0)
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      c.T_tr[a] = Ttr[a];
+      c.cand_T[a] = candTn[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) c.step[a] = stepn[a];
+    c.ab_eps[0] = ab_eps0;
+    c.ab_eps[1] = ab_eps1;
+    c.cand_ab[0] = ab_eps0 - stepn[6];
+    c.cand_ab[1] = ab_eps1 - stepn[7];
+    c.lambda = lambda;
+    c.energy = energy;
+    c.n_valid = n_valid;
+    c.converged = converged;
+    c.active = active;
+    c.iteration = iteration;
+    c.have_candidate = 1;
+  }
+}
+
 template <typename S>
 __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramidArgs a) {
-  __shared__ __attribute__((aligned(16))) double red[kAlignPartial * (kAlignThreads + 2)];
-  __shared__ AlignControl sc;
-  __shared__ double tot[kAlignPartial];
-  __shared__ int s_failed;
-  const int tid = threadIdx.x;
+  // one LDS block, the small hot arrays first: their addresses fit the 16-bit offset field of the LDS instructions (an address beyond
+  // 64 KB costs a v_mov per access — the control step makes ~120 of them), the 72 KB of point rows behind
+  struct PyramidLds {
+    AlignControl sc;                         // (H, H_used, b: not maintained by this kernel)
+    double tot[kAlignPartial];               // sums of the pass, affine prior folded in
+    double acc_sys[kAlignPartial];           // system of the accepted state, same packed form
+    double psum[kAlignWaves][kAlignPartial]; // per wave: its quarter of the participants' sums
+    double wsum[kAlignWaves][kAlignPartial]; // per wave: packed sums of its points
+    double T_cur[12], ab_cur[2];             // current estimate (T_target_reference rows, affine brightness)
+    int failed, same_xcd, pad[2];
+    double rows[kAlignWaves * kWaveRows];    // per wave: published point rows
+  };
+  __shared__ __attribute__((aligned(16))) PyramidLds lds;
+  AlignControl &sc = lds.sc;
+  double(&tot)[kAlignPartial] = lds.tot;
+  double(&acc_sys)[kAlignPartial] = lds.acc_sys;
+  double(&psum)[kAlignWaves][kAlignPartial] = lds.psum;
+  double(&wsum)[kAlignWaves][kAlignPartial] = lds.wsum;
+  double(&s_T_cur)[12] = lds.T_cur;
+  double(&s_ab_cur)[2] = lds.ab_cur;
+  int &s_failed = lds.failed, &s_same_xcd = lds.same_xcd;
+  double *const rows = lds.rows;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD co-location (speed only): the host launches `spread` x G workgroups and every spread-th one takes part — the dispatcher
   // deals workgroups round-robin over the 8 XCDs, so with spread = 8 the participants tend to share ONE XCD and its L2.  Whether
   // they really do is measured, not assumed: every participant publishes its XCC id in the first pass (agent-scope stores, valid
@@ -799,15 +997,23 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
   unsigned xcc_id = 0;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
   xcc_id &= 0xFu;
-  __shared__ int s_same_xcd;  // set after the first pass of the launch
+#ifdef DSOPP_HIP_STAMPS
+  if (a.debug_poison_lds) {
+    for (size_t i = tid; i < sizeof(PyramidLds) / 8; i += kAlignThreads) reinterpret_cast<unsigned long long *>(&lds)[i] = 0x7FF8DEADDEADBEEFull;
+    __syncthreads();
+  }
+#endif
   if (tid == 0) s_same_xcd = 0;
   unsigned pass_global = 0;  // barriers passed so far (identical in every workgroup)
-  // current estimate (T_target_reference rows, affine brightness): in LDS, not in every thread's registers — 28 VGPRs less, and the
-  // per-entry initialisation of the control block below needs no dynamically indexed private array (= scratch)
-  __shared__ double s_T_cur[12], s_ab_cur[2];
+  // current estimate (T_target_reference rows, affine brightness): in LDS, not in every thread's registers
   if (tid < 12) s_T_cur[tid] = a.T_tr0[hyp][tid];
   if (tid < 2) s_ab_cur[tid] = a.ab0[tid];
   if (tid == 0) s_failed = 0;
+  // where this lane's four result registers go in the packed sums (lane constants)
+  int pk[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) pk[v] = alignPackedIndex(lane, v);
+  double *const my_rows = rows + wave * kWaveRows;
   int levels_done = 0, success = 1, lm_iterations = 0;
   for (int lvl = a.n_levels - 1; lvl >= 0; --lvl) {
     const AlignLevelDev &L = a.level[lvl];
@@ -815,29 +1021,21 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
     AlignFrameDev tgt = L.tgt;
     tgt.ab0[0] = s_ab_cur[0];
     tgt.ab0[1] = s_ab_cur[1];
-    AlignParams prm;
-    prm.sigma_huber = a.sigma_huber;
-    prm.affine_reg[0] = a.affine_reg[0];
-    prm.affine_reg[1] = a.affine_reg[1];
-    prm.function_tolerance = a.function_tolerance;
-    prm.parameter_tolerance = a.parameter_tolerance;
-    prm.decrease_on_accept = a.decrease_on_accept;
-    prm.increase_on_reject = a.increase_on_reject;
-    prm.max_iterations = a.max_iterations;
-    prm.n_points = L.n_points;
-    prm.n_blocks = G;
+    // per-level constants of the sweep set-up: ArrayReprojector ctor — camera_reproject.hpp:235-260
+    const double ifx = 1.0 / L.ref.fx, ify = 1.0 / L.ref.fy, k02 = -L.ref.cx / L.ref.fx, k12 = -L.ref.cy / L.ref.fy;
+    const double s_ratio = tgt.exposure / L.ref.exposure;
     __syncthreads();  // previous level's reads of sc are done
     // reset(); pushFrame(reference); pushFrame(target, current estimate): the control block dsopp_hip_aligner_solve prepares, written
     // straight into LDS one entry per thread (as a private AlignControl filled by one lane it lived in 1.4 KB of scratch)
-    if (tid < 64) {
-      sc.H[tid] = 0;
-      sc.H_used[tid] = 0;
+    if (tid < 48) {
+      acc_sys[tid] = 0;
+    } else if (tid < 64) {
+      // (nothing)
     } else if (tid < 64 + 12) {
       sc.T_tr[tid - 64] = s_T_cur[tid - 64];
     } else if (tid < 64 + 24) {
       sc.cand_T[tid - 76] = s_T_cur[tid - 76];
     } else if (tid < 64 + 32) {
-      sc.b[tid - 88] = 0;
       sc.step[tid - 88] = 0;
     } else if (tid == 96) {
       sc.ab_eps[0] = sc.ab_eps[1] = sc.cand_ab[0] = sc.cand_ab[1] = 0;
@@ -868,15 +1066,10 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         rint[q] = have ? static_cast<S>(L.pint[ic]) : S(0);
       }
     }
-    const int total_passes = a.max_iterations + 2;  // initial evaluation + one per iteration + the closing control step
-    for (int pass = 0; pass < total_passes; ++pass) {
+    const int total_passes = a.max_iterations + 1;  // the initial evaluation + one per iteration, each followed by its control step
+    int pass = 0;
+    for (; pass < total_passes; ++pass) {
       AP_STAMP(0);
-      if (pass > 0) {
-        if (tid < 64) alignDecideWave(sc, tot, tgt, prm);
-        __syncthreads();
-        if (!sc.active) break;
-      }
-      AP_STAMP(1);
       // re-arm this workgroup's slots of the buffer the NEXT pass publishes into (its last readers finished two passes ago);
       // the stores complete behind the sweep and are waited for before this pass's sums go out
       const bool local_xcd = s_same_xcd != 0;  // (written once, behind barriers, after the first pass)
@@ -893,121 +1086,134 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
       if (tid < kAlignPartial)
         for (int slot = blk; slot < kPyramidMaxWorkgroups; slot += G)
           publish(h_partials + (static_cast<size_t>((buf_pass + 1u) % kPyramidBuffers) * kPyramidMaxWorkgroups + slot) * kAlignPartial + tid, kPyramidSentinel);
-      // ---- sweep of this workgroup's points at the candidate state, workgroup sums through the LDS transpose
+      // ---- sweep of this workgroup's points at the candidate state; the wave's sums come out of the matrix cores
       const int first = blk * kAlignThreads + tid;
-      double *dst = h_partials + (static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups + blk) * kAlignPartial;
-      if (blk * kAlignThreads < L.n_points) {
-        double acc[kAlignPartial];
+      const bool wg_has_points = blk * kAlignThreads < L.n_points;
+      if (wg_has_points) {
+        AlignSweepCtx<S> x;
+        alignSweepSetup<S>(x, L.ref, tgt, sc.cand_T, sc.cand_ab[0], sc.cand_ab[1], a.sigma_huber, ifx, ify, k02, k12, s_ratio);
+        AP_STAMP(1);
+        af64x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        double d[8], r, wgt, en, vl;
         if (preloaded) {
-          // this thread's points live in registers for the whole level: a pass starts with the texel gather
-#pragma unroll
-          for (int e = 0; e < kAlignPartial; ++e) acc[e] = 0;
-          AlignSweepCtx<S> x;
-          alignSweepSetup<S>(x, L.ref, tgt, sc, prm);
-          // point q of a thread exists on this level only when the level has more than q * G * 256 points: a grid-uniform test.
-          // (alignPoint is predicated, not branched: without the test a level of <= G * 256 points — every level of the C2
-          // workload — ran the whole second evaluation on a dummy texel in every pass, half of the sweep's 2.4 us)
+          // this thread's points live in registers for the whole level: a pass starts with the texel gather.
+          // point q of a thread exists on this level only when the level has more than q * G * 256 points: a grid-uniform test
 #pragma unroll
           for (int q = 0; q < kPreload; ++q) {
             if (q > 0 && L.n_points <= q * G * kAlignThreads) break;
-            alignPoint<S>(x, ru[q], rv[q], rid[q], rint[q], first + q * G * kAlignThreads < L.n_points, acc);
+            alignPointEval<S>(x, ru[q], rv[q], rid[q], rint[q], first + q * G * kAlignThreads < L.n_points, d, r, wgt, en, vl);
+            alignPublishRow(my_rows, d, r, wgt, en, vl);
+            AP_STAMP(2);
+            alignContract(my_rows, acc0, acc1);
           }
         } else {
-          alignSweep<S>(L.ref, tgt, L.pu, L.pv, L.pid, L.pint, sc, prm, first, G * kAlignThreads, acc);
-        }
-        constexpr int RS = kAlignThreads + 2;
-#pragma unroll
-        for (int e = 0; e < kAlignPartial; ++e) red[e * RS + tid] = acc[e];
-        __syncthreads();
-        AP_STAMP(2);
-        const int row_idx = tid >> 2, quarter = tid & 3;
-        double s = 0;
-        if (row_idx < kAlignPartial) {
-          const double2 *row = reinterpret_cast<const double2 *>(red + row_idx * RS) + quarter * (kAlignThreads / 8);
-          double s0 = 0, s1 = 0;
-#pragma unroll 8
-          for (int j = 0; j < kAlignThreads / 8; ++j) {
-            const double2 q = row[j];
-            s0 += q.x;
-            s1 += q.y;
+          // (a wave-uniform trip count: every lane of a wave publishes a row — weight zero behind the end — until the wave's first lane runs out)
+          const int wave_first = first - lane;
+          for (int base = 0; wave_first + base < L.n_points; base += G * kAlignThreads) {
+            const int i = first + base;
+            const int ic = i < L.n_points ? i : L.n_points - 1;
+            alignPointEval<S>(x, static_cast<S>(L.pu[ic]), static_cast<S>(L.pv[ic]), static_cast<S>(L.pid[ic]), static_cast<S>(L.pint[ic]),
+                              i < L.n_points, d, r, wgt, en, vl);
+            alignPublishRow(my_rows, d, r, wgt, en, vl);
+            alignContract(my_rows, acc0, acc1);
           }
-          s = s0 + s1;
         }
-        s += alignDpp<0xB1>(s);
-        s += alignDpp<0x4E>(s);
-        // (the re-arming stores of the previous pass target these addresses from other lanes: they were drained by the
-        // s_waitcnt below in that pass, ahead of the barriers in between)
-        // slots 46 / 47 (unused by the sums) carry x = XCC id + 1 and x^2: all ids are equal iff G * sum x^2 == (sum x)^2
-        if (row_idx == 46) s = static_cast<double>(xcc_id + 1u);
-        if (row_idx == 47) s = static_cast<double>((xcc_id + 1u) * (xcc_id + 1u));
-        if (row_idx < kAlignPartial && quarter == 0) publish(dst + row_idx, static_cast<unsigned long long>(__double_as_longlong(s)));
-      } else if (tid < kAlignPartial) {
-        // no points on this level for this workgroup: it still takes part in the exchange
-        const double idv = tid == 46 ? static_cast<double>(xcc_id + 1u) : (tid == 47 ? static_cast<double>((xcc_id + 1u) * (xcc_id + 1u)) : 0.0);
-        publish(dst + tid, static_cast<unsigned long long>(__double_as_longlong(idv)));
+        AP_STAMP(3);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (pk[v] >= 0) wsum[wave][pk[v]] = acc0[v] + acc1[v];
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores (sums and re-arming)
-      __syncthreads();                                   // ... and red[] is free for the sums below
-      AP_STAMP(3);
-      // ---- every workgroup polls and sums all partial sums in the same fixed order (thread e < 48 x 5 groups, as
-      // alignIterationKernel): a value that is not the sentinel IS the published sum
+      __syncthreads();  // B1: the waves' sums are in LDS
+      AP_STAMP(4);
+      // ---- wave 0: the workgroup's sums go out
+      if (wave == 0 && lane < kAlignPartial) {
+        double *dst = h_partials + (static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups + blk) * kAlignPartial;
+        double sv = 0;
+        if (wg_has_points && lane < 46) sv = (wsum[0][lane] + wsum[1][lane]) + (wsum[2][lane] + wsum[3][lane]);
+        // slots 46 / 47 (unused by the sums) carry x = XCC id + 1 and x^2: all ids are equal iff G * sum x^2 == (sum x)^2
+        if (lane == 46) sv = static_cast<double>(xcc_id + 1u);
+        if (lane == 47) sv = static_cast<double>((xcc_id + 1u) * (xcc_id + 1u));
+        // (the re-arming stores of the previous pass target this address from the same lane of the same wave: in order)
+        publish(dst + lane, static_cast<unsigned long long>(__double_as_longlong(sv)));
+#ifdef DSOPP_HIP_STAMPS
+        if (a.debug_sums && hyp == 0 && pass_global < 256u && (lane == 44 || lane == 0))
+          a.debug_sums[(static_cast<size_t>(pass_global) * kPyramidMaxWorkgroups + blk) * 4 + (lane == 0 ? 3 : 2)] = lane == 0 ? sc.cand_T[3] : sv;
+#endif
+      }
+      AP_STAMP(5);
+      // ---- every wave polls a quarter of the participants (lane e < 48: entry e of the participants 8 w .. 8 w + 7) and adds them in a
+      // fixed order: a value that is not the sentinel IS the published sum.  All loads of a poll are issued before the first test
+      // (clamped indices + a 0 / 1 factor instead of predicated loads): one round trip per poll
       {
-        constexpr int kGroups = kAlignThreads / kAlignPartial;  // 5
-        const int e = tid % kAlignPartial, grp = tid / kAlignPartial;
-        const double *src = h_partials + static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial + e;
-        if (grp < kGroups) {
-          // all loads of this thread are issued before the first test: clamped indices + a 0 / 1 factor instead of predicated
-          // loads (G <= 64: at most 13 per thread, one round trip per poll)
-          constexpr int kMaxPer = (kPyramidMaxWorkgroups + kGroups - 1) / kGroups;
-          unsigned long long w[kMaxPer];
+        constexpr int kPer = kPyramidMaxWorkgroups / kAlignWaves;  // 8
+        bool failed = false;
+        if (lane < kAlignPartial) {
+          const double *src = h_partials + static_cast<size_t>(buf_pass % kPyramidBuffers) * kPyramidMaxWorkgroups * kAlignPartial + lane;
+          unsigned long long w[kPer];
           unsigned spins = 0;
           for (;;) {
             bool ready = true;
 #pragma unroll
-            for (int j = 0; j < kMaxPer; ++j) {
-              const int b = grp + j * kGroups;
-              const int bc = b < G ? b : G - 1;
+            for (int j = 0; j < kPer; ++j) {
+              const int bi = wave * kPer + j;
+              const int bc = bi < G ? bi : G - 1;
               w[j] = __hip_atomic_load((const gu64 *)(src + static_cast<size_t>(bc) * kAlignPartial), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
 #pragma unroll
-            for (int j = 0; j < kMaxPer; ++j) ready = ready && (w[j] != kPyramidSentinel);
+            for (int j = 0; j < kPer; ++j) ready = ready && (w[j] != kPyramidSentinel);
             if (ready) break;
             if (++spins > (1u << 20) || __hip_atomic_load((gu32 *)h_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPyramidFailed) {
               __hip_atomic_store((gu32 *)h_failed, kPyramidFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              s_failed = 1;
+              failed = true;
               break;
             }
             __builtin_amdgcn_s_sleep(1);
           }
-          AP_STAMP(4);
-          double p0 = 0, p1 = 0;
+          double v[kPer];
 #pragma unroll
-          for (int j = 0; j < kMaxPer; ++j) {
-            const double v = (grp + j * kGroups < G) ? __longlong_as_double(static_cast<long long>(w[j])) : 0.0;
-            if (j & 1)
-              p1 += v;
-            else
-              p0 += v;
-          }
-          red[grp * kAlignPartial + e] = p0 + p1;
+          for (int j = 0; j < kPer; ++j) v[j] = (wave * kPer + j < G) ? __longlong_as_double(static_cast<long long>(w[j])) : 0.0;
+          psum[wave][lane] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
-        __syncthreads();
-        if (s_failed) {  // a workgroup never showed up (GPU shared with other work): the host falls back to launch-per-iteration
-          if (blk == 0 && tid == 0) h_out->failed = 1;
-          return;
-        }
-        if (tid < kAlignPartial) {
-          double t = 0;
-#pragma unroll
-          for (int g2 = 0; g2 < kGroups; ++g2) t += red[g2 * kAlignPartial + tid];
-          tot[tid] = t;
-        }
-        __syncthreads();
-        // first pass of the launch: do all participants sit on one XCD?  (identical sums in every workgroup -> identical verdict)
-        if (pass_global == 0 && tid == 0 && a.spread > 1) s_same_xcd = (static_cast<double>(G) * tot[47] == tot[46] * tot[46]) ? 1 : 0;
+        if (__any(failed) && lane == 0) s_failed = 1;  // a workgroup never showed up (GPU shared with other work): the host falls back to launch-per-iteration
       }
-      AP_STAMP(5);
+      AP_STAMP(6);
+      __syncthreads();  // B2: the four quarters are in LDS
+      // ---- wave 0: total (affine prior folded in, eigen_pose_alignment.cpp:183-190) and the LM control step; the others wait at B3
+      if (wave == 0 && !s_failed) {
+        const double reg0 = a.affine_reg[0], reg1 = a.affine_reg[1];
+        double total = 0;
+        if (lane < kAlignPartial) {
+          total = (psum[0][lane] + psum[1][lane]) + (psum[2][lane] + psum[3][lane]);
+          const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
+          const double prior = lane == 33 ? reg0 : (lane == 35 ? reg1 : (lane == 42 ? reg0 * tab0 : (lane == 43 ? reg1 * tab1 : 0.0)));
+          tot[lane] = (lane == 33 || lane == 35 || lane == 42 || lane == 43) ? total + prior : total;
+        }
+#ifdef DSOPP_HIP_STAMPS
+        if (a.debug_sums && hyp == 0 && pass_global < 256u && (lane == 44 || lane == 0))
+          a.debug_sums[(static_cast<size_t>(pass_global) * kPyramidMaxWorkgroups + blk) * 4 + (lane == 0 ? 1 : 0)] = total;
+#endif
+        // first pass of the launch: do all participants sit on one XCD?  (identical sums in every workgroup -> identical verdict)
+        if (pass_global == 0 && a.spread > 1) {
+          const double sx = __shfl(total, 46), sxx = __shfl(total, 47);
+          if (lane == 0) s_same_xcd = (static_cast<double>(G) * sxx == sx * sx) ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        AP_STAMP(7);
+        pyramidDecide(sc, tot, acc_sys, tgt.ab0[0], tgt.ab0[1], reg0, reg1, a.function_tolerance, a.parameter_tolerance, a.inv_decrease,
+                      a.increase_on_reject, a.max_iterations);
+        AP_STAMP(8);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the publishing wave drains its stores (sums and re-arming)
+      __syncthreads();                                   // B3: control block of the next pass (or the level's result) is in place
+      AP_STAMP(9);
       ++pass_global;
+      if (s_failed) {
+        if (blk == 0 && tid == 0) h_out->failed = 1;
+        return;
+      }
+      if (!sc.active) break;
     }
     // ---- the level's verdict (identical in every workgroup) — monocular_tracker.cpp:218-226, eigen_pose_alignment.cpp:320-328
     ++levels_done;
@@ -1679,6 +1885,7 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         args.parameter_tolerance = a->opt.parameter_tolerance;
         args.decrease_on_accept = 2.0;  // eigen_pose_alignment.cpp:304-305
         args.increase_on_reject = 2.0;
+        args.inv_decrease = 0.5;  // exactly 1 / decrease_on_accept
         args.lambda0 = 1.0 / a->opt.initial_trust_region_radius;
         args.n_hyp = nb;
         for (int h = 0; h < nb; ++h) {
@@ -1709,6 +1916,18 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
           args.start_phase[h] = a->pyr_phase[h];
           a->pyr_phase[h] = -1;  // (until this launch has reported how it left the buffers)
         }
+#ifdef DSOPP_HIP_STAMPS
+        static const bool check_sums = std::getenv("DSOPP_HIP_CHECK_SUMS") != nullptr;
+        static double *dbg_dev = nullptr;
+        constexpr size_t kDbgDoubles = 256 * kPyramidMaxWorkgroups * 4;
+        if (check_sums) {
+          if (!dbg_dev) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dbg_dev), kDbgDoubles * sizeof(double)));
+          HIP_CHECK(hipMemsetAsync(dbg_dev, 0, kDbgDoubles * sizeof(double), st));
+          args.debug_sums = dbg_dev;
+        }
+        static const bool poison = std::getenv("DSOPP_HIP_POISON_LDS") != nullptr;
+        args.debug_poison_lds = poison ? 1 : 0;
+#endif
         static const int spread_override = std::getenv("DSOPP_HIP_ALIGN_SPREAD") ? std::atoi(std::getenv("DSOPP_HIP_ALIGN_SPREAD")) : 0;  // tuning aid
         args.spread = (nb == 1 && spread_override > 0) ? spread_override : 8;
         if (a->opt.dtype == DSOPP_HIP_F64)
@@ -1720,11 +1939,56 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
 #ifdef DSOPP_HIP_STAMPS
         if (std::getenv("DSOPP_HIP_TRACE")) {
           const AlignPyramidResult &o = a->h_pyr_out[0];
-          std::fprintf(stderr, "alignPyramid pass (level 0): decide %.2f  sweep %.2f  wg-reduce+store %.2f  arrive+wait %.2f  global sum %.2f us (G = %d, one XCD: %d)\n",
-                       (o.stamps[1] - o.stamps[0]) / 100.0, (o.stamps[2] - o.stamps[1]) / 100.0, (o.stamps[3] - o.stamps[2]) / 100.0,
-                       (o.stamps[4] - o.stamps[3]) / 100.0, (o.stamps[5] - o.stamps[4]) / 100.0, G, o.same_xcd);
+          auto us = [&](int i, int j) { return (o.stamps[j] - o.stamps[i]) / 100.0; };
+          std::fprintf(stderr, "alignPyramid pass (level 0, wave 0 of workgroup 0): set-up %.2f  gather + point %.2f  rows + matrix cores %.2f  wave sums + barrier %.2f  "
+                               "workgroup sum + publish %.2f  poll + quarter sums %.2f  barrier + total %.2f  control step %.2f  drain + barrier %.2f  = %.2f us (G = %d, one XCD: %d)\n",
+                       us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(6, 7), us(7, 8), us(8, 9), us(0, 9), G, o.same_xcd);
         }
 #endif
+#ifdef DSOPP_HIP_STAMPS
+        if (check_sums) {
+          // every workgroup has to derive the same totals in every pass (a difference is a stale or missed value in the exchange), and a
+          // repeated call on the same inputs has to reproduce the first call's partial sums and totals bit for bit
+          std::vector<double> dbg(kDbgDoubles);
+          HIP_CHECK(hipMemcpy(dbg.data(), dbg_dev, kDbgDoubles * sizeof(double), hipMemcpyDeviceToHost));
+          static std::map<int, std::vector<double>> reference;  // by level count x participants
+          for (int pass = 0; pass < 256; ++pass) {
+            const double *row = dbg.data() + static_cast<size_t>(pass) * kPyramidMaxWorkgroups * 4;
+            for (int w = 0; w < G; ++w)
+              if (std::memcmp(row + 4 * w, row, 2 * sizeof(double)) != 0)
+                std::fprintf(stderr, "SUMS DIFFER pass %d: workgroup %d has energy %.17g H00 %.17g, workgroup 0 %.17g %.17g\n", pass, w, row[4 * w], row[4 * w + 1], row[0], row[1]);
+          }
+          const int key = levels * 1000 + G;
+          auto it = reference.find(key);
+          if (it == reference.end()) {
+            reference[key] = dbg;
+          } else {
+            bool reported = false;
+            for (int pass = 0; pass < 256 && !reported; ++pass)
+              for (int w = 0; w < G && !reported; ++w) {
+                const double *x = dbg.data() + (static_cast<size_t>(pass) * kPyramidMaxWorkgroups + w) * 4, *y = it->second.data() + (x - dbg.data());
+                if (std::memcmp(x, y, 4 * sizeof(double)) != 0) {
+                  std::fprintf(stderr, "FIRST DIFFERENCE to the first call: pass %d workgroup %d: own partial energy %.17g (first call %.17g) candidate t_x %.17g (%.17g); total energy %.17g (%.17g) "
+                                       "H00 %.17g (%.17g)\n", pass, w, x[2], y[2], x[3], y[3], x[0], y[0], x[1], y[1]);
+                  // the whole pass: which workgroups' partials differ
+                  for (int w2 = 0; w2 < G; ++w2) {
+                    const double *x2 = dbg.data() + (static_cast<size_t>(pass) * kPyramidMaxWorkgroups + w2) * 4, *y2 = it->second.data() + (x2 - dbg.data());
+                    if (x2[2] != y2[2] || x2[3] != y2[3])
+                      std::fprintf(stderr, "   workgroup %d differs: partial energy %.17g (%.17g), its candidate's t_x %.17g (%.17g)\n", w2, x2[2], y2[2], x2[3], y2[3]);
+                  }
+                  reported = true;
+                }
+              }
+          }
+        }
+#endif
+        static const bool trace_levels = std::getenv("DSOPP_HIP_TRACE") != nullptr;  // debugging aid: what every level of hypothesis 0 did
+        if (trace_levels) {
+          const AlignPyramidResult &o = a->h_pyr_out[0];
+          for (int lvl = levels - 1; lvl >= 0; --lvl)
+            std::fprintf(stderr, "  level %d: %d points, %d iterations, n_valid %d, rmse %.12g (G = %d)\n", lvl, args.level[lvl].n_points, o.iterations[lvl],
+                         o.n_valid[lvl], o.rmse[lvl], G);
+        }
         for (int h = 0; h < nb; ++h)
           if (a->h_pyr_out[h].failed) {
             a->pyramid_kernel_disabled = true;  // not all workgroups were resident in time: this GPU is busy with something else

@@ -88,7 +88,6 @@ DSOPP_HD Rigid rigidExp(const double *xi) {
   Rigid T;
   const double wx = xi[3], wy = xi[4], wz = xi[5];
   const double th2 = wx * wx + wy * wy + wz * wz;
-  const double th = sqrt(th2);
   double A, B, Cc;  // R = I + A*W + B*W^2 ; V = I + B*W + Cc*W^2
   if (th2 < 0.25) {
     // |omega| < 0.5 rad (always the case for the increments of a solve): even Taylor series in th2, truncation < 1e-17;
@@ -97,6 +96,7 @@ DSOPP_HD Rigid rigidExp(const double *xi) {
     B = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 + th2 * (-1.0 / 40320 + th2 * (1.0 / 3628800 + th2 * (-1.0 / 479001600 + th2 * (1.0 / 87178291200.0 + th2 * (-1.0 / 20922789888000.0)))))));
     Cc = 1.0 / 6 + th2 * (-1.0 / 120 + th2 * (1.0 / 5040 + th2 * (-1.0 / 362880 + th2 * (1.0 / 39916800 + th2 * (-1.0 / 6227020800.0 + th2 * (1.0 / 1307674368000.0 + th2 * (-1.0 / 355687428096000.0)))))));
   } else {
+    const double th = sqrt(th2);
     A = sin(th) / th;
     B = (1 - cos(th)) / th2;
     Cc = (th - sin(th)) / (th2 * th);

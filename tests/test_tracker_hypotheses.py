@@ -202,3 +202,24 @@ def test_concurrent_hypotheses_all_fail_keeps_the_first():
     for p in c["pyr"]:
         p.close()
     c["g"].close()
+
+
+@pytest.mark.gpu
+def test_persistent_tracker_kernel_is_bitwise_reproducible():
+    """estimatePose on bitwise identical inputs has to return the bitwise identical pose, per-level rmse and iteration count call after call —
+    with the participants on one XCD (plain stores in that XCD's L2) and dealt over all XCDs (agent-scope stores).  A stale or early read
+    anywhere in the persistent kernel (exchange buffers, LDS hand-overs, control block) shows up here as a second outcome: this is the
+    test that caught a write race in the level set-up of the round-6 kernel (scripts/stress_tracker.py is the long form)."""
+    import collections
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for spread in ("8", "1"):   # (read once per process by the library: one process per setting)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "stress_tracker.py"), "250"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, DSOPP_HIP_ALIGN_SPREAD=spread))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if "distinct outcome" in ln]
+        assert len(lines) == 3, r.stdout
+        for ln in lines:
+            assert " 1 distinct outcome(s)" in ln, ln
