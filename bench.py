@@ -500,6 +500,9 @@ def make_headline(line):
     head["config"] = {k: cfg[k] for k in ("workload", "name", "frames", "points_per_gpu", "total_points", "parallelism", "exchange", "ranks") if k in cfg}
     roof = line.get("roofline") or {}
     head["roofline"] = {k: roof[k] for k in ROOFLINE_KEYS if k in roof}
+    tm = line.get("timing") or {}
+    if tm:
+        head["timing"] = {k: tm[k] for k in ("blocks", "block_ms_min", "block_ms_median", "block_ms_max") if k in tm}
     if "same_workload_1gpu" in line:
         head["same_workload_1gpu"] = line["same_workload_1gpu"].get("value")
     cpu = line.get("cpu_baseline")

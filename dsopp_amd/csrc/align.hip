@@ -859,6 +859,74 @@ __device__ __forceinline__ int alignPackedIndex(int lane, int v) {
   return -1;
 }
 
+#ifdef DSOPP_HIP_MARKS
+#define PD_MARK(i) asm volatile("; ##PD_MARK " #i)
+#else
+#define PD_MARK(i) do { } while (0)
+#endif
+
+/**
+ * 8 x 8 NormalLinearSystem::solve for the persistent kernel's control step: (H + lambda diag(H)) x = b by an LDL^T factorisation, written for
+ * LATENCY.  One wave runs this alone, in order, at ~8 cycles per dependent f64 operation: what it costs is the length of its dependency
+ * chain, not its instruction count.  Hence
+ *   * right-looking: as soon as a pivot's reciprocal is known the whole trailing matrix is updated by independent FMAs, which the
+ *     scheduler interleaves with the NEXT pivot's reciprocal chain (the left-looking form the compiler made of the Cholesky above put a
+ *     dot-product chain in front of every pivot);
+ *   * the right-hand side is carried as a ninth column, so the forward substitution costs no extra chain;
+ *   * LDL^T: a reciprocal (v_rcp_f64 + 2 Newton steps, 5 dependent operations) per pivot instead of a reciprocal square root (8), unit
+ *     triangles in the substitutions;
+ *   * no branches: a basic-block boundary is a wall for the scheduler.  A pivot that fails the guard (the reference's zero-pivot test on
+ *     the Jacobi-scaled pivot d / (diag + 10), normal_linear_system.cpp:10-16,52-59) gets reciprocal 0: its column, its y and its x vanish.
+ * Chain: 8 x (reciprocal 5 + scale 1 + update 1) + back substitution 8 = ~64 dependent operations (the Cholesky form: ~170).
+ */
+template <typename GetH, typename GetB>
+__device__ __forceinline__ void solve8Ldl(GetH getH /* (i, j), j <= i */, GetB getB, double lambda, double *x) {
+  double A[36], y[8], dinv[8], guard[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) A[i * (i + 1) / 2 + j] = getH(i, j);
+    const double hii = getH(i, i);
+    const double dg = hii + hii * lambda;  // H + lambda * diag(H) (calculateStep, eigen_pose_alignment.cpp:194-198)
+    A[i * (i + 1) / 2 + i] = dg;
+    guard[i] = 1e-300 * (dg + 10.0);
+    y[i] = getB(i);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const double d = A[k * (k + 1) / 2 + k];
+    const bool ok = d > guard[k];
+    double r = __builtin_amdgcn_rcp(d);  // (a pivot that fails the guard: whatever this becomes is dropped by the select below)
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double inv = ok ? r : 0.0;
+    dinv[k] = inv;
+    // column k of L (unit diagonal): l_ik = a_ik / d_k, kept beside the unscaled a_ik the update needs
+    double l[8];
+#pragma unroll
+    for (int i = k + 1; i < 8; ++i) l[i] = A[i * (i + 1) / 2 + k] * inv;
+#pragma unroll
+    for (int j = k + 1; j < 8; ++j)
+#pragma unroll
+      for (int i = j; i < 8; ++i) A[i * (i + 1) / 2 + j] = fma(-l[i], A[j * (j + 1) / 2 + k], A[i * (i + 1) / 2 + j]);
+#pragma unroll
+    for (int i = k + 1; i < 8; ++i) {
+      y[i] = fma(-l[i], y[k], y[i]);
+      A[i * (i + 1) / 2 + k] = l[i];
+    }
+  }
+  // D z = y, L^T x = z
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    double sacc = y[i] * dinv[i];
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) sacc = fma(-A[j * (j + 1) / 2 + i], y[j], sacc);
+    y[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = y[i];
+}
+
 /**
  * The LM control step of the persistent kernel: alignDecideWave's state machine and arithmetic (levenberg_marquardt_algorithm.hpp:77-128,
  * eigen_pose_alignment.cpp:101-104,174-212) in the form one wave executes fastest — one instruction per ~4.7 cycles whatever it does, so
@@ -903,6 +971,7 @@ __device__ __forceinline__ void pyramidDecide(AlignControl &c, const double *tot
 #pragma unroll
   for (int a = 0; a < 8; ++a) step_sq += stepv[a] * stepv[a];
   const bool conv_p = step_sq < parameter_tolerance * ((a0 * a0 + a1 * a1) + parameter_tolerance);
+  PD_MARK(1);
   const bool accept = !first && has && better;   // acceptStep (eigen_pose_alignment.cpp:208-212)
   const bool take = first || accept;             // the evaluated state's system becomes the accepted state's
   iteration += first ? 0 : 1;
@@ -916,14 +985,17 @@ __device__ __forceinline__ void pyramidDecide(AlignControl &c, const double *tot
   ab_eps0 = accept ? cand_ab0 : ab_eps0;
   ab_eps1 = accept ? cand_ab1 : ab_eps1;
   // ---- calculateStep (eigen_pose_alignment.cpp:194-206): (H + lambda diag(H)) step = b from the packed sums of the accepted state
+  PD_MARK(2);
   // (a pointer the compiler cannot see through: left to itself it reads BOTH systems and selects entry by entry)
   using LdsDouble = const __attribute__((address_space(3))) double;
   LdsDouble *src = take ? (LdsDouble *)tot : (LdsDouble *)acc_sys;
   asm volatile("" : "+v"(src));
   double stepn[8];
-  solve8Impl([&](int i, int j) { return src[j * 8 - j * (j - 1) / 2 + (i - j)]; }, [&](int i) { return src[36 + i]; }, lambda, stepn);
+  solve8Ldl([&](int i, int j) { return src[j * 8 - j * (j - 1) / 2 + (i - j)]; }, [&](int i) { return src[36 + i]; }, lambda, stepn);
+  PD_MARK(3);
   if (take && lane < 44) acc_sys[lane] = sys_new;  // (behind the solve's reads: nothing waits for it)
   const Rigid E = rigidExp(stepn);
+  PD_MARK(4);
   double Em[12], candTn[12];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -932,6 +1004,7 @@ __device__ __forceinline__ void pyramidDecide(AlignControl &c, const double *tot
     Em[4 * i + 3] = E.t[i];
   }
   mat34Compose(Em, Ttr, candTn);
+  PD_MARK(5);
   // ---- one batch of stores (lane 0)
   if (lane == 0) {
 #pragma unroll
@@ -1014,6 +1087,9 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
 #pragma unroll
   for (int v = 0; v < 4; ++v) pk[v] = alignPackedIndex(lane, v);
   double *const my_rows = rows + wave * kWaveRows;
+  // affine prior of the packed sums (eigen_pose_alignment.cpp:183-190) as lane constants: entry e gets pc0 + pc1 * tab0 + pc2 * tab1
+  const double pc0 = lane == 33 ? a.affine_reg[0] : (lane == 35 ? a.affine_reg[1] : 0.0);
+  const double pc1 = lane == 42 ? a.affine_reg[0] : 0.0, pc2 = lane == 43 ? a.affine_reg[1] : 0.0;
   int levels_done = 0, success = 1, lm_iterations = 0;
   for (int lvl = a.n_levels - 1; lvl >= 0; --lvl) {
     const AlignLevelDev &L = a.level[lvl];
@@ -1185,8 +1261,7 @@ __global__ void __launch_bounds__(kAlignThreads) alignPyramidKernel(AlignPyramid
         if (lane < kAlignPartial) {
           total = (psum[0][lane] + psum[1][lane]) + (psum[2][lane] + psum[3][lane]);
           const double tab0 = tgt.ab0[0] + sc.cand_ab[0], tab1 = tgt.ab0[1] + sc.cand_ab[1];
-          const double prior = lane == 33 ? reg0 : (lane == 35 ? reg1 : (lane == 42 ? reg0 * tab0 : (lane == 43 ? reg1 * tab1 : 0.0)));
-          tot[lane] = (lane == 33 || lane == 35 || lane == 42 || lane == 43) ? total + prior : total;
+          tot[lane] = total + fma(pc2, tab1, fma(pc1, tab0, pc0));  // (+ 0 for the entries without a prior; one product, one sum for the others)
         }
 #ifdef DSOPP_HIP_STAMPS
         if (a.debug_sums && hyp == 0 && pass_global < 256u && (lane == 44 || lane == 0))

@@ -9,10 +9,15 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # kernel whose first loads depend on its leading pointer arguments alone starts them in its first cycles instead of behind an
 # argument fetch (the sweep, reduction and solve launches are laid out for this: profiles/r05/prologue_kernel_stats.txt)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${DSOPP_HIP_EXTRA_FLAGS:-}"
+# align.hip: the persistent tracker kernel's control step is ONE wave running a ~600-instruction dependency chain (8 x 8 LDL^T, SE3 exp): the
+# default scheduler orders for register pressure and puts whole FMA chains in front of every pivot; max-ilp interleaves the independent
+# updates with the reciprocal chains (profiles/r06/tracker_*: control step 1.76 -> see DESIGN.md section 4)
+FLAGS_align="${DSOPP_HIP_ALIGN_SCHED--mllvm -amdgpu-sched-strategy=max-ilp}"
 pids=()
 for src in pyramid pba align depth_estimation comm calibration window_group; do
   if [ -f "$HERE/$src.hip" ]; then
-    $HIPCC $FLAGS -c "$HERE/$src.hip" -o "$OUT/$src.o" &
+    extra="FLAGS_$src"
+    $HIPCC $FLAGS ${!extra:-} -c "$HERE/$src.hip" -o "$OUT/$src.o" &
     pids+=($!)
   fi
 done

@@ -10,6 +10,8 @@
 // never maps it.  Inside a process that already holds an RCCL (PyTorch ships one with the same SONAME) the loaded instance
 // is reused.
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -22,11 +24,15 @@ struct dsopp_hip_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   bool owned = true;
-  // dsopp_hip_comm_abort (called from the failing shard's worker thread while other workers may be inside nativeAllreduce): the handle
-  // only waits to be destroyed.  The flag is atomic and `comm` is never nulled by abort, so a worker that tested the flag just before the
-  // abort hands ncclAllReduce the aborted handle (RCCL's own abort flag makes that call fail) rather than a null pointer.  No mutex
-  // around the two: the abort exists to release workers that are BLOCKED inside RCCL, which would hold it.
+  // dsopp_hip_comm_abort is called from the failing shard's worker thread while other workers may be inside nativeAllreduce.
+  // ncclCommAbort frees the communicator, so it must not run while another thread is between its `aborted` test and the return of its
+  // ncclAllReduce: `in_flight` counts those threads; a thread that finds the flag set after it has announced itself backs out, and abort waits
+  // for the count to drain before it hands the communicator to ncclCommAbort.  The wait is bounded (a worker can sit inside RCCL's enqueue
+  // while a connection comes up: the abort exists to release exactly such workers) — after the bound the abort goes ahead, which is what
+  // RCCL documents ncclCommAbort for.  `abort_ran` says whether RCCL really freed the communicator: destroy skips ncclCommDestroy only then.
   std::atomic<bool> aborted{false};
+  std::atomic<bool> abort_ran{false};
+  std::atomic<int> in_flight{0};
 };
 
 namespace dsopp_hip {
@@ -86,7 +92,12 @@ void rcclCheck(ncclResult_t r, const char *what) {
 /** the dsopp_hip_allreduce_fn the window calls when a native communicator is attached (pba.hip: allreduceIfNeeded) */
 int nativeAllreduce(void *user, void *device_buffer, size_t count, void *stream) {
   auto *c = static_cast<dsopp_hip_comm *>(user);
-  if (c->aborted) {
+  struct InFlight {
+    std::atomic<int> &n;
+    explicit InFlight(std::atomic<int> &x) : n(x) { n.fetch_add(1, std::memory_order_acq_rel); }
+    ~InFlight() { n.fetch_sub(1, std::memory_order_acq_rel); }
+  } announced(c->in_flight);
+  if (c->aborted.load(std::memory_order_acquire)) {  // (tested AFTER the announcement: abort either sees this thread or this thread sees the flag)
     lastError() = "communicator was aborted (dsopp_hip_comm_abort): the collective is not enqueued";
     return -3;
   }
@@ -156,19 +167,26 @@ int dsopp_hip_comm_adopt(void *nccl_comm, int device, dsopp_hip_comm **out) {
 int dsopp_hip_comm_abort(dsopp_hip_comm *c) {
   return guarded([&] {
     if (!c) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null communicator");
-    if (c->aborted.exchange(true)) return;
+    if (c->aborted.exchange(true, std::memory_order_acq_rel)) return;
     // ncclCommAbort releases the kernels of collectives the OTHER ranks already enqueued and that would wait for this rank for ever
     // (a rank that failed between two collectives never enqueues its side); afterwards the communicator can only be destroyed
     if (c->owned && c->comm && rccl().CommAbort) {
+      // threads that passed the flag test before it was set are still inside ncclAllReduce with this handle: let them return first
+      // (an enqueue takes microseconds; bounded, see the struct's comment)
+      const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(2);
+      while (c->in_flight.load(std::memory_order_acquire) > 0 && std::chrono::steady_clock::now() < deadline) std::this_thread::yield();
       (void)hipSetDevice(c->device);
       (void)rccl().CommAbort(c->comm);  // (ncclCommAbort frees the communicator's resources: destroy skips ncclCommDestroy)
+      c->abort_ran.store(true, std::memory_order_release);
     }
   });
 }
 
 void dsopp_hip_comm_destroy(dsopp_hip_comm *c) {
   if (!c) return;
-  if (c->owned && c->comm && !c->aborted) {
+  // (every user of the handle has returned before the owner destroys it — the window / group detach first; a collective still inside
+  // RCCL here would be a caller error, as with any handle of this API)
+  if (c->owned && c->comm && !c->abort_ran.load(std::memory_order_acquire)) {  // aborted without ncclCommAbort in this RCCL: still ours to destroy
     (void)hipSetDevice(c->device);
     try {
       (void)rccl().CommDestroy(c->comm);

@@ -2296,7 +2296,10 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
         return !e ? 0 : (std::string(e) == "morton" ? 1 : (std::string(e) == "snake" ? 2 : 0));
       }();
       auto key = [&](int c) {
-        const long long u = static_cast<long long>(uv[2 * c]), v = static_cast<long long>(uv[2 * c + 1]);
+        // (a coordinate that is not a number, negative or beyond any image is clamped instead of cast: the cast would be undefined behaviour,
+        // and such a landmark is uploaded like any other — the sweep rejects it by its ROI test, as before the internal order existed)
+        auto coord = [](double x) -> long long { return !(x >= 0.0) ? 0ll : (x > 65535.0 ? 65535ll : static_cast<long long>(x)); };
+        const long long u = coord(uv[2 * c]), v = coord(uv[2 * c + 1]);
         const long long m = (1ll << tb) - 1;
         long long tu = u >> tb, tv = v >> tb, iu = u & m, iv = v & m, in;
         if (inner == 1) {
@@ -2316,9 +2319,13 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         const long long ka = key(a), kb = key(b);
         if (ka != kb) return ka < kb;
-        if (idepth[a] != idepth[b]) return idepth[a] < idepth[b];
-        return std::lexicographical_compare(patch + static_cast<size_t>(kPat) * a, patch + static_cast<size_t>(kPat) * (a + 1),
-                                            patch + static_cast<size_t>(kPat) * b, patch + static_cast<size_t>(kPat) * (b + 1));
+        // bit patterns, not values: a strict weak order whatever the numbers are (a NaN compares false both ways as a value, which
+        // std::stable_sort must never be given)
+        unsigned long long ia, ib;
+        std::memcpy(&ia, idepth + a, sizeof(ia));
+        std::memcpy(&ib, idepth + b, sizeof(ib));
+        if (ia != ib) return ia < ib;
+        return std::memcmp(patch + static_cast<size_t>(kPat) * a, patch + static_cast<size_t>(kPat) * b, sizeof(double) * kPat) < 0;
       });
       f.to_internal.resize(static_cast<size_t>(n_total));
       f.to_caller.resize(static_cast<size_t>(n_total));

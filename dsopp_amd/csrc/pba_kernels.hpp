@@ -492,6 +492,8 @@ const FrameDev *__restrict__ frames, const PairConst *__restrict__ pc,
   // every word is pinned below.  Until round 5 the compiler's own placement was descriptor head -> wait -> control block -> wait ->
   // run flag -> wait -> rest of the descriptor + remaining arguments -> wait: four scalar round trips in front of the first item word.
   const SweepBlock be = table[blockIdx.x];
+  // (the stand-in has to cover every word read through it)
+  static_assert(sizeof(SweepBlock) >= sizeof(LmControl) && sizeof(SweepBlock) >= sizeof(int), "the sweep table stands in for an absent control block / run flag");
   const LmControl DSOPP_CONSTANT *ctrl_or_any =
       ctrl_arg ? (const LmControl DSOPP_CONSTANT *)ctrl_arg : (const LmControl DSOPP_CONSTANT *)(const void DSOPP_CONSTANT *)table;
   const int DSOPP_CONSTANT *flag_or_any = run_flag_arg ? (const int DSOPP_CONSTANT *)run_flag_arg : (const int DSOPP_CONSTANT *)(const void DSOPP_CONSTANT *)table;

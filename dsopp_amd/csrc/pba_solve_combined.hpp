@@ -153,6 +153,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
   // Absent control block (isolated timing launches): the argument block stands in, the values are not used.
   const void DSOPP_CONSTANT *any_words = (const void DSOPP_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
   const LmControl DSOPP_CONSTANT *cin_src = dec_in_p ? (const LmControl DSOPP_CONSTANT *)dec_in_p : (const LmControl DSOPP_CONSTANT *)any_words;
+  // (the stand-in has to cover every word read through it, and the field-by-field copy below every field: `*a.ctrl = cin` writes all of it)
+  static_assert(sizeof(a) >= sizeof(LmControl) && sizeof(a) >= 4 * sizeof(double), "the argument block stands in for an absent control block / scalar block");
+  static_assert(sizeof(LmControl) == 6 * sizeof(double) + 8 * sizeof(int), "LmControl changed: extend the scalar copy below");
   LmControl cin;
   cin.lambda = cin_src->lambda;
   cin.energy = cin_src->energy;
@@ -983,7 +986,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       xs[2 * (THREADS / 64) + (tid >> 6)] = nstep;
     }
     ldsBarrier();
-    if (tid == 0) {
+    // (thread 64 — the thread that stored the whole control block after the decision, line ~505: two stores of one thread to the same words
+    // stay in order; with thread 0 here the struct store of wave 1 could land behind these fields, the barriers in between wait for LDS only)
+    if (tid == 64) {
       constexpr int kWaves = THREADS / 64;  // three groups of kWaves wave sums in xs
       double total = a.energy_marginalized, s_state = 0, s_step = 0;
       for (int w = 0; w < kWaves; ++w) {

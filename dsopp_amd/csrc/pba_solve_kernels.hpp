@@ -2,6 +2,7 @@
 // and the LM driver, levenberg_marquardt_algorithm.hpp:77-128, kept on the device so that a whole solve is one stream
 // of launches with no host round trip).
 #pragma once
+#include <cstddef>
 #include <type_traits>
 #include "pba_kernels.hpp"
 
@@ -424,6 +425,10 @@ __global__ void __launch_bounds__(kSchurThreads) reduceSchurKernel(const LmContr
   // Both are read through pointers that are valid whatever the launch passes (the argument block itself stands in for an absent control
   // block / an empty table), so that there is no branch in front of the loads: control block, descriptor head and the remaining
   // argument words leave together and are waited for once.
+  // (the stand-in — the argument segment, of which ReduceSchurArgs is a part — has to cover every word read through it)
+  static_assert(sizeof(ReduceSchurArgs) >= sizeof(LmControl), "the argument block stands in for an absent control block");
+  static_assert(sizeof(ReduceSchurArgs) >= offsetof(SchurBlock, flags) + sizeof(SchurBlock::flags) && sizeof(ReduceSchurArgs) >= offsetof(SchurBlock, ublk) + sizeof(SchurBlock::ublk),
+                "the argument block stands in for the head of an absent Schur descriptor");
   const void DSOPP_CONSTANT *any_words = (const void DSOPP_CONSTANT *)__builtin_amdgcn_kernarg_segment_ptr();
   const LmControl DSOPP_CONSTANT *cp = ctrl_p ? (const LmControl DSOPP_CONSTANT *)ctrl_p : (const LmControl DSOPP_CONSTANT *)any_words;
   int c_active = cp->active, c_lsv = cp->linear_system_valid;

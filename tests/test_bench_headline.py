@@ -38,7 +38,7 @@ def test_headline_is_compact_and_complete():
     # nothing nested beyond the three objects + the second metric
     for k, v in head.items():
         if isinstance(v, dict):
-            assert k in ("config", "roofline", "cpu_baseline", "frame_tracking_ms_per_frame_1280x1024"), k
+            assert k in ("config", "roofline", "cpu_baseline", "timing", "frame_tracking_ms_per_frame_1280x1024"), k
     assert set(head["frame_tracking_ms_per_frame_1280x1024"]) == {"5_levels", "4_levels"}
 
 

@@ -78,3 +78,45 @@ def test_f32_texels_at_1280x1024(fullres_window):
     (eo, no), (eg, ng) = o.calculate_energy(), g.calculate_energy()
     assert abs(no - ng) <= 2 and abs(eo - eg) <= 1e-4 * abs(eo)
     g.close()
+
+
+@pytest.mark.parametrize("name,F,P", [("12kf_50k", 12, 50000), ("15kf_5k", 15, 5000)])
+def test_bench_windows_at_1280x1024_against_the_checker(name, F, P):
+    """The two windows bench.py's `roofline_large_fullres` rows time (the reference's dense configuration, test/test_data/tummono/dense.yaml:
+    21-22,35,42: 1280 x 1024, up to 15 keyframes / 5000 points; and the C4 size, 12 KF / 50 000 points) against the CPU checker AT THEIR OWN
+    SIZE: energies 1e-10, systems 1e-9, step 1e-9, then the production solve() — poses 1e-7, statuses identical.  12 x 42 MB of f64 texels
+    live in HBM, not in the Infinity Cache; the two-stage Schur build and the coarse sweep table are the variants in use."""
+    from dsopp_amd import capi
+    from oracle import pyoracle as po
+    po.set_threads(16)
+    try:
+        win = syn.make_window(num_frames=F, num_points=P, width=1280, height=1024, seed=1, render_device="cuda")
+        o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
+        g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+        o.begin()
+        g.begin()
+        (eo, no), (eg, ng) = o.calculate_energy(), g.calculate_energy()
+        assert no == ng and no > 0.9 * P * (F - 1) * 0.5 and abs(eo - eg) <= 1e-10 * abs(eo)
+        o.linearize()
+        g.linearize()
+        for a, b in zip(o.get_system(), g.get_system()):
+            assert _close(b, a, 1e-9, 1e-9 * np.abs(a).max())
+        so, sg = o.calculate_step(1e-5), g.calculate_step(1e-5)
+        assert np.abs(so - sg).max() <= 1e-9 * max(1.0, np.abs(so).max())
+        g.close()
+        # the production call from the same start: fused loop + relinearisation + covariances + point statuses
+        o = syn.load_window(po.OracleWindow(po.default_pba_options()), win)
+        g = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+        eo, ito, nvo = o.solve()
+        eg, itg, nvg = g.solve()
+        assert (ito, nvo) == (itg, nvg) and abs(eo - eg) <= 1e-7 * abs(eo)
+        for f in win.frames:
+            To, abo = o.get_pose(f.frame_id)
+            Tg, abg = g.get_pose(f.frame_id)
+            assert np.abs(To - Tg).max() <= 1e-7 and np.abs(abo - abg).max() <= 1e-7
+            lo, lg = o.get_landmarks(f.frame_id), g.get_landmarks(f.frame_id, False)
+            assert _close(lg["idepth"], lo["idepth"], 1e-6, 1e-9)
+            assert np.array_equal(lo["flags"] & 3, lg["flags"] & 3) and np.array_equal(lo["n_inliers"], lg["n_inliers"])
+        g.close()
+    finally:
+        po.set_threads(max(1, min(__import__("os").cpu_count() or 1, 8) - 1))
