@@ -1376,6 +1376,7 @@ struct dsopp_hip_aligner {
   // the loop are no-ops, but each still costs a dispatch)
   std::map<int, int> launches_needed;
   DeviceBuffer<int> d_rows;  // row counts / offsets of the device-side depth-map scan
+  int *h_level_totals = nullptr;  // pinned: point counts of the levels scanned by one ensureAllLevelPoints
   DeviceBuffer<AlignControl> d_ctrl;
   std::map<int64_t, Rigid> known_poses;
 };
@@ -1454,16 +1455,29 @@ __global__ void countDepthMapRowsKernel(const double *__restrict__ idsum, const 
   if (threadIdx.x == 0) row_count[y] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
-/** exclusive scan of the row counts (one workgroup; H <= a few thousand); row_offset[H] = total */
-__global__ void scanDepthMapRowsKernel(const int *row_count, int H, int *row_offset) {
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int y = 0; y < H; ++y) {
-      row_offset[y] = acc;
-      acc += row_count[y];
-    }
-    row_offset[H] = acc;
+/** exclusive scan of the row counts (one workgroup of 256 threads, any H); row_offset[H] = total.  Every thread takes a run of consecutive
+ *  rows (loads in flight together), the 256 run sums are scanned in LDS.  (Until round 6 one thread walked the rows: a dependent load per
+ *  row, 47 us per level at 1280 x 1024 — 0.24 ms of the first estimatePose behind every keyframe.) */
+__global__ void __launch_bounds__(256) scanDepthMapRowsKernel(const int *__restrict__ row_count, int H, int *__restrict__ row_offset) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x;
+  const int per = (H + 255) / 256, y0 = tid * per, y1 = min(y0 + per, H);
+  int sum = 0;
+  for (int y = y0; y < y1; ++y) sum += row_count[y];
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
   }
+  int acc = part[tid] - sum;  // exclusive prefix of this thread's run
+  for (int y = y0; y < y1; ++y) {
+    row_offset[y] = acc;
+    acc += row_count[y];
+  }
+  if (tid == 255) row_offset[H] = part[255];
 }
 
 __global__ void compactDepthMapRowsKernel(const double *__restrict__ idsum, const double *__restrict__ weight, int W, int H,
@@ -1509,7 +1523,7 @@ dsopp_hip_depth_maps::LevelPoints &ensureLevelPoints(dsopp_hip_aligner *a, const
     a->d_rows.reserve(2 * static_cast<size_t>(H) + 2, 0, st);
     int *row_count = a->d_rows.ptr, *row_offset = a->d_rows.ptr + H;
     countDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_count);
-    scanDepthMapRowsKernel<<<1, 64, 0, st>>>(row_count, H, row_offset);
+    scanDepthMapRowsKernel<<<1, 256, 0, st>>>(row_count, H, row_offset);
     int total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
     a->sr.sync();
@@ -1526,6 +1540,57 @@ dsopp_hip_depth_maps::LevelPoints &ensureLevelPoints(dsopp_hip_aligner *a, const
     pts.pyramid = pyramid;
   }
   return pts;
+}
+
+/** ensureLevelPoints for all `levels` of the maps at once (estimatePose touches every level of fresh maps in the frame behind a keyframe):
+ *  the scans of all stale levels are enqueued together, their totals come back with ONE copy and ONE synchronisation, then all
+ *  compactions — instead of two synchronisations, a copy and a handful of allocations per level */
+void ensureAllLevelPoints(dsopp_hip_aligner *a, const dsopp_hip_depth_maps *maps, const dsopp_hip_pyramid *pyramid, int levels) {
+  hipStream_t st = a->sr.stream;
+  int stale[DSOPP_HIP_MAX_LEVELS], n_stale = 0;
+  size_t rows_total = 0;
+  size_t first_row[DSOPP_HIP_MAX_LEVELS];
+  for (int lvl = 0; lvl < levels; ++lvl) {
+    if (pyramid->dtype != a->opt.dtype || pyramid->sr.device != a->sr.device || pyramid->w(lvl) != maps->width[static_cast<size_t>(lvl)] ||
+        pyramid->h(lvl) != maps->height[static_cast<size_t>(lvl)])
+      return;  // (the caller's per-level checks raise the error)
+    const dsopp_hip_depth_maps::LevelPoints &pts = maps->points[static_cast<size_t>(lvl)];
+    if (pts.n >= 0 && pts.pyramid == pyramid) continue;
+    stale[n_stale++] = lvl;
+    first_row[lvl] = rows_total;
+    rows_total += 2 * static_cast<size_t>(pyramid->h(lvl)) + 2;
+  }
+  if (n_stale < 2) return;  // (one level: ensureLevelPoints does it as before)
+  a->d_rows.reserve(rows_total, 0, st);
+  if (!a->h_level_totals) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&a->h_level_totals), DSOPP_HIP_MAX_LEVELS * sizeof(int), hipHostMallocDefault));
+  for (int i = 0; i < n_stale; ++i) {
+    const int lvl = stale[i], W = pyramid->w(lvl), H = pyramid->h(lvl);
+    int *row_count = a->d_rows.ptr + first_row[lvl], *row_offset = row_count + H;
+    countDepthMapRowsKernel<<<H, 256, 0, st>>>(maps->idepth_sum[static_cast<size_t>(lvl)].ptr, maps->weight[static_cast<size_t>(lvl)].ptr, W, H, row_count);
+    scanDepthMapRowsKernel<<<1, 256, 0, st>>>(row_count, H, row_offset);
+    HIP_CHECK(hipMemcpyAsync(a->h_level_totals + i, row_offset + H, sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  HIP_CHECK(hipGetLastError());
+  a->sr.sync();
+  for (int i = 0; i < n_stale; ++i) {
+    const int lvl = stale[i], W = pyramid->w(lvl), H = pyramid->h(lvl);
+    dsopp_hip_depth_maps::LevelPoints &pts = maps->points[static_cast<size_t>(lvl)];
+    const int total = a->h_level_totals[i];
+    const size_t n = static_cast<size_t>(total);
+    pts.u.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.v.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.idepth.reserve(std::max<size_t>(n, 1), 0, st);
+    pts.intensity.reserve(std::max<size_t>(n, 1), 0, st);
+    const int *row_offset = a->d_rows.ptr + first_row[lvl] + H;
+    if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(maps->idepth_sum[static_cast<size_t>(lvl)].ptr, maps->weight[static_cast<size_t>(lvl)].ptr, W, H, row_offset,
+                                                         pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
+    HIP_CHECK(hipGetLastError());
+    sampleReferenceIntensitiesImpl(st, pyramid, lvl, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
+    pts.n = total;
+    pts.pyramid = pyramid;
+  }
+  // (no synchronisation: the consumers — the alignment kernels — are enqueued on this stream behind the compactions; d_rows is not reused
+  // before the next call of this function or of ensureLevelPoints, both behind them on the same stream)
 }
 
 void checkPyramid(dsopp_hip_aligner *a, const dsopp_hip_pyramid *p, int level) {
@@ -1562,6 +1627,7 @@ void dsopp_hip_aligner_destroy(dsopp_hip_aligner *a) {
   if (a->sr.stream) (void)hipStreamSynchronize(a->sr.stream);
   if (a->h_ctrl) (void)hipHostFree(a->h_ctrl);
   if (a->h_pyr_out) (void)hipHostFree(a->h_pyr_out);
+  if (a->h_level_totals) (void)hipHostFree(a->h_level_totals);
   StreamRef sr = a->sr;
   delete a;
   sr.destroy();
@@ -1927,6 +1993,10 @@ int dsopp_hip_aligner_estimate_pose(dsopp_hip_aligner *a, int64_t reference_time
         std::memset(&args, 0, sizeof(args));
         int max_blocks = 1;
         const double zero_ab[2] = {0, 0};
+        if (reference_depth_maps->sr.device == a->sr.device) {
+          if (reference_depth_maps->sr.stream != st) HIP_CHECK(hipStreamSynchronize(reference_depth_maps->sr.stream));
+          ensureAllLevelPoints(a, reference_depth_maps, reference_pyramid, levels);  // fresh maps: all levels in one round trip
+        }
         for (int lvl = 0; lvl < levels; ++lvl) {
           checkPyramid(a, reference_pyramid, lvl);
           checkPyramid(a, target_pyramid, lvl);

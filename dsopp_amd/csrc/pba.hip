@@ -160,7 +160,22 @@ struct dsopp_hip_window {
     char *base = nullptr;
     size_t capacity = 0, offset = 0;
   } stage;
-  DeviceBuffer<uint8_t> d_flag_stage;  // host-side flag bits of one frame on their way into the merge kernel
+  // Appends of a keyframe step (dsopp_hip_window_set_landmarks / _set_connection: ~120 calls per keyframe from the tracker, each of which used
+  // to cost one or more pinned-ring copies and a small kernel — 0.6 ms of host time per keyframe in the native driver, rocprofv3 --hip-trace,
+  // profiles/r06/keyframe_hip_trace_breakdown.json) are QUEUED here and leave as ONE copy + ONE kernel in front of the next call that touches the
+  // device (flushAppends): `blob` = the callers' data back to back, `ops` = what to do with it.
+  struct AppendOp {
+    int kind;                    // 0: copy; 1: merge landmark flags (+ clear the solver state of new landmarks); 2: new connection entries
+    int n;                       // elements (> 0)
+    int a;                       // kind 0: bytes per element (8, 4, 1); kind 1: n_old; kind 2: keep (first new entry)
+    int first_block;             // first workgroup of the launch that works on this operation
+    unsigned long long src_off;  // byte offset of the operation's data in the blob
+    void *dst;                   // kind 0: destination; kind 1: device flags; kind 2: statuses
+    void *p[6];                  // kind 1: idepth_step, idepth_fej, inv_hdd, b_d, relative_baseline, n_inliers (null: no new landmarks); kind 2: cand, fej_valid, energy
+  };
+  std::vector<uint8_t> append_blob;
+  std::vector<AppendOp> append_ops;
+  DeviceBuffer<uint8_t> d_append;
   // updateFrame read-back prefetched by solve(): the tracker calls updateFrame for every keyframe right after the solve
   // (refinePoses), so solve() packs all frames behind its own final synchronisation and the getters become host copies.
   // Valid until the next call that can change the window (every such entry point clears it).
@@ -301,6 +316,8 @@ __global__ void gatherRowsKernel(const uint8_t *__restrict__ src, uint8_t *__res
  * residual tables is re-ordered on the device.  Rare: the tracker's lists always end where a batch ends (LocalFrame::update appends
  * landmarks and their residuals together, local_frame.hpp:484-521); ragged test windows come through here.
  */
+void flushAppends(W &w);
+
 void splitBatchAt(W &w, HostFrame &f, int n) {
   if (!f.permuted() || n <= 0 || n >= f.n) return;
   int b0 = 0, b1 = f.n;
@@ -309,6 +326,7 @@ void splitBatchAt(W &w, HostFrame &f, int n) {
     if (e < n) b0 = std::max(b0, e);
     if (e > n) b1 = std::min(b1, e);
   }
+  flushAppends(w);  // the rows about to be permuted may still be on their way (queued appends)
   const int count = b1 - b0;
   std::vector<int> new_to_old;  // absolute device rows
   new_to_old.reserve(static_cast<size_t>(count));
@@ -370,7 +388,10 @@ void splitBatchAt(W &w, HostFrame &f, int n) {
 
 void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   if (n <= f.cap) return;
-  int cap = f.cap ? f.cap : 256;
+  flushAppends(w);  // the arrays move: queued appends hold their old addresses
+  // (first allocation for 1024 landmarks: a keyframe of the tracker gains its landmarks over several keyframes — from 256 every frame grew its
+  // ~34 device arrays twice on the way, a malloc + fill + copy + synchronisation + free each)
+  int cap = f.cap ? f.cap : 1024;
   while (cap < n) cap *= 2;
   hipStream_t st = w.sr.stream;
   const size_t keep = static_cast<size_t>(f.n);
@@ -397,6 +418,18 @@ void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   w.topology_dirty = true;
 }
 
+/** pinned read-back buffers grow geometrically (a window gains landmarks with every keyframe: sized exactly, the per-keyframe read-backs
+ *  paid a hipHostFree + hipHostMalloc — 0.17 ms — at every keyframe of the native driver; rocprofv3 --hip-trace, profiles/r06) */
+void growPinned(void *&ptr, size_t &have, size_t need) {
+  if (have >= need) return;
+  if (ptr) (void)hipHostFree(ptr);
+  ptr = nullptr;
+  size_t cap = std::max<size_t>(have, size_t(1) << 16);
+  while (cap < need) cap *= 2;
+  HIP_CHECK(hipHostMalloc(&ptr, cap, hipHostMallocDefault));
+  have = cap;
+}
+
 /** `bytes` of pinned staging whose previous contents are no longer in flight */
 void *stageAcquire(W &w, size_t bytes) {
   bytes = (bytes + 63) & ~static_cast<size_t>(63);
@@ -419,55 +452,119 @@ void *stageAcquire(W &w, size_t bytes) {
   w.stage.offset += bytes;
   return p;
 }
-/** asynchronous upload of caller memory through the pinned ring */
+constexpr int kAppendBlockElems = 2048;  // elements (kind 0: 8-byte words) one workgroup of applyAppendsKernel handles
+
+/** the queued appends of a keyframe step in one launch: workgroup b works on the operation whose block range holds b */
+__global__ void __launch_bounds__(256) applyAppendsKernel(const uint8_t *__restrict__ blob, const W::AppendOp *__restrict__ ops, int n_ops) {
+  __shared__ int s_op;
+  if (threadIdx.x == 0) {
+    int lo = 0;
+    for (int i = 1; i < n_ops; ++i)
+      if (ops[i].first_block <= static_cast<int>(blockIdx.x)) lo = i;
+    s_op = lo;
+  }
+  __syncthreads();
+  const W::AppendOp op = ops[s_op];
+  const int chunk = static_cast<int>(blockIdx.x) - op.first_block;
+  const uint8_t *src = blob + op.src_off;
+  const int e0 = chunk * kAppendBlockElems, e1 = e0 + kAppendBlockElems < op.n ? e0 + kAppendBlockElems : op.n;
+  if (op.kind == 0) {
+    // n elements of op.a bytes each (8: coordinates, inverse depths, patches; 4: row permutations); the blob entry is 8-byte aligned, the
+    // destination is aligned to its element size
+    if (op.a == 8) {
+      for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) static_cast<unsigned long long *>(op.dst)[i] = reinterpret_cast<const unsigned long long *>(src)[i];
+    } else if (op.a == 4) {
+      for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) static_cast<unsigned *>(op.dst)[i] = reinterpret_cast<const unsigned *>(src)[i];
+    } else {
+      for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) static_cast<uint8_t *>(op.dst)[i] = src[i];
+    }
+    return;
+  }
+  if (op.kind == 1) {
+    // landmark flags: {marginalized, to_marginalize} are decided on the host (LocalFrame::update), {outlier, ill_conditioned} live on the
+    // device (point statuses, Schur kernel): old landmarks keep the device bits, new ones take the host's outlier bit and a cleared solver state
+    uint8_t *dflags = static_cast<uint8_t *>(op.dst);
+    for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) {
+      const uint8_t h = src[i];
+      if (i < op.a) {
+        dflags[i] = static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize)));
+      } else {
+        dflags[i] = h;
+        if (op.p[0]) {
+          static_cast<double *>(op.p[0])[i] = 0;
+          static_cast<double *>(op.p[1])[i] = 0;
+          static_cast<double *>(op.p[2])[i] = 0;
+          static_cast<double *>(op.p[3])[i] = 0;
+          static_cast<double *>(op.p[4])[i] = 0;
+          static_cast<int32_t *>(op.p[5])[i] = 0;
+        }
+      }
+    }
+    return;
+  }
+  // kind 2 — new entries [keep, keep + n) of a connection: status from the caller, candidate = status, no FEJ cache, zero energy
+  for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) {
+    const uint8_t st = src[i];
+    const size_t j = static_cast<size_t>(op.a) + static_cast<size_t>(i);
+    static_cast<uint8_t *>(op.dst)[j] = st;
+    static_cast<uint8_t *>(op.p[0])[j] = st;
+    static_cast<uint8_t *>(op.p[1])[j] = 0;
+    static_cast<double *>(op.p[2])[j] = 0;
+  }
+}
+
+/** everything queued by set_landmarks / set_connection goes to the device: one pinned-ring copy, one launch.  Called in front of every
+ *  entry point that enqueues device work on the window or reads its device arrays, and before a queued destination is reallocated. */
+void flushAppends(W &w) {
+  if (w.append_ops.empty()) return;
+  const int n_ops = static_cast<int>(w.append_ops.size());
+  int blocks = 0;
+  for (W::AppendOp &op : w.append_ops) {
+    op.first_block = blocks;
+    blocks += (op.n + kAppendBlockElems - 1) / kAppendBlockElems;
+  }
+  const size_t data_bytes = (w.append_blob.size() + 15) & ~static_cast<size_t>(15), table_bytes = static_cast<size_t>(n_ops) * sizeof(W::AppendOp);
+  hipStream_t st = w.sr.stream;
+  w.d_append.reserve(data_bytes + table_bytes, 0, st);
+  uint8_t *p = static_cast<uint8_t *>(stageAcquire(w, data_bytes + table_bytes));
+  std::memcpy(p, w.append_blob.data(), w.append_blob.size());
+  std::memcpy(p + data_bytes, w.append_ops.data(), table_bytes);
+  HIP_CHECK(hipMemcpyAsync(w.d_append.ptr, p, data_bytes + table_bytes, hipMemcpyHostToDevice, st));
+  applyAppendsKernel<<<static_cast<unsigned>(blocks), 256, 0, st>>>(w.d_append.ptr, reinterpret_cast<const W::AppendOp *>(w.d_append.ptr + data_bytes), n_ops);
+  HIP_CHECK(hipGetLastError());
+  w.append_blob.clear();
+  w.append_ops.clear();
+}
+
+/** queue entry: data into the blob (8-byte aligned), flushing first when the new operation writes where a queued one does (operations
+ *  of ONE launch run concurrently: two of them must never touch the same array) */
+size_t queueAppendData(W &w, const void *host, size_t bytes, const void *dst_a, const void *dst_b = nullptr) {
+  for (const W::AppendOp &op : w.append_ops)
+    if (op.dst == dst_a || (dst_b && op.dst == dst_b)) {
+      flushAppends(w);
+      break;
+    }
+  const size_t off = (w.append_blob.size() + 7) & ~static_cast<size_t>(7);
+  w.append_blob.resize(off + bytes);
+  if (bytes) std::memcpy(w.append_blob.data() + off, host, bytes);
+  return off;
+}
+
+/** queued upload of caller memory (applyAppendsKernel, kind 0).  (Destinations of one frame's arrays are distinct allocations: the base
+ *  pointer of the buffer identifies the array in the conflict test.) */
 template <typename T>
 void uploadStaged(W &w, DeviceBuffer<T> &dst, const T *host, size_t count, size_t offset) {
   if (!count) return;
-  void *p = stageAcquire(w, count * sizeof(T));
-  std::memcpy(p, host, count * sizeof(T));
-  HIP_CHECK(hipMemcpyAsync(dst.ptr + offset, p, count * sizeof(T), hipMemcpyHostToDevice, w.sr.stream));
+  static_assert(sizeof(T) == 8 || sizeof(T) == 4 || sizeof(T) == 1, "element size of a queued copy");
+  W::AppendOp op{};
+  op.kind = 0;
+  op.n = static_cast<int>(count);
+  op.a = static_cast<int>(sizeof(T));
+  op.src_off = queueAppendData(w, host, count * sizeof(T), dst.ptr + offset);
+  op.dst = dst.ptr + offset;
+  w.append_ops.push_back(op);
 }
 
-/** landmark flags: {marginalized, to_marginalize} are decided on the host (LocalFrame::update), {outlier, ill_conditioned}
- *  live on the device (point statuses, Schur kernel): old landmarks keep the device bits, new ones take the host's outlier bit */
-__global__ void mergeLandmarkFlagsKernel(uint8_t *__restrict__ dflags, const uint8_t *__restrict__ host_bits, int n_old, int n_total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_total) return;
-  const uint8_t h = host_bits[i];
-  dflags[i] = i < n_old ? static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize))) : h;
-}
-/** the same for a frame that gained landmarks [n_old, n_total): also clears their solver state (one launch instead of six fills) */
-struct NewLandmarkArrays {
-  double *idepth_step, *idepth_fej, *inv_hdd, *b_d, *relative_baseline;
-  int32_t *n_inliers;
-};
-__global__ void mergeFlagsInitLandmarksKernel(uint8_t *__restrict__ dflags, const uint8_t *__restrict__ host_bits, int n_old, int n_total,
-                                              NewLandmarkArrays a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_total) return;
-  const uint8_t h = host_bits[i];
-  if (i < n_old) {
-    dflags[i] = static_cast<uint8_t>((dflags[i] & (kFlagOutlier | kFlagIllConditioned)) | (h & (kFlagMarginalized | kFlagToMarginalize)));
-    return;
-  }
-  dflags[i] = h;
-  a.idepth_step[i] = 0;
-  a.idepth_fej[i] = 0;
-  a.inv_hdd[i] = 0;
-  a.b_d[i] = 0;
-  a.relative_baseline[i] = 0;
-  a.n_inliers[i] = 0;
-}
-/** new entries [keep, keep + add) of a connection: candidate = status, no FEJ cache, zero energy (one launch instead of a
- *  copy and two fills) */
-__global__ void initConnectionKernel(const uint8_t *__restrict__ status, uint8_t *__restrict__ cand, uint8_t *__restrict__ fej_valid,
-                                     double *__restrict__ energy, int keep, int add) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= add) return;
-  cand[keep + i] = status[keep + i];
-  fej_valid[keep + i] = 0;
-  energy[keep + i] = 0;
-}
 __global__ void clearLandmarkFlagKernel(uint8_t *__restrict__ dflags, int n, uint8_t mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dflags[i] &= static_cast<uint8_t>(~mask);
@@ -742,6 +839,7 @@ void checkPyramidGenerations(W &w) {
 
 void prepare(W &w) {
   w.sr.use();
+  flushAppends(w);  // queued landmark / connection appends first: everything below reads what they write
   checkPyramidGenerations(w);
   downloadState(w);  // no-op unless a device-driven solve left the host mirror behind
   syncTopology(w);
@@ -754,6 +852,7 @@ void prepare(W &w) {
  *  its refresh (a read-back + synchronisation) is left to the first reader */
 void prepareDevice(W &w) {
   w.sr.use();
+  flushAppends(w);
   checkPyramidGenerations(w);
   if (w.state_dirty || w.topology_dirty || w.marg_dirty || !w.d_state.ptr) prepare(w);
 }
@@ -1430,6 +1529,7 @@ void lmSolveDevice(W &w, double &energy_out, int &iterations, int &n_valid_out) 
 void restoreHostSide(W &w) {
   if (!w.snap_valid || w.snap_F != w.F()) fail(DSOPP_HIP_ERR_STATE, "no snapshot matching the current window");
   w.sr.use();
+  flushAppends(w);
   for (auto &fp : w.frames) {
     if (fp->snap_n != fp->n) fail(DSOPP_HIP_ERR_STATE, "frame %d changed since the snapshot", fp->id);
     for (auto &kv : fp->residuals)
@@ -1862,12 +1962,7 @@ bool estimateUncertaintyEnqueue(W &w, bool force_state) {
   const bool want_state = force_state || (w.host_stale && !w.state_dirty);
   const size_t bytes = 2 * kk * sizeof(double) + sizeof(WindowState);
   // (a buffer of its own: the packed per-frame read-back of solve() uses h_export while the host is still working on this one)
-  if (w.h_uncertainty_bytes < bytes) {
-    if (w.h_uncertainty) (void)hipHostFree(w.h_uncertainty);
-    w.h_uncertainty = nullptr;
-    HIP_CHECK(hipHostMalloc(&w.h_uncertainty, bytes, hipHostMallocDefault));
-    w.h_uncertainty_bytes = bytes;
-  }
+  growPinned(w.h_uncertainty, w.h_uncertainty_bytes, bytes);
   if (!w.uncertainty_ready) HIP_CHECK(hipEventCreateWithFlags(&w.uncertainty_ready, hipEventDisableTiming));
   double *Hpp = static_cast<double *>(w.h_uncertainty), *Hsc = Hpp + kk;
   w.d_Hpp.download(Hpp, 2 * kk, 0, w.sr.stream);  // [H_pp | symmetric H_schur], stored back to back by the assemble kernel
@@ -2207,6 +2302,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
       fail(DSOPP_HIP_ERR_ORDER, "frames must be pushed in ascending order of time");
     if (w->slotOf(frame_id) >= 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "frame %d already in the window", frame_id);
     w->sr.use();
+    flushAppends(*w);
     if (w->frames.size() > 1) foldMarginalized(*w);
     if (w->F() >= kMaxFrames) fail(DSOPP_HIP_ERR_CAPACITY, "window holds %d frames already", kMaxFrames);
     downloadState(*w);
@@ -2339,21 +2435,28 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     if (add) f.batch_end.push_back(n_total);
     const bool permuted = f.permuted();
     if (n_total) {
-      w->d_flag_stage.reserve(static_cast<size_t>(n_total), 0, st);
+      // flag bits in the device's landmark order -> queued merge (applyAppendsKernel, kind 1)
+      W::AppendOp op{};
+      op.kind = 1;
+      op.n = n_total;
+      op.a = old;
       if (permuted) {
         std::vector<uint8_t> staged(static_cast<size_t>(n_total));
         for (int p = 0; p < n_total; ++p) staged[static_cast<size_t>(p)] = f.flags[static_cast<size_t>(f.to_caller[static_cast<size_t>(p)])];
-        uploadStaged(*w, w->d_flag_stage, staged.data(), staged.size(), 0);
+        op.src_off = queueAppendData(*w, staged.data(), staged.size(), f.dflags.ptr);
       } else {
-        uploadStaged(*w, w->d_flag_stage, f.flags.data(), static_cast<size_t>(n_total), 0);
+        op.src_off = queueAppendData(*w, f.flags.data(), static_cast<size_t>(n_total), f.dflags.ptr);
       }
+      op.dst = f.dflags.ptr;
       if (n_total > old) {
-        const NewLandmarkArrays na{f.idepth_step.ptr, f.idepth_fej.ptr, f.inv_hdd.ptr, f.b_d.ptr, f.relative_baseline.ptr, f.n_inliers.ptr};
-        mergeFlagsInitLandmarksKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total, na);
-      } else {
-        mergeLandmarkFlagsKernel<<<(n_total + 255) / 256, 256, 0, st>>>(f.dflags.ptr, w->d_flag_stage.ptr, old, n_total);
+        op.p[0] = f.idepth_step.ptr;
+        op.p[1] = f.idepth_fej.ptr;
+        op.p[2] = f.inv_hdd.ptr;
+        op.p[3] = f.b_d.ptr;
+        op.p[4] = f.relative_baseline.ptr;
+        op.p[5] = f.n_inliers.ptr;
       }
-      HIP_CHECK(hipGetLastError());
+      w->append_ops.push_back(op);
     }
     for (int i = old; i < n_total; ++i) f.flags[static_cast<size_t>(i)] &= kFlagMarginalized;  // the mirror keeps host-decided bits only
     if (add && permuted) {
@@ -2401,24 +2504,31 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     hipStream_t st = w->sr.stream;
     const size_t cap = static_cast<size_t>(std::max(f.cap, 1));
     const size_t keep = static_cast<size_t>(rt.n);
+    if (rt.status.ptr && cap > rt.status.capacity) flushAppends(*w);  // the arrays move: queued appends hold their old addresses
     rt.status.reserve(cap, keep, st);
     rt.cand.reserve(cap, keep, st);
     rt.fej_valid.reserve(cap, keep, st);
     rt.energy.reserve(cap, keep, st);
     if (n > rt.n) {
       const size_t add = static_cast<size_t>(n - rt.n);
+      W::AppendOp op{};
+      op.kind = 2;
+      op.n = static_cast<int>(add);
+      op.a = static_cast<int>(keep);
       if (f.permuted()) {
         // the list grows by the caller's landmarks [rt.n, n): they must be the device's [rt.n, n) as well (splitBatchAt), in the device's order
         splitBatchAt(*w, f, n);
         std::vector<uint8_t> staged(add);
         for (size_t k = 0; k < add; ++k) staged[k] = statuses[f.to_caller[keep + k]];
-        uploadStaged(*w, rt.status, staged.data(), add, keep);
+        op.src_off = queueAppendData(*w, staged.data(), add, rt.status.ptr);
       } else {
-        uploadStaged(*w, rt.status, statuses + rt.n, add, keep);
+        op.src_off = queueAppendData(*w, statuses + rt.n, add, rt.status.ptr);
       }
-      initConnectionKernel<<<static_cast<unsigned>((add + 255) / 256), 256, 0, st>>>(rt.status.ptr, rt.cand.ptr, rt.fej_valid.ptr, rt.energy.ptr,
-                                                                                    static_cast<int>(keep), static_cast<int>(add));
-      HIP_CHECK(hipGetLastError());
+      op.dst = rt.status.ptr;
+      op.p[0] = rt.cand.ptr;
+      op.p[1] = rt.fej_valid.ptr;
+      op.p[2] = rt.energy.ptr;
+      w->append_ops.push_back(op);
       rt.n = n;
     }
     w->topology_dirty = true;
@@ -2465,6 +2575,7 @@ int dsopp_hip_window_calculate_energy(dsopp_hip_window *w, double *energy, int32
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     auto r = stageEnergy(*w);
     if (energy) *energy = r.first;
     if (n_valid) *n_valid = r.second;
@@ -2476,6 +2587,7 @@ int dsopp_hip_window_linearize(dsopp_hip_window *w) {
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     stageLinearize(*w);
     w->sr.sync();
   });
@@ -2486,6 +2598,7 @@ int dsopp_hip_window_get_system(dsopp_hip_window *w, double *H_pp, double *b_pp,
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (!w->linearized) fail(DSOPP_HIP_ERR_STATE, "no linearised system available");
     w->sr.use();
+    flushAppends(*w);
     const size_t K = static_cast<size_t>(w->K());
     hipStream_t st = w->sr.stream;
     if (H_pp) w->d_Hpp.download(H_pp, K * K, 0, st);
@@ -2501,6 +2614,7 @@ int dsopp_hip_window_calculate_step(dsopp_hip_window *w, double lambda, double *
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     stageStep(*w, lambda);
     if (step) std::memcpy(step, w->last_step.data(), w->last_step.size() * sizeof(double));
   });
@@ -2511,6 +2625,7 @@ int dsopp_hip_window_accept_step(dsopp_hip_window *w, double *state_sq, double *
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     auto r = stageAccept(*w, true);
     if (state_sq) *state_sq = r.first;
     if (step_sq) *step_sq = r.second;
@@ -2522,6 +2637,7 @@ int dsopp_hip_window_reject_step(dsopp_hip_window *w) {
     if (w) w->export_valid = false;
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     stageAccept(*w, false);
   });
 }
@@ -2613,12 +2729,7 @@ void prefetchFrameUpdates(dsopp_hip_window &w) {
   }
   exportFramesKernel<<<dim3(static_cast<unsigned>((max_n + 255) / 256), static_cast<unsigned>(batch.n_frames)), 256, 0, st>>>(batch);
   HIP_CHECK(hipGetLastError());
-  if (w.h_update_bytes < words * 8) {
-    if (w.h_update) (void)hipHostFree(w.h_update);
-    w.h_update = nullptr;
-    HIP_CHECK(hipHostMalloc(&w.h_update, words * 8, hipHostMallocDefault));
-    w.h_update_bytes = words * 8;
-  }
+  growPinned(w.h_update, w.h_update_bytes, words * 8);
   HIP_CHECK(hipMemcpyAsync(w.h_update, w.d_update.ptr, words * 8, hipMemcpyDeviceToHost, st));
 }
 }  // namespace
@@ -2631,6 +2742,7 @@ int dsopp_hip_window_optimize_async(dsopp_hip_window *w) {
     if (w->lm_mode != 0) fail(DSOPP_HIP_ERR_STATE, "the asynchronous solve exists for the fused device loop only (lm_mode 0)");
     if (w->async_pending) fail(DSOPP_HIP_ERR_STATE, "an asynchronous solve is already pending: call dsopp_hip_window_optimize_wait first");
     w->sr.use();
+    flushAppends(*w);
     prepare(*w);
     fusedBegin(*w);
     lmSolveFusedEnqueue(*w);
@@ -2644,6 +2756,7 @@ int dsopp_hip_window_optimize_wait(dsopp_hip_window *w, double *energy, int32_t 
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     if (!w->async_pending) fail(DSOPP_HIP_ERR_STATE, "no asynchronous solve is pending");
     w->sr.use();
+    flushAppends(*w);
     double e = 0;
     int it = 0, nv = 0;
     w->async_pending = false;
@@ -2670,6 +2783,7 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
       // host inverts the reduced system.  (Step by step the GPU idled for the host synchronisation behind the LM loop and for
       // the 0.1 ms of the pseudo-inverse: rocprofv3 kernel trace, scripts/trace_solve.py.)
       w->sr.use();
+    flushAppends(*w);
       prepare(*w);
       HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
       fusedBegin(*w);
@@ -2727,6 +2841,7 @@ int dsopp_hip_window_get_frame_state(dsopp_hip_window *w, int32_t frame_id, doub
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     const int s = w->slotOf(frame_id);
     if (s < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", frame_id);
     downloadState(*w);
@@ -2749,6 +2864,7 @@ int dsopp_hip_window_get_pose(dsopp_hip_window *w, int32_t frame_id, double T_wo
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     const int s = w->slotOf(frame_id);
     if (s < 0) fail(DSOPP_HIP_ERR_NOT_FOUND, "frame %d is not in the window", frame_id);
     downloadState(*w);
@@ -2772,6 +2888,7 @@ int dsopp_hip_window_get_landmarks(dsopp_hip_window *w, int32_t frame_id, double
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     HostFrame &f = w->frameById(frame_id);
     hipStream_t st = w->sr.stream;
     const size_t n = static_cast<size_t>(f.n);
@@ -2817,6 +2934,7 @@ int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, dou
   return guarded([&] {
     if (!w || n_targets < 0 || n_targets > kMaxFrames || (n_targets && (!target_ids || !statuses))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
     w->sr.use();
+    flushAppends(*w);
     HostFrame &f = w->frameById(frame_id);
     const size_t n = static_cast<size_t>(f.n);
     if (n == 0) return;
@@ -2866,12 +2984,7 @@ int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, dou
     a.out_b = reinterpret_cast<uint8_t *>(w->d_export.ptr + 4 * n);
     exportFrameKernel<<<static_cast<unsigned>((n + 255) / 256), 256, 0, st>>>(a);
     HIP_CHECK(hipGetLastError());
-    if (w->h_export_bytes < words * 8) {
-      if (w->h_export) (void)hipHostFree(w->h_export);
-      w->h_export = nullptr;
-      HIP_CHECK(hipHostMalloc(&w->h_export, words * 8, hipHostMallocDefault));
-      w->h_export_bytes = words * 8;
-    }
+    growPinned(w->h_export, w->h_export_bytes, words * 8);
     HIP_CHECK(hipMemcpyAsync(w->h_export, w->d_export.ptr, words * 8, hipMemcpyDeviceToHost, st));
     w->sr.sync();
     const double *hd = static_cast<const double *>(w->h_export);
@@ -2891,6 +3004,7 @@ int dsopp_hip_window_get_residuals(dsopp_hip_window *w, int32_t reference_id, in
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     HostFrame &f = w->frameById(reference_id);
     auto it = f.residuals.find(target_id);
     if (it == f.residuals.end()) fail(DSOPP_HIP_ERR_NOT_FOUND, "no connection %d -> %d", reference_id, target_id);
@@ -3175,6 +3289,7 @@ int dsopp_hip_window_time_kernel(dsopp_hip_window *w, int kernel_class, int repe
     if (w) w->export_valid = false;
     if (!w || !avg_us || repeats < 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "bad argument");
     w->sr.use();
+    flushAppends(*w);
     if (!w->begun) stageBegin(*w);
     const bool saved = w->profiling;
     w->profiling = false;
@@ -3260,6 +3375,7 @@ namespace {
  *  cannot overshoot; solves that stop early are made up for by further ones, exactly as in the sequential loop. */
 void optimizeRepeatedPipelined(dsopp_hip_window &w, int target, int &done, double &energy) {
   w.sr.use();
+  flushAppends(w);
   hipStream_t st = w.sr.stream;
   const int configured = w.opt.max_iterations;
   constexpr int kSlots = 32;  // solves per batch: their results are fetched with ONE copy and ONE synchronisation
@@ -3367,6 +3483,7 @@ int dsopp_hip_window_snapshot(dsopp_hip_window *w) {
   return guarded([&] {
     if (!w) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null window");
     w->sr.use();
+    flushAppends(*w);
     prepare(*w);
     downloadState(*w);
     hipStream_t st = w->sr.stream;
@@ -3440,6 +3557,7 @@ int dsopp_hip_window_last_solve_ms(dsopp_hip_window *w, float *ms) {
     if (!w || !ms) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (w->solve_events_pending) {
       w->sr.use();
+    flushAppends(*w);
       HIP_CHECK(hipEventSynchronize(w->ev1));
       HIP_CHECK(hipEventElapsedTime(&w->last_solve_ms, w->ev0, w->ev1));
       w->solve_events_pending = false;
@@ -3511,6 +3629,7 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     if (n_keyframes < 1 || n_keyframes > kMaxFrames - 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_keyframes must be in [1, %d]", kMaxFrames - 1);
     if (number_of_desired_points < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "number_of_desired_points < 0");
     w->sr.use();
+    flushAppends(*w);
     prepare(*w);  // device state current, host mirror of the poses current
     hipStream_t st = w->sr.stream;
     const int F = n_keyframes + 1;
@@ -3700,12 +3819,7 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     HIP_CHECK(hipGetLastError());
     // ---- one packed read-back: idepth (8 nI) | counters (8 ints) | distance | statuses (nI)
     const size_t bytes = nI * 8 + 32 + 8 + nI;
-    if (w->h_export_bytes < bytes) {
-      if (w->h_export) (void)hipHostFree(w->h_export);
-      w->h_export = nullptr;
-      HIP_CHECK(hipHostMalloc(&w->h_export, bytes, hipHostMallocDefault));
-      w->h_export_bytes = bytes;
-    }
+    growPinned(w->h_export, w->h_export_bytes, bytes);
     char *h = static_cast<char *>(w->h_export);
     HIP_CHECK(hipMemcpyAsync(h, S.idepth_out.ptr, nI * 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipMemcpyAsync(h + nI * 8, S.counters.ptr, 32, hipMemcpyDeviceToHost, st));

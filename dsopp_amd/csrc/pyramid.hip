@@ -248,7 +248,8 @@ __global__ void getLevelKernel(const Texel<S> *tex, double *pixelinfo, size_t n)
   pixelinfo[3 * i + 2] = static_cast<double>(tex[i].Iy);
 }
 
-/** texels -> tiled intensity plane (pyramid.hpp): one thread per pixel of the padded tile grid */
+/** texels -> tiled intensity plane (pyramid.hpp): one thread per pixel of the padded tile grid.
+ *  f64: 8-byte words, 4 x 2 pixels per 64-byte tile; f32: 4-byte words, 4 x 4 pixels per 64-byte tile.  CameraMask bit in the lowest mantissa bit. */
 __global__ void buildIntensityPlaneKernel(const Texel<double> *__restrict__ tex, int W, int H, int tiles_x, int tiles_y,
                                           unsigned long long *__restrict__ out) {
   const int x = blockIdx.x * kTileX + threadIdx.x;
@@ -260,6 +261,18 @@ __global__ void buildIntensityPlaneKernel(const Texel<double> *__restrict__ tex,
     bits = (static_cast<unsigned long long>(__double_as_longlong(t.I)) & ~1ull) | (t.mask != 0.0 ? 1ull : 0ull);
   }
   out[(static_cast<size_t>(y >> 1) * tiles_x + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3)] = bits;
+}
+
+__global__ void buildIntensityPlaneKernel(const Texel<float> *__restrict__ tex, int W, int H, int tiles_x, int tiles_y, unsigned *__restrict__ out) {
+  const int x = blockIdx.x * kTileX + threadIdx.x;
+  const int y = blockIdx.y * kTileY + threadIdx.y;
+  if (x >= 4 * tiles_x || y >= 4 * tiles_y) return;
+  unsigned bits = 0;
+  if (x < W && y < H) {
+    const Texel<float> t = tex[static_cast<size_t>(y) * W + x];
+    bits = (__float_as_uint(t.I) & ~1u) | (t.mask != 0.0f ? 1u : 0u);
+  }
+  out[(static_cast<size_t>(y >> 2) * tiles_x + (x >> 2)) * 16 + ((y & 3) << 2) + (x & 3)] = bits;
 }
 
 template <typename S>
@@ -324,16 +337,20 @@ void checkLevel(dsopp_hip_pyramid *p, int level) {
 using namespace dsopp_hip;
 
 const void *dsopp_hip_pyramid::intensityPlane(int level, hipStream_t consumer) const {
-  if (dtype != DSOPP_HIP_F64 || level < 0 || level >= levels) return nullptr;
+  if (level < 0 || level >= levels) return nullptr;
   std::lock_guard<std::mutex> lock(iplane_mutex);
   const int tx = itilesX(level), ty = itilesY(level);
   if (!iplane_valid[level]) {
-    if (!iplane[level]) HIP_CHECK(hipMalloc(&iplane[level], static_cast<size_t>(tx) * ty * 8 * sizeof(double)));
+    if (!iplane[level]) HIP_CHECK(hipMalloc(&iplane[level], static_cast<size_t>(tx) * ty * 64));  // one 64-byte tile per (tx, ty)
     if (!iplane_ready[level]) HIP_CHECK(hipEventCreateWithFlags(&iplane_ready[level], hipEventDisableTiming));
     waitReady(consumer);  // the texels' last build
-    dim3 block(kTileX, kTileY), grid((4 * tx + kTileX - 1) / kTileX, (2 * ty + kTileY - 1) / kTileY);
-    buildIntensityPlaneKernel<<<grid, block, 0, consumer>>>(static_cast<const Texel<double> *>(texels[level]), w(level), h(level), tx, ty,
-                                                            static_cast<unsigned long long *>(iplane[level]));
+    dim3 block(kTileX, kTileY), grid((4 * tx + kTileX - 1) / kTileX, ((dtype == DSOPP_HIP_F64 ? 2 : 4) * ty + kTileY - 1) / kTileY);
+    if (dtype == DSOPP_HIP_F64)
+      buildIntensityPlaneKernel<<<grid, block, 0, consumer>>>(static_cast<const Texel<double> *>(texels[level]), w(level), h(level), tx, ty,
+                                                              static_cast<unsigned long long *>(iplane[level]));
+    else
+      buildIntensityPlaneKernel<<<grid, block, 0, consumer>>>(static_cast<const Texel<float> *>(texels[level]), w(level), h(level), tx, ty,
+                                                              static_cast<unsigned *>(iplane[level]));
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(iplane_ready[level], consumer));
     iplane_stream[level] = consumer;

@@ -101,10 +101,11 @@ struct dsopp_hip_pyramid {
     for (bool &v : iplane_valid) v = false;  // the texels changed: the intensity planes derived from them are stale
     ++generation;  // (a window that borrowed this pyramid compares it before its next sweep and rebuilds the plane it samples)
   }
-  // Intensity planes (f64 pyramids; built on demand by the first consumer, pyramid.hip: intensityPlane): 8 bytes per pixel —
-  // the intensity with the CameraMask bit in the lowest mantissa bit — tiled 4 x 2 pixels per 64-byte segment.  What the
-  // residual-only sweeps read instead of the 32-byte texels: a bilinear footprint then lies in 1.9 segments on average
-  // instead of 3, and a pattern's 8 footprints share them.
+  // Intensity planes (built on demand by the first consumer, pyramid.hip: intensityPlane): one word per pixel — the intensity
+  // with the CameraMask bit in the lowest mantissa bit — tiled per 64-byte segment: 8-byte words, 4 x 2 pixels (f64 pyramids);
+  // 4-byte words, 4 x 4 pixels (f32 pyramids, the reference's -DUSE_FLOAT build; round 6).  What the residual-only sweeps read
+  // instead of the 32- / 16-byte texels: a bilinear footprint then lies in 1.9 (f32: 1.6) segments on average instead of 3, and
+  // a pattern's 8 footprints share them.
   mutable void *iplane[DSOPP_HIP_MAX_LEVELS] = {nullptr};
   mutable bool iplane_valid[DSOPP_HIP_MAX_LEVELS] = {false};
   unsigned generation = 0;  // number of rewrites of the texels (markReady)
@@ -112,8 +113,8 @@ struct dsopp_hip_pyramid {
   mutable hipStream_t iplane_stream[DSOPP_HIP_MAX_LEVELS] = {nullptr};
   mutable std::mutex iplane_mutex;
   int itilesX(int l) const { return (w(l) + 3) / 4; }
-  int itilesY(int l) const { return (h(l) + 1) / 2; }
-  /** the level's intensity plane, valid for everything enqueued on `consumer` after the call (nullptr for f32 pyramids) */
+  int itilesY(int l) const { return dtype == DSOPP_HIP_F64 ? (h(l) + 1) / 2 : (h(l) + 3) / 4; }
+  /** the level's intensity plane, valid for everything enqueued on `consumer` after the call */
   const void *intensityPlane(int level, hipStream_t consumer) const;
   /** everything enqueued on `consumer` after this call sees the texels of the last build (no host synchronisation) */
   void waitReady(hipStream_t consumer) const {

@@ -152,6 +152,9 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 }  // namespace
 
 int main(int argc, char **argv) {
+  // DSOPP_TICK_PHASE_LOG=<file>: the phase boundaries of every frame / keyframe as CLOCK_MONOTONIC seconds — what scripts/hip_api_breakdown.py
+  // buckets the calls of a rocprofv3 --hip-trace run by
+  std::FILE *phase_log = std::getenv("DSOPP_TICK_PHASE_LOG") ? std::fopen(std::getenv("DSOPP_TICK_PHASE_LOG"), "w") : nullptr;
   if (argc < 2) {
     std::fprintf(stderr, "usage: %s sequence.bin [poses_out.txt]\n", argv[0]);
     return 64;
@@ -309,6 +312,7 @@ int main(int argc, char **argv) {
       const double t_e = now();
       t_frame.push_back(t_e - t0);
       phase[0] += t_a - t0, phase[1] += t_b - t_a, phase[2] += t_c - t_b, phase[3] += t_d - t_c, phase[4] += t_e - t_d;
+      if (phase_log) std::fprintf(phase_log, "frame %d %.9f %.9f %.9f %.9f %.9f %.9f\n", k, t0, t_a, t_b, t_c, t_d, t_e);
       if (!need_kf) {
         pyramid_pool.push_back(std::move(pyr));  // the frame's images go back to the pool (a tracker keeps a ring of them)
         continue;
@@ -382,6 +386,7 @@ int main(int argc, char **argv) {
       const double t7 = now();
       t_keyframe.push_back(t7 - t1);
       kphase[0] += t2 - t1, kphase[1] += t3 - t2, kphase[2] += t4 - t3, kphase[3] += t5 - t4, kphase[4] += t6 - t5, kphase[5] += t7 - t6;
+      if (phase_log) std::fprintf(phase_log, "keyframe %d %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", k, t1, t2, t3, t4, t5, t6, t7);
       // frames marginalised at the PREVIOUS keyframe were folded into the prior by this keyframe's pushFrame: their resources go now
       // (images back to the pool; unloadMarginalizedResources, monocular_tracker.cpp:504) — device memory management, not tracker time
       for (auto &old_kf : retired_before) pyramid_pool.push_back(std::move(old_kf->pyramid));
@@ -389,6 +394,7 @@ int main(int argc, char **argv) {
       retired_before.swap(retired);
     }
 
+    if (phase_log) std::fclose(phase_log);
     // ---- report
     auto stat = [](std::vector<double> v, double q) {
       if (v.empty()) return 0.0;
