@@ -837,7 +837,9 @@ __device__ __forceinline__ void alignContract(const double *wave_rows, af64x4 &a
     av[t] = src[4 * t * kRowStride];
     bv[t] = src[64 * kRowStride + 4 * t * kRowStride];
   }
-  asm volatile("" ::: "memory");  // (all operands are requested before the first matrix instruction waits for one)
+  asm volatile("" ::: "memory");
+  // (pinning all 32 operands in registers before the first matrix instruction was measured and dropped: the phase is bound by the sixteen
+  // 64-cycle matrix instructions themselves, 0.68 against 0.64 us — profiles/r06/tracker_stamps.txt)
 #pragma unroll
   for (int t = 0; t < 16; t += 2) {
     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[t], acc0, 0, 0, 0);

@@ -550,6 +550,22 @@ size_t queueAppendData(W &w, const void *host, size_t bytes, const void *dst_a, 
   return off;
 }
 
+/** queued upload of `bytes` of host memory to a device address (applyAppendsKernel, kind 0): the descriptor tables, frame states and the
+ *  marginal prior of prepare() travel with the appends — one pinned copy and one launch instead of ten copies from pageable memory and three
+ *  synchronisations per prepare() (twice per keyframe: pushFrame's fold-in and solve) */
+void uploadStagedBytes(W &w, void *dst, const void *host, size_t bytes) {
+  if (!bytes) return;
+  W::AppendOp op{};
+  op.kind = 0;
+  const bool words = (bytes & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
+  const bool half = (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0;
+  op.a = words ? 8 : (half ? 4 : 1);
+  op.n = static_cast<int>(bytes / static_cast<size_t>(op.a));
+  op.src_off = queueAppendData(w, host, bytes, dst);
+  op.dst = dst;
+  w.append_ops.push_back(op);
+}
+
 /** queued upload of caller memory (applyAppendsKernel, kind 0).  (Destinations of one frame's arrays are distinct allocations: the base
  *  pointer of the buffer identifies the array in the conflict test.) */
 template <typename T>
@@ -752,25 +768,25 @@ void syncTopology(W &w) {
     sweep.swap(launch);
   }
   w.d_frames.reserve(kMaxFrames, 0, st);
-  w.d_frames.upload(fd.data(), kMaxFrames, 0, st);
+  uploadStagedBytes(w, w.d_frames.ptr, fd.data(), (kMaxFrames) * sizeof(*w.d_frames.ptr));
   w.n_sweep_blocks = static_cast<int>(sweep.size());
   w.n_schur_blocks = static_cast<int>(schur.size());
   w.d_sweep_table.reserve(std::max<size_t>(1, sweep.size()), 0, st);
-  w.d_sweep_table.upload(sweep.data(), sweep.size(), 0, st);
+  uploadStagedBytes(w, w.d_sweep_table.ptr, sweep.data(), (sweep.size()) * sizeof(*w.d_sweep_table.ptr));
   if (groups > 1) {
     w.d_fine_table.reserve(std::max<size_t>(1, fine.size()), 0, st);
-    w.d_fine_table.upload(fine.data(), fine.size(), 0, st);
+    uploadStagedBytes(w, w.d_fine_table.ptr, fine.data(), (fine.size()) * sizeof(*w.d_fine_table.ptr));
     w.n_fine_blocks = static_cast<int>(fine.size());
   } else {
     w.d_fine_table.release();
     w.n_fine_blocks = static_cast<int>(sweep.size());
   }
   w.d_schur_table.reserve(std::max<size_t>(1, schur.size()), 0, st);
-  w.d_schur_table.upload(schur.data(), schur.size(), 0, st);
+  uploadStagedBytes(w, w.d_schur_table.ptr, schur.data(), (schur.size()) * sizeof(*w.d_schur_table.ptr));
   w.d_pair_first.reserve(kMaxFrames * kMaxFrames, 0, st);
-  w.d_pair_first.upload(pair_first.data(), pair_first.size(), 0, st);
+  uploadStagedBytes(w, w.d_pair_first.ptr, pair_first.data(), (pair_first.size()) * sizeof(*w.d_pair_first.ptr));
   w.d_pair_count.reserve(kMaxFrames * kMaxFrames, 0, st);
-  w.d_pair_count.upload(pair_count.data(), pair_count.size(), 0, st);
+  uploadStagedBytes(w, w.d_pair_count.ptr, pair_count.data(), (pair_count.size()) * sizeof(*w.d_pair_count.ptr));
   w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
   w.d_ctrl.reserve(2, 0, st);
@@ -784,7 +800,7 @@ void syncTopology(W &w) {
   w.d_bm.reserve(KK, 0, st);
   w.d_step.reserve(KK, 0, st);
   w.d_scalars.reserve(16 + 4 * kScalarGroups, 0, st);
-  w.sr.sync();  // host staging vectors go out of scope
+  // (the tables above are queued uploads — copied into the append blob — and leave with prepare()'s flush: no synchronisation here)
   w.topology_dirty = false;
   w.pair_valid = false;
 }
@@ -792,8 +808,7 @@ void syncTopology(W &w) {
 void uploadState(W &w) {
   if (!w.state_dirty) return;
   w.d_state.reserve(1, 0, w.sr.stream);
-  w.d_state.upload(&w.hst, 1, 0, w.sr.stream);
-  w.sr.sync();
+  uploadStagedBytes(w, w.d_state.ptr, &w.hst, sizeof(WindowState));  // (queued: leaves with prepare()'s flush)
   w.state_dirty = false;
   w.pair_valid = false;
 }
@@ -812,8 +827,8 @@ void uploadMarginal(W &w) {
   w.marg_nonzero = w.energy_marginalized != 0;
   for (double v : w.Hm) w.marg_nonzero = w.marg_nonzero || v != 0;
   for (double v : w.bm) w.marg_nonzero = w.marg_nonzero || v != 0;
-  w.d_Hm.upload(w.Hm.data(), static_cast<size_t>(K) * K, 0, w.sr.stream);
-  w.d_bm.upload(w.bm.data(), static_cast<size_t>(K), 0, w.sr.stream);
+  uploadStagedBytes(w, w.d_Hm.ptr, w.Hm.data(), static_cast<size_t>(K) * K * sizeof(double));
+  uploadStagedBytes(w, w.d_bm.ptr, w.bm.data(), static_cast<size_t>(K) * sizeof(double));
   // ... and the matrix in the combined system's own layout (8 x 8 blocks of the lower triangle, row-major inside: combBlockIndex), which
   // the fused loop's solve launch adds while it loads the system (SolveCombArgs::HmPacked)
   const int F = w.F();
@@ -825,8 +840,7 @@ void uploadMarginal(W &w) {
           packed[static_cast<size_t>(combBlockIndex(bi, bj)) * 64 + static_cast<size_t>(i * kBlk + j)] =
               w.Hm[static_cast<size_t>(kBlk * bi + i) * K + static_cast<size_t>(kBlk * bj + j)];
   w.d_Hm_packed.reserve(static_cast<size_t>(combBlockCount(kMaxFrames)) * 64, 0, w.sr.stream);
-  w.d_Hm_packed.upload(packed.data(), packed.size(), 0, w.sr.stream);
-  w.sr.sync();
+  uploadStagedBytes(w, w.d_Hm_packed.ptr, packed.data(), packed.size() * sizeof(double));
   w.marg_dirty = false;
 }
 
@@ -845,6 +859,7 @@ void prepare(W &w) {
   syncTopology(w);
   uploadState(w);
   uploadMarginal(w);
+  flushAppends(w);  // tables, states and prior queued by the three calls above
 }
 
 /** prepare() for steps that only touch device state: when nothing on the host is newer than the device (no pending state,
@@ -1536,6 +1551,7 @@ void restoreHostSide(W &w) {
       if (kv.second->snap_n != kv.second->n) fail(DSOPP_HIP_ERR_STATE, "connection of frame %d changed since the snapshot", fp->id);
   }
   syncTopology(w);
+  flushAppends(w);  // (its tables are queued uploads)
   w.hst = w.snap_state;
   w.state_dirty = false;
   w.host_stale = false;
@@ -3511,6 +3527,7 @@ int dsopp_hip_window_snapshot(dsopp_hip_window *w) {
     w->sr.sync();
     w->topology_dirty = true;  // the frame table must carry the snapshot pointers
     syncTopology(*w);
+    flushAppends(*w);  // (its tables are queued uploads)
   });
 }
 
