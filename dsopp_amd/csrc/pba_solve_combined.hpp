@@ -658,6 +658,9 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
 #ifndef DSOPP_HIP_PAIRED_PIVOTS
 #pragma unroll
     for (int k = 0; k < kBlk; ++k) {
+#ifdef DSOPP_HIP_MARKS
+      asm volatile("; ##PANEL_PIVOT");  // ISA reading aid (scripts/panel_pivot_isa.sh): where a pivot's instructions begin
+#endif
       const double d = readLane(c[k], k);
       // pivots whose Jacobi-scaled value d / (diag + 10) is below 1e-30 are treated as zero, as a rank-revealing factorisation would
       const bool okp = d > guard[k];
@@ -748,6 +751,132 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];  // diagonal of the inverse; completed below
     }
   };
+  // ---- round 6 (-DDSOPP_HIP_DPP_PANEL: built, parity-green on 74 GPU tests, measured and NOT the default): the same elimination with the
+  // row-k factors broadcast by the VALU's own cross-lane path instead of v_readlane.  Result: C1 37.1 - 37.2 us per iteration against 36.8,
+  // the solve launch alone 16.47 against 16.28 us (12 KF / 50 k: 28.5 against 27.6; 15 KF / 5 k: 38.6 against 37.2) — profiles/r06/
+  // solve_panel_ab.txt.  The second pass that 32 rows per pass force on the first block columns, the two wait states in front of every DPP
+  // read and the serialisation of the inline assembly cost what the 84 v_readlane pairs per block did; the panel wave's LDS traffic (8 loads
+  // + 8 stores per lane and pass) is untouched either way.
+  // The 64-bit VALU operations take ONE DPP control, row_newbcast:k — lane k of every row of 16 lanes is the source for that row
+  // (scripts/probes/dpp64_probe.hip) — so `c_j -= l l_jk` is ONE instruction (v_fmac_f64_dpp) where the loop above needs two v_readlane
+  // (~8 cycles each on the lone panel wave) and an fma.  The price is the layout: a row of 16 lanes can only hear its own lanes, so each of
+  // the wave's four rows carries the diagonal block in its lanes 0 .. 7 (eliminated four times over, redundantly — same instructions) and
+  // eight panel rows in its lanes 8 .. 15: 32 panel rows per pass instead of 64, further passes substitute with the finished block's
+  // factors (lane j, register k = l_jk) through the same broadcast.  Arithmetic per entry as above, operation for operation.
+  auto factorAndPanelDpp = [&](int kb) {
+    const int k0 = kb * kBlk, k1 = k0 + kBlk;
+    const int sub = lane & 15, rowgrp = lane >> 4;
+    const bool diag_lane = sub < kBlk;
+    const int prow = rowgrp * kBlk + (sub - kBlk);  // panel row of this lane within a pass (lanes 8 .. 15 of every row of 16)
+    double c[kBlk], invd[kBlk];
+    {
+      const int row = diag_lane ? k0 + sub : k1 + prow;
+      const double *src = A + (row < N ? row : k0) * ld + k0;
+#pragma unroll
+      for (int j = 0; j < kBlk; ++j) c[j] = src[j];
+    }
+    double guard[kBlk];  // zero-pivot thresholds, fetched before the pivot chain starts
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k) guard[k] = 1e-30 * pv[min(k0 + k, K - 1)];
+    auto rsqrtRefined = [](double d) {
+      const double hd = 0.5 * d;
+      double inv = __builtin_amdgcn_rsq(d);
+      inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
+      inv = fma(inv, fma(-hd * inv, inv, 0.5), inv);
+      return inv;
+    };
+    // (s_nop 1: a VALU result read through DPP needs two wait states, which the assembler does not insert inside inline assembly)
+#define DSOPP_BCAST(dst, src, k) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #k " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
+#define DSOPP_FMAC_BCAST(acc, src_bcast, mul, k) \
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #k " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src_bcast), "v"(mul))
+#define DSOPP_PIVOT(k)                                                                                   \
+  {                                                                                                      \
+    double d;                                                                                            \
+    DSOPP_BCAST(d, c[k], k);                                                                             \
+    const bool okp = d > guard[k];                                                                       \
+    double inv = rsqrtRefined(d);                                                                        \
+    inv = okp ? inv : 0.0;                                                                               \
+    invd[k] = inv;                                                                                       \
+    l = c[k] * inv; /* lane k of a row: sqrt(d); diagonal lanes i > k and panel lanes: l_ik */           \
+    c[k] = l;                                                                                            \
+    nl = -l;                                                                                             \
+  }
+    double l, nl;
+    DSOPP_PIVOT(0)
+    DSOPP_FMAC_BCAST(c[1], l, nl, 1); DSOPP_FMAC_BCAST(c[2], l, nl, 2); DSOPP_FMAC_BCAST(c[3], l, nl, 3); DSOPP_FMAC_BCAST(c[4], l, nl, 4);
+    DSOPP_FMAC_BCAST(c[5], l, nl, 5); DSOPP_FMAC_BCAST(c[6], l, nl, 6); DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(1)
+    DSOPP_FMAC_BCAST(c[2], l, nl, 2); DSOPP_FMAC_BCAST(c[3], l, nl, 3); DSOPP_FMAC_BCAST(c[4], l, nl, 4); DSOPP_FMAC_BCAST(c[5], l, nl, 5);
+    DSOPP_FMAC_BCAST(c[6], l, nl, 6); DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(2)
+    DSOPP_FMAC_BCAST(c[3], l, nl, 3); DSOPP_FMAC_BCAST(c[4], l, nl, 4); DSOPP_FMAC_BCAST(c[5], l, nl, 5); DSOPP_FMAC_BCAST(c[6], l, nl, 6);
+    DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(3)
+    DSOPP_FMAC_BCAST(c[4], l, nl, 4); DSOPP_FMAC_BCAST(c[5], l, nl, 5); DSOPP_FMAC_BCAST(c[6], l, nl, 6); DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(4)
+    DSOPP_FMAC_BCAST(c[5], l, nl, 5); DSOPP_FMAC_BCAST(c[6], l, nl, 6); DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(5)
+    DSOPP_FMAC_BCAST(c[6], l, nl, 6); DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(6)
+    DSOPP_FMAC_BCAST(c[7], l, nl, 7);
+    DSOPP_PIVOT(7)
+    {
+      const int row = diag_lane ? k0 + sub : k1 + prow;
+      if (row < N && (!diag_lane || rowgrp == 0)) {
+        double *dst = A + row * ld + k0;
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j)
+          if (!diag_lane || j <= sub) dst[j] = c[j];  // the diagonal block keeps its lower triangle only
+      }
+    }
+    // panel rows beyond the first 32 of this block column: substitution with the finished block's factors (lane j of a row, register k)
+    for (int base = k1 + 32; base < N; base += 32) {
+      const int r2 = base + prow;
+      const bool live = !diag_lane && r2 < N;
+      double v[kBlk];
+      {
+        const double *src = A + (live ? r2 : k0) * ld + k0;
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) v[j] = src[j];
+      }
+      double nv;
+#define DSOPP_SUBST(k) \
+  v[k] *= invd[k];     \
+  nv = -v[k];
+      DSOPP_SUBST(0)
+      DSOPP_FMAC_BCAST(v[1], c[0], nv, 1); DSOPP_FMAC_BCAST(v[2], c[0], nv, 2); DSOPP_FMAC_BCAST(v[3], c[0], nv, 3); DSOPP_FMAC_BCAST(v[4], c[0], nv, 4);
+      DSOPP_FMAC_BCAST(v[5], c[0], nv, 5); DSOPP_FMAC_BCAST(v[6], c[0], nv, 6); DSOPP_FMAC_BCAST(v[7], c[0], nv, 7);
+      DSOPP_SUBST(1)
+      DSOPP_FMAC_BCAST(v[2], c[1], nv, 2); DSOPP_FMAC_BCAST(v[3], c[1], nv, 3); DSOPP_FMAC_BCAST(v[4], c[1], nv, 4); DSOPP_FMAC_BCAST(v[5], c[1], nv, 5);
+      DSOPP_FMAC_BCAST(v[6], c[1], nv, 6); DSOPP_FMAC_BCAST(v[7], c[1], nv, 7);
+      DSOPP_SUBST(2)
+      DSOPP_FMAC_BCAST(v[3], c[2], nv, 3); DSOPP_FMAC_BCAST(v[4], c[2], nv, 4); DSOPP_FMAC_BCAST(v[5], c[2], nv, 5); DSOPP_FMAC_BCAST(v[6], c[2], nv, 6);
+      DSOPP_FMAC_BCAST(v[7], c[2], nv, 7);
+      DSOPP_SUBST(3)
+      DSOPP_FMAC_BCAST(v[4], c[3], nv, 4); DSOPP_FMAC_BCAST(v[5], c[3], nv, 5); DSOPP_FMAC_BCAST(v[6], c[3], nv, 6); DSOPP_FMAC_BCAST(v[7], c[3], nv, 7);
+      DSOPP_SUBST(4)
+      DSOPP_FMAC_BCAST(v[5], c[4], nv, 5); DSOPP_FMAC_BCAST(v[6], c[4], nv, 6); DSOPP_FMAC_BCAST(v[7], c[4], nv, 7);
+      DSOPP_SUBST(5)
+      DSOPP_FMAC_BCAST(v[6], c[5], nv, 6); DSOPP_FMAC_BCAST(v[7], c[5], nv, 7);
+      DSOPP_SUBST(6)
+      DSOPP_FMAC_BCAST(v[7], c[6], nv, 7);
+      DSOPP_SUBST(7)
+#undef DSOPP_SUBST
+      if (live) {
+        double *dst = A + r2 * ld + k0;
+#pragma unroll
+        for (int j = 0; j < kBlk; ++j) dst[j] = v[j];
+      }
+    }
+#undef DSOPP_PIVOT
+#undef DSOPP_FMAC_BCAST
+#undef DSOPP_BCAST
+    if (lane == 0) {
+#pragma unroll
+      for (int cidx = 0; cidx < kBlk; ++cidx) Linv[kb * 36 + lowIdx(cidx, cidx)] = invd[cidx];  // diagonal of the inverse; completed below
+    }
+  };
+  (void)factorAndPanelDpp;
   // (tuning aid, stamps build: where the panel wave's time goes over the block steps — slots 12 column update, 13 its barrier, 14 factor +
   // panel, 15 the barrier behind it)
   long long cs_acc[4] = {0, 0, 0, 0}, cs_t = (kStamps && a.dbg_stamps) ? wall_clock64() : 0;
@@ -758,7 +887,11 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
       cs_t = now;
     }
   };
+#ifdef DSOPP_HIP_DPP_PANEL
+  if (wave == 0) factorAndPanelDpp(0);
+#else
   if (wave == 0) factorAndPanel(0);
+#endif
   ldsBarrier();
   csMark(2);
   for (int kb = 0; kb < F; ++kb) {
@@ -780,7 +913,11 @@ __global__ void __launch_bounds__(THREADS, 1) solveCombinedKernel(unsigned *bs_t
     ldsBarrier();
     csMark(1);
     if (wave == 0) {
+#ifdef DSOPP_HIP_DPP_PANEL
+      if (kb + 1 < F) factorAndPanelDpp(kb + 1);
+#else
       if (kb + 1 < F) factorAndPanel(kb + 1);
+#endif
       csMark(2);
     } else {
       // trailing update of columns >= k2 with panel kb: A_ij -= sum_c L_ic L_jc  (the other waves as a 12 x 16 / 28 x 16 tile)

@@ -14,7 +14,8 @@ import sys
 PEAK_TFLOPS = 78.6
 d = sys.argv[1]
 out = {"peak_tflops_fp64_matrix": PEAK_TFLOPS, "peak_source": "AMD MI355X spec (fp64 matrix); MI355X_MICROARCH.md has no fp64 row", "kernels": {}}
-for target, stats in (("c1", "c1_kernel_stats.csv"), ("large_loop", "large_loop_kernel_stats.csv"), ("large", "large_kernel_stats.csv")):
+for target, stats in (("c1", "c1_kernel_stats.csv"), ("large_loop", "large_loop_kernel_stats.csv"), ("large", "large_kernel_stats.csv"),
+                      ("tracker", "tracker_kernel_stats.csv")):
     sq_path = os.path.join(d, f"sq_{target}.json")
     if not os.path.exists(sq_path):
         continue
