@@ -165,7 +165,7 @@ struct dsopp_hip_window {
   // profiles/r06/keyframe_hip_trace_breakdown.json) are QUEUED here and leave as ONE copy + ONE kernel in front of the next call that touches the
   // device (flushAppends): `blob` = the callers' data back to back, `ops` = what to do with it.
   struct AppendOp {
-    int kind;                    // 0: copy; 1: merge landmark flags (+ clear the solver state of new landmarks); 2: new connection entries
+    int kind;                    // 0: copy; 1: merge landmark flags (+ clear the solver state of new landmarks); 2: new connection entries; 3: clear flag bits (mask in `a`)
     int n;                       // elements (> 0)
     int a;                       // kind 0: bytes per element (8, 4, 1); kind 1: n_old; kind 2: keep (first new entry)
     int first_block;             // first workgroup of the launch that works on this operation
@@ -502,6 +502,11 @@ __global__ void __launch_bounds__(256) applyAppendsKernel(const uint8_t *__restr
     }
     return;
   }
+  if (op.kind == 3) {  // landmark flag bits cleared (to_marginalize after the fold-in: one operation per frame, one launch for all of them)
+    uint8_t *dflags = static_cast<uint8_t *>(op.dst);
+    for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) dflags[i] &= static_cast<uint8_t>(~op.a);
+    return;
+  }
   // kind 2 — new entries [keep, keep + n) of a connection: status from the caller, candidate = status, no FEJ cache, zero energy
   for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) {
     const uint8_t st = src[i];
@@ -581,10 +586,6 @@ void uploadStaged(W &w, DeviceBuffer<T> &dst, const T *host, size_t count, size_
   w.append_ops.push_back(op);
 }
 
-__global__ void clearLandmarkFlagKernel(uint8_t *__restrict__ dflags, int n, uint8_t mask) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dflags[i] &= static_cast<uint8_t>(~mask);
-}
 
 /** rebuild the FrameDev table, the sweep / Schur block tables and upload them */
 void syncTopology(W &w) {
@@ -2114,7 +2115,15 @@ void foldMarginalized(W &w) {
         changed = true;
       }
     if (changed && f.n)  // on the device too (its other bits — outlier, ill_conditioned — are the device's own)
-      clearLandmarkFlagKernel<<<(f.n + 255) / 256, 256, 0, w.sr.stream>>>(f.dflags.ptr, f.n, kFlagToMarginalize);
+      {
+        W::AppendOp op{};  // queued: leaves with the next flush (prepare() of the solve behind this pushFrame, or any reader)
+        op.kind = 3;
+        op.n = f.n;
+        op.a = kFlagToMarginalize;
+        op.src_off = queueAppendData(w, nullptr, 0, f.dflags.ptr);
+        op.dst = f.dflags.ptr;
+        w.append_ops.push_back(op);
+      }
   }
   std::vector<int> marginalized_part;
   for (int f = 0; f < F; ++f)
@@ -2428,8 +2437,10 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       };
       // (ties — two landmarks on one pixel — are broken by their content, so that the device order, and with it every sum of the
       // deterministic build, depends on the SET of landmarks only, not on the order the caller lists them in)
+      std::vector<long long> keys(add);  // computed once per landmark, not twice per comparison (the sort was 0.1 ms of a keyframe's appends)
+      for (size_t k = 0; k < add; ++k) keys[k] = key(old + static_cast<int>(k));
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const long long ka = key(a), kb = key(b);
+        const long long ka = keys[static_cast<size_t>(a - old)], kb = keys[static_cast<size_t>(b - old)];
         if (ka != kb) return ka < kb;
         // bit patterns, not values: a strict weak order whatever the numbers are (a NaN compares false both ways as a value, which
         // std::stable_sort must never be given)

@@ -24,7 +24,7 @@ for target, stats in (("c1", "c1_kernel_stats.csv"), ("large_loop", "large_loop_
     sp = os.path.join(d, stats)
     if os.path.exists(sp):
         for row in csv.DictReader(open(sp)):
-            n = re.sub(r"\(.*", "", row["Name"]).replace("dsopp_hip::", "").replace("void ", "")
+            n = re.sub(r"\(.*", "", row["Name"].replace("(anonymous namespace)::", "")).replace("dsopp_hip::", "").replace("void ", "")
             dur[n] = float(row["AverageNs"])
     for name, c in sq.items():
         n_mfma = c.get("SQ_INSTS_MFMA", 0)

@@ -23,7 +23,7 @@ import csv, sys, collections, re, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 filt = re.compile(sys.argv[2])
 for r in csv.DictReader(open(sys.argv[1])):
-    n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("dsopp_hip::", "").replace("void ", "")
+    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("dsopp_hip::", "").replace("void ", "")
     if not filt.search(n): continue
     acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 json.dump({n: {c: {"avg": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for n, cs in acc.items()}, open(sys.argv[3], "w"))
