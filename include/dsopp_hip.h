@@ -130,7 +130,11 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
 /* LocalFrame ctor landmark copy + LocalFrame::update (PBA_INT/local_frame.hpp:309-335,484-505).  n_total >= current count;
  * existing landmarks only get their flags refreshed (to_marginalize = newly marginalised && !outlier), new ones are
  * appended.  uv = landmark.projection(), patch = 8 intensities of the host level-0 image (src/track/frames/src/
- * active_keyframe.cpp:96-110).  flags bit0 = isMarginalized, bit1 = isOutlier. */
+ * active_keyframe.cpp:96-110).  flags bit0 = isMarginalized, bit1 = isOutlier.
+ * The arrays are copied before the call returns; the device side of set_landmarks / set_connection is QUEUED and applied — one transfer,
+ * one launch for everything queued — in front of the next call that uses the window's device state (any solve / stage / getter /
+ * push_frame / activation call): a keyframe step's ~120 appends cost host time only.  A device error of a queued append is reported by
+ * that later call. */
 int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
                                    const double *patch, const uint8_t *flags);
 /* residual lists from FrameConnection statuses (PROB_SRC/photometric_bundle_adjustment.cpp:109-123, local_frame.hpp:507-519):
