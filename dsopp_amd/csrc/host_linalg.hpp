@@ -208,22 +208,32 @@ inline bool pinvDropSmallestSpd(const Mat &H, int n, Mat &out, int *why = nullpt
   return true;
 }
 
-/** lower Cholesky factor of a dense symmetric matrix (row-major n x n, lower triangle read); false if a pivot <= floor */
+/** lower Cholesky factor of a dense symmetric matrix (row-major n x n, lower triangle read); false if a pivot <= floor.
+ *  Right-looking with the finished column kept in a contiguous buffer: the trailing update is a row-wise axpy the compiler vectorises
+ *  (the dot-product form is a floating-point reduction, which it may not reorder) — this routine and the two below are on the critical
+ *  path of every production solve(): the host inverts the K x K system while the device is already idle (DSOPP_HIP_HOST_TIMES). */
 inline bool choleskyLower(const Mat &A, int n, double floor, Mat &L) {
   const size_t N = static_cast<size_t>(n);
   L.assign(N * N, 0.0);
-  for (int j = 0; j < n; ++j)
-    for (int i = j; i < n; ++i) {
-      double s = A[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
-      const double *li = &L[N * static_cast<size_t>(i)], *lj = &L[N * static_cast<size_t>(j)];
-      for (int k = 0; k < j; ++k) s -= li[k] * lj[k];
-      if (i == j) {
-        if (!(s > floor)) return false;
-        L[N * static_cast<size_t>(j) + static_cast<size_t>(j)] = std::sqrt(s);
-      } else {
-        L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = s / lj[j];
-      }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = A[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
+  std::vector<double> col(N);
+  for (int j = 0; j < n; ++j) {
+    const double d = L[N * static_cast<size_t>(j) + static_cast<size_t>(j)];
+    if (!(d > floor)) return false;
+    const double r = std::sqrt(d), inv = 1.0 / r;
+    L[N * static_cast<size_t>(j) + static_cast<size_t>(j)] = r;
+    for (int i = j + 1; i < n; ++i) {
+      const double l = L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] * inv;
+      L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = l;
+      col[static_cast<size_t>(i)] = l;
     }
+    for (int i = j + 1; i < n; ++i) {
+      const double l = col[static_cast<size_t>(i)];
+      double *row = &L[N * static_cast<size_t>(i)];
+      for (int k = j + 1; k <= i; ++k) row[k] -= l * col[static_cast<size_t>(k)];
+    }
+  }
   return true;
 }
 /** x <- (L L^T)^-1 x */
@@ -244,22 +254,34 @@ inline void choleskySolveInPlace(const Mat &L, int n, std::vector<double> &x) {
 /** (L L^T)^-1 as a dense symmetric matrix */
 inline Mat choleskyInverse(const Mat &L, int n) {
   const size_t N = static_cast<size_t>(n);
-  Mat Li(N * N, 0.0), out(N * N, 0.0);
-  for (int i = 0; i < n; ++i) {
-    const double *li = &L[N * static_cast<size_t>(i)];
-    const double inv = 1.0 / li[i];
-    for (int j = 0; j <= i; ++j) {
-      double s = i == j ? 1.0 : 0.0;
-      for (int k = j; k < i; ++k) s -= li[k] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
-      Li[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = s * inv;
+  // X = L^-1 column by column, kept TRANSPOSED (Xt[j] = column j of L^-1, entries i >= j): forward substitution as row-wise axpy
+  Mat Xt(N * N, 0.0), out(N * N, 0.0);
+  for (int j = 0; j < n; ++j) {
+    double *x = &Xt[N * static_cast<size_t>(j)];
+    x[j] = 1.0;
+    for (int i = j; i < n; ++i) {
+      const double xi = x[i] / L[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+      x[i] = xi;
+      // x[k] -= L[k][i] * x[i] for k > i: column i of L is strided — walk it once per (j, i)
+      for (int k = i + 1; k < n; ++k) x[k] -= L[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * xi;
+    }
+  }
+  // out = X^T X: out[i][j] = sum_k X[k][i] X[k][j] = sum_k Xt[i][k] Xt[j][k]; as axpy over the rows of X (= columns of Xt) it needs X
+  // itself row-major: build it once
+  Mat X(N * N, 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) X[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = Xt[N * static_cast<size_t>(j) + static_cast<size_t>(i)];
+  for (int k = 0; k < n; ++k) {
+    const double *xk = &X[N * static_cast<size_t>(k)];  // row k of L^-1: entries 0 .. k
+    for (int i = 0; i <= k; ++i) {
+      const double a = xk[i];
+      if (a == 0) continue;
+      double *orow = &out[N * static_cast<size_t>(i)];
+      for (int j = 0; j <= i; ++j) orow[j] += a * xk[j];
     }
   }
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = 0;
-      for (int k = i; k < n; ++k) s += Li[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * Li[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
-      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = s;
-    }
+    for (int j = 0; j < i; ++j) out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = out[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
   return out;
 }
 
@@ -359,24 +381,39 @@ inline bool pinvDropNullDirection(const Mat &H, int n, Mat &out, int *why = null
     }
   fro = std::sqrt(fro);
   if (!(sigma * fro < 1e-6)) return no(16, sigma * fro);  // the dropped direction is not (numerically) a null space
-  // H pinv H = H in the scaled metric
-  Mat HP(N * N, 0.0);
-  for (int i = 0; i < n; ++i)
-    for (int k = 0; k < n; ++k) {
-      const double h = H[N * static_cast<size_t>(i) + static_cast<size_t>(k)];
-      if (h == 0) continue;
-      const double *prow = &out[N * static_cast<size_t>(k)];
-      double *orow = &HP[N * static_cast<size_t>(i)];
-      for (int j = 0; j < n; ++j) orow[j] += h * prow[j];
-    }
+  // H pinv H = H in the scaled metric, tested on three fixed probe vectors instead of entry by entry: with E = D (H pinv H - H) D the
+  // entrywise bound max |E_ij| < 1e-7 implies |E x|_inf < 1e-7 |x|_1, and a pinv that is wrong in ANY direction fails the probes unless that
+  // direction is orthogonal to all three (the two full K x K products of the entrywise test were half of this routine's time, which sits on
+  // the critical path of every production solve(): the device is idle by the time the host gets here)
   double worst = 0;
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double s = 0;
-      const double *row = &HP[N * static_cast<size_t>(i)];
-      for (int k = 0; k < n; ++k) s += row[k] * H[N * static_cast<size_t>(k) + static_cast<size_t>(j)];
-      worst = std::max(worst, std::abs(s - H[N * static_cast<size_t>(i) + static_cast<size_t>(j)]) * d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)]);
+  {
+    std::vector<double> x(N), y(N), z(N), u(N);
+    for (int probe = 0; probe < 3; ++probe) {
+      double x1 = 0;
+      for (int i = 0; i < n; ++i) {
+        const double xt = probe == 0 ? 1.0 : (probe == 1 ? ((i & 1) ? -1.0 : 1.0) : std::sin(1.0 + 2.3 * i));
+        x1 += std::abs(xt);
+        x[static_cast<size_t>(i)] = d[static_cast<size_t>(i)] * xt;  // x = D x~
+      }
+      auto mul = [&](const Mat &M, const std::vector<double> &in, std::vector<double> &res) {
+        for (int i = 0; i < n; ++i) {
+          const double *row = &M[N * static_cast<size_t>(i)];
+          double s0 = 0, s1 = 0;
+          int k = 0;
+          for (; k + 1 < n; k += 2) {
+            s0 += row[k] * in[static_cast<size_t>(k)];
+            s1 += row[k + 1] * in[static_cast<size_t>(k) + 1];
+          }
+          if (k < n) s0 += row[k] * in[static_cast<size_t>(k)];
+          res[static_cast<size_t>(i)] = s0 + s1;
+        }
+      };
+      mul(H, x, y);    // H x
+      mul(out, y, z);  // pinv H x
+      mul(H, z, u);    // H pinv H x
+      for (int i = 0; i < n; ++i) worst = std::max(worst, std::abs(u[static_cast<size_t>(i)] - y[static_cast<size_t>(i)]) * d[static_cast<size_t>(i)] / x1);
     }
+  }
   if (!(worst < 1e-7)) return no(17, worst);
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < i; ++j) {

@@ -316,7 +316,7 @@ __global__ void gatherRowsKernel(const uint8_t *__restrict__ src, uint8_t *__res
  * residual tables is re-ordered on the device.  Rare: the tracker's lists always end where a batch ends (LocalFrame::update appends
  * landmarks and their residuals together, local_frame.hpp:484-521); ragged test windows come through here.
  */
-void flushAppends(W &w);
+void flushAppends(W &w, const char *why = "flush: in front of an entry point");
 
 void splitBatchAt(W &w, HostFrame &f, int n) {
   if (!f.permuted() || n <= 0 || n >= f.n) return;
@@ -326,7 +326,7 @@ void splitBatchAt(W &w, HostFrame &f, int n) {
     if (e < n) b0 = std::max(b0, e);
     if (e > n) b1 = std::min(b1, e);
   }
-  flushAppends(w);  // the rows about to be permuted may still be on their way (queued appends)
+  flushAppends(w, "flush: splitBatchAt");  // the rows about to be permuted may still be on their way (queued appends)
   const int count = b1 - b0;
   std::vector<int> new_to_old;  // absolute device rows
   new_to_old.reserve(static_cast<size_t>(count));
@@ -388,7 +388,7 @@ void splitBatchAt(W &w, HostFrame &f, int n) {
 
 void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   if (n <= f.cap) return;
-  flushAppends(w);  // the arrays move: queued appends hold their old addresses
+  flushAppends(w, "flush: landmark arrays grow");  // the arrays move: queued appends hold their old addresses
   // (first allocation for 1024 landmarks: a keyframe of the tracker gains its landmarks over several keyframes — from 256 every frame grew its
   // ~34 device arrays twice on the way, a malloc + fill + copy + synchronisation + free each)
   int cap = f.cap ? f.cap : 1024;
@@ -520,8 +520,9 @@ __global__ void __launch_bounds__(256) applyAppendsKernel(const uint8_t *__restr
 
 /** everything queued by set_landmarks / set_connection goes to the device: one pinned-ring copy, one launch.  Called in front of every
  *  entry point that enqueues device work on the window or reads its device arrays, and before a queued destination is reallocated. */
-void flushAppends(W &w) {
+void flushAppends(W &w, const char *why) {
   if (w.append_ops.empty()) return;
+  HostTimes ht_(why);
   const int n_ops = static_cast<int>(w.append_ops.size());
   int blocks = 0;
   for (W::AppendOp &op : w.append_ops) {
@@ -546,7 +547,7 @@ void flushAppends(W &w) {
 size_t queueAppendData(W &w, const void *host, size_t bytes, const void *dst_a, const void *dst_b = nullptr) {
   for (const W::AppendOp &op : w.append_ops)
     if (op.dst == dst_a || (dst_b && op.dst == dst_b)) {
-      flushAppends(w);
+      flushAppends(w, "flush: a queued operation writes the same array");
       break;
     }
   const size_t off = (w.append_blob.size() + 7) & ~static_cast<size_t>(7);
@@ -589,13 +590,25 @@ void uploadStaged(W &w, DeviceBuffer<T> &dst, const T *host, size_t count, size_
 
 /** rebuild the FrameDev table, the sweep / Schur block tables and upload them */
 void syncTopology(W &w) {
+  HostTimes ht_("syncTopology");
   if (!w.topology_dirty) return;
   hipStream_t st = w.sr.stream;
   const int F = w.F();
-  std::vector<FrameDev> fd(static_cast<size_t>(kMaxFrames));
+  // (scratch kept per thread: the tables are rebuilt twice per keyframe — pushFrame's fold-in and solve — and 500 vector constructions +
+  // their growth were a good part of the 125 us a rebuild cost on the host; DSOPP_HIP_HOST_TIMES)
+  static thread_local std::vector<FrameDev> fd;
+  static thread_local std::vector<SweepBlock> sweep, fine;
+  static thread_local std::vector<SchurBlock> schur;
+  static thread_local std::vector<std::vector<SweepBlock>> pair_blocks, pair_fine_blocks;
+  fd.assign(static_cast<size_t>(kMaxFrames), FrameDev{});
   std::memset(fd.data(), 0, fd.size() * sizeof(FrameDev));
-  std::vector<SweepBlock> sweep, fine;
-  std::vector<SchurBlock> schur;
+  sweep.clear();
+  fine.clear();
+  schur.clear();
+  pair_blocks.resize(kMaxFrames * kMaxFrames);
+  pair_fine_blocks.resize(kMaxFrames * kMaxFrames);
+  for (auto &v : pair_blocks) v.clear();
+  for (auto &v : pair_fine_blocks) v.clear();
   // large windows: a sweep workgroup takes 4 groups of 16 items (pba_kernels.hpp: SweepBlock::n_groups)
   size_t total_items = 0;
   for (int r = 0; r < F; ++r)
@@ -604,7 +617,6 @@ void syncTopology(W &w) {
   // measured: 7 KF / 20k points (120k items) 36.8 / 33.1 / 38.8 us at 2 / 4 / 6 groups; 12 KF / 50k points (550k items) 143 / 125 / 119 us
   const int groups = groups_override > 0 ? groups_override : (total_items >= 300000 ? 6 : (total_items >= 30000 ? 4 : 1));
   std::vector<int> pair_first(kMaxFrames * kMaxFrames, -1), pair_count(kMaxFrames * kMaxFrames, 0);
-  std::vector<std::vector<SweepBlock>> pair_blocks(kMaxFrames * kMaxFrames), pair_fine_blocks(kMaxFrames * kMaxFrames);
   for (int r = 0; r < F; ++r) {
     HostFrame &f = *w.frames[static_cast<size_t>(r)];
     FrameDev &d = fd[static_cast<size_t>(r)];
@@ -854,13 +866,13 @@ void checkPyramidGenerations(W &w) {
 
 void prepare(W &w) {
   w.sr.use();
-  flushAppends(w);  // queued landmark / connection appends first: everything below reads what they write
+  flushAppends(w, "flush: prepare() entry");  // queued landmark / connection appends first: everything below reads what they write
   checkPyramidGenerations(w);
   downloadState(w);  // no-op unless a device-driven solve left the host mirror behind
   syncTopology(w);
   uploadState(w);
   uploadMarginal(w);
-  flushAppends(w);  // tables, states and prior queued by the three calls above
+  flushAppends(w, "flush: prepare() tables / state / prior");  // tables, states and prior queued by the three calls above
 }
 
 /** prepare() for steps that only touch device state: when nothing on the host is newer than the device (no pending state,
@@ -2052,6 +2064,7 @@ void estimateUncertaintyHost(W &w, bool want_state) {
 
 /** updateMarginalizedLinearSystem — problem.hpp:146-203, called from pushFrame before the new frame is appended */
 void foldMarginalized(W &w) {
+  HostTimes ht_("foldMarginalized (total)");
   prepareDevice(w);
   firstEstimate(w);  // pushFrame calls firstEstimateJacobians unconditionally (eigen_photometric_bundle_adjustment.cpp:123)
   w.begun = true;
@@ -2082,7 +2095,11 @@ void foldMarginalized(W &w) {
   w.d_bscDownload(bsc, k1, 0, w.sr.stream);
   w.d_scalars.download(scal, 2, 0, w.sr.stream);
   if (want_state) HIP_CHECK(hipMemcpyAsync(scal + 2, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
-  w.sr.sync();
+  {
+    HostTimes ht2_("foldMarginalized: wait for the device");
+    w.sr.sync();
+  }
+  HostTimes ht3_("foldMarginalized: host arithmetic behind the wait");
   if (want_state) {
     std::memcpy(&w.hst, scal + 2, sizeof(WindowState));
     w.host_stale = false;
@@ -2318,6 +2335,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
                                 const double intrinsics[4], const double T_world_agent[7], double exposure_time,
                                 const double affine_brightness[2], int fixed, int is_marginalized) {
   return guarded([&] {
+    HostTimes ht_("push_frame (total)");
     if (w) w->export_valid = false;
     if (!w || !pyramid || !intrinsics || !T_world_agent || !affine_brightness) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (level < 0 || level >= pyramid->levels) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "level out of range");
@@ -2382,6 +2400,7 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
 int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
                                    const double *patch, const uint8_t *flags) {
   return guarded([&] {
+    HostTimes ht_("set_landmarks");
     if (w) w->export_valid = false;
     if (!w || n_total < 0 || (n_total && (!uv || !idepth || !patch || !flags))) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     w->sr.use();
@@ -2511,6 +2530,7 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
 
 int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses) {
   return guarded([&] {
+    HostTimes ht_("set_connection");
     if (w) w->export_valid = false;
     if (!w || n < 0 || (n && !statuses)) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     w->sr.use();
@@ -2529,9 +2549,11 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     }
     ResidualTable &rt = *slot;
     hipStream_t st = w->sr.stream;
-    const size_t cap = static_cast<size_t>(std::max(f.cap, 1));
+    // (at least 1024 entries: tables come back from the pool with whatever capacity their last owner needed, and a frame's capacity starts at
+    // 1024 — a smaller pooled table cost a flush of the queue + four reallocations (malloc, fill, copy, synchronise, free) per connection)
+    const size_t cap = static_cast<size_t>(std::max(f.cap, 1024));
     const size_t keep = static_cast<size_t>(rt.n);
-    if (rt.status.ptr && cap > rt.status.capacity) flushAppends(*w);  // the arrays move: queued appends hold their old addresses
+    if (rt.status.ptr && cap > rt.status.capacity) flushAppends(*w, "flush: connection table grows");  // the arrays move: queued appends hold their old addresses
     rt.status.reserve(cap, keep, st);
     rt.cand.reserve(cap, keep, st);
     rt.fej_valid.reserve(cap, keep, st);
@@ -2809,9 +2831,12 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
       // of its systems follow, then point statuses and the packed per-frame read-back — and while the GPU is busy with those the
       // host inverts the reduced system.  (Step by step the GPU idled for the host synchronisation behind the LM loop and for
       // the 0.1 ms of the pseudo-inverse: rocprofv3 kernel trace, scripts/trace_solve.py.)
+      HostTimes ht_("solve (total)");
       w->sr.use();
-    flushAppends(*w);
-      prepare(*w);
+      {
+        HostTimes ht2_("solve: prepare");
+        prepare(*w);  // (flushes the queued appends first)
+      }
       HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
       fusedBegin(*w);
       lmSolveFusedEnqueue(*w);
@@ -2832,8 +2857,14 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
       if (w->opt.estimate_uncertainty) want_state = estimateUncertaintyEnqueue(*w, /*force_state=*/true);
       updatePointStatusesDevice(*w);
       prefetchFrameUpdates(*w);
-      if (w->opt.estimate_uncertainty) estimateUncertaintyHost(*w, want_state);
-      w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
+      {
+        HostTimes ht2_("solve: uncertainty on the host (under the device's work)");
+        if (w->opt.estimate_uncertainty) estimateUncertaintyHost(*w, want_state);
+      }
+      {
+        HostTimes ht2_("solve: final wait for the device");
+        w->sr.sync();  // solve() is a blocking call: every result is in place when it returns
+      }
       checkSolveLaunchFault(*w);
       e = w->h_ctrl->energy;
       it = w->h_ctrl->iteration;
@@ -3085,6 +3116,7 @@ int dsopp_hip_window_get_covariance(dsopp_hip_window *w, int32_t reference_id, i
 namespace {
 /** fills `maps` (allocated for `levels` levels of the newest keyframe's size) from the window's landmarks */
 void fillReferenceDepthMaps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
+  HostTimes ht_("fillReferenceDepthMaps");
   hipStream_t st = w->sr.stream;
   const int levels = maps->levels;
   const int F = w->F(), newest = F - 1;
@@ -3652,6 +3684,7 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
                                         double sigma_huber_loss, uint8_t *const *activation_status, double *const *idepth,
                                         dsopp_hip_activation_result *result) {
   return guarded([&] {
+    HostTimes ht_("activate_landmarks (total)");
     if (!w || !frame_ids || !immature || !newest_pyramid || !T_world_newest || !affine_newest || !min_distance_to_neighbor)
       fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     if (n_keyframes < 1 || n_keyframes > kMaxFrames - 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_keyframes must be in [1, %d]", kMaxFrames - 1);

@@ -420,6 +420,7 @@ void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p) {
   }
   if (p->staging_u8) (void)hipFree(p->staging_u8);
   if (p->staging_vig) (void)hipFree(p->staging_vig);
+  if (p->h_image) (void)hipHostFree(p->h_image);
   if (p->lut_dev) (void)hipFree(p->lut_dev);
   if (p->ready) (void)hipEventDestroy(p->ready);
   p->sr.destroy();
@@ -449,7 +450,19 @@ int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, con
     if (!p || !image_host) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "null argument");
     p->sr.use();
     const size_t n = static_cast<size_t>(p->width) * p->height;
-    HIP_CHECK(hipMemcpyAsync(p->staging_u8, image_host, n, hipMemcpyHostToDevice, p->sr.stream));
+    // The caller's image is pageable memory: copied from there the upload is a staged, blocking transfer (100 us for 1280 x 1024, the
+    // largest part of the tracker's per-frame pyramid time, rocprofv3 --hip-trace).  It is copied into this pyramid's own pinned buffer
+    // instead (a memcpy of 1.3 MB) and leaves from there as a DMA the call does not wait for: consumers order themselves behind the build
+    // with waitReady(), as they do behind build_device.  (The buffer's previous upload has long completed: a pyramid is rebuilt once per
+    // frame, and the synchronisation below covers the paths that keep it.)
+    if (!p->h_image) {
+      HIP_CHECK(hipStreamSynchronize(p->sr.stream));
+      HIP_CHECK(hipHostMalloc(&p->h_image, n, hipHostMallocDefault));
+    } else {
+      HIP_CHECK(hipStreamSynchronize(p->sr.stream));  // (free when the stream is idle — the usual case; guards a rebuild while the last upload is in flight)
+    }
+    std::memcpy(p->h_image, image_host, n);
+    HIP_CHECK(hipMemcpyAsync(p->staging_u8, p->h_image, n, hipMemcpyHostToDevice, p->sr.stream));
     double vmax = 0;
     if (vignetting_host) {
       // cv::minMaxLoc(vignetting, nullptr, &max) — photometrically_corrected_image.cpp:11-13
@@ -458,7 +471,8 @@ int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, con
     }
     int rc = dsopp_hip_pyramid_build_device(p, p->staging_u8, lut256, vignetting_host ? p->staging_vig : nullptr, vmax);
     if (rc != DSOPP_HIP_OK) throw Error(rc, lastError());
-    p->sr.sync();  // host buffers may be reused by the caller after return
+    // the LUT and the vignette are read straight from the caller's (pageable) arrays: those paths wait; the plain image path does not
+    if (lut256 || vignetting_host) p->sr.sync();
   });
 }
 

@@ -89,6 +89,7 @@ struct dsopp_hip_pyramid {
   void *planes[DSOPP_HIP_MAX_LEVELS] = {nullptr};  // S[h_l * w_l] scalar plane (downscale source)
   void *staging_u8 = nullptr;                       // level-0 u8 image / vignette / mask staging
   void *staging_vig = nullptr;
+  void *h_image = nullptr;                          // pinned copy of the caller's 8-bit image (dsopp_hip_pyramid_build): the upload is a true DMA, the call does not wait for it
   double *lut_dev = nullptr;                        // 256 doubles
   // Recorded on the pyramid's stream behind every write of the texels (build / build_device / set_level / set_mask).  A
   // consumer that reads the texels on another stream orders itself behind it with waitReady(): build_device only ENQUEUES

@@ -93,7 +93,9 @@ int dsopp_hip_pyramid_create(int device, void *stream, int width, int height, in
 void dsopp_hip_pyramid_destroy(dsopp_hip_pyramid *p);
 /* PixelDataFrame ctor (src/features/src/pixel_data_frame.cpp:12-31): photometric correction LUT[u8] * vmax/(vignette+1)
  * (src/features/src/photometrically_corrected_image.cpp:9-29), 2x2 box pyramid (downscale_image.hpp:16-33), per-level
- * (I, dI/dx, dI/dy) (src/features/src/calculate_pixelinfo.cpp:340-374).  lut256 / vignetting may be NULL. */
+ * (I, dI/dx, dI/dy) (src/features/src/calculate_pixelinfo.cpp:340-374).  lut256 / vignetting may be NULL.
+ * The host arrays are consumed before the call returns (the image through a pinned copy: its upload and the build run behind the call on
+ * the pyramid's stream; every consumer of the library orders itself behind them). */
 int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, const double *lut256, const uint8_t *vignetting_host);
 /* same, the u8 image (and vignette) already in HBM: no PCIe transfer of pixels inside the call and no host sync
  * (the call only enqueues work on the pyramid's stream).  vignetting_max = max over the vignette image

@@ -143,6 +143,8 @@ def run_native(path, exe=None, timeout=600):
     r = subprocess.run([exe, path, poses_path], capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"native tick sequence failed ({r.returncode}): {r.stdout[-500:]} {r.stderr[-1500:]}")
+    if os.environ.get("DSOPP_HIP_HOST_TIMES"):   # the library's host-time table of the NATIVE process (tuning aid)
+        print("\n".join("[native] " + ln for ln in r.stderr.splitlines() if "[host times]" in ln), file=sys.stderr)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     poses = {}
     for ln in open(poses_path):
