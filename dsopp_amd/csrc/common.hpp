@@ -68,6 +68,62 @@ int guarded(F &&body) {
   }
 }
 
+/** Tuning aid (DSOPP_HIP_HOST_TIMES=1): host wall time per named region of the library, summed over the process and printed at exit — where a
+ *  blocking entry point's time goes between enqueueing, waiting for the device and host arithmetic (scripts/gpu_r6_keyframe_trace.sh).
+ *  Without the variable a region costs one predictable branch. */
+struct HostTimes {
+  static bool on() {
+    static const bool v = std::getenv("DSOPP_HIP_HOST_TIMES") != nullptr;
+    return v;
+  }
+  struct Acc {
+    double seconds = 0;
+    long calls = 0;
+  };
+  static std::map<std::string, Acc> &table() {
+    static std::map<std::string, Acc> *t = [] {
+      auto *m = new std::map<std::string, Acc>();
+      std::atexit([] {
+        if (!HostTimes::on()) return;
+        for (const auto &kv : HostTimes::table())
+          std::fprintf(stderr, "[host times] %-44s %9.3f ms in %7ld calls = %8.2f us per call\n", kv.first.c_str(), kv.second.seconds * 1e3, kv.second.calls,
+                       kv.second.calls ? kv.second.seconds * 1e6 / kv.second.calls : 0.0);
+      });
+      return m;
+    }();
+    return *t;
+  }
+  /** one event without a duration (e.g. a device buffer growing: who asked, counted per call site) */
+  static void count(const std::string &what, long by = 1) {
+    if (!on()) return;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    table()[what].calls += by;
+  }
+  static void add(const std::string &what, double seconds) {
+    if (!on()) return;
+    static std::mutex mtx;
+    std::lock_guard<std::mutex> lock(mtx);
+    Acc &a = table()[what];
+    a.seconds += seconds;
+    a.calls += 1;
+  }
+  const char *name;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimes(const char *n) : name(n) {
+    if (on()) t0 = std::chrono::steady_clock::now();
+  }
+  ~HostTimes() {
+    if (!on()) return;
+    static std::mutex mtx;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lock(mtx);
+    Acc &a = table()[name];
+    a.seconds += dt;
+    a.calls += 1;
+  }
+};
+
 /** growable device buffer (never shrinks); contents preserved on growth */
 template <typename T>
 struct DeviceBuffer {
@@ -94,8 +150,9 @@ struct DeviceBuffer {
     capacity = 0;
   }
   /** ensure capacity >= n elements; keeps the first `keep` elements */
-  void reserve(size_t n, size_t keep, hipStream_t stream) {
+  void reserve(size_t n, size_t keep, hipStream_t stream, const char *who = __builtin_FUNCTION(), int line = __builtin_LINE()) {
     if (n <= capacity) return;
+    if (HostTimes::on()) HostTimes::count(std::string("device buffer grows: ") + who + ":" + std::to_string(line) + (ptr ? " (re-allocation)" : " (first)"));
     size_t cap = capacity ? capacity : 64;
     while (cap < n) cap *= 2;
     T *np = nullptr;
@@ -114,47 +171,6 @@ struct DeviceBuffer {
   }
   void download(T *host, size_t n, size_t offset, hipStream_t stream) const {
     if (n) HIP_CHECK(hipMemcpyAsync(host, ptr + offset, n * sizeof(T), hipMemcpyDeviceToHost, stream));
-  }
-};
-
-/** Tuning aid (DSOPP_HIP_HOST_TIMES=1): host wall time per named region of the library, summed over the process and printed at exit — where a
- *  blocking entry point's time goes between enqueueing, waiting for the device and host arithmetic (scripts/gpu_r6_keyframe_trace.sh).
- *  Without the variable a region costs one predictable branch. */
-struct HostTimes {
-  static bool on() {
-    static const bool v = std::getenv("DSOPP_HIP_HOST_TIMES") != nullptr;
-    return v;
-  }
-  struct Acc {
-    double seconds = 0;
-    long calls = 0;
-  };
-  static std::map<std::string, Acc> &table() {
-    static std::map<std::string, Acc> *t = [] {
-      auto *m = new std::map<std::string, Acc>();
-      std::atexit([] {
-        if (!HostTimes::on()) return;
-        for (const auto &kv : HostTimes::table())
-          std::fprintf(stderr, "[host times] %-44s %9.3f ms in %7ld calls = %8.2f us per call\n", kv.first.c_str(), kv.second.seconds * 1e3, kv.second.calls,
-                       kv.second.calls ? kv.second.seconds * 1e6 / kv.second.calls : 0.0);
-      });
-      return m;
-    }();
-    return *t;
-  }
-  const char *name;
-  std::chrono::steady_clock::time_point t0;
-  explicit HostTimes(const char *n) : name(n) {
-    if (on()) t0 = std::chrono::steady_clock::now();
-  }
-  ~HostTimes() {
-    if (!on()) return;
-    static std::mutex mtx;
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::lock_guard<std::mutex> lock(mtx);
-    Acc &a = table()[name];
-    a.seconds += dt;
-    a.calls += 1;
   }
 };
 

@@ -734,6 +734,7 @@ void dsopp_hip_immature_set_destroy(dsopp_hip_immature_set *s) {
   if (s->h_stage) (void)hipHostFree(s->h_stage);
   if (s->h_tables) (void)hipHostFree(s->h_tables);
   if (s->tables_copied) (void)hipEventDestroy(s->tables_copied);
+  if (s->batch_done) (void)hipEventDestroy(s->batch_done);
   StreamRef sr = s->sr;
   delete s;
   sr.destroy();
@@ -866,10 +867,17 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     if (trace)
       std::fprintf(stderr, "[dsopp_hip] immature_sets_estimate: host side of the call %.1f us (tables + upload + launch enqueued)\n",
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
-    // later per-set calls run on the sets' own streams: they must see this launch finished
+    // later per-set calls run on the sets' own streams: they must see this launch finished — ordered by an event their streams wait for, so
+    // that the call itself stays asynchronous (a tracker computes the optical flows of the keyframe decision while the estimator runs;
+    // blocking here put the kernel's 45 us on every frame's critical path)
     bool other_streams = false;
     for (int k = 0; k < n_sets; ++k) other_streams = other_streams || sets[k]->sr.stream != st;
-    if (other_streams) HIP_CHECK(hipStreamSynchronize(st));
+    if (other_streams) {
+      if (!lead->batch_done) HIP_CHECK(hipEventCreateWithFlags(&lead->batch_done, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(lead->batch_done, st));
+      for (int k = 0; k < n_sets; ++k)
+        if (sets[k]->sr.stream != st) HIP_CHECK(hipStreamWaitEvent(sets[k]->sr.stream, lead->batch_done, 0));
+    }
   });
 }
 

@@ -41,6 +41,11 @@ struct HostFrame {
   bool fixed = false, is_marginalized = false, to_marginalize = false;
   int n = 0;
   int cap = 0;
+  // statuses (caller's order) of connections whose target is NOT in the window: kept on the host, as the reference keeps every residual list
+  // of LocalFrame::update whether or not the solver holds the target (local_frame.hpp:507-519) — they become a device table when a frame
+  // with that id is pushed (a tracker declares its connections towards a frame that was just folded into the prior once more, and towards
+  // a new frame possibly before it is pushed: neither needs device memory)
+  std::map<int, std::vector<uint8_t>> pending;
   std::vector<uint8_t> flags;  // host mirror of the landmark flags as last uploaded
   DeviceBuffer<double> uv, idepth, idepth_step, idepth_fej, patch, inv_hdd, b_d, relative_baseline, ublk;
   DeviceBuffer<int32_t> n_inliers;
@@ -386,12 +391,18 @@ void splitBatchAt(W &w, HostFrame &f, int n) {
   w.export_valid = false;
 }
 
+// First capacity of a frame's landmark arrays and of a connection table.  The reference's configurations ask for 2000 points over 7 keyframes
+// (test/test_data/tummono/*.yaml) and the first keyframe of a sequence holds most of them: at 1024 three frames of the 200-frame sequence
+// grew once — 11 arrays + 4 per connection table re-allocated (malloc, fill, copy, synchronise, free), ~120 of those over the run
+// (DSOPP_HIP_HOST_TIMES=1 counts them per call site).  2048 entries cost 4.3 MB per frame, most of it the per-target ublk planes.
+constexpr int kFirstLandmarkCapacity = 2048;
+
 void ensureLandmarkCapacity(W &w, HostFrame &f, int n) {
   if (n <= f.cap) return;
   flushAppends(w, "flush: landmark arrays grow");  // the arrays move: queued appends hold their old addresses
-  // (first allocation for 1024 landmarks: a keyframe of the tracker gains its landmarks over several keyframes — from 256 every frame grew its
+  // (first allocation for kFirstLandmarkCapacity landmarks: a keyframe of the tracker gains its landmarks over several keyframes — from 256 every frame grew its
   // ~34 device arrays twice on the way, a malloc + fill + copy + synchronisation + free each)
-  int cap = f.cap ? f.cap : 1024;
+  int cap = f.cap ? f.cap : kFirstLandmarkCapacity;
   while (cap < n) cap *= 2;
   hipStream_t st = w.sr.stream;
   const size_t keep = static_cast<size_t>(f.n);
@@ -2186,6 +2197,7 @@ void foldMarginalized(W &w) {
       for (auto &kv : gone->residuals)
         if (kv.second) w.table_pool.push_back(std::move(kv.second));
       gone->residuals.clear();
+      gone->pending.clear();
       gone->covariance.clear();
       erased_ids.push_back(gone->id);
       w.frame_pool.push_back(std::move(gone));
@@ -2257,6 +2269,67 @@ void lmSolve(W &w, double &energy_out, int &iterations, int &n_valid_out) {
   if (!early_return) stageEnergy(w);
   energy_out = energy;
   n_valid_out = n_valid;
+}
+
+/** entries [current size, n) of the (f, target) connection: the table comes from the pool (or is allocated), the entries are queued */
+void appendConnection(W &w, HostFrame &f, int target_id, int n, const uint8_t *statuses) {
+  hipStream_t st = w.sr.stream;
+  auto &slot = f.residuals[target_id];
+  if (!slot) {
+    if (!w.table_pool.empty()) {
+      // best fit: the smallest pooled table that holds the frame's capacity (the tracker's first keyframe carries more landmarks than the
+      // others: its tables towards every new keyframe found a smaller pooled table on top and re-allocated all four arrays — a flush, four
+      // malloc + fill + synchronise + free, ~0.1 ms per keyframe — while the table its last connection had returned lay further down)
+      const size_t need = static_cast<size_t>(std::max(f.cap, kFirstLandmarkCapacity));
+      size_t pick = w.table_pool.size() - 1;
+      bool fits = false;
+      for (size_t k = 0; k < w.table_pool.size(); ++k) {
+        const size_t have = w.table_pool[k]->status.capacity;
+        if (have < need) continue;
+        if (!fits || have < w.table_pool[pick]->status.capacity) pick = k, fits = true;
+      }
+      slot = std::move(w.table_pool[pick]);
+      w.table_pool.erase(w.table_pool.begin() + static_cast<std::ptrdiff_t>(pick));
+      slot->n = 0;
+      slot->snap_n = 0;
+    } else {
+      slot = std::make_unique<ResidualTable>();
+    }
+  }
+  ResidualTable &rt = *slot;
+  // (at least kFirstLandmarkCapacity entries: tables come back from the pool with whatever capacity their last owner needed, and a frame's
+  // capacity starts there — a smaller pooled table cost a flush of the queue + four reallocations (malloc, fill, copy, synchronise, free) per connection)
+  const size_t cap = static_cast<size_t>(std::max(f.cap, kFirstLandmarkCapacity));
+  const size_t keep = static_cast<size_t>(rt.n);
+  if (rt.status.ptr && cap > rt.status.capacity) flushAppends(w, "flush: connection table grows");  // the arrays move: queued appends hold their old addresses
+  rt.status.reserve(cap, keep, st);
+  rt.cand.reserve(cap, keep, st);
+  rt.fej_valid.reserve(cap, keep, st);
+  rt.energy.reserve(cap, keep, st);
+  if (n > rt.n) {
+    const size_t add = static_cast<size_t>(n - rt.n);
+    W::AppendOp op{};
+    op.kind = 2;
+    op.n = static_cast<int>(add);
+    op.a = static_cast<int>(keep);
+    if (f.permuted()) {
+      // the list grows by the caller's landmarks [rt.n, n): they must be the device's [rt.n, n) as well (splitBatchAt), in the device's order
+      splitBatchAt(w, f, n);
+      std::vector<uint8_t> staged(add);
+      for (size_t k = 0; k < add; ++k) staged[k] = statuses[f.to_caller[keep + k]];
+      op.src_off = queueAppendData(w, staged.data(), add, rt.status.ptr);
+    } else {
+      op.src_off = queueAppendData(w, statuses + rt.n, add, rt.status.ptr);
+    }
+    op.dst = rt.status.ptr;
+    op.p[0] = rt.cand.ptr;
+    op.p[1] = rt.fej_valid.ptr;
+    op.p[2] = rt.energy.ptr;
+    w.append_ops.push_back(op);
+    rt.n = n;
+  }
+  w.topology_dirty = true;
+  w.begun = false;
 }
 
 }  // namespace
@@ -2380,6 +2453,13 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
     w->hst.ab0[s][1] = affine_brightness[1];
     for (int a = 0; a < kBlk; ++a) w->hst.eps[s][a] = w->hst.step[s][a] = 0;
     w->frames.push_back(std::move(f));
+    for (auto &h : w->frames) {  // connections towards this id that were declared before the frame came
+      auto it = h->pending.find(frame_id);
+      if (it == h->pending.end()) continue;
+      std::vector<uint8_t> statuses = std::move(it->second);
+      h->pending.erase(it);
+      if (!statuses.empty() && static_cast<int>(statuses.size()) <= h->n) appendConnection(*w, *h, frame_id, static_cast<int>(statuses.size()), statuses.data());
+    }
     // system_marginalized_.resize(new_size) keeping old entries, new rows/cols zero (:134-140)
     const int Kn = w->K(), Ko = w->marg_size;
     std::vector<double> Hn(static_cast<size_t>(Kn) * Kn, 0.0), bn(static_cast<size_t>(Kn), 0.0);
@@ -2536,52 +2616,13 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     w->sr.use();
     HostFrame &f = w->frameById(reference_id);
     if (n > f.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection has %d entries, frame %d only %d landmarks", n, reference_id, f.n);
-    auto &slot = f.residuals[target_id];
-    if (!slot) {
-      if (!w->table_pool.empty()) {
-        slot = std::move(w->table_pool.back());
-        w->table_pool.pop_back();
-        slot->n = 0;
-        slot->snap_n = 0;
-      } else {
-        slot = std::make_unique<ResidualTable>();
-      }
+    if (w->slotOf(target_id) < 0 && f.residuals.find(target_id) == f.residuals.end()) {
+      // the target is not in the window: the list waits on the host (materialised by the push_frame that brings the target)
+      std::vector<uint8_t> &pv = f.pending[target_id];
+      if (static_cast<size_t>(n) > pv.size()) pv.insert(pv.end(), statuses + pv.size(), statuses + n);
+      return;
     }
-    ResidualTable &rt = *slot;
-    hipStream_t st = w->sr.stream;
-    // (at least 1024 entries: tables come back from the pool with whatever capacity their last owner needed, and a frame's capacity starts at
-    // 1024 — a smaller pooled table cost a flush of the queue + four reallocations (malloc, fill, copy, synchronise, free) per connection)
-    const size_t cap = static_cast<size_t>(std::max(f.cap, 1024));
-    const size_t keep = static_cast<size_t>(rt.n);
-    if (rt.status.ptr && cap > rt.status.capacity) flushAppends(*w, "flush: connection table grows");  // the arrays move: queued appends hold their old addresses
-    rt.status.reserve(cap, keep, st);
-    rt.cand.reserve(cap, keep, st);
-    rt.fej_valid.reserve(cap, keep, st);
-    rt.energy.reserve(cap, keep, st);
-    if (n > rt.n) {
-      const size_t add = static_cast<size_t>(n - rt.n);
-      W::AppendOp op{};
-      op.kind = 2;
-      op.n = static_cast<int>(add);
-      op.a = static_cast<int>(keep);
-      if (f.permuted()) {
-        // the list grows by the caller's landmarks [rt.n, n): they must be the device's [rt.n, n) as well (splitBatchAt), in the device's order
-        splitBatchAt(*w, f, n);
-        std::vector<uint8_t> staged(add);
-        for (size_t k = 0; k < add; ++k) staged[k] = statuses[f.to_caller[keep + k]];
-        op.src_off = queueAppendData(*w, staged.data(), add, rt.status.ptr);
-      } else {
-        op.src_off = queueAppendData(*w, statuses + rt.n, add, rt.status.ptr);
-      }
-      op.dst = rt.status.ptr;
-      op.p[0] = rt.cand.ptr;
-      op.p[1] = rt.fej_valid.ptr;
-      op.p[2] = rt.energy.ptr;
-      w->append_ops.push_back(op);
-      rt.n = n;
-    }
-    w->topology_dirty = true;
-    w->begun = false;
+    appendConnection(*w, f, target_id, n, statuses);
   });
 }
 

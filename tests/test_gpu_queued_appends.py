@@ -82,3 +82,48 @@ def test_stacked_flag_updates_keep_the_last_one():
     eg, itg, nvg = g.solve()
     assert (ito, nvo) == (itg, nvg) and abs(eo - eg) <= 1e-7 * abs(eo)
     g.close()
+
+
+def test_connections_declared_before_their_target_is_pushed():
+    """LocalFrame::update keeps the residual list of EVERY connection of the frame, whether or not the solver holds the target yet
+    (local_frame.hpp:507-519): a connection declared towards an id that is not in the window waits on the host (no device table) and becomes
+    one when a frame with that id is pushed; towards an id that never comes it costs nothing and changes nothing.  Loaded that way — in two
+    steps, the second after the push — the window must equal the one loaded in the usual order (to summation order: the tables are created
+    in another sequence, and with them the order in which a landmark's connections are added up)."""
+    from dsopp_amd import capi
+    win = syn.make_window(num_frames=4, num_points=2400, width=320, height=240, seed=29)
+    intr = win.scene.intrinsics
+    early = capi.HipWindow(capi.default_pba_options())
+    for i, f in enumerate(win.frames):
+        early.push_frame(f.frame_id, f.timestamp, f.pixelinfo, None, intr, syn.mat_to_params(f.T_w_c_init), f.exposure, f.affine_init, f.fixed, False)
+        early.set_landmarks(f.frame_id, f.uv, f.idepth_init, f.patch, np.zeros(len(f.uv), dtype=np.uint8))
+        half = len(f.uv) // 2
+        for g in win.frames:
+            if g is f:
+                continue
+            # towards the frames already there: everything; towards the ones to come: the first half now ...
+            early.set_connection(f.frame_id, g.frame_id, np.zeros(len(f.uv) if g.frame_id in [h.frame_id for h in win.frames[:i]] else half, dtype=np.uint8))
+        early.set_connection(f.frame_id, 10_000 + i, np.zeros(len(f.uv), dtype=np.uint8))  # an id that never comes
+        for h in win.frames[:i]:
+            # ... and the rest once the target is in the window (h declared f early)
+            early.set_connection(h.frame_id, f.frame_id, np.zeros(len(h.uv), dtype=np.uint8))
+    usual = syn.load_window(capi.HipWindow(capi.default_pba_options()), win)
+    early.begin()
+    usual.begin()
+    (ee, ne), (eu, nu) = early.calculate_energy(), usual.calculate_energy()
+    assert ne == nu and abs(ee - eu) <= 1e-13 * abs(eu)
+    early.linearize()
+    usual.linearize()
+    for a, b in zip(early.get_system(), usual.get_system()):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    ee, ite, nve = early.solve()
+    eu, itu, nvu = usual.solve()
+    assert (ite, nve) == (itu, nvu) and abs(ee - eu) <= 1e-10 * abs(eu)
+    for f in win.frames:
+        Te, abe = early.get_pose(f.frame_id)
+        Tu, abu = usual.get_pose(f.frame_id)
+        assert np.abs(Te - Tu).max() <= 1e-9 and np.abs(abe - abu).max() <= 1e-9
+        le, lu = early.get_landmarks(f.frame_id, False), usual.get_landmarks(f.frame_id, False)
+        assert np.array_equal(le["flags"], lu["flags"]) and np.allclose(le["idepth"], lu["idepth"], rtol=1e-9, atol=1e-12)
+    early.close()
+    usual.close()
