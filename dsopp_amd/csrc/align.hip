@@ -1537,6 +1537,7 @@ dsopp_hip_depth_maps::LevelPoints &ensureLevelPoints(dsopp_hip_aligner *a, const
     if (n) compactDepthMapRowsKernel<<<H, 256, 0, st>>>(idsum, wgt, W, H, row_offset, pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
     HIP_CHECK(hipGetLastError());
     sampleReferenceIntensitiesImpl(st, pyramid, level, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
+    pts.markReady(st);
     a->sr.sync();
     pts.n = total;
     pts.pyramid = pyramid;
@@ -1588,6 +1589,7 @@ void ensureAllLevelPoints(dsopp_hip_aligner *a, const dsopp_hip_depth_maps *maps
                                                          pts.u.ptr, pts.v.ptr, pts.idepth.ptr);
     HIP_CHECK(hipGetLastError());
     sampleReferenceIntensitiesImpl(st, pyramid, lvl, pts.u.ptr, pts.v.ptr, pts.intensity.ptr, n);
+    pts.markReady(st);
     pts.n = total;
     pts.pyramid = pyramid;
   }

@@ -734,7 +734,6 @@ void dsopp_hip_immature_set_destroy(dsopp_hip_immature_set *s) {
   if (s->h_stage) (void)hipHostFree(s->h_stage);
   if (s->h_tables) (void)hipHostFree(s->h_tables);
   if (s->tables_copied) (void)hipEventDestroy(s->tables_copied);
-  if (s->batch_done) (void)hipEventDestroy(s->batch_done);
   StreamRef sr = s->sr;
   delete s;
   sr.destroy();
@@ -867,17 +866,13 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     if (trace)
       std::fprintf(stderr, "[dsopp_hip] immature_sets_estimate: host side of the call %.1f us (tables + upload + launch enqueued)\n",
                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count());
-    // later per-set calls run on the sets' own streams: they must see this launch finished — ordered by an event their streams wait for, so
-    // that the call itself stays asynchronous (a tracker computes the optical flows of the keyframe decision while the estimator runs;
-    // blocking here put the kernel's 45 us on every frame's critical path)
+    // later per-set calls run on the sets' own streams: they must see this launch finished.  (Ordering the other streams behind an event
+    // instead — hipStreamWaitEvent on each — was built and measured: six barrier submissions cost more host time, 20-30 us, than this wait
+    // saves a caller who synchronises right behind the call anyway, as the tracker does; running the estimator under the optical-flow pass
+    // of the same frame lost as well: the two kernels share the device and the flow waits behind the estimator's workgroups.)
     bool other_streams = false;
     for (int k = 0; k < n_sets; ++k) other_streams = other_streams || sets[k]->sr.stream != st;
-    if (other_streams) {
-      if (!lead->batch_done) HIP_CHECK(hipEventCreateWithFlags(&lead->batch_done, hipEventDisableTiming));
-      HIP_CHECK(hipEventRecord(lead->batch_done, st));
-      for (int k = 0; k < n_sets; ++k)
-        if (sets[k]->sr.stream != st) HIP_CHECK(hipStreamWaitEvent(sets[k]->sr.stream, lead->batch_done, 0));
-    }
+    if (other_streams) HIP_CHECK(hipStreamSynchronize(st));
   });
 }
 

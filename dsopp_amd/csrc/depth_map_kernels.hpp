@@ -200,4 +200,101 @@ __global__ void __launch_bounds__(256) opticalFlowFinishKernel(const double *__r
   }
 }
 
+
+/** The same measure over the level's REFERENCE POINTS when the tracker has extracted them (depth_maps.hpp: LevelPoints — the pixels inside the
+ *  4-px border with positive weight and idepth >= 1e-6, in row-major order: exactly the pixels the dense pass above keeps).  A level-0 map of
+ *  1280 x 1024 holds ~12 000 of them among 1.3 M pixels: one thread per point, per-workgroup partial sums, and the workgroup that takes the
+ *  last ticket adds the partials in index order (fixed summation order whatever the arrival order) — ONE launch instead of a 21 MB pass and
+ *  a closing launch (19 + 6 us).  scratch: partials (2 kMaxFlowTransforms per workgroup); ticket: one unsigned the last workgroup re-arms. */
+constexpr int kFlowPointThreads = 256;
+__global__ void __launch_bounds__(kFlowPointThreads) opticalFlowPointsKernel(const double *__restrict__ pu, const double *__restrict__ pv,
+                                                                            const double *__restrict__ pid, int n, FlowArgs a, double *partials,
+                                                                            unsigned *ticket, double *__restrict__ out) {
+  __shared__ double lds[kFlowPointThreads / 64][2 * kMaxFlowTransforms];
+  __shared__ unsigned s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double sum[kMaxFlowTransforms], cnt[kMaxFlowTransforms];
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) sum[t] = cnt[t] = 0;
+  const double W = a.width, H = a.height;
+  const int i = static_cast<int>(blockIdx.x) * kFlowPointThreads + tid;
+  if (i < n) {
+    const double u = pu[i], v = pv[i], idepth = pid[i];
+    const double ax = (u - a.cx) * a.ifx, ay = (v - a.cy) * a.ify;
+#pragma unroll
+    for (int t = 0; t < kMaxFlowTransforms; ++t) {
+      if (t >= a.n_transforms) break;
+      const double *M = a.M[t];
+      const double px = M[0] * u + M[1] * v + (M[2] + M[3] * idepth);
+      const double py = M[4] * u + M[5] * v + (M[6] + M[7] * idepth);
+      const double pz = M[8] * u + M[9] * v + (M[10] + M[11] * idepth);
+      const double tu = px / pz, tv = py / pz;
+      if (validIdepth(idepth) && insideROI(u, v, W, H) && (pz > 0) && insideROI(tu, tv, W, H)) {
+        const double bx = (tu - a.cx) * a.ifx, by = (tv - a.cy) * a.ify;
+        sum[t] = (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+        cnt[t] = 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) {
+    double s = sum[t], c = cnt[t];
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_down(s, off);
+      c += __shfl_down(c, off);
+    }
+    if (lane == 0) {
+      lds[wave][2 * t] = s;
+      lds[wave][2 * t + 1] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * kMaxFlowTransforms) {
+    double s = 0;
+    for (int w = 0; w < kFlowPointThreads / 64; ++w) s += lds[w][tid];
+    __hip_atomic_store(&partials[static_cast<size_t>(blockIdx.x) * 2 * kMaxFlowTransforms + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // (device scope: the partials above are visible before the ticket)
+    s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the last workgroup: all partials are in memory; thread j adds workgroups j, j + 256, ... in order, then shuffles and wave order
+  double s[kMaxFlowTransforms], c[kMaxFlowTransforms];
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) s[t] = c[t] = 0;
+  for (unsigned b = tid; b < gridDim.x; b += kFlowPointThreads) {
+#pragma unroll
+    for (int t = 0; t < kMaxFlowTransforms; ++t) {
+      s[t] += __hip_atomic_load(&partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c[t] += __hip_atomic_load(&partials[(static_cast<size_t>(b) * kMaxFlowTransforms + t) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();  // (lds is reused)
+#pragma unroll
+  for (int t = 0; t < kMaxFlowTransforms; ++t) {
+    double ss = s[t], cc = c[t];
+    for (int off = 32; off > 0; off >>= 1) {
+      ss += __shfl_down(ss, off);
+      cc += __shfl_down(cc, off);
+    }
+    if (lane == 0) {
+      lds[wave][2 * t] = ss;
+      lds[wave][2 * t + 1] = cc;
+    }
+  }
+  __syncthreads();
+  if (tid < a.n_transforms) {
+    double ss = 0, cc = 0;
+    for (int w = 0; w < kFlowPointThreads / 64; ++w) {
+      ss += lds[w][2 * tid];
+      cc += lds[w][2 * tid + 1];
+    }
+    out[tid] = sqrt(ss / cc);  // 0 / 0 = NaN for an empty map, as in the reference
+  }
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // armed for the next launch
+}
+
 }  // namespace dsopp_hip

@@ -21,6 +21,31 @@ struct dsopp_hip_depth_maps {
     int n = -1;  // -1: not extracted yet
     const void *pyramid = nullptr;
     dsopp_hip::DeviceBuffer<double> u, v, idepth, intensity;
+    // recorded by the extracting stream behind the compaction: a consumer on ANOTHER stream (the optical-flow measure runs on the maps' own)
+    // orders itself behind it
+    hipEvent_t ready = nullptr;
+    hipStream_t ordered = nullptr;  // the consumer stream that has already been ordered behind `ready` (one wait per extraction, not per frame)
+    LevelPoints() = default;
+    LevelPoints(const LevelPoints &) = delete;
+    LevelPoints &operator=(const LevelPoints &) = delete;
+    LevelPoints(LevelPoints &&o) noexcept
+        : n(o.n), pyramid(o.pyramid), u(std::move(o.u)), v(std::move(o.v)), idepth(std::move(o.idepth)), intensity(std::move(o.intensity)), ready(o.ready), ordered(o.ordered) {
+      o.ready = nullptr;
+      o.n = -1;
+    }
+    ~LevelPoints() {
+      if (ready) (void)hipEventDestroy(ready);
+    }
+    void markReady(hipStream_t producer) {
+      if (!ready) HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(ready, producer));
+      ordered = producer;
+    }
+    void orderBehind(hipStream_t consumer) {
+      if (!ready || ordered == consumer) return;
+      HIP_CHECK(hipStreamWaitEvent(consumer, ready, 0));
+      ordered = consumer;
+    }
   };
   mutable std::vector<LevelPoints> points;
   mutable dsopp_hip::DeviceBuffer<double> flow_scratch;  // per-workgroup partials of the optical-flow measure

@@ -16,5 +16,4 @@ struct dsopp_hip_immature_set {
   void *h_tables = nullptr;                  // pinned descriptor tables of a batched estimate led by this set
   dsopp_hip::DeviceBuffer<char> d_tables;
   hipEvent_t tables_copied = nullptr;        // the previous batch's table upload has left the pinned buffer
-  hipEvent_t batch_done = nullptr;           // end of the last batched estimate this set led (the other sets' streams wait for it)
 };

@@ -3705,10 +3705,23 @@ int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m,
     a.n_transforms = n_transforms;
     const dim3 grid(static_cast<unsigned>((a.width + 255) / 256), static_cast<unsigned>((a.height + kFlowRows - 1) / kFlowRows));
     const size_t n_blocks = static_cast<size_t>(grid.x) * grid.y;
-    m->flow_scratch.reserve(n_blocks * 2 * kMaxFlowTransforms + kMaxFlowTransforms, 0, st);
-    double *out = m->flow_scratch.ptr + n_blocks * 2 * kMaxFlowTransforms;
-    opticalFlowPartialsKernel<<<grid, 256, 0, st>>>(m->idepth_sum[static_cast<size_t>(level)].ptr, m->weight[static_cast<size_t>(level)].ptr, a, m->flow_scratch.ptr);
-    opticalFlowFinishKernel<<<1, 256, 0, st>>>(m->flow_scratch.ptr, static_cast<int>(n_blocks), n_transforms, out);
+    // the level's reference points, when the tracker has extracted them from THESE maps (estimatePose does, in front of the flows of the same
+    // frame; a refill marks them stale): the list holds exactly the pixels the dense pass keeps.  DSOPP_HIP_FLOW_DENSE=1: always the dense pass
+    static const bool dense_only = std::getenv("DSOPP_HIP_FLOW_DENSE") != nullptr;
+    dsopp_hip_depth_maps::LevelPoints &pts = m->points[static_cast<size_t>(level)];
+    const bool by_points = !dense_only && pts.n >= 0;
+    const size_t point_blocks = static_cast<size_t>(std::max(1, (pts.n + kFlowPointThreads - 1) / kFlowPointThreads));
+    // scratch: [ticket of the point pass (zero-filled with the buffer, re-armed by the kernel) | result, kMaxFlowTransforms | partials per workgroup]
+    m->flow_scratch.reserve(8 + std::max(n_blocks, by_points ? point_blocks : 0) * 2 * kMaxFlowTransforms, 0, st);
+    double *out = m->flow_scratch.ptr + 1, *partials = m->flow_scratch.ptr + 8;
+    if (by_points) {
+      pts.orderBehind(st);
+      opticalFlowPointsKernel<<<static_cast<unsigned>(point_blocks), kFlowPointThreads, 0, st>>>(pts.u.ptr, pts.v.ptr, pts.idepth.ptr, pts.n, a, partials,
+                                                                                                 reinterpret_cast<unsigned *>(m->flow_scratch.ptr), out);
+    } else {
+      opticalFlowPartialsKernel<<<grid, 256, 0, st>>>(m->idepth_sum[static_cast<size_t>(level)].ptr, m->weight[static_cast<size_t>(level)].ptr, a, partials);
+      opticalFlowFinishKernel<<<1, 256, 0, st>>>(partials, static_cast<int>(n_blocks), n_transforms, out);
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(flow, out, sizeof(double) * static_cast<size_t>(n_transforms), hipMemcpyDeviceToHost, st));
     m->sr.sync();

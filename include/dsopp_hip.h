@@ -428,9 +428,7 @@ int dsopp_hip_immature_set_estimate(dsopp_hip_immature_set *s, const dsopp_hip_p
                                     double target_exposure, const double target_affine[2], double sigma_huber_loss);
 /* estimateDepths of the tracker (monocular_tracker.cpp:74-102: the estimator runs for EVERY keyframe of the window on every
  * frame) as one call and one launch over n_sets sets: T_target_reference 7 per set, reference_exposure 1 per set,
- * reference_affine 2 per set.  Runs on the first set's stream and returns when the launch is enqueued; sets with streams of their own
- * have them ordered behind the launch by an event.  dsopp_hip_immature_set_download_state (with or without outputs) on any of the sets
- * waits for the result; the target pyramid must stay alive until then. */
+ * reference_affine 2 per set.  Runs on the first set's stream; asynchronous when all sets share it. */
 int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *const *sets, const dsopp_hip_pyramid *target_pyramid, int level,
                                      const double intrinsics[4], const double *T_target_reference, const double *reference_exposure,
                                      const double *reference_affine, double target_exposure, const double target_affine[2],

@@ -214,6 +214,9 @@ def test_gpu_depth_maps_and_device_scan():
     tgt.build(win.frames[-2].image_u8)
     T_ref, _ = g.get_pose(newest.frame_id)
     T_init = syn.mat_to_params(win.frames[-2].T_w_c_init)
+    # the optical-flow measure while no reference points exist for these maps: the dense pass over the planes
+    _, _, Ts = _flow_case()
+    flow_dense = {lvl: maps.mean_square_optical_flow(lvl, win.scene.intrinsics / (1 << lvl), [syn.mat_to_params(T) for T in Ts]) for lvl in (2, 0)}
     for lvl in (2, 0):
         intr = win.scene.intrinsics / (1 << lvl)
         ids, wgt = maps.get_level(lvl)
@@ -233,6 +236,17 @@ def test_gpu_depth_maps_and_device_scan():
         assert n_dev == n_host and n_dev > 50
         assert r_dev["iterations"] == r_host["iterations"] and r_dev["n_valid"] == r_host["n_valid"]
         assert r_dev["energy"] == r_host["energy"] and np.array_equal(r_dev["T_w_target"], r_host["T_w_target"])
+        # ... and once the tracker has extracted the level's reference points the measure walks that list (the same pixels, one launch):
+        # equal to the dense pass up to summation order, and to the CPU checker
+        flow_points = maps.mean_square_optical_flow(lvl, intr, [syn.mat_to_params(T) for T in Ts])
+        want = np.array([po.mean_square_optical_flow(ids, wgt, intr, syn.mat_to_params(T)) for T in Ts])
+        assert np.all(np.abs(flow_points - flow_dense[lvl]) <= 1e-12 * np.maximum(flow_dense[lvl], 1e-3)), (lvl, flow_points, flow_dense[lvl])
+        assert np.all(np.abs(flow_points - want) <= 1e-12 * np.maximum(want, 1e-3)), (lvl, flow_points, want)
+        assert maps.mean_square_optical_flow(lvl, intr, [syn.mat_to_params(Ts[0])])[0] == flow_points[0]
+    # a refill makes the lists stale: the measure falls back to the dense pass on the new planes
+    g.refill_reference_depth_maps(maps)
+    again = maps.mean_square_optical_flow(0, win.scene.intrinsics, [syn.mat_to_params(T) for T in Ts])
+    assert np.all(np.abs(again - flow_dense[0]) <= 1e-10 * np.maximum(flow_dense[0], 1e-3))
     for obj in (maps, pyr, tgt, g):
         obj.close()
 
