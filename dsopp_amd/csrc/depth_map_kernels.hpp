@@ -1,6 +1,7 @@
 // Kernels of createReferenceDepthMaps (src/tracker/tracker/src/create_depth_maps.cpp:18-147).  Tiny, HBM-streaming work:
-// one splat launch per older keyframe (fp64 atomics into the fine map), one 2x2 sum-pool per coarser level, one dilation
-// per level (ping-pong planes: the reference reads neighbours through a backup of the weights, :94-99).
+// a splat of every older keyframe's landmarks (fp64 atomics into the fine map), the 2x2 sum-pools of all coarser levels from
+// level-0 tiles, the dilation of all levels (separate input / output planes: the reference reads neighbours through a backup of the
+// weights, :94-99).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -20,8 +21,15 @@ struct SplatArgs {
   const uint8_t *flags, *status;
 };
 
-/** fillFineDepthMap — create_depth_maps.cpp:18-59; one thread per landmark of one older keyframe */
-__global__ void splatDepthMapKernel(SplatArgs a, double *__restrict__ idsum, double *__restrict__ wsum) {
+// One launch per step (until round 6: one splat per older keyframe, one pool per coarser level, one dilation per level — 17 launches per
+// keyframe whose launch gaps were half of the call's 0.15 ms)
+constexpr int kSplatMaxSources = kMaxFrames - 1;
+struct SplatBatch {
+  SplatArgs src[kSplatMaxSources];  // (3.3 KB of kernel arguments: below the 4 KB the dispatch packet takes)
+};
+/** fillFineDepthMap — create_depth_maps.cpp:18-59 — for every older keyframe: blockIdx.y = source, one thread per landmark */
+__global__ void __launch_bounds__(256) splatDepthMapsKernel(SplatBatch b, double *__restrict__ idsum, double *__restrict__ wsum) {
+  const SplatArgs &a = b.src[blockIdx.y];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   if (a.status[i] != DSOPP_HIP_STATUS_OK) return;                 // :36
@@ -51,21 +59,56 @@ __global__ void splatDepthMapKernel(SplatArgs a, double *__restrict__ idsum, dou
   atomicAdd(&wsum[cell], weight);                          // :53
 }
 
-/** fillCoarseDepthMaps — create_depth_maps.cpp:70-88 */
-__global__ void poolDepthMapKernel(const double *__restrict__ up_id, const double *__restrict__ up_w, int up_width, double *__restrict__ id,
-                                   double *__restrict__ w, int width, int height) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= width || y >= height) return;
-  const size_t a = static_cast<size_t>(2 * y) * up_width + 2 * x, b = a + up_width;
-  id[static_cast<size_t>(y) * width + x] = up_id[a] + up_id[a + 1] + up_id[b] + up_id[b + 1];
-  w[static_cast<size_t>(y) * width + x] = up_w[a] + up_w[a + 1] + up_w[b] + up_w[b + 1];
+constexpr int kDepthMapLevels = 5;  // dsopp_hip_window_create_reference_depth_maps: levels in [1, 5]
+struct DepthMapLevels {
+  double *id[kDepthMapLevels], *w[kDepthMapLevels];          // undilated planes (pool: level 0 read, coarser written; dilation: read)
+  double *out_id[kDepthMapLevels], *out_w[kDepthMapLevels];  // dilated planes (dilation only)
+  int width[kDepthMapLevels], height[kDepthMapLevels];
+  int first_row[kDepthMapLevels + 1];                        // dilation: blockIdx.y in [first_row[l], first_row[l + 1]) works on level l
+  int levels;
+};
+/** fillCoarseDepthMaps — create_depth_maps.cpp:70-88 — for all coarser levels: a workgroup owns a 16 x 16 tile of level 0 and pools it down in LDS — every coarse pixel is the
+ *  sum of its four children in one fixed order (a, a + 1, row below: b, b + 1).  Level sizes halve with floor: the
+ *  children of an existing pixel exist. */
+__global__ void __launch_bounds__(256) poolDepthMapsKernel(DepthMapLevels L) {
+  __shared__ double s_id[2][16 * 16], s_w[2][16 * 16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int x0 = blockIdx.x * 16 + tx, y0 = blockIdx.y * 16 + ty;
+  const bool in0 = x0 < L.width[0] && y0 < L.height[0];
+  s_id[0][threadIdx.x] = in0 ? L.id[0][static_cast<size_t>(y0) * L.width[0] + x0] : 0.0;
+  s_w[0][threadIdx.x] = in0 ? L.w[0][static_cast<size_t>(y0) * L.width[0] + x0] : 0.0;
+  __syncthreads();
+  int side = 16, cur = 0;
+  for (int l = 1; l < L.levels; ++l) {
+    const int half = side >> 1;
+    if (half == 0) break;
+    if (tx < half && ty < half) {
+      const int a = (2 * ty) * side + 2 * tx, b = a + side;
+      const double vi = s_id[cur][a] + s_id[cur][a + 1] + s_id[cur][b] + s_id[cur][b + 1];
+      const double vw = s_w[cur][a] + s_w[cur][a + 1] + s_w[cur][b] + s_w[cur][b + 1];
+      s_id[cur ^ 1][ty * half + tx] = vi;
+      s_w[cur ^ 1][ty * half + tx] = vw;
+      const int x = blockIdx.x * half + tx, y = blockIdx.y * half + ty;
+      if (x < L.width[l] && y < L.height[l]) {
+        L.id[l][static_cast<size_t>(y) * L.width[l] + x] = vi;
+        L.w[l][static_cast<size_t>(y) * L.width[l] + x] = vw;
+      }
+    }
+    __syncthreads();
+    side = half;
+    cur ^= 1;
+  }
 }
 
-/** dilateDepthMaps — create_depth_maps.cpp:90-122; in -> out planes (out must differ from in) */
-__global__ void dilateDepthMapKernel(const double *__restrict__ in_id, const double *__restrict__ in_w, double *__restrict__ out_id,
-                                     double *__restrict__ out_w, int width, int height, int diagonal) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+/** dilateDepthMaps — create_depth_maps.cpp:90-122 — for all levels: blockIdx.y walks the rows of level 0, then of level 1, ...; in -> out planes */
+__global__ void __launch_bounds__(128) dilateDepthMapsKernel(DepthMapLevels L) {
+  int l = 0;
+  while (l + 1 < L.levels && static_cast<int>(blockIdx.y) >= L.first_row[l + 1]) ++l;
+  const int width = L.width[l], height = L.height[l];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = static_cast<int>(blockIdx.y) - L.first_row[l];
   if (x >= width || y >= height) return;
+  const double *__restrict__ in_id = L.id[l], *__restrict__ in_w = L.w[l];
+  const int diagonal = l > 1 ? 0 : 1;
   const size_t c = static_cast<size_t>(y) * width + x;
   double id = in_id[c], w = in_w[c];
   if (!(w > 0) && x >= 1 && y >= 1 && x < width - 1 && y < height - 1) {
@@ -89,8 +132,8 @@ __global__ void dilateDepthMapKernel(const double *__restrict__ in_id, const dou
       w = num / numn;
     }
   }
-  out_id[c] = id;
-  out_w[c] = w;
+  L.out_id[l][c] = id;
+  L.out_w[l][c] = w;
 }
 
 /** calculateMeanSquareOpticalFlow — src/tracker/tracker/src/monocular_tracker.cpp:104-134 — for up to kMaxFlowTransforms

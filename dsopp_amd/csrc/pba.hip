@@ -198,7 +198,7 @@ struct dsopp_hip_window {
   // landmark arrays and 12 connection tables of 5 arrays each — about 70 hipMallocs (0.5 ms) when allocated afresh
   std::vector<std::unique_ptr<HostFrame>> frame_pool;
   std::vector<std::unique_ptr<ResidualTable>> table_pool;
-  std::vector<DeviceBuffer<double>> dm_tmp_id, dm_tmp_w;  // undilated reference depth maps (temporaries of createReferenceDepthMaps)
+  DeviceBuffer<double> dm_tmp;  // undilated reference depth maps, all levels (temporaries of createReferenceDepthMaps)
   std::vector<dsopp_hip_depth_maps *> live_maps;          // maps this window produced and that still borrow its stream
   struct ActivationScratch {            // work buffers of dsopp_hip_window_activate_landmarks
     DeviceBuffer<ActKeyframe> keyframes;
@@ -3163,31 +3163,43 @@ void fillReferenceDepthMaps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
   const int F = w->F(), newest = F - 1;
   const HostFrame &fn = *w->frames[static_cast<size_t>(newest)];
   const LevelView lv = fn.pyramid->view(fn.level);
-  // temporaries (the undilated maps) live with the window: no allocation per keyframe after the first call
-  auto &tmp_id = w->dm_tmp_id, &tmp_w = w->dm_tmp_w;
-  if (tmp_id.size() < static_cast<size_t>(levels)) {
-    tmp_id.resize(static_cast<size_t>(levels));
-    tmp_w.resize(static_cast<size_t>(levels));
-  }
+  // temporaries (the undilated maps) live with the window, all levels in one buffer — level l: [idepth sums | weights] — so that the planes
+  // the splat accumulates into are cleared by ONE fill and completed across landmark shards by ONE collective
+  DepthMapLevels L;
+  std::memset(&L, 0, sizeof(L));
+  L.levels = levels;
+  size_t total = 0, first[kDepthMapLevels];
+  int rows = 0;
   for (int l = 0; l < levels; ++l) {
-    const size_t n = static_cast<size_t>(maps->width[static_cast<size_t>(l)]) * maps->height[static_cast<size_t>(l)];
-    tmp_id[static_cast<size_t>(l)].reserve(n, 0, st);
-    tmp_w[static_cast<size_t>(l)].reserve(n, 0, st);
+    first[l] = total;
+    L.width[l] = maps->width[static_cast<size_t>(l)];
+    L.height[l] = maps->height[static_cast<size_t>(l)];
+    L.first_row[l] = rows;
+    rows += L.height[l];
+    total += 2 * static_cast<size_t>(L.width[l]) * L.height[l];
     maps->points[static_cast<size_t>(l)].n = -1;  // cached reference points of an earlier fill are stale
+    if (l && (L.width[l] != L.width[l - 1] / 2 || L.height[l] != L.height[l - 1] / 2)) fail(DSOPP_HIP_ERR_STATE, "depth-map level %d is not half of level %d", l, l - 1);
   }
-  {
-    const size_t n0 = static_cast<size_t>(maps->width[0]) * maps->height[0];
-    HIP_CHECK(hipMemsetAsync(tmp_id[0].ptr, 0, n0 * sizeof(double), st));  // the splat accumulates; every other plane is overwritten
-    HIP_CHECK(hipMemsetAsync(tmp_w[0].ptr, 0, n0 * sizeof(double), st));
+  L.first_row[levels] = rows;
+  w->dm_tmp.reserve(total, 0, st);
+  for (int l = 0; l < levels; ++l) {
+    L.id[l] = w->dm_tmp.ptr + first[l];
+    L.w[l] = L.id[l] + static_cast<size_t>(L.width[l]) * L.height[l];
+    L.out_id[l] = maps->idepth_sum[static_cast<size_t>(l)].ptr;
+    L.out_w[l] = maps->weight[static_cast<size_t>(l)].ptr;
   }
-  // fillFineDepthMap — :18-59 (into the temporaries; the dilation writes the final planes)
+  const size_t n0 = static_cast<size_t>(L.width[0]) * L.height[0];
+  HIP_CHECK(hipMemsetAsync(L.id[0], 0, 2 * n0 * sizeof(double), st));  // the splat accumulates; every other plane is overwritten
+  // fillFineDepthMap — :18-59 (into the temporaries; the dilation writes the final planes): every older keyframe in one launch
   const Rigid T_newest_inv = rigidInverse(poseOf(*w, newest));
+  SplatBatch batch;
+  int n_sources = 0, max_n = 0;
   for (int f = 0; f < newest; ++f) {
     const HostFrame &fr = *w->frames[static_cast<size_t>(f)];
     auto it = fr.residuals.find(fn.id);
     if (fr.n == 0 || it == fr.residuals.end() || it->second->n == 0) continue;
     const Rigid T = rigidMul(T_newest_inv, poseOf(*w, f));  // t_t_r, :28
-    SplatArgs a;
+    SplatArgs &a = batch.src[n_sources++];
     const double ifx = 1.0 / fr.intr[0], ify = 1.0 / fr.intr[1];
     const double k02 = -fr.intr[2] / fr.intr[0], k12 = -fr.intr[3] / fr.intr[1];
     double U[12];
@@ -3219,29 +3231,18 @@ void fillReferenceDepthMaps(dsopp_hip_window *w, dsopp_hip_depth_maps *maps) {
     a.inv_hdd = fr.inv_hdd.ptr;
     a.flags = fr.dflags.ptr;
     a.status = it->second->status.ptr;
-    splatDepthMapKernel<<<(a.n + 255) / 256, 256, 0, st>>>(a, tmp_id[0].ptr, tmp_w[0].ptr);
+    max_n = std::max(max_n, a.n);
   }
+  if (n_sources) splatDepthMapsKernel<<<dim3(static_cast<unsigned>((max_n + 255) / 256), static_cast<unsigned>(n_sources)), 256, 0, st>>>(batch, L.id[0], L.w[0]);
   if (w->allreduce && w->world > 1) {
-    // landmark shards: every shard splatted its own landmarks; the level-0 planes are sums over landmarks, so one collective per
-    // plane completes them on every shard (pooling and dilation below are then replicated work on the full maps)
-    const size_t n0 = static_cast<size_t>(maps->width[0]) * maps->height[0];
-    allreduceIfNeeded(*w, tmp_id[0].ptr, n0);
-    allreduceIfNeeded(*w, tmp_w[0].ptr, n0);
+    // landmark shards: every shard splatted its own landmarks; the level-0 planes are sums over landmarks, so one collective over both
+    // planes completes them on every shard (pooling and dilation below are then replicated work on the full maps)
+    allreduceIfNeeded(*w, L.id[0], 2 * n0);
   }
-  // fillCoarseDepthMaps — :70-88
-  for (int l = 1; l < levels; ++l) {
-    const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
-    poolDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l - 1)].ptr, tmp_w[static_cast<size_t>(l - 1)].ptr,
-                                                                maps->width[static_cast<size_t>(l - 1)], tmp_id[static_cast<size_t>(l)].ptr,
-                                                                tmp_w[static_cast<size_t>(l)].ptr, W, H);
-  }
-  // dilateDepthMaps — :90-122 (after ALL levels were pooled from the undilated maps, as in the reference)
-  for (int l = 0; l < levels; ++l) {
-    const int W = maps->width[static_cast<size_t>(l)], H = maps->height[static_cast<size_t>(l)];
-    dilateDepthMapKernel<<<dim3((W + 127) / 128, H), 128, 0, st>>>(tmp_id[static_cast<size_t>(l)].ptr, tmp_w[static_cast<size_t>(l)].ptr,
-                                                                  maps->idepth_sum[static_cast<size_t>(l)].ptr, maps->weight[static_cast<size_t>(l)].ptr, W,
-                                                                  H, l > 1 ? 0 : 1);
-  }
+  // fillCoarseDepthMaps — :70-88: all coarser levels from the level-0 tiles in one launch
+  if (levels > 1) poolDepthMapsKernel<<<dim3(static_cast<unsigned>((L.width[0] + 15) / 16), static_cast<unsigned>((L.height[0] + 15) / 16)), 256, 0, st>>>(L);
+  // dilateDepthMaps — :90-122 (after ALL levels were pooled from the undilated maps, as in the reference): all levels in one launch
+  dilateDepthMapsKernel<<<dim3(static_cast<unsigned>((L.width[0] + 127) / 128), static_cast<unsigned>(rows)), 128, 0, st>>>(L);
   HIP_CHECK(hipGetLastError());
   w->sr.sync();  // consumers may live on other streams
 }
