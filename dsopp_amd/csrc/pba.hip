@@ -204,10 +204,12 @@ struct dsopp_hip_window {
     DeviceBuffer<ActKeyframe> keyframes;
     DeviceBuffer<ActPair> pairs;
     DeviceBuffer<const void *> texels0;
-    DeviceBuffer<double> px, py, distance, idepth_out;
+    DeviceBuffer<double> px, py;
     DeviceBuffer<double> sx, sy;
-    DeviceBuffer<int> counters, state, cell_start, cell_cursor, sid, accepted, nbr, nbr_count;
-    DeviceBuffer<uint8_t> act_status;
+    DeviceBuffer<int> state, cell_cursor, sid, accepted, nbr, nbr_count;
+    // results and counters in one buffer: [inverse depths nI | distance | statuses nI bytes | counters 8 ints | cell_start]: what the host reads
+    // back is one contiguous range (one copy), what a call clears (counters, cell_start) another (one fill)
+    DeviceBuffer<double> pack;
   } act;
   bool marg_dirty = true;
   bool pair_valid = false;   // pair constants match the device state
@@ -3860,11 +3862,12 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     S.texels0.reserve(static_cast<size_t>(F), 0, st);
     S.px.reserve(nP, 0, st);
     S.py.reserve(nP, 0, st);
-    S.distance.reserve(1, 0, st);
-    S.idepth_out.reserve(nI, 0, st);
-    S.counters.reserve(8, 0, st);
+    const size_t status_words = (nI + 7) / 8, cell_words = (static_cast<size_t>(a.grid_cap) + 2) / 2;
+    S.pack.reserve(nI + 1 + status_words + 4 + cell_words, 0, st);
+    double *const d_idepth_out = S.pack.ptr, *const d_distance = S.pack.ptr + nI;
+    uint8_t *const d_act_status = reinterpret_cast<uint8_t *>(S.pack.ptr + nI + 1);
+    int *const d_counters = reinterpret_cast<int *>(S.pack.ptr + nI + 1 + status_words), *const d_cell_start = d_counters + 8;
     S.state.reserve(nI, 0, st);
-    S.cell_start.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
     S.cell_cursor.reserve(static_cast<size_t>(a.grid_cap) + 1, 0, st);
     S.sx.reserve(nP, 0, st);
     S.sy.reserve(nP, 0, st);
@@ -3872,12 +3875,12 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     S.nbr.reserve(nI * kActNbrCap, 0, st);
     S.nbr_count.reserve(nI, 0, st);
     S.accepted.reserve(nI, 0, st);
-    S.act_status.reserve(nI, 0, st);
-    S.keyframes.upload(kfs.data(), kfs.size(), 0, st);
-    S.pairs.upload(pairs.data(), pairs.size(), 0, st);
-    S.texels0.upload(tex.data(), tex.size(), 0, st);
-    HIP_CHECK(hipMemsetAsync(S.counters.ptr, 0, 8 * sizeof(int), st));
-    HIP_CHECK(hipMemsetAsync(S.cell_start.ptr, 0, (static_cast<size_t>(a.grid_cap) + 1) * sizeof(int), st));
+    // the three tables travel like a keyframe step's appends: one pinned copy + one scatter launch (three copies from pageable memory before)
+    uploadStagedBytes(*w, S.keyframes.ptr, kfs.data(), kfs.size() * sizeof(ActKeyframe));
+    uploadStagedBytes(*w, S.pairs.ptr, pairs.data(), pairs.size() * sizeof(ActPair));
+    uploadStagedBytes(*w, S.texels0.ptr, tex.data(), tex.size() * sizeof(const void *));
+    flushAppends(*w, "flush: activation tables");
+    HIP_CHECK(hipMemsetAsync(d_counters, 0, (8 + static_cast<size_t>(a.grid_cap) + 1) * sizeof(int), st));
     a.distance_in = *min_distance_to_neighbor;
     a.keyframes = S.keyframes.ptr;
     a.pairs = S.pairs.ptr;
@@ -3901,10 +3904,10 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     a.refine = refine ? 1 : 0;
     a.px = S.px.ptr;
     a.py = S.py.ptr;
-    a.counters = S.counters.ptr;
-    a.distance = S.distance.ptr;
+    a.counters = d_counters;
+    a.distance = d_distance;
     a.state = S.state.ptr;
-    a.cell_start = S.cell_start.ptr;
+    a.cell_start = d_cell_start;
     a.cell_cursor = S.cell_cursor.ptr;
     a.sx = S.sx.ptr;
     a.sy = S.sy.ptr;
@@ -3912,8 +3915,8 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     a.nbr = S.nbr.ptr;
     a.nbr_count = S.nbr_count.ptr;
     a.accepted = S.accepted.ptr;
-    a.act_status = S.act_status.ptr;
-    a.idepth_out = S.idepth_out.ptr;
+    a.act_status = d_act_status;
+    a.idepth_out = d_idepth_out;
     const bool f64 = p0->dtype == DSOPP_HIP_F64;
     if (max_items > 0) {
       const dim3 grid(static_cast<unsigned>((max_items + 255) / 256), static_cast<unsigned>(n_keyframes));
@@ -3933,19 +3936,16 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
       else activationRefineKernel<float><<<static_cast<unsigned>(n_immature), 64, 0, st>>>(a);
     }
     HIP_CHECK(hipGetLastError());
-    // ---- one packed read-back: idepth (8 nI) | counters (8 ints) | distance | statuses (nI)
-    const size_t bytes = nI * 8 + 32 + 8 + nI;
+    // ---- one read-back of the contiguous results: idepth (nI doubles) | distance | statuses (nI bytes, padded to words) | counters (8 ints)
+    const size_t bytes = (nI + 1 + status_words + 4) * sizeof(double);
     growPinned(w->h_export, w->h_export_bytes, bytes);
     char *h = static_cast<char *>(w->h_export);
-    HIP_CHECK(hipMemcpyAsync(h, S.idepth_out.ptr, nI * 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(h + nI * 8, S.counters.ptr, 32, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(h + nI * 8 + 32, S.distance.ptr, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipMemcpyAsync(h + nI * 8 + 40, S.act_status.ptr, nI, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(h, S.pack.ptr, bytes, hipMemcpyDeviceToHost, st));
     w->sr.sync();
     const double *h_id = reinterpret_cast<const double *>(h);
-    const int *h_cnt = reinterpret_cast<const int *>(h + nI * 8);
-    const uint8_t *h_st = reinterpret_cast<const uint8_t *>(h + nI * 8 + 40);
-    *min_distance_to_neighbor = *reinterpret_cast<const double *>(h + nI * 8 + 32);
+    const int *h_cnt = reinterpret_cast<const int *>(h + (nI + 1 + status_words) * sizeof(double));
+    const uint8_t *h_st = reinterpret_cast<const uint8_t *>(h + (nI + 1) * sizeof(double));
+    *min_distance_to_neighbor = h_id[nI];
     dsopp_hip_activation_result res;
     std::memset(&res, 0, sizeof(res));
     res.number_of_active_points = h_cnt[0];
