@@ -609,6 +609,23 @@ __global__ void DSOPP_DEPTH_BOUNDS estimateDepthsBatchKernel(const DepthFrame *_
   estimateDepthsBody<S>(f, L, blockIdx.x, energies);
 }
 
+/** the same launch with the descriptor tables of up to kArgSets keyframes in the kernel arguments (3.6 KB of the 4 KB a dispatch takes): no
+ *  table upload in front of the launch — a pinned copy, its copy kernel and the gap behind it were 15 us of the tracker's per-frame call */
+constexpr int kArgSets = 8;
+struct ArgTables {
+  DepthFrame f[kArgSets];
+  DepthLandmarks l[kArgSets];
+};
+static_assert(sizeof(ArgTables) <= 3840, "the tables must fit the kernel-argument segment next to nothing else");
+template <typename S>
+__global__ void DSOPP_DEPTH_BOUNDS estimateDepthsBatchArgKernel(ArgTables t) {
+  extern __shared__ double energies[];
+  const DepthFrame f = t.f[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= f.n) return;
+  const DepthLandmarks L = t.l[blockIdx.y];
+  estimateDepthsBody<S>(f, L, blockIdx.x, energies);
+}
+
 }  // namespace
 }  // namespace dsopp_hip
 
@@ -837,31 +854,47 @@ int dsopp_hip_immature_sets_estimate(int32_t n_sets, dsopp_hip_immature_set *con
     lead->sr.use();
     hipStream_t st = lead->sr.stream;  // the launch runs on the first set's stream, ordered against the others' below
     target_pyramid->waitReady(st);
-    if (!lead->h_tables) {  // (sets created before the tables moved into dsopp_hip_immature_set_create)
-      HIP_CHECK(hipHostMalloc(&lead->h_tables, sizeof(Tables), hipHostMallocDefault));
-      HIP_CHECK(hipEventCreateWithFlags(&lead->tables_copied, hipEventDisableTiming));
-    } else {
-      HIP_CHECK(hipEventSynchronize(lead->tables_copied));  // the pinned table is about to be rewritten
-    }
-    lead->d_tables.reserve(sizeof(Tables), 0, st);
-    Tables &t = *static_cast<Tables *>(lead->h_tables);
-    for (int k = 0; k < n_sets; ++k) {
-      dsopp_hip_immature_set *s = sets[k];
-      if (s->sr.stream != st) HIP_CHECK(hipStreamSynchronize(s->sr.stream));  // earlier work on that set's own stream
-      t.f[k] = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference + 7 * k, reference_exposure[k], reference_affine + 2 * k,
-                              target_exposure, target_affine, sigma_huber_loss, s->n);
-      t.l[k] = landmarkPointers(s);
-    }
-    HIP_CHECK(hipMemcpyAsync(lead->d_tables.ptr, &t, sizeof(Tables), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipEventRecord(lead->tables_copied, st));
-    const DepthFrame *df = reinterpret_cast<const DepthFrame *>(lead->d_tables.ptr);
-    const DepthLandmarks *dl = reinterpret_cast<const DepthLandmarks *>(lead->d_tables.ptr + offsetof(Tables, l));
     const dim3 grid(static_cast<unsigned>(max_n), static_cast<unsigned>(n_sets));
-    const size_t smem = static_cast<size_t>(t.f[0].max_line) * sizeof(double);
-    if (target_pyramid->dtype == DSOPP_HIP_F64)
-      estimateDepthsBatchKernel<double><<<grid, 64, smem, st>>>(df, dl);
-    else
-      estimateDepthsBatchKernel<float><<<grid, 64, smem, st>>>(df, dl);
+    if (n_sets <= kArgSets) {
+      ArgTables t;
+      for (int k = 0; k < n_sets; ++k) {
+        dsopp_hip_immature_set *s = sets[k];
+        if (s->sr.stream != st) HIP_CHECK(hipStreamSynchronize(s->sr.stream));  // earlier work on that set's own stream
+        t.f[k] = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference + 7 * k, reference_exposure[k], reference_affine + 2 * k,
+                                target_exposure, target_affine, sigma_huber_loss, s->n);
+        t.l[k] = landmarkPointers(s);
+      }
+      const size_t smem = static_cast<size_t>(t.f[0].max_line) * sizeof(double);
+      if (target_pyramid->dtype == DSOPP_HIP_F64)
+        estimateDepthsBatchArgKernel<double><<<grid, 64, smem, st>>>(t);
+      else
+        estimateDepthsBatchArgKernel<float><<<grid, 64, smem, st>>>(t);
+    } else {
+      if (!lead->h_tables) {  // (sets created before the tables moved into dsopp_hip_immature_set_create)
+        HIP_CHECK(hipHostMalloc(&lead->h_tables, sizeof(Tables), hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&lead->tables_copied, hipEventDisableTiming));
+      } else {
+        HIP_CHECK(hipEventSynchronize(lead->tables_copied));  // the pinned table is about to be rewritten
+      }
+      lead->d_tables.reserve(sizeof(Tables), 0, st);
+      Tables &t = *static_cast<Tables *>(lead->h_tables);
+      for (int k = 0; k < n_sets; ++k) {
+        dsopp_hip_immature_set *s = sets[k];
+        if (s->sr.stream != st) HIP_CHECK(hipStreamSynchronize(s->sr.stream));  // earlier work on that set's own stream
+        t.f[k] = makeDepthFrame(target_pyramid, level, intrinsics, T_target_reference + 7 * k, reference_exposure[k], reference_affine + 2 * k,
+                                target_exposure, target_affine, sigma_huber_loss, s->n);
+        t.l[k] = landmarkPointers(s);
+      }
+      HIP_CHECK(hipMemcpyAsync(lead->d_tables.ptr, &t, sizeof(Tables), hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipEventRecord(lead->tables_copied, st));
+      const DepthFrame *df = reinterpret_cast<const DepthFrame *>(lead->d_tables.ptr);
+      const DepthLandmarks *dl = reinterpret_cast<const DepthLandmarks *>(lead->d_tables.ptr + offsetof(Tables, l));
+      const size_t smem = static_cast<size_t>(t.f[0].max_line) * sizeof(double);
+      if (target_pyramid->dtype == DSOPP_HIP_F64)
+        estimateDepthsBatchKernel<double><<<grid, 64, smem, st>>>(df, dl);
+      else
+        estimateDepthsBatchKernel<float><<<grid, 64, smem, st>>>(df, dl);
+    }
     HIP_CHECK(hipGetLastError());
     if (trace)
       std::fprintf(stderr, "[dsopp_hip] immature_sets_estimate: host side of the call %.1f us (tables + upload + launch enqueued)\n",

@@ -49,4 +49,13 @@ struct dsopp_hip_depth_maps {
   };
   mutable std::vector<LevelPoints> points;
   mutable dsopp_hip::DeviceBuffer<double> flow_scratch;  // per-workgroup partials of the optical-flow measure
+  // its result, in pinned host memory the closing workgroup writes itself (the tracker asks for the flow on every frame: a 16-byte copy into
+  // the caller's pageable array was a staged transfer — a copy kernel, 20 us inside hipMemcpyAsync and a second wait)
+  mutable double *h_flow = nullptr;
+  dsopp_hip_depth_maps() = default;
+  dsopp_hip_depth_maps(const dsopp_hip_depth_maps &) = delete;
+  dsopp_hip_depth_maps &operator=(const dsopp_hip_depth_maps &) = delete;
+  ~dsopp_hip_depth_maps() {
+    if (h_flow) (void)hipHostFree(h_flow);
+  }
 };

@@ -3714,9 +3714,10 @@ int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m,
     dsopp_hip_depth_maps::LevelPoints &pts = m->points[static_cast<size_t>(level)];
     const bool by_points = !dense_only && pts.n >= 0;
     const size_t point_blocks = static_cast<size_t>(std::max(1, (pts.n + kFlowPointThreads - 1) / kFlowPointThreads));
-    // scratch: [ticket of the point pass (zero-filled with the buffer, re-armed by the kernel) | result, kMaxFlowTransforms | partials per workgroup]
+    // scratch: [ticket of the point pass (zero-filled with the buffer, re-armed by the kernel) | 7 unused | partials per workgroup]
     m->flow_scratch.reserve(8 + std::max(n_blocks, by_points ? point_blocks : 0) * 2 * kMaxFlowTransforms, 0, st);
-    double *out = m->flow_scratch.ptr + 1, *partials = m->flow_scratch.ptr + 8;
+    if (!m->h_flow) HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->h_flow), 8 * sizeof(double), hipHostMallocDefault));
+    double *out = m->h_flow, *partials = m->flow_scratch.ptr + 8;
     if (by_points) {
       pts.orderBehind(st);
       opticalFlowPointsKernel<<<static_cast<unsigned>(point_blocks), kFlowPointThreads, 0, st>>>(pts.u.ptr, pts.v.ptr, pts.idepth.ptr, pts.n, a, partials,
@@ -3726,8 +3727,8 @@ int dsopp_hip_depth_maps_mean_square_optical_flow(const dsopp_hip_depth_maps *m,
       opticalFlowFinishKernel<<<1, 256, 0, st>>>(partials, static_cast<int>(n_blocks), n_transforms, out);
     }
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(flow, out, sizeof(double) * static_cast<size_t>(n_transforms), hipMemcpyDeviceToHost, st));
-    m->sr.sync();
+    m->sr.sync();  // (the closing workgroup's stores to the pinned result are visible once its kernel has completed)
+    std::memcpy(flow, out, sizeof(double) * static_cast<size_t>(n_transforms));
   });
 }
 

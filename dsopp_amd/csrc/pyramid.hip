@@ -461,8 +461,16 @@ int dsopp_hip_pyramid_build(dsopp_hip_pyramid *p, const uint8_t *image_host, con
     } else {
       HIP_CHECK(hipStreamSynchronize(p->sr.stream));  // (free when the stream is idle — the usual case; guards a rebuild while the last upload is in flight)
     }
-    std::memcpy(p->h_image, image_host, n);
-    HIP_CHECK(hipMemcpyAsync(p->staging_u8, p->h_image, n, hipMemcpyHostToDevice, p->sr.stream));
+    // In pieces: the DMA of a piece (1.3 MB over the host link: ~50 us, as long as the memcpy itself) runs while the host copies the next
+    // one — the consumer's wait for the pyramid shrinks by three quarters of the transfer (DSOPP_HIP_IMAGE_PIECES=1: one piece, A/B)
+    static const int pieces_env = std::getenv("DSOPP_HIP_IMAGE_PIECES") ? std::atoi(std::getenv("DSOPP_HIP_IMAGE_PIECES")) : 4;
+    const size_t pieces = n >= (size_t(1) << 19) ? static_cast<size_t>(std::max(1, std::min(pieces_env, 16))) : 1;
+    const size_t piece = ((n + pieces - 1) / pieces + 4095) & ~static_cast<size_t>(4095);
+    for (size_t off = 0; off < n; off += piece) {
+      const size_t len = std::min(piece, n - off);
+      std::memcpy(static_cast<uint8_t *>(p->h_image) + off, image_host + off, len);
+      HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(p->staging_u8) + off, static_cast<uint8_t *>(p->h_image) + off, len, hipMemcpyHostToDevice, p->sr.stream));
+    }
     double vmax = 0;
     if (vignetting_host) {
       // cv::minMaxLoc(vignetting, nullptr, &max) — photometrically_corrected_image.cpp:11-13
