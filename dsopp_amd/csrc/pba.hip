@@ -879,13 +879,14 @@ void checkPyramidGenerations(W &w) {
 
 void prepare(W &w) {
   w.sr.use();
-  flushAppends(w, "flush: prepare() entry");  // queued landmark / connection appends first: everything below reads what they write
+  // (queued landmark / connection appends are NOT flushed here: nothing below reads the device, and what it queues — tables, states, the prior —
+  // goes to other arrays; everything leaves with the one flush at the end.  A flush at entry as well was a second copy + launch per call)
   checkPyramidGenerations(w);
   downloadState(w);  // no-op unless a device-driven solve left the host mirror behind
   syncTopology(w);
   uploadState(w);
   uploadMarginal(w);
-  flushAppends(w, "flush: prepare() tables / state / prior");  // tables, states and prior queued by the three calls above
+  flushAppends(w, "flush: prepare()");  // the appends of the keyframe step + the tables, states and prior queued by the three calls above
 }
 
 /** prepare() for steps that only touch device state: when nothing on the host is newer than the device (no pending state,
@@ -2075,6 +2076,23 @@ void estimateUncertaintyHost(W &w, bool want_state) {
     }
 }
 
+/** several device arrays (8-byte words) gathered into ONE pinned host buffer by one launch: the stores go over the host link, the caller
+ *  synchronises the stream and reads.  (Five hipMemcpyAsync read-backs of the fold-in ran one behind the other — three copy kernels and two
+ *  DMA transfers, 40 us on the timeline — for 66 KB.) */
+struct GatherPieces {
+  const unsigned long long *src[6];
+  int first_word[7];  // piece i lands at words [first_word[i], first_word[i + 1]) of the destination
+  int n;
+};
+__global__ void __launch_bounds__(256) gatherToHostKernel(GatherPieces g, unsigned long long *__restrict__ dst) {
+  const int total = g.first_word[g.n];
+  for (int i = static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x); i < total; i += static_cast<int>(gridDim.x) * 256) {
+    int p = 0;
+    while (p + 1 < g.n && i >= g.first_word[p + 1]) ++p;
+    dst[i] = g.src[p][i - g.first_word[p]];
+  }
+}
+
 /** updateMarginalizedLinearSystem — problem.hpp:146-203, called from pushFrame before the new frame is appended */
 void foldMarginalized(W &w) {
   HostTimes ht_("foldMarginalized (total)");
@@ -2102,12 +2120,21 @@ void foldMarginalized(W &w) {
   const bool want_state = w.host_stale && !w.state_dirty;
   double *stg = static_cast<double *>(stageAcquire(w, (2 * kk + 2 * k1 + 2) * sizeof(double) + sizeof(WindowState)));
   double *Hpp = stg, *Hsc = Hpp + kk, *bpp = Hsc + kk, *bsc = bpp + k1, *scal = bsc + k1;
-  w.d_Hpp.download(Hpp, kk, 0, w.sr.stream);
-  w.d_HscDownload(Hsc, kk, 0, w.sr.stream);
-  w.d_bpp.download(bpp, k1, 0, w.sr.stream);
-  w.d_bscDownload(bsc, k1, 0, w.sr.stream);
-  w.d_scalars.download(scal, 2, 0, w.sr.stream);
-  if (want_state) HIP_CHECK(hipMemcpyAsync(scal + 2, w.d_state.ptr, sizeof(WindowState), hipMemcpyDeviceToHost, w.sr.stream));
+  {
+    static_assert(sizeof(WindowState) % 8 == 0, "the frame states are gathered as 8-byte words");
+    GatherPieces g;
+    std::memset(&g, 0, sizeof(g));
+    const void *src[6] = {w.d_Hpp.ptr, w.dHsc(), w.d_bpp.ptr, w.dbsc(), w.d_scalars.ptr, w.d_state.ptr};
+    const size_t words[6] = {kk, kk, k1, k1, 2, sizeof(WindowState) / 8};
+    g.n = want_state ? 6 : 5;
+    for (int i = 0; i < g.n; ++i) {
+      g.src[i] = static_cast<const unsigned long long *>(src[i]);
+      g.first_word[i + 1] = g.first_word[i] + static_cast<int>(words[i]);
+    }
+    const int blocks = std::min(64, (g.first_word[g.n] + 1023) / 1024);
+    gatherToHostKernel<<<static_cast<unsigned>(blocks), 256, 0, w.sr.stream>>>(g, reinterpret_cast<unsigned long long *>(stg));
+    HIP_CHECK(hipGetLastError());
+  }
   {
     HostTimes ht2_("foldMarginalized: wait for the device");
     w.sr.sync();
@@ -2276,6 +2303,12 @@ void lmSolve(W &w, double &energy_out, int &iterations, int &n_valid_out) {
 /** entries [current size, n) of the (f, target) connection: the table comes from the pool (or is allocated), the entries are queued */
 void appendConnection(W &w, HostFrame &f, int target_id, int n, const uint8_t *statuses) {
   hipStream_t st = w.sr.stream;
+  {
+    // nothing to append to a list that exists: the call leaves the window as it is (no table rebuild behind it) — most of a keyframe step's
+    // ~130 set_connection calls, since LocalFrame::update walks every connection of every keyframe
+    const auto have = f.residuals.find(target_id);
+    if (have != f.residuals.end() && have->second && n <= have->second->n) return;
+  }
   auto &slot = f.residuals[target_id];
   if (!slot) {
     if (!w.table_pool.empty()) {
@@ -2494,14 +2527,20 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
     // existing landmarks: only flags move (LocalFrame::update, local_frame.hpp:492-497).  The host mirror holds the bits the
     // host decides (marginalized, to_marginalize); the device flags also carry outlier / ill_conditioned, which stay
     f.flags.resize(static_cast<size_t>(n_total));
+    bool changed = false;
     for (int i = 0; i < old; ++i) {
       const bool was_marg = f.flags[static_cast<size_t>(i)] & kFlagMarginalized;
       const bool marg = flags[i] & 1, outl = flags[i] & 2;
       uint8_t v = 0;  // (to_marginalize is ASSIGNED by every update, local_frame.hpp:493-496: a pending one does not survive a second update)
       if (marg) v |= kFlagMarginalized;
       if (!was_marg && marg && !outl) v |= kFlagToMarginalize;
+      changed = changed || v != f.flags[static_cast<size_t>(i)];
       f.flags[static_cast<size_t>(i)] = v;
     }
+    // An update that brings no landmark and leaves every host-decided flag as it is changes nothing on the device: no operation is queued and
+    // the window's tables stay valid.  (The tracker calls updateLocalFrame for every keyframe of the window three times per keyframe step —
+    // after the activation, in pushFrame, at the marginalisation: two thirds of those 21 calls are of this kind.)
+    if (n_total == old && !changed) return;
     for (int i = old; i < n_total; ++i)
       f.flags[static_cast<size_t>(i)] = static_cast<uint8_t>(((flags[i] & 1) ? kFlagMarginalized : 0) | ((flags[i] & 2) ? kFlagOutlier : 0));
     // the new batch in the device's order: by 32 x 32-pixel tile (rows of tiles, then tiles), raster inside a tile — what a grid-cell
@@ -2620,8 +2659,10 @@ int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, i
     if (n > f.n) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "connection has %d entries, frame %d only %d landmarks", n, reference_id, f.n);
     if (w->slotOf(target_id) < 0 && f.residuals.find(target_id) == f.residuals.end()) {
       // the target is not in the window: the list waits on the host (materialised by the push_frame that brings the target)
+      // (the whole list as the caller holds it now: for a target that LEFT the window these are the statuses the last updateFrame handed out —
+      // what the reference's residual list towards a dropped frame keeps, and what get_frame_update returns for such a target)
       std::vector<uint8_t> &pv = f.pending[target_id];
-      if (static_cast<size_t>(n) > pv.size()) pv.insert(pv.end(), statuses + pv.size(), statuses + n);
+      if (static_cast<size_t>(n) >= pv.size()) pv.assign(statuses, statuses + n);
       return;
     }
     appendConnection(*w, f, target_id, n, statuses);
@@ -3039,6 +3080,36 @@ int dsopp_hip_window_get_frame_update(dsopp_hip_window *w, int32_t frame_id, dou
     HostFrame &f = w->frameById(frame_id);
     const size_t n = static_cast<size_t>(f.n);
     if (n == 0) return;
+    {
+      // connections towards frames that are not in the window live on the host (set_connection): their rows are the statuses as declared
+      std::vector<int32_t> held;
+      bool any_pending = false;
+      for (int t = 0; t < n_targets; ++t) {
+        if (f.residuals.find(target_ids[t]) != f.residuals.end()) {
+          held.push_back(target_ids[t]);
+          continue;
+        }
+        const auto p = f.pending.find(target_ids[t]);
+        if (p == f.pending.end()) fail(DSOPP_HIP_ERR_NOT_FOUND, "no connection %d -> %d", frame_id, target_ids[t]);
+        if (p->second.size() != n) fail(DSOPP_HIP_ERR_STATE, "connection %d -> %d holds %zu residuals, frame has %d landmarks", frame_id, target_ids[t], p->second.size(), f.n);
+        any_pending = true;
+      }
+      if (any_pending) {
+        std::vector<uint8_t> rows(held.size() * n);
+        const int rc = dsopp_hip_window_get_frame_update(w, frame_id, idepth, inv_hessian_idepth, relative_baseline, n_inliers, flags_out,
+                                                         static_cast<int32_t>(held.size()), held.data(), rows.data());
+        if (rc != DSOPP_HIP_OK) fail(rc, "%s", dsopp_hip_last_error());
+        size_t k = 0;
+        for (int t = 0; t < n_targets; ++t) {
+          const auto p = f.pending.find(target_ids[t]);
+          if (p != f.pending.end() && f.residuals.find(target_ids[t]) == f.residuals.end())
+            std::memcpy(statuses + static_cast<size_t>(t) * n, p->second.data(), n);
+          else
+            std::memcpy(statuses + static_cast<size_t>(t) * n, rows.data() + (k++) * n, n);
+        }
+        return;
+      }
+    }
     if (w->export_valid) {  // packed by the last solve(): a host copy
       for (const auto &e : w->export_entries) {
         if (e.frame_id != frame_id || e.n != f.n) continue;
@@ -3748,8 +3819,7 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     if (n_keyframes < 1 || n_keyframes > kMaxFrames - 1) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "n_keyframes must be in [1, %d]", kMaxFrames - 1);
     if (number_of_desired_points < 0) fail(DSOPP_HIP_ERR_INVALID_ARGUMENT, "number_of_desired_points < 0");
     w->sr.use();
-    flushAppends(*w);
-    prepare(*w);  // device state current, host mirror of the poses current
+    prepare(*w);  // queued appends flushed, device state current, host mirror of the poses current
     hipStream_t st = w->sr.stream;
     const int F = n_keyframes + 1;
     std::vector<int> slots(static_cast<size_t>(n_keyframes));

@@ -140,7 +140,10 @@ int dsopp_hip_window_push_frame(dsopp_hip_window *w, int32_t frame_id, int64_t t
 int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_t n_total, const double *uv, const double *idepth,
                                    const double *patch, const uint8_t *flags);
 /* residual lists from FrameConnection statuses (PROB_SRC/photometric_bundle_adjustment.cpp:109-123, local_frame.hpp:507-519):
- * appends entries [current size, n) of the (reference, target) connection */
+ * appends entries [current size, n) of the (reference, target) connection.  A target that is not in the window (not pushed yet, or
+ * folded into the prior) is legal, as in LocalFrame::update, which keeps the list of every connection: the statuses are kept on the
+ * host as given — they become the device list when a frame with that id is pushed, and they are what get_frame_update returns
+ * for such a target. */
 int dsopp_hip_window_set_connection(dsopp_hip_window *w, int32_t reference_id, int32_t target_id, int32_t n, const uint8_t *statuses);
 /* updateLocalFrame's frame flags (PROB_SRC/eigen_photometric_bundle_adjustment.cpp:106-113) */
 int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_id);
