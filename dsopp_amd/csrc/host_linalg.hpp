@@ -212,12 +212,11 @@ inline bool pinvDropSmallestSpd(const Mat &H, int n, Mat &out, int *why = nullpt
  *  Right-looking with the finished column kept in a contiguous buffer: the trailing update is a row-wise axpy the compiler vectorises
  *  (the dot-product form is a floating-point reduction, which it may not reorder) — this routine and the two below are on the critical
  *  path of every production solve(): the host inverts the K x K system while the device is already idle (DSOPP_HIP_HOST_TIMES). */
-inline bool choleskyLower(const Mat &A, int n, double floor, Mat &L) {
+// (cores on raw pointers with __restrict__: the inner loops are contiguous axpy updates the compiler vectorises.  A second build of them for
+// AVX2 + FMA picked at load time — target_clones — was tried and brought nothing over the SSE2 baseline at K = 64: 97 against 96 us for the
+// whole pseudo-inverse; what did was walking L by rows of its transpose: 171 -> 96 us)
+inline bool choleskyLowerCore(double *__restrict__ L, double *__restrict__ c, int n, double floor) {
   const size_t N = static_cast<size_t>(n);
-  L.assign(N * N, 0.0);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j <= i; ++j) L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = A[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
-  std::vector<double> col(N);
   for (int j = 0; j < n; ++j) {
     const double d = L[N * static_cast<size_t>(j) + static_cast<size_t>(j)];
     if (!(d > floor)) return false;
@@ -226,63 +225,129 @@ inline bool choleskyLower(const Mat &A, int n, double floor, Mat &L) {
     for (int i = j + 1; i < n; ++i) {
       const double l = L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] * inv;
       L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = l;
-      col[static_cast<size_t>(i)] = l;
+      c[i] = l;
     }
     for (int i = j + 1; i < n; ++i) {
-      const double l = col[static_cast<size_t>(i)];
-      double *row = &L[N * static_cast<size_t>(i)];
-      for (int k = j + 1; k <= i; ++k) row[k] -= l * col[static_cast<size_t>(k)];
+      const double l = c[i];
+      double *__restrict__ row = L + N * static_cast<size_t>(i);
+      for (int k = j + 1; k <= i; ++k) row[k] -= l * c[k];
     }
   }
   return true;
 }
+inline bool choleskyLower(const Mat &A, int n, double floor, Mat &L) {
+  const size_t N = static_cast<size_t>(n);
+  L.assign(N * N, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) L[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = A[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
+  std::vector<double> col(N);
+  return choleskyLowerCore(L.data(), col.data(), n, floor);
+}
 /** x <- (L L^T)^-1 x */
-inline void choleskySolveInPlace(const Mat &L, int n, std::vector<double> &x) {
+inline void choleskySolveCore(const double *__restrict__ L, int n, double *__restrict__ x) {
   const size_t N = static_cast<size_t>(n);
   for (int i = 0; i < n; ++i) {
-    double s = x[static_cast<size_t>(i)];
-    const double *li = &L[N * static_cast<size_t>(i)];
-    for (int k = 0; k < i; ++k) s -= li[k] * x[static_cast<size_t>(k)];
-    x[static_cast<size_t>(i)] = s / li[i];
+    double s = x[i];
+    const double *li = L + N * static_cast<size_t>(i);
+    for (int k = 0; k < i; ++k) s -= li[k] * x[k];
+    x[i] = s / li[i];
   }
   for (int i = n - 1; i >= 0; --i) {
-    double s = x[static_cast<size_t>(i)];
-    for (int k = i + 1; k < n; ++k) s -= L[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * x[static_cast<size_t>(k)];
-    x[static_cast<size_t>(i)] = s / L[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+    double s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= L[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * x[k];
+    x[i] = s / L[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
   }
 }
-/** (L L^T)^-1 as a dense symmetric matrix */
-inline Mat choleskyInverse(const Mat &L, int n) {
+inline void choleskySolveInPlace(const Mat &L, int n, std::vector<double> &x) { choleskySolveCore(L.data(), n, x.data()); }
+/** (L L^T)^-1 as a dense symmetric matrix.  Lt, Xt, X: n x n work arrays, zero-filled; out: zero-filled */
+inline void choleskyInverseCore(const double *__restrict__ L, int n, double *__restrict__ Lt, double *__restrict__ Xt, double *__restrict__ X,
+                                                 double *__restrict__ out) {
   const size_t N = static_cast<size_t>(n);
+  // L^T row-major: column i of L (what a forward substitution walks) is its row i — contiguous
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) Lt[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = L[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
   // X = L^-1 column by column, kept TRANSPOSED (Xt[j] = column j of L^-1, entries i >= j): forward substitution as row-wise axpy
-  Mat Xt(N * N, 0.0), out(N * N, 0.0);
   for (int j = 0; j < n; ++j) {
-    double *x = &Xt[N * static_cast<size_t>(j)];
+    double *__restrict__ x = Xt + N * static_cast<size_t>(j);
     x[j] = 1.0;
     for (int i = j; i < n; ++i) {
-      const double xi = x[i] / L[N * static_cast<size_t>(i) + static_cast<size_t>(i)];
+      const double *__restrict__ li = Lt + N * static_cast<size_t>(i);
+      const double xi = x[i] / li[i];
       x[i] = xi;
-      // x[k] -= L[k][i] * x[i] for k > i: column i of L is strided — walk it once per (j, i)
-      for (int k = i + 1; k < n; ++k) x[k] -= L[N * static_cast<size_t>(k) + static_cast<size_t>(i)] * xi;
+      for (int k = i + 1; k < n; ++k) x[k] -= li[k] * xi;  // x[k] -= L[k][i] x[i] for k > i
     }
   }
-  // out = X^T X: out[i][j] = sum_k X[k][i] X[k][j] = sum_k Xt[i][k] Xt[j][k]; as axpy over the rows of X (= columns of Xt) it needs X
-  // itself row-major: build it once
-  Mat X(N * N, 0.0);
+  // out = X^T X: out[i][j] = sum_k X[k][i] X[k][j]; as axpy over the rows of X (= columns of Xt) it needs X itself row-major: build it once
   for (int j = 0; j < n; ++j)
     for (int i = j; i < n; ++i) X[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = Xt[N * static_cast<size_t>(j) + static_cast<size_t>(i)];
   for (int k = 0; k < n; ++k) {
-    const double *xk = &X[N * static_cast<size_t>(k)];  // row k of L^-1: entries 0 .. k
+    const double *__restrict__ xk = X + N * static_cast<size_t>(k);  // row k of L^-1: entries 0 .. k
     for (int i = 0; i <= k; ++i) {
       const double a = xk[i];
       if (a == 0) continue;
-      double *orow = &out[N * static_cast<size_t>(i)];
+      double *__restrict__ orow = out + N * static_cast<size_t>(i);
       for (int j = 0; j <= i; ++j) orow[j] += a * xk[j];
     }
   }
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < i; ++j) out[N * static_cast<size_t>(j) + static_cast<size_t>(i)] = out[N * static_cast<size_t>(i) + static_cast<size_t>(j)];
+}
+inline Mat choleskyInverse(const Mat &L, int n) {
+  const size_t N = static_cast<size_t>(n);
+  Mat work(3 * N * N, 0.0), out(N * N, 0.0);
+  choleskyInverseCore(L.data(), n, work.data(), work.data() + N * N, work.data() + 2 * N * N, out.data());
   return out;
+}
+
+/** y = M x (four running sums per row, fixed order) */
+inline void matVecCore(const double *__restrict__ M, const double *__restrict__ x, int n, double *__restrict__ y) {
+  const size_t N = static_cast<size_t>(n);
+  for (int i = 0; i < n; ++i) {
+    const double *__restrict__ row = M + N * static_cast<size_t>(i);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 3 < n; k += 4) {
+      s0 += row[k] * x[k];
+      s1 += row[k + 1] * x[k + 1];
+      s2 += row[k + 2] * x[k + 2];
+      s3 += row[k + 3] * x[k + 3];
+    }
+    for (; k < n; ++k) s0 += row[k] * x[k];
+    y[i] = (s0 + s1) + (s2 + s3);
+  }
+}
+/** out[i][j] = in[i][j] * d[i] * d[j] (+ c * e[i] * e[j] when e is given) — the element-wise passes of pinvDropNullDirection */
+inline void scaleSymmetricCore(const double *__restrict__ in, const double *__restrict__ d, int n, double *__restrict__ out, double c,
+                                                const double *__restrict__ e) {
+  const size_t N = static_cast<size_t>(n);
+  for (int i = 0; i < n; ++i) {
+    const double di = d[i], ce = e ? c * e[i] : 0.0;
+    const double *__restrict__ r = in + N * static_cast<size_t>(i);
+    double *__restrict__ o = out + N * static_cast<size_t>(i);
+    if (e)
+      for (int j = 0; j < n; ++j) o[j] = r[j] * di * d[j] + ce * e[j];
+    else
+      for (int j = 0; j < n; ++j) o[j] = r[j] * di * d[j];
+  }
+}
+/** out = M - Mv v^T - v Mv^T + vMv v v^T; returns the squared Frobenius norm of out */
+inline double projectOutCore(const double *__restrict__ M, const double *__restrict__ Mv, const double *__restrict__ v, double vMv, int n,
+                                              double *__restrict__ out) {
+  const size_t N = static_cast<size_t>(n);
+  double fro = 0;
+  for (int i = 0; i < n; ++i) {
+    const double mvi = Mv[i], vi = v[i], a = vMv * vi;
+    const double *__restrict__ r = M + N * static_cast<size_t>(i);
+    double *__restrict__ o = out + N * static_cast<size_t>(i);
+    double f = 0;
+    for (int j = 0; j < n; ++j) {
+      const double w = r[j] - mvi * v[j] - vi * Mv[j] + a * v[j];
+      o[j] = w;
+      f += w * w;
+    }
+    fro += f;
+  }
+  return fro;
 }
 
 /**
@@ -307,8 +372,7 @@ inline bool pinvDropNullDirection(const Mat &H, int n, Mat &out, int *why = null
     d[static_cast<size_t>(i)] = 1.0 / std::sqrt(a);
   }
   Mat S(N * N);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) S[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = H[N * static_cast<size_t>(i) + static_cast<size_t>(j)] * d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+  scaleSymmetricCore(H.data(), d.data(), n, S.data(), 0.0, nullptr);
   Mat St = S, L;
   const double tau = 1e-9;
   for (int i = 0; i < n; ++i) St[N * static_cast<size_t>(i) + static_cast<size_t>(i)] += tau;
@@ -346,40 +410,27 @@ inline bool pinvDropNullDirection(const Mat &H, int n, Mat &out, int *why = null
     Dv[static_cast<size_t>(i)] = d[static_cast<size_t>(i)] * v[static_cast<size_t>(i)];
     dv2 += Dv[static_cast<size_t>(i)] * Dv[static_cast<size_t>(i)];
   }
-  for (int i = 0; i < n; ++i) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += H[N * static_cast<size_t>(i) + static_cast<size_t>(k)] * v[static_cast<size_t>(k)];
-    sigma += s * s;
+  {
+    std::vector<double> Hv(N);
+    matVecCore(H.data(), v.data(), n, Hv.data());
+    for (int i = 0; i < n; ++i) sigma += Hv[static_cast<size_t>(i)] * Hv[static_cast<size_t>(i)];
   }
   sigma = std::sqrt(sigma);  // singular value of the dropped direction
   // S_M = D (H + c v v^T) D = S + c (Dv)(Dv)^T with c |Dv|^2 = 1
   const double c = 1.0 / dv2;
-  Mat SM = S;
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) SM[N * static_cast<size_t>(i) + static_cast<size_t>(j)] += c * Dv[static_cast<size_t>(i)] * Dv[static_cast<size_t>(j)];
+  Mat SM(N * N);
+  scaleSymmetricCore(H.data(), d.data(), n, SM.data(), c, Dv.data());
   if (!choleskyLower(SM, n, 1e-11, L)) return no(15, 0);
-  Mat Minv = choleskyInverse(L, n);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) Minv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] *= d[static_cast<size_t>(i)] * d[static_cast<size_t>(j)];
+  const Mat Minv_scaled = choleskyInverse(L, n);
+  Mat Minv(N * N);
+  scaleSymmetricCore(Minv_scaled.data(), d.data(), n, Minv.data(), 0.0, nullptr);
   // P Minv P
   std::vector<double> Mv(N, 0.0);
   double vMv = 0;
-  for (int i = 0; i < n; ++i) {
-    double s = 0;
-    for (int k = 0; k < n; ++k) s += Minv[N * static_cast<size_t>(i) + static_cast<size_t>(k)] * v[static_cast<size_t>(k)];
-    Mv[static_cast<size_t>(i)] = s;
-    vMv += s * v[static_cast<size_t>(i)];
-  }
+  matVecCore(Minv.data(), v.data(), n, Mv.data());
+  for (int i = 0; i < n; ++i) vMv += Mv[static_cast<size_t>(i)] * v[static_cast<size_t>(i)];
   out.assign(N * N, 0.0);
-  double fro = 0;
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      const double w = Minv[N * static_cast<size_t>(i) + static_cast<size_t>(j)] - Mv[static_cast<size_t>(i)] * v[static_cast<size_t>(j)] -
-                       v[static_cast<size_t>(i)] * Mv[static_cast<size_t>(j)] + vMv * v[static_cast<size_t>(i)] * v[static_cast<size_t>(j)];
-      out[N * static_cast<size_t>(i) + static_cast<size_t>(j)] = w;
-      fro += w * w;
-    }
-  fro = std::sqrt(fro);
+  const double fro = std::sqrt(projectOutCore(Minv.data(), Mv.data(), v.data(), vMv, n, out.data()));
   if (!(sigma * fro < 1e-6)) return no(16, sigma * fro);  // the dropped direction is not (numerically) a null space
   // H pinv H = H in the scaled metric, tested on three fixed probe vectors instead of entry by entry: with E = D (H pinv H - H) D the
   // entrywise bound max |E_ij| < 1e-7 implies |E x|_inf < 1e-7 |x|_1, and a pinv that is wrong in ANY direction fails the probes unless that
@@ -395,19 +446,7 @@ inline bool pinvDropNullDirection(const Mat &H, int n, Mat &out, int *why = null
         x1 += std::abs(xt);
         x[static_cast<size_t>(i)] = d[static_cast<size_t>(i)] * xt;  // x = D x~
       }
-      auto mul = [&](const Mat &M, const std::vector<double> &in, std::vector<double> &res) {
-        for (int i = 0; i < n; ++i) {
-          const double *row = &M[N * static_cast<size_t>(i)];
-          double s0 = 0, s1 = 0;
-          int k = 0;
-          for (; k + 1 < n; k += 2) {
-            s0 += row[k] * in[static_cast<size_t>(k)];
-            s1 += row[k + 1] * in[static_cast<size_t>(k) + 1];
-          }
-          if (k < n) s0 += row[k] * in[static_cast<size_t>(k)];
-          res[static_cast<size_t>(i)] = s0 + s1;
-        }
-      };
+      auto mul = [&](const Mat &M, const std::vector<double> &in, std::vector<double> &res) { matVecCore(M.data(), in.data(), n, res.data()); };
       mul(H, x, y);    // H x
       mul(out, y, z);  // pinv H x
       mul(H, z, u);    // H pinv H x
