@@ -77,7 +77,7 @@ struct HostTimes {
     return v;
   }
   struct Acc {
-    double seconds = 0;
+    double seconds = 0, longest = 0;
     long calls = 0;
   };
   static std::map<std::string, Acc> &table() {
@@ -86,8 +86,9 @@ struct HostTimes {
       std::atexit([] {
         if (!HostTimes::on()) return;
         for (const auto &kv : HostTimes::table())
-          std::fprintf(stderr, "[host times] %-44s %9.3f ms in %7ld calls = %8.2f us per call\n", kv.first.c_str(), kv.second.seconds * 1e3, kv.second.calls,
-                       kv.second.calls ? kv.second.seconds * 1e6 / kv.second.calls : 0.0);
+          std::fprintf(stderr, "[host times] %-44s %9.3f ms in %7ld calls = %8.2f us per call (longest %9.2f us, the others %8.2f us per call)\n",
+                       kv.first.c_str(), kv.second.seconds * 1e3, kv.second.calls, kv.second.calls ? kv.second.seconds * 1e6 / kv.second.calls : 0.0,
+                       kv.second.longest * 1e6, kv.second.calls > 1 ? (kv.second.seconds - kv.second.longest) * 1e6 / (kv.second.calls - 1) : 0.0);
       });
       return m;
     }();
@@ -106,6 +107,7 @@ struct HostTimes {
     std::lock_guard<std::mutex> lock(mtx);
     Acc &a = table()[what];
     a.seconds += seconds;
+    a.longest = seconds > a.longest ? seconds : a.longest;
     a.calls += 1;
   }
   const char *name;
@@ -120,6 +122,7 @@ struct HostTimes {
     std::lock_guard<std::mutex> lock(mtx);
     Acc &a = table()[name];
     a.seconds += dt;
+    a.longest = dt > a.longest ? dt : a.longest;
     a.calls += 1;
   }
 };

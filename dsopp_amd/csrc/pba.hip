@@ -143,6 +143,8 @@ struct dsopp_hip_window {
   size_t combCopyStride() const { return (combCount() + 1) & ~static_cast<size_t>(1); }
   int n_sweep_blocks = 0, n_schur_blocks = 0;
   bool topology_dirty = true;
+  bool frames_dirty = false;          // only the frames' marginalisation flags changed since the tables were built: the frame table is patched
+  std::vector<FrameDev> h_frames;     // the frame table as last uploaded (what such a patch starts from)
   bool state_dirty = true;   // host mirror newer than device
   bool host_stale = false;   // device state newer than the host mirror (after a device-driven solve): see downloadState
   LmControl *h_ctrl = nullptr;  // pinned read-back buffer of the solve result
@@ -604,7 +606,20 @@ void uploadStaged(W &w, DeviceBuffer<T> &dst, const T *host, size_t count, size_
 /** rebuild the FrameDev table, the sweep / Schur block tables and upload them */
 void syncTopology(W &w) {
   HostTimes ht_("syncTopology");
-  if (!w.topology_dirty) return;
+  if (!w.topology_dirty) {
+    if (w.frames_dirty && w.h_frames.size() == static_cast<size_t>(kMaxFrames) && w.d_frames.ptr) {
+      // a keyframe was marked marginalised (dsopp_hip_window_mark_frame_marginalized): nothing the sweep / Schur tables hold has changed —
+      // they carry pointers and counts — only two flags of the frame table: patched and sent alone (a full rebuild is 25 us on the host
+      // and 400 KB of tables through the queue, once per keyframe in front of the reference depth maps)
+      for (int r = 0; r < w.F(); ++r) {
+        w.h_frames[static_cast<size_t>(r)].is_marginalized = w.frames[static_cast<size_t>(r)]->is_marginalized;
+        w.h_frames[static_cast<size_t>(r)].to_marginalize = w.frames[static_cast<size_t>(r)]->to_marginalize;
+      }
+      uploadStagedBytes(w, w.d_frames.ptr, w.h_frames.data(), static_cast<size_t>(kMaxFrames) * sizeof(FrameDev));
+    }
+    w.frames_dirty = false;
+    return;
+  }
   hipStream_t st = w.sr.stream;
   const int F = w.F();
   // (scratch kept per thread: the tables are rebuilt twice per keyframe — pushFrame's fold-in and solve — and 500 vector constructions +
@@ -795,6 +810,8 @@ void syncTopology(W &w) {
   }
   w.d_frames.reserve(kMaxFrames, 0, st);
   uploadStagedBytes(w, w.d_frames.ptr, fd.data(), (kMaxFrames) * sizeof(*w.d_frames.ptr));
+  w.h_frames = fd;
+  w.frames_dirty = false;
   w.n_sweep_blocks = static_cast<int>(sweep.size());
   w.n_schur_blocks = static_cast<int>(schur.size());
   w.d_sweep_table.reserve(std::max<size_t>(1, sweep.size()), 0, st);
@@ -896,7 +913,7 @@ void prepareDevice(W &w) {
   w.sr.use();
   flushAppends(w);
   checkPyramidGenerations(w);
-  if (w.state_dirty || w.topology_dirty || w.marg_dirty || !w.d_state.ptr) prepare(w);
+  if (w.state_dirty || w.topology_dirty || w.frames_dirty || w.marg_dirty || !w.d_state.ptr) prepare(w);
 }
 
 void ensurePairConstants(W &w) {
@@ -2644,7 +2661,7 @@ int dsopp_hip_window_set_landmarks(dsopp_hip_window *w, int32_t frame_id, int32_
       uploadStaged(*w, f.patch, patch + kPat * old, kPat * add, kPat * static_cast<size_t>(old));
     }
     f.n = n_total;
-    w->topology_dirty = true;
+    if (add) w->topology_dirty = true;  // (a flag update leaves counts and addresses — all the tables hold — as they are)
     w->begun = false;
   });
 }
@@ -2676,7 +2693,7 @@ int dsopp_hip_window_mark_frame_marginalized(dsopp_hip_window *w, int32_t frame_
     HostFrame &f = w->frameById(frame_id);
     f.to_marginalize = !f.is_marginalized;
     f.is_marginalized = true;
-    w->topology_dirty = true;
+    w->frames_dirty = true;
   });
 }
 
