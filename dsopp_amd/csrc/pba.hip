@@ -172,7 +172,7 @@ struct dsopp_hip_window {
   // profiles/r06/keyframe_hip_trace_breakdown.json) are QUEUED here and leave as ONE copy + ONE kernel in front of the next call that touches the
   // device (flushAppends): `blob` = the callers' data back to back, `ops` = what to do with it.
   struct AppendOp {
-    int kind;                    // 0: copy; 1: merge landmark flags (+ clear the solver state of new landmarks); 2: new connection entries; 3: clear flag bits (mask in `a`)
+    int kind;                    // 0: copy; 1: merge landmark flags (+ clear the solver state of new landmarks); 2: new connection entries; 3: clear flag bits (mask in `a`); 4: sweep-table entries of a frame pair from its template
     int n;                       // elements (> 0)
     int a;                       // kind 0: bytes per element (8, 4, 1); kind 1: n_old; kind 2: keep (first new entry)
     int first_block;             // first workgroup of the launch that works on this operation
@@ -517,6 +517,21 @@ __global__ void __launch_bounds__(256) applyAppendsKernel(const uint8_t *__restr
     }
     return;
   }
+  if (op.kind == 4) {
+    // sweep-table entries of ONE frame pair written from the pair's template (syncTopology): entry k covers the landmarks from
+    // k * step * kItemsPerBlock on, sums into row first + k, and — in the coarse table of a large window — sweeps up to `step` groups
+    const SweepBlock tmpl = *reinterpret_cast<const SweepBlock *>(src);
+    const int step = op.a, first = static_cast<int>(reinterpret_cast<intptr_t>(op.p[0])), n_all = static_cast<int>(reinterpret_cast<intptr_t>(op.p[1]));
+    SweepBlock *out = static_cast<SweepBlock *>(op.dst);
+    for (int k = e0 + static_cast<int>(threadIdx.x); k < e1; k += 256) {
+      SweepBlock sb = tmpl;
+      sb.offset = k * step * kItemsPerBlock;
+      sb.n_groups = n_all ? (step < n_all - k * step ? step : n_all - k * step) : 1;
+      sb.partial_row = first + k;
+      out[k] = sb;
+    }
+    return;
+  }
   if (op.kind == 3) {  // landmark flag bits cleared (to_marginalize after the fold-in: one operation per frame, one launch for all of them)
     uint8_t *dflags = static_cast<uint8_t *>(op.dst);
     for (int i = e0 + static_cast<int>(threadIdx.x); i < e1; i += 256) dflags[i] &= static_cast<uint8_t>(~op.a);
@@ -627,16 +642,15 @@ void syncTopology(W &w) {
   static thread_local std::vector<FrameDev> fd;
   static thread_local std::vector<SweepBlock> sweep, fine;
   static thread_local std::vector<SchurBlock> schur;
-  static thread_local std::vector<std::vector<SweepBlock>> pair_blocks, pair_fine_blocks;
+  static thread_local std::vector<SweepBlock> pair_tmpl;  // one template per frame pair (slot r * kMaxFrames + t)
+  static thread_local std::vector<int> pair_items;       // its entries of kItemsPerBlock items (0: no residuals)
   fd.assign(static_cast<size_t>(kMaxFrames), FrameDev{});
   std::memset(fd.data(), 0, fd.size() * sizeof(FrameDev));
   sweep.clear();
   fine.clear();
   schur.clear();
-  pair_blocks.resize(kMaxFrames * kMaxFrames);
-  pair_fine_blocks.resize(kMaxFrames * kMaxFrames);
-  for (auto &v : pair_blocks) v.clear();
-  for (auto &v : pair_fine_blocks) v.clear();
+  pair_tmpl.resize(kMaxFrames * kMaxFrames);
+  pair_items.assign(kMaxFrames * kMaxFrames, 0);
   // large windows: a sweep workgroup takes 4 groups of 16 items (pba_kernels.hpp: SweepBlock::n_groups)
   size_t total_items = 0;
   for (int r = 0; r < F; ++r)
@@ -692,40 +706,35 @@ void syncTopology(W &w) {
       d.n_res[t] = rt.n;
       d.snap_status[t] = hbm(rt.snap_status.ptr);
       if (d.first_conn < 0) d.first_conn = t;
-      std::vector<SweepBlock> &pair_sweep = pair_blocks[static_cast<size_t>(r * kMaxFrames + t)];
-      std::vector<SweepBlock> &pair_fine = pair_fine_blocks[static_cast<size_t>(r * kMaxFrames + t)];
-      for (int off = 0; off < rt.n; off += kItemsPerBlock) {
-        const bool coarse_entry = (off / kItemsPerBlock) % groups == 0;
-        SweepBlock sb;
-        std::memset(&sb, 0, sizeof(sb));
-        sb.r = r;
-        sb.t = t;
-        sb.offset = off;
-        sb.n_res = rt.n;
-        sb.cap = f.cap;
-        sb.owns_landmark_sums = d.first_conn == t ? 1 : 0;
-        sb.width_r = lv.width;
-        sb.height_r = lv.height;
-        sb.uv = d.uv;
-        sb.idepth = d.idepth;
-        sb.patch = d.patch;
-        sb.idepth_fej = d.idepth_fej;
-        sb.b_d = d.b_d;
-        sb.inv_hdd = d.inv_hdd;
-        sb.idepth_step = d.idepth_step;
-        sb.ublk = d.ublk;
-        sb.energy = hbm(rt.energy.ptr);
-        sb.flags = d.flags;
-        sb.status = hbm(rt.status.ptr);
-        sb.fej_valid = hbm(rt.fej_valid.ptr);
-        sb.cand = hbm(rt.cand.ptr);
-        sb.n_groups = 1;
-        if (groups > 1) pair_fine.push_back(sb);
-        if (coarse_entry) {
-          sb.n_groups = std::min(groups, (rt.n - off + kItemsPerBlock - 1) / kItemsPerBlock);
-          pair_sweep.push_back(sb);
-        }
-      }
+      // the pair's entries differ in three fields (first landmark, row of the sums, groups of the coarse table): the host states ONE
+      // template per pair, the entries are written from it — on the device (applyAppendsKernel, kind 4), or below for the experiment that
+      // re-orders them.  (Listing them here and sending them whole was 25 us of host time and 350 KB through the queue per rebuild, twice per
+      // keyframe of the tracker.)
+      SweepBlock sb;
+      std::memset(&sb, 0, sizeof(sb));
+      sb.r = r;
+      sb.t = t;
+      sb.n_res = rt.n;
+      sb.cap = f.cap;
+      sb.owns_landmark_sums = d.first_conn == t ? 1 : 0;
+      sb.width_r = lv.width;
+      sb.height_r = lv.height;
+      sb.uv = d.uv;
+      sb.idepth = d.idepth;
+      sb.patch = d.patch;
+      sb.idepth_fej = d.idepth_fej;
+      sb.b_d = d.b_d;
+      sb.inv_hdd = d.inv_hdd;
+      sb.idepth_step = d.idepth_step;
+      sb.ublk = d.ublk;
+      sb.energy = hbm(rt.energy.ptr);
+      sb.flags = d.flags;
+      sb.status = hbm(rt.status.ptr);
+      sb.fej_valid = hbm(rt.fej_valid.ptr);
+      sb.cand = hbm(rt.cand.ptr);
+      sb.n_groups = 1;
+      pair_tmpl[static_cast<size_t>(r * kMaxFrames + t)] = sb;
+      pair_items[static_cast<size_t>(r * kMaxFrames + t)] = (rt.n + kItemsPerBlock - 1) / kItemsPerBlock;
     }
     for (int off = 0; off < f.n; off += kSchurLandmarks) {
       SchurBlock sb;
@@ -756,34 +765,52 @@ void syncTopology(W &w) {
   // sweep is bound by the rate at which the fabric serves randomly placed 64-byte requests, and every L2 hit is one
   // request less.  (Reference-major until round 4: consecutive pairs switched the image.)  DSOPP_HIP_SWEEP_ORDER=rt restores it (A/B).
   static const bool reference_major = std::getenv("DSOPP_HIP_SWEEP_ORDER") != nullptr && std::string(std::getenv("DSOPP_HIP_SWEEP_ORDER")) == "rt";
+  // entry k of a pair in the sweep table / in the fine table (what applyAppendsKernel's kind 4 writes on the device)
+  const int step = groups > 1 ? groups : 1;
+  auto sweepEntry = [&](const SweepBlock &tmpl, int n_all, int first, int k) {
+    SweepBlock sb = tmpl;
+    sb.offset = k * step * kItemsPerBlock;
+    sb.n_groups = groups > 1 ? std::min(step, n_all - k * step) : 1;
+    sb.partial_row = first + k;
+    return sb;
+  };
+  struct PairRange {
+    size_t pi;
+    int first_sweep, n_sweep, first_fine, n_fine;
+  };
+  static thread_local std::vector<PairRange> ranges;
+  ranges.clear();
+  int total_sweep = 0, total_fine = 0;
   for (int outer = 0; outer < F; ++outer)
     for (int inner = 0; inner < F; ++inner) {
       const int r = reference_major ? outer : inner, t = reference_major ? inner : outer;
       const size_t pi = static_cast<size_t>(r * kMaxFrames + t);
-      if (pair_blocks[pi].empty()) continue;
-      pair_first[pi] = static_cast<int>(sweep.size());
-      pair_count[pi] = static_cast<int>(pair_blocks[pi].size());
-      sweep.insert(sweep.end(), pair_blocks[pi].begin(), pair_blocks[pi].end());
-      fine.insert(fine.end(), pair_fine_blocks[pi].begin(), pair_fine_blocks[pi].end());
-    }
-  for (std::vector<SweepBlock> *tbl : {&sweep, &fine})
-    for (SweepBlock &sb : *tbl) {
-      const FrameDev &dr = fd[static_cast<size_t>(sb.r)], &dt = fd[static_cast<size_t>(sb.t)];
-      sb.width_t = dt.width;
-      sb.height_t = dt.height;
-      sb.texels_t = dt.texels;
-      sb.iplane_t = dt.iplane;
-      sb.itiles_t = dt.itiles;
+      const int n_all = pair_items[pi];
+      if (n_all == 0) continue;
+      SweepBlock &tm = pair_tmpl[pi];
+      const FrameDev &dr = fd[static_cast<size_t>(r)], &dt = fd[static_cast<size_t>(t)];
+      tm.width_t = dt.width;
+      tm.height_t = dt.height;
+      tm.texels_t = dt.texels;
+      tm.iplane_t = dt.iplane;
+      tm.itiles_t = dt.itiles;
       for (int k = 0; k < F; ++k)
-        if (dr.status[k] != nullptr) sb.conn_mask |= 1u << k;
+        if (dr.status[k] != nullptr) tm.conn_mask |= 1u << k;
+      const int n_sweep = (n_all + step - 1) / step;
+      pair_first[pi] = total_sweep;
+      pair_count[pi] = n_sweep;
+      ranges.push_back({pi, total_sweep, n_sweep, total_fine, groups > 1 ? n_all : 0});
+      total_sweep += n_sweep;
+      total_fine += groups > 1 ? n_all : 0;
     }
-  for (size_t b = 0; b < sweep.size(); ++b) sweep[b].partial_row = static_cast<int>(b);
-  for (size_t b = 0; b < fine.size(); ++b) fine[b].partial_row = static_cast<int>(b);
   // EXPERIMENT (DSOPP_HIP_SWEEP_XCD_BANDS=1, off by default): launch order such that XCD x (= blockIdx % 8 under round-robin dispatch)
   // sweeps the x-th eighth of every pair's landmarks.  With landmarks in a spatial order (rows of the image) an XCD then samples one
   // band of a target image from all reference frames — 1.2 MB of texels, which its 4 MB L2 holds — instead of the whole image.
   // Measures how much of the 2.6-fold re-use of texel lines across pairs an L2-aware order could turn into hits.
   static const bool xcd_bands = std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS") != nullptr && std::atoi(std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS")) != 0;
+  if (xcd_bands)  // (this experiment re-orders the entries: they are listed on the host, as all tables were until round 6)
+    for (const PairRange &pr : ranges)
+      for (int k = 0; k < pr.n_sweep; ++k) sweep.push_back(sweepEntry(pair_tmpl[pr.pi], pair_items[pr.pi], pr.first_sweep, k));
   if (xcd_bands && !sweep.empty()) {
     std::vector<std::vector<int>> queue(8);
     for (size_t b = 0; b < sweep.size(); ++b) {
@@ -812,17 +839,37 @@ void syncTopology(W &w) {
   uploadStagedBytes(w, w.d_frames.ptr, fd.data(), (kMaxFrames) * sizeof(*w.d_frames.ptr));
   w.h_frames = fd;
   w.frames_dirty = false;
-  w.n_sweep_blocks = static_cast<int>(sweep.size());
+  // one queued operation per pair and table: its template travels (176 bytes), the device writes the entries
+  auto queuePairEntries = [&](SweepBlock *table, const SweepBlock &tmpl, int first, int count, int entry_step, int n_all_for_groups) {
+    W::AppendOp op{};
+    op.kind = 4;
+    op.n = count;
+    op.a = entry_step;
+    op.src_off = queueAppendData(w, &tmpl, sizeof(SweepBlock), table + first);
+    op.dst = table + first;
+    op.p[0] = reinterpret_cast<void *>(static_cast<intptr_t>(first));
+    op.p[1] = reinterpret_cast<void *>(static_cast<intptr_t>(n_all_for_groups));
+    w.append_ops.push_back(op);
+  };
+  const size_t n_sweep_entries = xcd_bands ? sweep.size() : static_cast<size_t>(total_sweep);
+  w.n_sweep_blocks = static_cast<int>(n_sweep_entries);
   w.n_schur_blocks = static_cast<int>(schur.size());
-  w.d_sweep_table.reserve(std::max<size_t>(1, sweep.size()), 0, st);
-  uploadStagedBytes(w, w.d_sweep_table.ptr, sweep.data(), (sweep.size()) * sizeof(*w.d_sweep_table.ptr));
+  if (n_sweep_entries > w.d_sweep_table.capacity || (groups > 1 && static_cast<size_t>(total_fine) > w.d_fine_table.capacity))
+    flushAppends(w, "flush: sweep tables grow");  // (nothing queued may still point into a table that moves)
+  w.d_sweep_table.reserve(std::max<size_t>(1, n_sweep_entries), 0, st);
+  if (xcd_bands) {
+    uploadStagedBytes(w, w.d_sweep_table.ptr, sweep.data(), (sweep.size()) * sizeof(*w.d_sweep_table.ptr));
+  } else {
+    for (const PairRange &pr : ranges)
+      queuePairEntries(w.d_sweep_table.ptr, pair_tmpl[pr.pi], pr.first_sweep, pr.n_sweep, step, groups > 1 ? pair_items[pr.pi] : 0);
+  }
   if (groups > 1) {
-    w.d_fine_table.reserve(std::max<size_t>(1, fine.size()), 0, st);
-    uploadStagedBytes(w, w.d_fine_table.ptr, fine.data(), (fine.size()) * sizeof(*w.d_fine_table.ptr));
-    w.n_fine_blocks = static_cast<int>(fine.size());
+    w.d_fine_table.reserve(std::max<size_t>(1, static_cast<size_t>(total_fine)), 0, st);
+    for (const PairRange &pr : ranges) queuePairEntries(w.d_fine_table.ptr, pair_tmpl[pr.pi], pr.first_fine, pr.n_fine, 1, 0);
+    w.n_fine_blocks = total_fine;
   } else {
     w.d_fine_table.release();
-    w.n_fine_blocks = static_cast<int>(sweep.size());
+    w.n_fine_blocks = static_cast<int>(n_sweep_entries);
   }
   w.d_schur_table.reserve(std::max<size_t>(1, schur.size()), 0, st);
   uploadStagedBytes(w, w.d_schur_table.ptr, schur.data(), (schur.size()) * sizeof(*w.d_schur_table.ptr));
@@ -830,7 +877,7 @@ void syncTopology(W &w) {
   uploadStagedBytes(w, w.d_pair_first.ptr, pair_first.data(), (pair_first.size()) * sizeof(*w.d_pair_first.ptr));
   w.d_pair_count.reserve(kMaxFrames * kMaxFrames, 0, st);
   uploadStagedBytes(w, w.d_pair_count.ptr, pair_count.data(), (pair_count.size()) * sizeof(*w.d_pair_count.ptr));
-  w.d_partials.reserve(std::max<size_t>(1, sweep.size()) * kPartial, 0, st);
+  w.d_partials.reserve(std::max<size_t>(1, n_sweep_entries) * kPartial, 0, st);
   w.d_pc.reserve(kMaxFrames * kMaxFrames, 0, st);
   w.d_ctrl.reserve(2, 0, st);
   const size_t KK = static_cast<size_t>(kBlk * kMaxFrames);
