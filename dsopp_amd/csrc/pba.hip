@@ -807,6 +807,9 @@ void syncTopology(W &w) {
   // sweeps the x-th eighth of every pair's landmarks.  With landmarks in a spatial order (rows of the image) an XCD then samples one
   // band of a target image from all reference frames — 1.2 MB of texels, which its 4 MB L2 holds — instead of the whole image.
   // Measures how much of the 2.6-fold re-use of texel lines across pairs an L2-aware order could turn into hits.
+  // A measurement aid for the sweep only: the point-status kernels walk the same table, padding entries included, and solve()'s statuses /
+  // inlier counts then differ from the checker's (tests/test_gpu_fullres.py::test_full_solve_parity_at_1280x1024 fails under the switch,
+  // as it did when the experiment was built in round 5).
   static const bool xcd_bands = std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS") != nullptr && std::atoi(std::getenv("DSOPP_HIP_SWEEP_XCD_BANDS")) != 0;
   if (xcd_bands)  // (this experiment re-orders the entries: they are listed on the host, as all tables were until round 6)
     for (const PairRange &pr : ranges)
