@@ -94,21 +94,15 @@ struct HostTimes {
     }();
     return *t;
   }
+  static std::mutex &tableMutex() {  // (ONE lock for the table: regions close and growths are counted from a window group's worker threads too)
+    static std::mutex m;
+    return m;
+  }
   /** one event without a duration (e.g. a device buffer growing: who asked, counted per call site) */
   static void count(const std::string &what, long by = 1) {
     if (!on()) return;
-    static std::mutex mtx;
-    std::lock_guard<std::mutex> lock(mtx);
+    std::lock_guard<std::mutex> lock(tableMutex());
     table()[what].calls += by;
-  }
-  static void add(const std::string &what, double seconds) {
-    if (!on()) return;
-    static std::mutex mtx;
-    std::lock_guard<std::mutex> lock(mtx);
-    Acc &a = table()[what];
-    a.seconds += seconds;
-    a.longest = seconds > a.longest ? seconds : a.longest;
-    a.calls += 1;
   }
   const char *name;
   std::chrono::steady_clock::time_point t0;
@@ -117,9 +111,8 @@ struct HostTimes {
   }
   ~HostTimes() {
     if (!on()) return;
-    static std::mutex mtx;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::lock_guard<std::mutex> lock(mtx);
+    std::lock_guard<std::mutex> lock(tableMutex());
     Acc &a = table()[name];
     a.seconds += dt;
     a.longest = dt > a.longest ? dt : a.longest;

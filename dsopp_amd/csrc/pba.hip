@@ -640,14 +640,13 @@ void syncTopology(W &w) {
   // (scratch kept per thread: the tables are rebuilt twice per keyframe — pushFrame's fold-in and solve — and 500 vector constructions +
   // their growth were a good part of the 125 us a rebuild cost on the host; DSOPP_HIP_HOST_TIMES)
   static thread_local std::vector<FrameDev> fd;
-  static thread_local std::vector<SweepBlock> sweep, fine;
+  static thread_local std::vector<SweepBlock> sweep;  // (listed on the host only by the XCD-banded launch order experiment)
   static thread_local std::vector<SchurBlock> schur;
   static thread_local std::vector<SweepBlock> pair_tmpl;  // one template per frame pair (slot r * kMaxFrames + t)
   static thread_local std::vector<int> pair_items;       // its entries of kItemsPerBlock items (0: no residuals)
   fd.assign(static_cast<size_t>(kMaxFrames), FrameDev{});
   std::memset(fd.data(), 0, fd.size() * sizeof(FrameDev));
   sweep.clear();
-  fine.clear();
   schur.clear();
   pair_tmpl.resize(kMaxFrames * kMaxFrames);
   pair_items.assign(kMaxFrames * kMaxFrames, 0);
