@@ -64,6 +64,7 @@ struct ActArgs {
   double fx, fy, cx, cy;         // level 0
   double sigma;
   int desired, minimum_inliers, refine, grid_cap;
+  int work_cap;  // undecided candidates the greedy rounds may list in LDS (<= kActWorkCap; DSOPP_HIP_ACT_WORK_CAP: the test of the scan-all fallback)
   // work
   double *px, *py;               // [0, active_cap): reprojected active landmarks; active_cap + g: immature landmark g
   int *counters;                 // 0 number_of_active_points, 1 reprojected active points, 2 accepted, 3 rounds, 4 grid_w, 5 grid_h
@@ -287,47 +288,89 @@ __global__ void __launch_bounds__(256) activationNeighboursKernel(ActArgs a) {
     }
     return true;
   });
+  // (no earlier candidate within the distance: accepted whatever the others become — decided here, on all CUs, instead of in the one
+  // workgroup of the greedy rounds; in the tracker's scenes that is the majority of the candidates)
   if (blocked) a.state[g] = kCandBlocked;
+  else if (cnt == 0) a.state[g] = kCandAccepted;
   a.nbr_count[g] = cnt;
 }
 
 /** the reference's sequential greedy selection ("activate if no earlier accepted point is closer than the distance")
  *  resolved in parallel rounds by one workgroup: a candidate is decided as soon as every earlier candidate within the distance
  *  is decided; the lowest undecided index always is, so the loop terminates with exactly the sequential result */
+constexpr int kActWorkCap = 8192;  // undecided candidates the greedy rounds keep as a list in LDS (more: every round scans all candidates)
 __global__ void __launch_bounds__(kActSelectThreads) activationResolveKernel(ActArgs a) {
+  __shared__ int s_work[2][kActWorkCap];
+  __shared__ int s_n[2];
   const int tid = threadIdx.x;
   const ActGrid grid = actGrid(a);
   const int nI = a.n_immature;
-  int rounds = 0;
-  for (;;) {
-    int undecided = 0;
-    for (int g = tid; g < nI; g += kActSelectThreads) {
-      if (actLoad(&a.state[g]) != kCandUndecided) continue;
-      bool blocked = false, wait = false;
-      const int cnt = a.nbr_count[g];
-      if (cnt <= kActNbrCap) {
-        const int *list = a.nbr + static_cast<size_t>(g) * kActNbrCap;
-        for (int k = 0; k < cnt; ++k) {
-          const int sj = actLoad(&a.state[list[k]]);
+  const int cap = a.work_cap < kActWorkCap ? a.work_cap : kActWorkCap;
+  // one candidate's step of a round: blocked by an accepted earlier neighbour, accepted when all of them are decided, else it waits
+  auto step = [&](int g) -> bool {
+    bool blocked = false, wait = false;
+    const int cnt = a.nbr_count[g];
+    if (cnt <= kActNbrCap) {
+      const int *list = a.nbr + static_cast<size_t>(g) * kActNbrCap;
+      for (int k = 0; k < cnt; ++k) {
+        const int sj = actLoad(&a.state[list[k]]);
+        blocked = blocked || sj == kCandAccepted;
+        wait = wait || sj == kCandUndecided;
+      }
+    } else {  // more neighbours than the list holds: rescan the cells
+      actForNeighbours(a, grid, a.px[a.active_cap + g], a.py[a.active_cap + g], [&](int id) {
+        if (id >= 0 && id < g) {
+          const int sj = actLoad(&a.state[id]);
           blocked = blocked || sj == kCandAccepted;
           wait = wait || sj == kCandUndecided;
         }
-      } else {  // more neighbours than the list holds: rescan the cells
-        actForNeighbours(a, grid, a.px[a.active_cap + g], a.py[a.active_cap + g], [&](int id) {
-          if (id >= 0 && id < g) {
-            const int sj = actLoad(&a.state[id]);
-            blocked = blocked || sj == kCandAccepted;
-            wait = wait || sj == kCandUndecided;
-          }
-          return true;
-        });
-      }
-      if (blocked) actStore(&a.state[g], kCandBlocked);
-      else if (!wait) actStore(&a.state[g], kCandAccepted);
-      else undecided = 1;
+        return true;
+      });
     }
-    ++rounds;
-    if (!__syncthreads_or(undecided) || rounds > nI + 1) break;  // (the bound is the longest possible dependency chain)
+    if (blocked) actStore(&a.state[g], kCandBlocked);
+    else if (!wait) actStore(&a.state[g], kCandAccepted);
+    return !blocked && wait;  // still undecided
+  };
+  // the candidates the neighbour pass left undecided (those with an earlier candidate within the distance), as a list: a round touches
+  // only them (every round walked all candidates before: 9 dependent load chains per thread and round for 9000 candidates)
+  if (tid < 2) s_n[tid] = 0;
+  __syncthreads();
+  for (int g = tid; g < nI; g += kActSelectThreads)
+    if (actLoad(&a.state[g]) == kCandUndecided) {
+      const int pos = atomicAdd(&s_n[0], 1);
+      if (pos < cap) s_work[0][pos] = g;
+    }
+  __syncthreads();
+  int rounds = 0;
+  if (s_n[0] <= cap) {
+    int cur = 0;
+    for (;;) {
+      const int n = s_n[cur];
+      if (n == 0) {
+        if (rounds == 0) rounds = 1;  // (nothing was left to decide: the neighbour pass was the round)
+        break;
+      }
+      for (int i = tid; i < n; i += kActSelectThreads) {
+        const int g = s_work[cur][i];
+        if (step(g)) s_work[cur ^ 1][atomicAdd(&s_n[cur ^ 1], 1)] = g;
+      }
+      ++rounds;
+      __syncthreads();
+      if (tid == 0) s_n[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+      if (rounds > nI + 1) break;  // (the bound is the longest possible dependency chain)
+    }
+  } else {
+    for (;;) {
+      int undecided = 0;
+      for (int g = tid; g < nI; g += kActSelectThreads) {
+        if (actLoad(&a.state[g]) != kCandUndecided) continue;
+        if (step(g)) undecided = 1;
+      }
+      ++rounds;
+      if (!__syncthreads_or(undecided) || rounds > nI + 1) break;
+    }
   }
   for (int g = tid; g < nI; g += kActSelectThreads)
     if (a.state[g] == kCandAccepted) {

@@ -4039,6 +4039,8 @@ int dsopp_hip_window_activate_landmarks(dsopp_hip_window *w, int32_t n_keyframes
     a.desired = number_of_desired_points;
     a.minimum_inliers = std::min(1, F - 1);  // kMinimumInliers, :334
     a.refine = refine ? 1 : 0;
+    static const int work_cap_env = std::getenv("DSOPP_HIP_ACT_WORK_CAP") ? std::atoi(std::getenv("DSOPP_HIP_ACT_WORK_CAP")) : kActWorkCap;
+    a.work_cap = std::max(0, work_cap_env);
     a.px = S.px.ptr;
     a.py = S.py.ptr;
     a.counters = d_counters;
