@@ -307,14 +307,20 @@ class HipPhotometricBundleAdjustment {
     check(dsopp_hip_window_group_get_pose(g_, frame.keyframe_id, frame.t_world_agent.data(), frame.affine_brightness.data()));
     int32_t n = 0;
     check(dsopp_hip_window_group_num_landmarks(g_, frame.keyframe_id, &n));
-    std::vector<double> idepth(n), inv_h(n), baseline(n);
-    std::vector<int32_t> inliers(n);
-    std::vector<uint8_t> flags(n);
+    std::vector<double> &idepth = scratch_idepth_, &inv_h = scratch_uv_, &baseline = scratch_patch_;  // (the solver's scratch: see uploadLandmarks)
+    std::vector<int32_t> &inliers = scratch_inliers_;
+    std::vector<uint8_t> &flags = scratch_flags_, &statuses = scratch_statuses_;
+    idepth.resize(static_cast<size_t>(n));
+    inv_h.resize(static_cast<size_t>(n));
+    baseline.resize(static_cast<size_t>(n));
+    inliers.resize(static_cast<size_t>(n));
+    flags.resize(static_cast<size_t>(n));
     // one packed transfer for the landmark arrays and the statuses towards every connected frame
-    std::vector<int32_t> targets;
+    std::vector<int32_t> &targets = scratch_targets_;
+    targets.clear();
     for (const auto &kv : frame.reprojection_statuses)
       if (static_cast<int32_t>(kv.second.size()) == n && n > 0) targets.push_back(kv.first);
-    std::vector<uint8_t> statuses(targets.size() * static_cast<size_t>(n));
+    statuses.resize(targets.size() * static_cast<size_t>(n));
     check(dsopp_hip_window_group_get_frame_update(g_, frame.keyframe_id, idepth.data(), inv_h.data(), baseline.data(), inliers.data(), flags.data(),
                                             static_cast<int32_t>(targets.size()), targets.data(), statuses.data()));
     // entries of landmarks the solver has not written yet start at the reference's defaults; entries of marginalised
@@ -377,8 +383,14 @@ class HipPhotometricBundleAdjustment {
     // arrays from its own landmark count on)
     int32_t held = 0;
     check(dsopp_hip_window_group_num_landmarks(g_, frame.keyframe_id, &held));
-    std::vector<double> uv(2 * n), idepth(n), patch(DSOPP_HIP_PATTERN_SIZE * n);
-    std::vector<uint8_t> flags(n);
+    // (scratch kept with the solver: updateLocalFrame runs for every keyframe of the window three times per keyframe step, and four fresh
+    // zero-filled arrays of all its landmarks per call were a measurable part of that step's host time)
+    std::vector<double> &uv = scratch_uv_, &idepth = scratch_idepth_, &patch = scratch_patch_;
+    std::vector<uint8_t> &flags = scratch_flags_;
+    uv.resize(2 * n);
+    idepth.resize(n);
+    patch.resize(DSOPP_HIP_PATTERN_SIZE * n);
+    flags.resize(n);
     for (size_t i = 0; i < n; ++i) {
       const LandmarkView &lm = frame.active_landmarks[i];
       flags[i] = static_cast<uint8_t>((lm.is_marginalized ? 1 : 0) | (lm.is_outlier ? 2 : 0));
@@ -399,6 +411,9 @@ class HipPhotometricBundleAdjustment {
       if (rc != DSOPP_HIP_OK && rc != DSOPP_HIP_ERR_NOT_FOUND) check(rc);
     }
   }
+  std::vector<double> scratch_uv_, scratch_idepth_, scratch_patch_;
+  std::vector<uint8_t> scratch_flags_, scratch_statuses_;
+  std::vector<int32_t> scratch_inliers_, scratch_targets_;
   dsopp_hip_window_group *g_ = nullptr;
   dsopp_hip_window *w_ = nullptr;  // shard 0's window when the group has one shard
   int n_shards_ = 1;
