@@ -2988,8 +2988,11 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
         prepare(*w);  // (flushes the queued appends first)
       }
       HIP_CHECK(hipEventRecord(w->ev0, w->sr.stream));
-      fusedBegin(*w);
-      lmSolveFusedEnqueue(*w);
+      {
+        HostTimes ht2_("solve: enqueue of the LM loop");
+        fusedBegin(*w);
+        lmSolveFusedEnqueue(*w);
+      }
       {
         // closing problem.calculateEnergy() at the reverted state iff the last step was rejected (lmSolveFusedFinish does this
         // on the host's say-so; here the final control block's flag decides on the device)
@@ -3002,11 +3005,20 @@ int dsopp_hip_window_solve(dsopp_hip_window *w, double *energy, int32_t *iterati
       }
       HIP_CHECK(hipEventRecord(w->ev1, w->sr.stream));
       w->solve_events_pending = true;
-      relinearize(*w);
+      {
+        HostTimes ht2_("solve: enqueue of the re-linearisation");
+        relinearize(*w);
+      }
       bool want_state = false;
-      if (w->opt.estimate_uncertainty) want_state = estimateUncertaintyEnqueue(*w, /*force_state=*/true);
-      updatePointStatusesDevice(*w);
-      prefetchFrameUpdates(*w);
+      {
+        HostTimes ht2_("solve: enqueue of the covariance linearisation");
+        if (w->opt.estimate_uncertainty) want_state = estimateUncertaintyEnqueue(*w, /*force_state=*/true);
+      }
+      {
+        HostTimes ht2_("solve: enqueue of point statuses + frame export");
+        updatePointStatusesDevice(*w);
+        prefetchFrameUpdates(*w);
+      }
       {
         HostTimes ht2_("solve: uncertainty on the host (under the device's work)");
         if (w->opt.estimate_uncertainty) estimateUncertaintyHost(*w, want_state);
